@@ -1,0 +1,238 @@
+"""Plan-time graph fusion: swap op chains for the fused kernels the GPU actually runs.
+
+A whole MNIST training step (reference ``tf_distributed.py:62-76``) is ~48 MFLOP, so on an
+MI355X it is bounded by kernel count, not arithmetic. The planner therefore rewrites the
+pruned subgraph before execution:
+
+* ``act(add(matmul(x, W), b))``                      -> ``FusedDense`` (bias + activation in the
+  GEMM epilogue);
+* ``reduce_mean(-reduce_sum(labels * log(softmax(z)), 1))`` -> ``SoftmaxXentMean`` (log-softmax
+  form; also yields the softmax for the accuracy branch);
+* the backward chain from d(loss) to d(logits)        -> ``SoftmaxXentMeanGrad`` (emits the
+  logits gradient and the bias gradient);
+* ``SigmoidGrad`` + the bias-gradient column sum      -> ``DenseGradSigmoid``;
+* every ``ApplyGradientDescent`` (+ the ``global_step`` increment) -> one ``MultiApplySGD``.
+
+Rewrites are expressed as *tensor replacements* (``original tensor -> output k of a fused
+node``) and *op replacements* (for control edges). The original ops stay in the graph; after
+re-pruning from the fetches the replaced chains are simply unreachable. ``graph.grad_map``
+(filled by ``gradients``) tells which tensor holds d(loss)/d(t), which is what lets whole
+backward chains be replaced without pattern-matching their internals.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Set, Tuple
+
+from ..framework import dtypes
+from ..framework.graph import Graph, Operation, Tensor
+
+
+class FusedNode:
+    """A synthetic operation that exists only inside an execution plan."""
+
+    __slots__ = ("type", "name", "inputs", "control_inputs", "attrs", "outputs", "device",
+                 "graph", "id")
+
+    def __init__(self, graph: Graph, op_type: str, name: str, inputs: Sequence[Tensor],
+                 out_specs: Sequence[Tuple], attrs: Optional[dict] = None,
+                 control_inputs: Sequence = (), device: str = ""):
+        self.graph = graph
+        self.type = op_type
+        self.name = name
+        self.inputs = list(inputs)
+        self.control_inputs = list(control_inputs)
+        self.attrs = dict(attrs or {})
+        self.outputs = [Tensor(self, i, dt, shape) for i, (dt, shape) in enumerate(out_specs)]
+        self.device = device
+        self.id = -1
+
+    def get_attr(self, key):
+        return self.attrs[key]
+
+    def __repr__(self):
+        return "<FusedNode %r type=%s>" % (self.name, self.type)
+
+
+class Rewrite:
+    def __init__(self):
+        self.tensor_map: Dict[Tensor, Tensor] = {}      # original tensor -> fused output
+        self.op_map: Dict[Operation, FusedNode] = {}    # original op -> fused node (control)
+
+    def resolve(self, t: Tensor) -> Tensor:
+        seen = 0
+        while t in self.tensor_map and seen < 8:
+            t = self.tensor_map[t]
+            seen += 1
+        return t
+
+    def resolve_op(self, op):
+        return self.op_map.get(op, op)
+
+
+def _consumers(ops: Sequence[Operation]) -> Dict[Tensor, List[Operation]]:
+    out: Dict[Tensor, List[Operation]] = {}
+    for op in ops:
+        for t in op.inputs:
+            out.setdefault(t, []).append(op)
+    return out
+
+
+_ACT_TYPES = {"Sigmoid": "sigmoid", "Relu": "relu", "Tanh": "tanh"}
+
+
+def _match_dense(add_op: Operation) -> Optional[Tuple[Tensor, Tensor, Tensor, Operation]]:
+    """``Add(MatMul(x, W), b)`` with b rank-1 -> (x, W, b, matmul_op)."""
+    if add_op.type != "Add":
+        return None
+    for mm_t, b_t in (add_op.inputs, reversed(add_op.inputs)):
+        mm = mm_t.op
+        if mm.type != "MatMul" or mm.attrs["transpose_a"] or mm.attrs["transpose_b"]:
+            continue
+        if b_t.shape is None or len(b_t.shape) != 1:
+            continue
+        if mm_t.dtype != dtypes.float32:
+            continue
+        return mm.inputs[0], mm.inputs[1], b_t, mm
+    return None
+
+
+def _match_xent(mean_op: Operation):
+    """``Mean(Neg(Sum(Mul(labels, Log(Softmax(z))), axis=last)))`` -> (z, labels, softmax_t)."""
+    if mean_op.type != "Mean" or mean_op.attrs["axis"] is not None:
+        return None
+    neg = mean_op.inputs[0].op
+    if neg.type != "Neg":
+        return None
+    sm = neg.inputs[0].op
+    if sm.type != "Sum" or sm.attrs["keepdims"]:
+        return None
+    mul = sm.inputs[0].op
+    if mul.type != "Mul":
+        return None
+    rank = None if mul.outputs[0].shape is None else len(mul.outputs[0].shape)
+    if rank != 2 or sm.attrs["axis"] != (1,):
+        return None
+    for labels_t, log_t in (mul.inputs, reversed(mul.inputs)):
+        lg = log_t.op
+        if lg.type != "Log":
+            continue
+        soft = lg.inputs[0].op
+        if soft.type != "Softmax":
+            continue
+        if soft.outputs[0].dtype != dtypes.float32:
+            continue
+        return soft.inputs[0], labels_t, soft.outputs[0]
+    return None
+
+
+def build_rewrite(graph: Graph, ops: Sequence[Operation], fed: Set[Tensor],
+                  fetched: Set[Tensor] = frozenset()) -> Rewrite:
+    """Find fusable patterns among ``ops`` (the pruned, topologically ordered subgraph)."""
+    rw = Rewrite()
+    alive = set(ops)
+    consumers = _consumers(ops)
+    grad_map = graph.grad_map
+    dense_of: Dict[Tensor, FusedNode] = {}     # dense output tensor -> its FusedDense node
+
+    def only_consumer(t: Tensor, op: Operation) -> bool:
+        return all(c is op for c in consumers.get(t, []))
+
+    # -- forward: dense layers ----------------------------------------------------------
+    for op in ops:
+        hit = _match_dense(op) if op.type == "Add" else None
+        if hit is None or op.outputs[0] in fed:
+            continue
+        x, w, b, mm = hit
+        if mm.outputs[0] in fed or not only_consumer(mm.outputs[0], op):
+            continue
+        z = op.outputs[0]
+        act_name, act_op = "none", None
+        users = [c for c in consumers.get(z, []) if c in alive]
+        # fold the activation into the GEMM epilogue when nothing else needs the
+        # pre-activation (activation gradients are written in terms of the activation output)
+        if (len(users) == 1 and users[0].type in _ACT_TYPES and z not in fetched
+                and users[0].outputs[0] not in fed):
+            act_op = users[0]
+            act_name = _ACT_TYPES[act_op.type]
+        out_t = act_op.outputs[0] if act_op is not None else z
+        node = FusedNode(graph, "FusedDense", out_t.op.name + "/fused_dense", [x, w, b],
+                         [(out_t.dtype, out_t.shape)], {"activation": act_name},
+                         device=op.device)
+        rw.tensor_map[out_t] = node.outputs[0]
+        dense_of[out_t] = node
+        node.attrs["_pre_activation"] = z
+        node.attrs["_bias"] = b
+
+        # -- backward of a sigmoid dense: dz = da*a*(1-a), db = colsum(dz) ---------------
+        if act_name == "sigmoid":
+            dz_t = grad_map.get(z)
+            db_t = grad_map.get(b)
+            da_t = grad_map.get(out_t)
+            if (dz_t is not None and da_t is not None and dz_t.op in alive
+                    and dz_t.op.type == "SigmoidGrad"):
+                outs = [(dz_t.dtype, dz_t.shape)]
+                fuse_bias = (db_t is not None and db_t.op in alive
+                             and db_t.op.type == "SumToShapeOf" and db_t.op.inputs[0] is dz_t)
+                if fuse_bias:
+                    outs.append((db_t.dtype, db_t.shape))
+                    gnode = FusedNode(graph, "DenseGradSigmoid", z.op.name + "/fused_grad",
+                                      [da_t, out_t], outs, device=op.device)
+                    rw.tensor_map[dz_t] = gnode.outputs[0]
+                    rw.tensor_map[db_t] = gnode.outputs[1]
+
+    # -- forward + backward: softmax cross-entropy ----------------------------------------
+    for op in ops:
+        hit = _match_xent(op) if op.type == "Mean" else None
+        if hit is None:
+            continue
+        logits, labels, soft_t = hit
+        loss_t = op.outputs[0]
+        node = FusedNode(graph, "SoftmaxXentMean", op.name + "/fused_xent", [logits, labels],
+                         [(loss_t.dtype, loss_t.shape), (soft_t.dtype, soft_t.shape)],
+                         device=op.device)
+        rw.tensor_map[loss_t] = node.outputs[0]
+        rw.tensor_map[soft_t] = node.outputs[1]
+        dlogits_t = grad_map.get(logits)
+        dloss_t = grad_map.get(loss_t)
+        if dlogits_t is not None and dloss_t is not None and dlogits_t.op in alive:
+            outs = [(dlogits_t.dtype, dlogits_t.shape)]
+            bias_t = None
+            dense = dense_of.get(logits)
+            if dense is not None:
+                bias_t = dense.attrs["_bias"]
+            db_t = grad_map.get(bias_t) if bias_t is not None else None
+            emit_bias = (db_t is not None and db_t.op in alive
+                         and db_t.op.type == "SumToShapeOf" and db_t.op.inputs[0] is dlogits_t)
+            if emit_bias:
+                outs.append((db_t.dtype, db_t.shape))
+            gnode = FusedNode(graph, "SoftmaxXentMeanGrad", op.name + "/fused_xent_grad",
+                              [soft_t, labels, dloss_t], outs,
+                              {"emit_bias_grad": emit_bias}, device=op.device)
+            rw.tensor_map[dlogits_t] = gnode.outputs[0]
+            if emit_bias:
+                rw.tensor_map[db_t] = gnode.outputs[1]
+
+    # -- optimizer: one multi-tensor SGD launch --------------------------------------------
+    applies = [op for op in ops if op.type == "ApplyGradientDescent"
+               and not consumers.get(op.outputs[0]) and op.outputs[0] not in fetched]
+    if len(applies) >= 1:
+        var_ops = [a.inputs[0].op for a in applies]
+        node = FusedNode(graph, "MultiApplySGD", "fused_sgd", [a.inputs[1] for a in applies], [],
+                         {"var_ops": var_ops,
+                          "learning_rates": [a.attrs["learning_rate"] for a in applies],
+                          "counter_increments": []},
+                         control_inputs=[c for a in applies for c in a.control_inputs],
+                         device=applies[0].device)
+        for a in applies:
+            rw.op_map[a] = node
+        apply_set = set(applies)
+        for op in ops:
+            if (op.type == "AssignAdd" and op.inputs[1].op.type in ("Const", "Fill")
+                    and op.control_inputs and set(op.control_inputs) <= apply_set
+                    and not consumers.get(op.outputs[0]) and op.outputs[0] not in fed
+                    and op.outputs[0] not in fetched):
+                src = op.inputs[1].op
+                delta = src.attrs["value"]
+                node.attrs["counter_increments"].append((op.inputs[0].op, float(delta)))
+                rw.op_map[op] = node
+    return rw

@@ -1,0 +1,550 @@
+"""Session: prune -> plan -> execute for ``run(fetches, feed_dict)``.
+
+The reference's hot loop is one blocking
+``sess.run([train_op, cross_entropy, summary_op, global_step], feed_dict={x:..., y_:...})``
+per step (``tf_distributed.py:111``) plus an eval-only ``sess.run(accuracy, ...)`` with a
+different fetch signature (``:126``). ``Session.run`` therefore:
+
+1. flattens the fetch structure (ops fetch as ``None``, ``None`` entries stay ``None``);
+2. looks up / builds an ``ExecutionPlan`` keyed by *(fetches, fed tensors)*: the subgraph
+   reachable from the fetches (stopping at fed tensors), rewritten by the fusion pass and
+   topologically ordered, with variables grouped by the store that owns them;
+3. executes the plan. On an MI355X the plan's device phase is launched eagerly once (warm-up),
+   then captured into a HIP graph keyed by the feed shapes, so that a steady-state step is one
+   graph launch + one packed device->host copy of the fetched values;
+4. runs the host phase (summary protobuf encoding) on the fetched scalars.
+
+Variable placement decides *where state lives*: ops on ``/job:ps/task:K`` are served by the
+store bound to that task (a remote parameter server in CPU plumbing mode; the local HBM store
+in single-process and collective modes).
+"""
+from __future__ import annotations
+
+import contextlib
+import os
+import threading
+import time
+from typing import Any, Dict, List, Optional, Sequence, Set, Tuple
+
+import numpy as np
+import torch
+
+from ..framework import dtypes
+from ..framework.device import DeviceSpec
+from ..framework.graph import Graph, Operation, Tensor, get_default_graph, value_inputs
+from ..framework.op_registry import get_opdef
+from ..ops import ref_kernels  # noqa: F401  (registers the reference kernels)
+from . import fusion
+from .variable_store import FailedPreconditionError, LocalVariableStore
+
+_VAR_TYPES = ("VariableV2",)
+
+
+class ConfigProto:
+    """Session options (the subset that means something here).
+
+    ``graph_fusion``   -- enable the plan-time fusion pass (default on).
+    ``hip_graphs``     -- capture steady-state steps into HIP graphs on GPU (default on).
+    ``device``         -- torch device string; default: ``cuda:<LOCAL_RANK>`` when a GPU is
+                          visible, else ``cpu``.
+    ``allow_soft_placement`` / ``log_device_placement`` -- accepted for compatibility.
+    """
+
+    def __init__(self, graph_fusion: bool = True, hip_graphs: bool = True,
+                 device: Optional[str] = None, allow_soft_placement: bool = True,
+                 log_device_placement: bool = False, strategy: Optional[str] = None):
+        self.graph_fusion = graph_fusion
+        self.hip_graphs = hip_graphs
+        self.device = device
+        self.allow_soft_placement = allow_soft_placement
+        self.log_device_placement = log_device_placement
+        self.strategy = strategy
+
+
+class RunOptions:
+    NO_TRACE, FULL_TRACE = 0, 3
+
+    def __init__(self, trace_level: int = 0):
+        self.trace_level = trace_level
+
+
+class RunMetadata:
+    """Receives per-op timings when ``RunOptions(trace_level=FULL_TRACE)`` is passed."""
+
+    def __init__(self):
+        self.step_stats: List[Dict[str, Any]] = []
+
+    def to_chrome_trace(self) -> Dict[str, Any]:
+        from ..utils.tracing import chrome_trace
+        return chrome_trace(self.step_stats)
+
+
+def default_device() -> torch.device:
+    if torch.cuda.is_available():
+        return torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))
+                            % max(1, torch.cuda.device_count()))
+    return torch.device("cpu")
+
+
+# ---------------------------------------------------------------------------------------
+# execution context: what kernels see
+# ---------------------------------------------------------------------------------------
+class ExecContext:
+    def __init__(self, session: "Session"):
+        self.session = session
+        self.device = session.device
+        self.const_cache: Dict[Any, torch.Tensor] = {}
+        self._nd_seed = int.from_bytes(os.urandom(4), "little")
+
+    def nondeterministic_seed(self) -> int:
+        self._nd_seed = (self._nd_seed * 1103515245 + 12345) & 0x7FFFFFFF
+        return self._nd_seed
+
+    def _store(self, var_op):
+        return self.session._store_for(var_op)
+
+    def var_read(self, var_op) -> torch.Tensor:
+        return self._store(var_op).read(var_op.name)
+
+    def var_assign(self, var_op, value: torch.Tensor) -> torch.Tensor:
+        return self._store(var_op).assign(var_op.name, value)
+
+    def var_assign_add(self, var_op, delta) -> torch.Tensor:
+        return self._store(var_op).assign_add(var_op.name, delta)
+
+    def var_apply_sgd(self, var_op, lr: float, grad: torch.Tensor) -> torch.Tensor:
+        return self._store(var_op).apply_sgd(var_op.name, lr, grad)
+
+    def var_is_initialized(self, var_op) -> bool:
+        return self._store(var_op).is_initialized(var_op.name)
+
+
+# ---------------------------------------------------------------------------------------
+# plans
+# ---------------------------------------------------------------------------------------
+class _Step:
+    __slots__ = ("node", "kernel", "in_slots", "out_slots", "host")
+
+    def __init__(self, node, kernel, in_slots, out_slots, host):
+        self.node = node
+        self.kernel = kernel
+        self.in_slots = in_slots
+        self.out_slots = out_slots
+        self.host = host
+
+
+class ExecutionPlan:
+    def __init__(self):
+        self.steps: List[_Step] = []          # device phase, topological
+        self.host_steps: List[_Step] = []     # host phase (string-valued ops)
+        self.num_slots = 0
+        self.feed_slots: List[Tuple[Tensor, int]] = []
+        self.fetch_slots: List[Optional[int]] = []   # per flattened fetch; None for ops
+        self.host_input_slots: List[int] = []        # device values the host phase needs
+        self.var_ops: List[Any] = []                 # VariableV2 ops read by the plan
+        self.mutates_state = False
+        self.capturable = True
+        self.graphs: Dict[Tuple, "_CapturedStep"] = {}
+        self.runs = 0
+
+
+class _CapturedStep:
+    """One HIP-graph instantiation of a plan for fixed feed shapes."""
+
+    def __init__(self):
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.static_feeds: List[torch.Tensor] = []
+        self.host_buf: Optional[torch.Tensor] = None      # pinned staging for packed scalars
+        self.layout: List[Tuple[int, int, torch.Size, torch.dtype]] = []
+        self.slot_values: List[Any] = []
+
+
+_default_session = threading.local()
+
+
+def get_default_session() -> Optional["Session"]:
+    stack = getattr(_default_session, "stack", None)
+    return stack[-1] if stack else None
+
+
+class Session:
+    def __init__(self, target: str = "", graph: Optional[Graph] = None,
+                 config: Optional[ConfigProto] = None):
+        self.graph = graph or get_default_graph()
+        self.config = config or ConfigProto()
+        self.target = target or ""
+        self._closed = False
+        self._plans: Dict[Tuple, ExecutionPlan] = {}
+        self._lock = threading.RLock()
+        self.device = torch.device(self.config.device) if self.config.device \
+            else default_device()
+        self._runtime = None
+        self._stores: Dict[Tuple[str, int], Any] = {}
+        if self.target:
+            from ..train.server import lookup_server
+            server = lookup_server(self.target)
+            self._runtime = server.runtime
+            if self.config.device is None:
+                self.device = self._runtime.device
+        if self.device.type == "cuda":
+            torch.cuda.set_device(self.device)
+            from ..ops import hip_kernels  # noqa: F401  (registers HIP kernels; fails loudly)
+        self._local_store = (self._runtime.local_store if self._runtime is not None
+                             else LocalVariableStore(self.device))
+        self._ctx = ExecContext(self)
+        self.stats = {"runs": 0, "graph_replays": 0, "eager_runs": 0, "captures": 0}
+
+    # -- context-manager / default-session protocol ---------------------------------------
+    def __enter__(self) -> "Session":
+        stack = getattr(_default_session, "stack", None)
+        if stack is None:
+            stack = _default_session.stack = []
+        stack.append(self)
+        return self
+
+    def __exit__(self, exc_type, exc, tb) -> None:
+        _default_session.stack.pop()
+        self.close()
+
+    @contextlib.contextmanager
+    def as_default(self):
+        stack = getattr(_default_session, "stack", None)
+        if stack is None:
+            stack = _default_session.stack = []
+        stack.append(self)
+        try:
+            yield self
+        finally:
+            stack.pop()
+
+    def close(self) -> None:
+        if self._closed:
+            return
+        self._closed = True
+        for plan in self._plans.values():
+            plan.graphs.clear()
+        self._plans.clear()
+
+    # -- variable routing ------------------------------------------------------------------
+    def _store_for(self, var_op):
+        """The store that owns ``var_op``: decided by the variable's device (its ps task)."""
+        if self._runtime is None:
+            return self._local_store
+        return self._runtime.store_for_device(var_op.device)
+
+    @property
+    def variable_store(self) -> LocalVariableStore:
+        return self._local_store
+
+    # -- fetch handling --------------------------------------------------------------------
+    def _flatten(self, fetches) -> Tuple[List[Any], Any]:
+        flat: List[Any] = []
+
+        def walk(f):
+            if f is None:
+                return ("none",)
+            if isinstance(f, (list, tuple)):
+                return ("seq", type(f), [walk(x) for x in f])
+            if isinstance(f, dict):
+                return ("dict", [(k, walk(v)) for k, v in f.items()])
+            elem = self.graph.as_graph_element(f)
+            flat.append(elem)
+            return ("leaf", len(flat) - 1)
+
+        return flat, walk(fetches)
+
+    @staticmethod
+    def _unflatten(structure, values: List[Any]):
+        kind = structure[0]
+        if kind == "none":
+            return None
+        if kind == "leaf":
+            return values[structure[1]]
+        if kind == "seq":
+            items = [Session._unflatten(s, values) for s in structure[2]]
+            return items if structure[1] is list else tuple(items)
+        return {k: Session._unflatten(s, values) for k, s in structure[1]}
+
+    # -- planning --------------------------------------------------------------------------
+    def _build_plan(self, flat: List[Any], fed: List[Tensor]) -> ExecutionPlan:
+        fed_set: Set[Tensor] = set(fed)
+        fetched_tensors = {f for f in flat if isinstance(f, Tensor)}
+        # fetched tensors that are themselves fed need no producer
+        live = [f for f in flat if not (isinstance(f, Tensor) and f in fed_set)]
+
+        def prune(rw: fusion.Rewrite) -> List[Any]:
+            """Post-order DFS from the fetches over the (rewritten) graph = topological order
+            of exactly the nodes the fetches need."""
+            order: List[Any] = []
+            state: Dict[Any, int] = {}
+            for f in live:
+                root = rw.resolve(f).op if isinstance(f, Tensor) else rw.resolve_op(f)
+                stack = [(root, False)]
+                while stack:
+                    node, done = stack.pop()
+                    if done:
+                        order.append(node)
+                        continue
+                    if state.get(node):
+                        continue
+                    state[node] = 1
+                    stack.append((node, True))
+                    deps = []
+                    for _i, t in value_inputs(node):
+                        if t in fed_set:
+                            continue
+                        rt = rw.resolve(t)
+                        if rt not in fed_set:
+                            deps.append(rt.op)
+                    deps.extend(rw.resolve_op(c) for c in node.control_inputs)
+                    for d in reversed(deps):
+                        if not state.get(d):
+                            stack.append((d, False))
+            return order
+
+        rw = fusion.Rewrite()
+        order = prune(rw)
+        if self.config.graph_fusion:
+            rw = fusion.build_rewrite(self.graph, sorted(order, key=lambda o: o.id), fed_set,
+                                      fetched_tensors)
+            if rw.tensor_map or rw.op_map:
+                order = prune(rw)
+
+        plan = ExecutionPlan()
+        slot_of: Dict[Tensor, int] = {}
+
+        def slot(t: Tensor) -> int:
+            if t not in slot_of:
+                slot_of[t] = plan.num_slots
+                plan.num_slots += 1
+            return slot_of[t]
+
+        for t in fed:
+            plan.feed_slots.append((t, slot(t)))
+        use_hip = self.device.type == "cuda"
+        for node in order:
+            d = get_opdef(node.type)
+            kernel = d.hip_kernel if (use_hip and d.hip_kernel is not None) else d.ref_kernel
+            if kernel is None:
+                raise NotImplementedError("op type %r has no kernel" % node.type)
+            ins = [-1] * len(node.inputs)          # -1: a variable reference, not a value
+            for i, t in value_inputs(node):
+                rt = t if t in fed_set else rw.resolve(t)
+                ins[i] = slot(rt)
+            outs = [slot(o) for o in node.outputs]
+            step = _Step(node, kernel, ins, outs, d.host_only)
+            if d.host_only:
+                plan.host_steps.append(step)
+            else:
+                plan.steps.append(step)
+            if node.type in _VAR_TYPES:
+                plan.var_ops.append(node)
+            if d.stateful and node.type not in ("VariableV2", "NoOp", "Placeholder"):
+                plan.mutates_state = True
+        host_nodes = {s.node for s in plan.host_steps}
+        needed: List[int] = []
+        for s in plan.host_steps:
+            for t, sl in zip(s.node.inputs, s.in_slots):
+                if sl < 0:
+                    continue
+                producer = (t if t in fed_set else rw.resolve(t)).op
+                if producer not in host_nodes and sl not in needed:
+                    needed.append(sl)
+        plan.host_input_slots = needed
+        for f in flat:
+            if isinstance(f, Tensor):
+                rt = f if f in fed_set else rw.resolve(f)
+                plan.fetch_slots.append(slot(rt))
+            else:
+                plan.fetch_slots.append(None)
+        # anything that talks to another process, or initialises storage, stays eager
+        for s in plan.steps:
+            if s.node.type in ("Assign", "RandomStandardNormal", "RandomUniform",
+                               "TruncatedNormal", "IsVariableInitialized"):
+                plan.capturable = False
+        if self._runtime is not None and not self._runtime.capturable:
+            plan.capturable = False
+        return plan
+
+    # -- execution -------------------------------------------------------------------------
+    def _to_device(self, t: Tensor, value: Any) -> torch.Tensor:
+        if isinstance(value, torch.Tensor):
+            out = value.to(device=self.device, dtype=t.dtype.torch)
+        else:
+            arr = np.asarray(value)
+            if t.dtype.numpy is not None and arr.dtype != np.dtype(t.dtype.numpy):
+                arr = arr.astype(t.dtype.numpy)
+            out = torch.from_numpy(np.ascontiguousarray(arr))
+            if t.dtype.numpy is None:
+                out = out.to(t.dtype.torch)
+            out = out.to(self.device, non_blocking=False)
+        if t.shape is not None:
+            if len(t.shape) != out.dim() or any(
+                    d is not None and d != s for d, s in zip(t.shape, out.shape)):
+                raise ValueError("Cannot feed value of shape %s for Tensor %r, which has shape %s"
+                                 % (tuple(out.shape), t.name, t.shape))
+        return out.contiguous()
+
+    def _run_steps(self, steps: Sequence[_Step], vals: List[Any], trace=None) -> None:
+        ctx = self._ctx
+        for s in steps:
+            ins = [vals[i] if i >= 0 else None for i in s.in_slots]
+            if trace is not None:
+                t0 = time.perf_counter()
+                if self.device.type == "cuda":
+                    torch.cuda.synchronize(self.device)
+                    t0 = time.perf_counter()
+            outs = s.kernel(s.node, ins, ctx)
+            if trace is not None:
+                if self.device.type == "cuda":
+                    torch.cuda.synchronize(self.device)
+                trace.append({"name": s.node.name, "op": s.node.type, "start": t0,
+                              "end": time.perf_counter(), "device": str(self.device)})
+            for sl, o in zip(s.out_slots, outs):
+                vals[sl] = o
+
+    @staticmethod
+    def _to_host(value: Any) -> Any:
+        if isinstance(value, torch.Tensor):
+            if value.dtype in (torch.bfloat16, torch.float8_e4m3fn):
+                value = value.float()
+            arr = value.detach().cpu().numpy()
+            return arr[()] if arr.ndim == 0 else arr
+        return value
+
+    def run(self, fetches, feed_dict: Optional[Dict[Any, Any]] = None,
+            options: Optional[RunOptions] = None,
+            run_metadata: Optional[RunMetadata] = None):
+        if self._closed:
+            raise RuntimeError("Attempted to use a closed Session.")
+        feed_dict = feed_dict or {}
+        fed_pairs: List[Tuple[Tensor, Any]] = []
+        for k, v in feed_dict.items():
+            t = self.graph.as_graph_element(k, allow_operation=False)
+            fed_pairs.append((t, v))
+        fed_pairs.sort(key=lambda p: (p[0].op.id, p[0].value_index))
+        flat, structure = self._flatten(fetches)
+        key = (tuple(id(f) for f in flat), tuple(id(t) for t, _ in fed_pairs),
+               self.graph.version if not self.graph.finalized else -1)
+        with self._lock:
+            plan = self._plans.get(key)
+            if plan is None:
+                plan = self._build_plan(flat, [t for t, _ in fed_pairs])
+                self._plans[key] = plan
+        self.stats["runs"] += 1
+        trace = [] if (options is not None and options.trace_level) else None
+
+        token = self._begin_step(plan)
+        try:
+            feeds = [self._to_device(t, v) for t, v in fed_pairs]
+            use_graph = (self.device.type == "cuda" and self.config.hip_graphs
+                         and plan.capturable and trace is None and plan.runs >= 1)
+            if use_graph:
+                slot_vals = self._run_captured(plan, feeds)
+            else:
+                vals: List[Any] = [None] * plan.num_slots
+                for (_, sl), v in zip(plan.feed_slots, feeds):
+                    vals[sl] = v
+                self._run_steps(plan.steps, vals, trace)
+                self.stats["eager_runs"] += 1
+                slot_vals = {sl: vals[sl] for sl in plan.fetch_slots if sl is not None}
+                slot_vals.update((sl, vals[sl]) for sl in plan.host_input_slots)
+            plan.runs += 1
+        finally:
+            self._end_step(plan, token)
+
+        host_out: Dict[int, Any] = {}
+        if plan.host_steps:
+            hv: List[Any] = [None] * plan.num_slots
+            for sl in plan.host_input_slots:
+                hv[sl] = self._to_host(slot_vals[sl])
+            self._run_steps(plan.host_steps, hv, trace)
+            for s in plan.host_steps:
+                for sl in s.out_slots:
+                    host_out[sl] = hv[sl]
+        if run_metadata is not None and trace is not None:
+            run_metadata.step_stats.extend(trace)
+        results = [None if sl is None else
+                   (host_out[sl] if sl in host_out else self._to_host(slot_vals[sl]))
+                   for sl in plan.fetch_slots]
+        return self._unflatten(structure, results)
+
+    # -- step brackets for remote stores ---------------------------------------------------
+    def _begin_step(self, plan: ExecutionPlan):
+        if self._runtime is None:
+            return None
+        return self._runtime.begin_step(plan)
+
+    def _end_step(self, plan: ExecutionPlan, token) -> None:
+        if self._runtime is not None:
+            self._runtime.end_step(plan, token)
+
+    # -- HIP-graph path --------------------------------------------------------------------
+    def _run_captured(self, plan: ExecutionPlan, feeds: List[torch.Tensor]):
+        sig = tuple((tuple(f.shape), f.dtype) for f in feeds)
+        cap = plan.graphs.get(sig)
+        if cap is None:
+            cap = self._capture(plan, feeds)
+            plan.graphs[sig] = cap
+            self.stats["captures"] += 1
+        for static, f in zip(cap.static_feeds, feeds):
+            static.copy_(f, non_blocking=True)
+        cap.graph.replay()
+        self.stats["graph_replays"] += 1
+        out: Dict[int, Any] = {}
+        if cap.host_buf is not None:
+            torch.cuda.current_stream(self.device).synchronize()
+            for slot_idx, off, shape, _dt in cap.layout:
+                n = int(np.prod(shape)) if len(shape) else 1
+                out[slot_idx] = cap.host_buf[off:off + n].view(shape).clone()
+        for sl in list(plan.fetch_slots) + plan.host_input_slots:
+            if sl is not None and sl not in out:
+                out[sl] = cap.slot_values[sl]
+        return out
+
+    def _capture(self, plan: ExecutionPlan, feeds: List[torch.Tensor]) -> _CapturedStep:
+        cap = _CapturedStep()
+        cap.static_feeds = [torch.empty_like(f) for f in feeds]
+        for static, f in zip(cap.static_feeds, feeds):
+            static.copy_(f)
+        # small fp32 results (loss, step, accuracy ...) are packed into one pinned buffer by
+        # copy nodes inside the graph, so a step needs a single stream synchronisation
+        want = [sl for sl in plan.fetch_slots if sl is not None] + plan.host_input_slots
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        vals: List[Any] = [None] * plan.num_slots
+        with torch.cuda.graph(graph):
+            for (_, sl), v in zip(plan.feed_slots, cap.static_feeds):
+                vals[sl] = v
+            self._run_steps(plan.steps, vals)
+            packed = []
+            off = 0
+            for sl in dict.fromkeys(want):
+                v = vals[sl]
+                if isinstance(v, torch.Tensor) and v.dtype == torch.float32 and v.numel() <= 64:
+                    packed.append((sl, off, v.shape, v.dtype, v))
+                    off += v.numel()
+            if packed:
+                stage = torch.empty(off, dtype=torch.float32, device=self.device)
+                for sl, o, shape, dt, v in packed:
+                    stage[o:o + v.numel()].copy_(v.reshape(-1))
+                cap.host_buf = torch.empty(off, dtype=torch.float32, pin_memory=True)
+                cap.host_buf.copy_(stage, non_blocking=True)
+                cap.layout = [(sl, o, shape, dt) for sl, o, shape, dt, _ in packed]
+        cap.graph = graph
+        cap.slot_values = vals
+        return cap
+
+    # -- conveniences ----------------------------------------------------------------------
+    def list_devices(self) -> List[str]:
+        spec = DeviceSpec(job="localhost", replica=0, task=0,
+                          device_type="GPU" if self.device.type == "cuda" else "CPU",
+                          device_index=self.device.index or 0)
+        return [spec.to_string()]
+
+
+class InteractiveSession(Session):
+    def __init__(self, target: str = "", graph: Optional[Graph] = None,
+                 config: Optional[ConfigProto] = None):
+        super().__init__(target, graph, config)
+        self.__enter__()

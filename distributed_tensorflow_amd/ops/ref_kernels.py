@@ -1,0 +1,408 @@
+"""Reference kernels: every op type written with plain torch ops.
+
+These run the CPU plumbing configuration (parameter-server training on localhost without a
+GPU) and are the numerical oracle for the HIP kernels in tests. They never run on the GPU hot
+path of an op that has a HIP kernel: the executor picks ``OpDef.hip_kernel`` there.
+
+A kernel has the signature ``kernel(op, inputs, ctx) -> list of outputs`` where ``inputs`` are
+torch tensors (or host objects for string-typed edges) and ``ctx`` is the session's execution
+context (device, variable access).
+"""
+from __future__ import annotations
+
+import math
+from typing import List
+
+import numpy as np
+import torch
+
+from ..framework.op_registry import ref_kernel
+from . import philox
+
+
+def _numel(shape) -> int:
+    n = 1
+    for d in shape:
+        n *= int(d)
+    return n
+
+
+# -- sources ----------------------------------------------------------------------------
+@ref_kernel("Const")
+def _const(op, inputs, ctx):
+    cached = ctx.const_cache.get(op)
+    if cached is None:
+        dt = op.attrs["dtype"]
+        value = op.attrs["value"]
+        cached = torch.as_tensor(np.ascontiguousarray(value)).to(device=ctx.device, dtype=dt.torch)
+        ctx.const_cache[op] = cached
+    return [cached]
+
+
+@ref_kernel("Placeholder", stateful=True)
+def _placeholder(op, inputs, ctx):
+    raise RuntimeError("You must feed a value for placeholder tensor %r with dtype %s"
+                       % (op.name, op.outputs[0].dtype.name))
+
+
+@ref_kernel("Fill")
+def _fill(op, inputs, ctx):
+    dt = op.attrs["dtype"].torch
+    return [torch.full(tuple(op.attrs["shape"]), op.attrs["value"], dtype=dt, device=ctx.device)]
+
+
+@ref_kernel("ZerosLike")
+def _zeros_like(op, inputs, ctx):
+    return [torch.zeros_like(inputs[0])]
+
+
+@ref_kernel("OnesLike")
+def _ones_like(op, inputs, ctx):
+    return [torch.ones_like(inputs[0])]
+
+
+def _stream_keys(op, ctx):
+    if op.attrs.get("deterministic", True):
+        return op.attrs["seed"], op.attrs["seed2"]
+    return ctx.nondeterministic_seed(), op.attrs["seed2"]
+
+
+@ref_kernel("RandomStandardNormal", stateful=True)
+def _random_normal(op, inputs, ctx):
+    shape = tuple(op.attrs["shape"])
+    seed, seed2 = _stream_keys(op, ctx)
+    vals = philox.normal(_numel(shape), seed, seed2)
+    t = torch.from_numpy(vals.reshape(shape).copy())
+    t = t * op.attrs["stddev"] + op.attrs["mean"]
+    return [t.to(device=ctx.device, dtype=op.attrs["dtype"].torch)]
+
+
+@ref_kernel("RandomUniform", stateful=True)
+def _random_uniform(op, inputs, ctx):
+    shape = tuple(op.attrs["shape"])
+    seed, seed2 = _stream_keys(op, ctx)
+    vals = philox.uniform(_numel(shape), seed, seed2)
+    lo, hi = op.attrs["minval"], op.attrs["maxval"]
+    t = torch.from_numpy(vals.reshape(shape).copy()) * (hi - lo) + lo
+    return [t.to(device=ctx.device, dtype=op.attrs["dtype"].torch)]
+
+
+@ref_kernel("TruncatedNormal", stateful=True)
+def _truncated_normal(op, inputs, ctx):
+    shape = tuple(op.attrs["shape"])
+    seed, seed2 = _stream_keys(op, ctx)
+    u = torch.from_numpy(philox.uniform(_numel(shape), seed, seed2).reshape(shape).copy())
+    lo = 0.5 * (1.0 + math.erf(-2.0 / math.sqrt(2.0)))
+    hi = 1.0 - lo
+    z = math.sqrt(2.0) * torch.erfinv(2.0 * (lo + u.double() * (hi - lo)) - 1.0)
+    t = z.float() * op.attrs["stddev"] + op.attrs["mean"]
+    return [t.to(device=ctx.device, dtype=op.attrs["dtype"].torch)]
+
+
+# -- variables --------------------------------------------------------------------------
+@ref_kernel("VariableV2", stateful=True)
+def _variable(op, inputs, ctx):
+    return [ctx.var_read(op)]
+
+
+@ref_kernel("Assign", stateful=True)
+def _assign(op, inputs, ctx):
+    return [ctx.var_assign(op.inputs[0].op, inputs[1])]
+
+
+@ref_kernel("AssignAdd", stateful=True)
+def _assign_add(op, inputs, ctx):
+    return [ctx.var_assign_add(op.inputs[0].op, inputs[1])]
+
+
+@ref_kernel("AssignSub", stateful=True)
+def _assign_sub(op, inputs, ctx):
+    return [ctx.var_assign_add(op.inputs[0].op, -inputs[1])]
+
+
+@ref_kernel("ApplyGradientDescent", stateful=True)
+def _apply_sgd(op, inputs, ctx):
+    return [ctx.var_apply_sgd(op.inputs[0].op, op.attrs["learning_rate"], inputs[1])]
+
+
+@ref_kernel("IsVariableInitialized", stateful=True)
+def _is_var_init(op, inputs, ctx):
+    return [torch.tensor(ctx.var_is_initialized(op.inputs[0].op))]
+
+
+@ref_kernel("ReportUninitializedVariables", stateful=True, host_only=True)
+def _report_uninit(op, inputs, ctx):
+    missing = [n.encode() for t, n in zip(op.inputs, op.attrs["names"])
+               if not ctx.var_is_initialized(t.op)]
+    return [np.array(missing, dtype=object)]
+
+
+@ref_kernel("NoOp", stateful=True)
+def _noop(op, inputs, ctx):
+    return []
+
+
+# -- elementwise ------------------------------------------------------------------------
+def _bin(fn):
+    def kernel(op, inputs, ctx):
+        return [fn(inputs[0], inputs[1])]
+    return kernel
+
+
+def _un(fn):
+    def kernel(op, inputs, ctx):
+        return [fn(inputs[0])]
+    return kernel
+
+
+ref_kernel("Add")(_bin(torch.add))
+ref_kernel("Sub")(_bin(torch.sub))
+ref_kernel("Mul")(_bin(torch.mul))
+ref_kernel("RealDiv")(_bin(torch.div))
+ref_kernel("Maximum")(_bin(torch.maximum))
+ref_kernel("Minimum")(_bin(torch.minimum))
+ref_kernel("Pow")(_bin(torch.pow))
+ref_kernel("Equal")(_bin(torch.eq))
+ref_kernel("NotEqual")(_bin(torch.ne))
+ref_kernel("Less")(_bin(torch.lt))
+ref_kernel("Greater")(_bin(torch.gt))
+ref_kernel("Neg")(_un(torch.neg))
+ref_kernel("Log")(_un(torch.log))
+ref_kernel("Exp")(_un(torch.exp))
+ref_kernel("Sqrt")(_un(torch.sqrt))
+ref_kernel("Square")(_un(torch.square))
+ref_kernel("Reciprocal")(_un(torch.reciprocal))
+ref_kernel("Abs")(_un(torch.abs))
+ref_kernel("Sigmoid")(_un(torch.sigmoid))
+ref_kernel("Tanh")(_un(torch.tanh))
+ref_kernel("Relu")(_un(torch.relu))
+ref_kernel("Identity")(_un(lambda x: x))
+ref_kernel("StopGradient")(_un(lambda x: x))
+
+
+@ref_kernel("Cast")
+def _cast(op, inputs, ctx):
+    return [inputs[0].to(op.attrs["dtype"].torch)]
+
+
+@ref_kernel("AddN")
+def _add_n(op, inputs, ctx):
+    out = inputs[0]
+    for t in inputs[1:]:
+        out = out + t
+    return [out]
+
+
+@ref_kernel("Scale")
+def _scale(op, inputs, ctx):
+    return [inputs[0] * op.attrs["alpha"]]
+
+
+@ref_kernel("Axpby")
+def _axpby(op, inputs, ctx):
+    return [inputs[0] * op.attrs["alpha"] + inputs[1] * op.attrs["beta"]]
+
+
+@ref_kernel("SigmoidGrad")
+def _sigmoid_grad(op, inputs, ctx):
+    y, dy = inputs
+    return [dy * y * (1 - y)]
+
+
+@ref_kernel("TanhGrad")
+def _tanh_grad(op, inputs, ctx):
+    y, dy = inputs
+    return [dy * (1 - y * y)]
+
+
+@ref_kernel("ReluGrad")
+def _relu_grad(op, inputs, ctx):
+    y, dy = inputs
+    return [dy * (y > 0).to(dy.dtype)]
+
+
+# -- matmul -----------------------------------------------------------------------------
+@ref_kernel("MatMul")
+def _matmul(op, inputs, ctx):
+    a, b = inputs
+    if op.attrs["transpose_a"]:
+        a = a.t()
+    if op.attrs["transpose_b"]:
+        b = b.t()
+    if a.dtype in (torch.bfloat16, torch.float16) and a.device.type == "cpu":
+        return [(a.float() @ b.float()).to(a.dtype)]
+    return [a @ b]
+
+
+# -- reductions / shapes ----------------------------------------------------------------
+def _axes(op, x):
+    axes = op.attrs["axis"]
+    return tuple(range(x.dim())) if axes is None else tuple(axes)
+
+
+@ref_kernel("Sum")
+def _sum(op, inputs, ctx):
+    x = inputs[0]
+    axes = _axes(op, x)
+    return [x.sum(dim=axes, keepdim=op.attrs["keepdims"]) if axes else x.clone()]
+
+
+@ref_kernel("Mean")
+def _mean(op, inputs, ctx):
+    x = inputs[0]
+    axes = _axes(op, x)
+    return [x.mean(dim=axes, keepdim=op.attrs["keepdims"]) if axes else x.clone()]
+
+
+@ref_kernel("Max")
+def _max(op, inputs, ctx):
+    x = inputs[0]
+    return [x.amax(dim=_axes(op, x), keepdim=op.attrs["keepdims"])]
+
+
+@ref_kernel("ArgMax")
+def _argmax(op, inputs, ctx):
+    return [inputs[0].argmax(dim=op.attrs["axis"]).to(op.outputs[0].dtype.torch)]
+
+
+@ref_kernel("Reshape")
+def _reshape(op, inputs, ctx):
+    return [inputs[0].reshape(op.attrs["shape"])]
+
+
+@ref_kernel("ReshapeLike")
+def _reshape_like(op, inputs, ctx):
+    return [inputs[0].reshape(inputs[1].shape)]
+
+
+@ref_kernel("Transpose")
+def _transpose(op, inputs, ctx):
+    return [inputs[0].permute(op.attrs["perm"]).contiguous()]
+
+
+@ref_kernel("SumToShapeOf")
+def _sum_to_shape_of(op, inputs, ctx):
+    x, like = inputs
+    if x.shape == like.shape:
+        return [x]
+    lead = x.dim() - like.dim()
+    if lead > 0:
+        x = x.sum(dim=tuple(range(lead)))
+    dims = tuple(i for i, (a, b) in enumerate(zip(x.shape, like.shape)) if b == 1 and a != 1)
+    if dims:
+        x = x.sum(dim=dims, keepdim=True)
+    return [x]
+
+
+@ref_kernel("BroadcastLike")
+def _broadcast_like(op, inputs, ctx):
+    return [inputs[0].expand_as(inputs[1]).contiguous()]
+
+
+@ref_kernel("ReduceGrad")
+def _reduce_grad(op, inputs, ctx):
+    g, x = inputs
+    axes = op.attrs["axis"]
+    axes = tuple(range(x.dim())) if axes is None else tuple(axes)
+    if not op.attrs["keepdims"]:
+        for a in sorted(axes):
+            g = g.unsqueeze(a)
+    out = g.expand_as(x)
+    if op.attrs["mean"]:
+        count = 1
+        for a in axes:
+            count *= x.shape[a]
+        out = out / count
+    return [out.contiguous()]
+
+
+# -- nn ---------------------------------------------------------------------------------
+@ref_kernel("Softmax")
+def _softmax(op, inputs, ctx):
+    return [torch.softmax(inputs[0], dim=-1)]
+
+
+@ref_kernel("LogSoftmax")
+def _log_softmax(op, inputs, ctx):
+    return [torch.log_softmax(inputs[0], dim=-1)]
+
+
+@ref_kernel("SoftmaxGrad")
+def _softmax_grad(op, inputs, ctx):
+    y, dy = inputs
+    return [(dy - (dy * y).sum(dim=-1, keepdim=True)) * y]
+
+
+@ref_kernel("LogSoftmaxGrad")
+def _log_softmax_grad(op, inputs, ctx):
+    y, dy = inputs
+    return [dy - torch.exp(y) * dy.sum(dim=-1, keepdim=True)]
+
+
+@ref_kernel("SoftmaxCrossEntropyWithLogits")
+def _sxent(op, inputs, ctx):
+    logits, labels = inputs
+    logp = torch.log_softmax(logits, dim=-1)
+    loss = -(labels * logp).sum(dim=-1)
+    backprop = torch.exp(logp) * labels.sum(dim=-1, keepdim=True) - labels
+    return [loss, backprop]
+
+
+@ref_kernel("RowScale")
+def _row_scale(op, inputs, ctx):
+    x, s = inputs
+    return [x * s.unsqueeze(-1)]
+
+
+# -- fused ops produced by the session's planner ----------------------------------------
+_ACTS = {"none": lambda x: x, "sigmoid": torch.sigmoid, "relu": torch.relu, "tanh": torch.tanh}
+
+
+@ref_kernel("FusedDense")
+def _fused_dense(op, inputs, ctx):
+    x, w, b = inputs
+    return [_ACTS[op.attrs["activation"]](x @ w + b)]
+
+
+@ref_kernel("SoftmaxXentMean")
+def _softmax_xent_mean(op, inputs, ctx):
+    """(logits, labels) -> (mean loss, softmax). Loss uses log-softmax, which agrees with
+    ``mean(-sum(labels*log(softmax)))`` wherever the naive form is finite."""
+    logits, labels = inputs
+    logp = torch.log_softmax(logits, dim=-1)
+    return [-(labels * logp).sum(dim=-1).mean(), torch.exp(logp)]
+
+
+@ref_kernel("SoftmaxXentMeanGrad")
+def _softmax_xent_mean_grad(op, inputs, ctx):
+    """(softmax, labels, dloss) -> dlogits = dloss/B * (y*sum(labels) - labels), and, when
+    ``emit_bias_grad`` is set, the column sum of dlogits (gradient of the logits' bias)."""
+    y, labels, dloss = inputs
+    b = y.shape[0]
+    dz = (y * labels.sum(dim=-1, keepdim=True) - labels) * (dloss / b)
+    return [dz, dz.sum(dim=0)] if op.attrs.get("emit_bias_grad") else [dz]
+
+
+@ref_kernel("DenseGradSigmoid")
+def _dense_grad_sigmoid(op, inputs, ctx):
+    """(da, a) -> (dz, dbias): dz = da*a*(1-a), dbias = sum over batch."""
+    da, a = inputs
+    dz = da * a * (1 - a)
+    return [dz, dz.sum(dim=0)]
+
+
+@ref_kernel("BiasGrad")
+def _bias_grad(op, inputs, ctx):
+    return [inputs[0].sum(dim=0)]
+
+
+@ref_kernel("MultiApplySGD", stateful=True)
+def _multi_apply_sgd(op, inputs, ctx):
+    var_ops = op.attrs["var_ops"]
+    lrs = op.attrs["learning_rates"]
+    for var_op, lr, g in zip(var_ops, lrs, inputs):
+        ctx.var_apply_sgd(var_op, lr, g)
+    for var_op, delta in op.attrs.get("counter_increments", []):
+        ctx.var_assign_add(var_op, torch.tensor(delta, dtype=var_op.outputs[0].dtype.torch,
+                                                device=ctx.device))
+    return []

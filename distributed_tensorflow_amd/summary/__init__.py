@@ -1,0 +1,316 @@
+"""Summaries and the event-file writer.
+
+Reference usage: ``tf.summary.scalar("cost", ...)``, ``tf.summary.scalar("accuracy", ...)``,
+``tf.summary.merge_all()`` (``tf_distributed.py:84-88``; returns ``None`` when nothing was
+registered, as in ``tf_distributed_1000Matrix.py:51``), ``tf.summary.FileWriter(logs_path,
+graph=...)`` and ``writer.add_summary(summary, step)`` every step (``tf_distributed.py:97,112``).
+
+A scalar summary is a *host* op: the session fetches the scalar together with the other
+fetched values in the step's single device->host copy and encodes the ``Summary`` protobuf on
+the CPU, so summaries add no GPU kernel.
+
+Event files are ``events.out.tfevents.<unix_ts>.<hostname>``; records are TFRecord framed
+(``u64 length | u32 masked_crc32c(length) | payload | u32 masked_crc32c(payload)``) ``Event``
+protobufs; the first record carries ``file_version = "brain.Event:2"``.
+"""
+from __future__ import annotations
+
+import os
+import queue
+import socket
+import struct
+import threading
+import time
+from typing import Iterator, List, Optional, Tuple
+
+import numpy as np
+
+from ..framework import dtypes
+from ..framework import ops as F
+from ..framework.graph import Graph, GraphKeys, Tensor, get_default_graph
+from ..framework.op_registry import ref_kernel
+from ..utils import crc32c as _crc
+from ..utils import native
+from ..utils import protowire as pw
+
+
+# ---------------------------------------------------------------------------------------
+# protobuf encoders
+# ---------------------------------------------------------------------------------------
+def encode_scalar_summary(tag: str, value: float) -> bytes:
+    """``Summary{ value{ tag, simple_value } }``."""
+    return pw.f_message(1, pw.f_bytes(1, tag) + pw.f_float(2, float(value)))
+
+
+def decode_summary(data: bytes) -> List[Tuple[str, float]]:
+    out = []
+    for field, _w, value in pw.iter_fields(data):
+        if field != 1:
+            continue
+        v = pw.parse(value)
+        tag = v.get(1, [b""])[0].decode("utf-8")
+        simple = pw.as_float(v[2][0]) if 2 in v else float("nan")
+        out.append((tag, simple))
+    return out
+
+
+def encode_event(wall_time: float, step: Optional[int] = None, file_version: Optional[str] = None,
+                 graph_def: Optional[bytes] = None, summary: Optional[bytes] = None) -> bytes:
+    out = pw.f_double(1, wall_time)
+    if step is not None:
+        out += pw.f_varint(2, int(step))
+    if file_version is not None:
+        out += pw.f_bytes(3, file_version)
+    if graph_def is not None:
+        out += pw.f_bytes(4, graph_def)
+    if summary is not None:
+        out += pw.f_message(5, summary)
+    return out
+
+
+def decode_event(data: bytes) -> dict:
+    f = pw.parse(data)
+    out = {"wall_time": pw.as_double(f[1][0]) if 1 in f else 0.0}
+    if 2 in f:
+        out["step"] = pw.as_signed64(f[2][0])
+    if 3 in f:
+        out["file_version"] = f[3][0].decode("utf-8")
+    if 4 in f:
+        out["graph_def"] = f[4][0]
+    if 5 in f:
+        out["summary"] = decode_summary(f[5][0])
+    return out
+
+
+def frame_record(payload: bytes) -> bytes:
+    header = struct.pack("<Q", len(payload))
+    return (header + struct.pack("<I", _crc.masked_crc32c(header)) + payload
+            + struct.pack("<I", _crc.masked_crc32c(payload)))
+
+
+def read_records(path: str) -> Iterator[bytes]:
+    """Iterate the payloads of a TFRecord file, verifying both checksums."""
+    with open(path, "rb") as fh:
+        while True:
+            header = fh.read(8)
+            if not header:
+                return
+            if len(header) < 8:
+                raise IOError("truncated record header in %s" % path)
+            (length,) = struct.unpack("<Q", header)
+            (hcrc,) = struct.unpack("<I", fh.read(4))
+            if hcrc != _crc.masked_crc32c(header):
+                raise IOError("corrupted record length in %s" % path)
+            payload = fh.read(length)
+            (pcrc,) = struct.unpack("<I", fh.read(4))
+            if len(payload) < length or pcrc != _crc.masked_crc32c(payload):
+                raise IOError("corrupted record payload in %s" % path)
+            yield payload
+
+
+def read_events(path: str) -> List[dict]:
+    return [decode_event(r) for r in read_records(path)]
+
+
+# ---------------------------------------------------------------------------------------
+# graph ops
+# ---------------------------------------------------------------------------------------
+def scalar(name: str, tensor, collections=None) -> Tensor:
+    t = F.convert_to_tensor(tensor)
+    if t.shape is not None and len(t.shape) != 0 and any(d != 1 for d in t.shape):
+        raise ValueError("summary.scalar needs a scalar tensor, got shape %s" % (t.shape,))
+    g = t.graph
+    scope = g._name_stack
+    tag = (scope + "/" + name) if scope else name
+    op = g.create_op("ScalarSummary", [t], [(dtypes.string, ())], name=name.replace(" ", "_"),
+                     attrs={"tag": tag})
+    for c in (collections or [GraphKeys.SUMMARIES]):
+        g.add_to_collection(c, op.outputs[0])
+    return op.outputs[0]
+
+
+def merge(inputs, collections=None, name: Optional[str] = None) -> Tensor:
+    inputs = [F.convert_to_tensor(i) for i in inputs]
+    g = inputs[0].graph
+    op = g.create_op("MergeSummary", inputs, [(dtypes.string, ())], name=name or "Merge")
+    for c in (collections or []):
+        g.add_to_collection(c, op.outputs[0])
+    return op.outputs[0]
+
+
+def merge_all(key: str = GraphKeys.SUMMARIES, scope: Optional[str] = None) -> Optional[Tensor]:
+    items = get_default_graph().get_collection(key, scope)
+    if not items:
+        return None
+    return merge(items, name="Merge/MergeSummary")
+
+
+@ref_kernel("ScalarSummary", host_only=True)
+def _scalar_summary_kernel(op, inputs, ctx):
+    value = np.asarray(inputs[0]).reshape(-1)[0]
+    return [encode_scalar_summary(op.attrs["tag"], float(value))]
+
+
+@ref_kernel("MergeSummary", host_only=True)
+def _merge_summary_kernel(op, inputs, ctx):
+    # Summary is `repeated Value value = 1`, so concatenating serialized messages merges them
+    return [b"".join(bytes(i) for i in inputs)]
+
+
+# ---------------------------------------------------------------------------------------
+# event file writer
+# ---------------------------------------------------------------------------------------
+class _PyEventsFile:
+    def __init__(self, path: str):
+        self._fh = open(path, "ab")
+
+    def write(self, payload: bytes) -> None:
+        self._fh.write(frame_record(payload))
+
+    def flush(self) -> None:
+        self._fh.flush()
+
+    def close(self) -> None:
+        self._fh.close()
+
+
+class _NativeEventsFile:
+    """Framing + CRC + buffered file I/O in the C++ runtime library."""
+
+    def __init__(self, lib, path: str):
+        self._lib = lib
+        self._h = lib.dtf_events_open(path.encode())
+        if not self._h:
+            raise IOError("cannot open event file %s: %s"
+                          % (path, lib.dtf_last_error().decode()))
+
+    def write(self, payload: bytes) -> None:
+        if self._lib.dtf_events_write(self._h, payload, len(payload)) != 0:
+            raise IOError(self._lib.dtf_last_error().decode())
+
+    def flush(self) -> None:
+        self._lib.dtf_events_flush(self._h)
+
+    def close(self) -> None:
+        if self._h:
+            self._lib.dtf_events_close(self._h)
+            self._h = None
+
+
+class EventFileWriter:
+    """Asynchronous writer: ``add_event`` enqueues, a daemon thread frames and writes, and
+    the file is flushed every ``flush_secs``."""
+
+    def __init__(self, logdir: str, max_queue: int = 10, flush_secs: float = 120.0,
+                 filename_suffix: str = ""):
+        self._logdir = str(logdir)
+        os.makedirs(self._logdir, exist_ok=True)
+        fname = "events.out.tfevents.%010d.%s%s" % (time.time(), socket.gethostname(),
+                                                    filename_suffix)
+        self.path = os.path.join(self._logdir, fname)
+        lib = native.load()
+        self._file = _NativeEventsFile(lib, self.path) if lib is not None \
+            else _PyEventsFile(self.path)
+        self._queue: "queue.Queue" = queue.Queue(max_queue)
+        self._flush_secs = flush_secs
+        self._closed = False
+        self._lock = threading.Lock()
+        self._worker = threading.Thread(target=self._run, name="EventFileWriter", daemon=True)
+        self._file.write(encode_event(time.time(), file_version="brain.Event:2"))
+        self._file.flush()
+        self._worker.start()
+
+    def get_logdir(self) -> str:
+        return self._logdir
+
+    def _run(self) -> None:
+        next_flush = time.time() + self._flush_secs
+        while True:
+            try:
+                item = self._queue.get(timeout=max(0.0, min(1.0, next_flush - time.time())))
+            except queue.Empty:
+                item = None
+            if item is _STOP:
+                self._queue.task_done()
+                return
+            if item is not None:
+                try:
+                    with self._lock:
+                        self._file.write(item)
+                finally:
+                    self._queue.task_done()
+            if time.time() >= next_flush:
+                with self._lock:
+                    self._file.flush()
+                next_flush = time.time() + self._flush_secs
+
+    def add_event(self, event: bytes) -> None:
+        if not self._closed:
+            self._queue.put(event)
+
+    def flush(self) -> None:
+        if self._closed:
+            return
+        self._queue.join()
+        with self._lock:
+            self._file.flush()
+
+    def close(self) -> None:
+        if self._closed:
+            return
+        self.flush()
+        self._closed = True
+        self._queue.put(_STOP)
+        self._worker.join(timeout=5.0)
+        with self._lock:
+            self._file.close()
+
+
+_STOP = object()
+
+
+class FileWriter:
+    """``FileWriter(logdir, graph=None)`` with ``add_summary`` / ``add_graph`` / ``flush`` /
+    ``close``; usable as a context manager."""
+
+    def __init__(self, logdir: str, graph: Optional[Graph] = None, max_queue: int = 10,
+                 flush_secs: float = 120.0, filename_suffix: str = ""):
+        self.event_writer = EventFileWriter(logdir, max_queue, flush_secs, filename_suffix)
+        if graph is not None:
+            self.add_graph(graph)
+
+    def get_logdir(self) -> str:
+        return self.event_writer.get_logdir()
+
+    def add_summary(self, summary, global_step=None) -> None:
+        """``summary`` is the serialized ``Summary`` a fetch of ``merge_all()`` returned.
+        ``None`` (the fetch of a ``None`` summary op) is ignored."""
+        if summary is None:
+            return
+        if isinstance(summary, np.ndarray):
+            summary = summary.item()
+        step = None if global_step is None else int(global_step)
+        self.event_writer.add_event(encode_event(time.time(), step=step, summary=bytes(summary)))
+
+    def add_graph(self, graph: Graph, global_step=None) -> None:
+        step = None if global_step is None else int(global_step)
+        self.event_writer.add_event(
+            encode_event(time.time(), step=step, graph_def=graph.as_graph_def()))
+
+    def add_event(self, event: bytes) -> None:
+        self.event_writer.add_event(event)
+
+    def flush(self) -> None:
+        self.event_writer.flush()
+
+    def close(self) -> None:
+        self.event_writer.close()
+
+    def reopen(self) -> None:
+        pass
+
+    def __enter__(self) -> "FileWriter":
+        return self
+
+    def __exit__(self, *exc) -> None:
+        self.close()

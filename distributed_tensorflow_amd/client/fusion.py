@@ -11,6 +11,7 @@ pruned subgraph before execution:
 * the backward chain from d(loss) to d(logits)        -> ``SoftmaxXentMeanGrad`` (emits the
   logits gradient and the bias gradient);
 * ``SigmoidGrad`` + the bias-gradient column sum      -> ``DenseGradSigmoid``;
+* ``reduce_mean(cast(equal(argmax(y,1), argmax(y_,1))))``  -> ``ArgmaxAccuracy``;
 * every ``ApplyGradientDescent`` (+ the ``global_step`` increment) -> one ``MultiApplySGD``.
 
 Rewrites are expressed as *tensor replacements* (``original tensor -> output k of a fused
@@ -125,6 +126,28 @@ def _match_xent(mean_op: Operation):
     return None
 
 
+def _match_accuracy(mean_op: Operation):
+    """``Mean(Cast(Equal(ArgMax(a, 1), ArgMax(b, 1)), float32))`` over rank-2 fp32 -> (a, b)."""
+    if mean_op.type != "Mean" or mean_op.attrs["axis"] is not None:
+        return None
+    cast = mean_op.inputs[0].op
+    if cast.type != "Cast" or cast.outputs[0].dtype != dtypes.float32:
+        return None
+    eq = cast.inputs[0].op
+    if eq.type != "Equal":
+        return None
+    srcs = []
+    for t in eq.inputs:
+        am = t.op
+        if am.type != "ArgMax" or am.attrs["axis"] != 1:
+            return None
+        x = am.inputs[0]
+        if x.dtype != dtypes.float32 or x.shape is None or len(x.shape) != 2:
+            return None
+        srcs.append(x)
+    return srcs[0], srcs[1]
+
+
 def build_rewrite(graph: Graph, ops: Sequence[Operation], fed: Set[Tensor],
                   fetched: Set[Tensor] = frozenset()) -> Rewrite:
     """Find fusable patterns among ``ops`` (the pruned, topologically ordered subgraph)."""
@@ -211,6 +234,15 @@ def build_rewrite(graph: Graph, ops: Sequence[Operation], fed: Set[Tensor],
             rw.tensor_map[dlogits_t] = gnode.outputs[0]
             if emit_bias:
                 rw.tensor_map[db_t] = gnode.outputs[1]
+
+    # -- metric: argmax-compare-mean --------------------------------------------------------
+    for op in ops:
+        hit = _match_accuracy(op) if op.type == "Mean" else None
+        if hit is None or op.outputs[0] in rw.tensor_map:
+            continue
+        node = FusedNode(graph, "ArgmaxAccuracy", op.name + "/fused_accuracy", list(hit),
+                         [(op.outputs[0].dtype, op.outputs[0].shape)], device=op.device)
+        rw.tensor_map[op.outputs[0]] = node.outputs[0]
 
     # -- optimizer: one multi-tensor SGD launch --------------------------------------------
     applies = [op for op in ops if op.type == "ApplyGradientDescent"

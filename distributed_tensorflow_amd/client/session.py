@@ -38,6 +38,7 @@ from . import fusion
 from .variable_store import FailedPreconditionError, LocalVariableStore
 
 _VAR_TYPES = ("VariableV2",)
+_PACK_WORDS = 256     # fp32 words of pinned staging per captured step for small fetches
 
 
 class ConfigProto:
@@ -508,8 +509,10 @@ class Session:
         for static, f in zip(cap.static_feeds, feeds):
             static.copy_(f)
         # small fp32 results (loss, step, accuracy ...) are packed into one pinned buffer by
-        # copy nodes inside the graph, so a step needs a single stream synchronisation
+        # copy nodes inside the graph, so a step needs a single stream synchronisation. The
+        # pinned buffer is allocated before capture starts (host allocation is not capturable).
         want = [sl for sl in plan.fetch_slots if sl is not None] + plan.host_input_slots
+        host_buf = torch.empty(_PACK_WORDS, dtype=torch.float32, pin_memory=True)
         torch.cuda.synchronize(self.device)
         graph = torch.cuda.CUDAGraph()
         vals: List[Any] = [None] * plan.num_slots
@@ -521,15 +524,18 @@ class Session:
             off = 0
             for sl in dict.fromkeys(want):
                 v = vals[sl]
-                if isinstance(v, torch.Tensor) and v.dtype == torch.float32 and v.numel() <= 64:
+                if (isinstance(v, torch.Tensor) and v.dtype == torch.float32
+                        and v.numel() <= 64 and off + v.numel() <= _PACK_WORDS):
                     packed.append((sl, off, v.shape, v.dtype, v))
                     off += v.numel()
+            packed = packed[:16]
             if packed:
+                from ..ops import hip
+                off = sum(p[4].numel() for p in packed)
                 stage = torch.empty(off, dtype=torch.float32, device=self.device)
-                for sl, o, shape, dt, v in packed:
-                    stage[o:o + v.numel()].copy_(v.reshape(-1))
-                cap.host_buf = torch.empty(off, dtype=torch.float32, pin_memory=True)
-                cap.host_buf.copy_(stage, non_blocking=True)
+                hip.pack_f32([p[4] for p in packed], stage)      # one gather launch
+                host_buf[:off].copy_(stage, non_blocking=True)   # one device->host copy
+                cap.host_buf = host_buf
                 cap.layout = [(sl, o, shape, dt) for sl, o, shape, dt, _ in packed]
         cap.graph = graph
         cap.slot_values = vals

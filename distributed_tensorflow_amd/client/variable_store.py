@@ -43,6 +43,10 @@ class LocalVariableStore:
             raise FailedPreconditionError(
                 "Attempting to use uninitialized value %s" % name)
 
+    def local_tensor(self, name: str) -> Optional[torch.Tensor]:
+        """The live storage of ``name`` (for kernels that update it in place), or ``None``."""
+        return self._values.get(name)
+
     def names(self) -> List[str]:
         return sorted(self._values)
 

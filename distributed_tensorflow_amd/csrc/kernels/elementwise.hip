@@ -1,0 +1,357 @@
+// Vectorised elementwise kernels (memory-bound: 16 B per lane, grid-stride, <= 2048 blocks).
+//
+// Covers the pointwise ops of the reference graphs -- add with bias broadcast, mul, neg, log,
+// sigmoid, cast, equal (tf_distributed.py:62-81) -- their gradient pointwise pieces, and the
+// add/scale primitive (axpby) used on sharded-GEMM partial sums. Broadcasting is expressed as
+// "operand index = i % operand_numel", which covers same-shape, trailing-vector ([R,C] op [C])
+// and scalar operands without materialising the broadcast.
+#include "common.h"
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr int MAX_BLOCKS = 2048;
+
+inline int grid_for(long n, int per_thread) {
+  long blocks = (n + (long)BLOCK * per_thread - 1) / ((long)BLOCK * per_thread);
+  if (blocks < 1) blocks = 1;
+  return (int)(blocks > MAX_BLOCKS ? MAX_BLOCKS : blocks);
+}
+
+enum BinaryOp { B_ADD = 0, B_SUB, B_MUL, B_DIV, B_MAX, B_MIN, B_POW, B_SIGMOID_GRAD, B_TANH_GRAD,
+                B_RELU_GRAD };
+enum CompareOp { C_EQ = 0, C_NE, C_LT, C_GT };
+enum UnaryOp { U_NEG = 0, U_LOG, U_EXP, U_SQRT, U_SQUARE, U_RECIP, U_ABS, U_SIGMOID, U_TANH,
+               U_RELU };
+
+template <int OP>
+__device__ __forceinline__ float bin(float a, float b) {
+  if (OP == B_ADD) return a + b;
+  if (OP == B_SUB) return a - b;
+  if (OP == B_MUL) return a * b;
+  if (OP == B_DIV) return a / b;
+  if (OP == B_MAX) return fmaxf(a, b);
+  if (OP == B_MIN) return fminf(a, b);
+  if (OP == B_POW) return powf(a, b);
+  if (OP == B_SIGMOID_GRAD) return b * a * (1.f - a);   // (y, dy)
+  if (OP == B_TANH_GRAD) return b * (1.f - a * a);      // (y, dy)
+  return a > 0.f ? b : 0.f;                             // relu grad (y, dy)
+}
+
+template <int OP>
+__device__ __forceinline__ float una(float x) {
+  if (OP == U_NEG) return -x;
+  if (OP == U_LOG) return logf(x);
+  if (OP == U_EXP) return expf(x);
+  if (OP == U_SQRT) return sqrtf(x);
+  if (OP == U_SQUARE) return x * x;
+  if (OP == U_RECIP) return 1.f / x;
+  if (OP == U_ABS) return fabsf(x);
+  if (OP == U_SIGMOID) return 1.f / (1.f + expf(-x));
+  if (OP == U_TANH) return tanhf(x);
+  return x > 0.f ? x : 0.f;
+}
+
+// same-shape fast path: 16 B per lane
+template <int OP>
+__global__ __launch_bounds__(BLOCK) void binary_vec_kernel(const f32x4* __restrict__ a,
+                                                           const f32x4* __restrict__ b,
+                                                           f32x4* __restrict__ out, long n4) {
+  for (long i = blockIdx.x * (long)BLOCK + threadIdx.x; i < n4; i += (long)gridDim.x * BLOCK) {
+    f32x4 x = a[i], y = b[i], r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = bin<OP>(x[j], y[j]);
+    out[i] = r;
+  }
+}
+
+template <int OP>
+__global__ __launch_bounds__(BLOCK) void binary_bcast_kernel(const float* __restrict__ a,
+                                                             const float* __restrict__ b,
+                                                             float* __restrict__ out, long n,
+                                                             long an, long bn) {
+  for (long i = blockIdx.x * (long)BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * BLOCK)
+    out[i] = bin<OP>(a[an == n ? i : i % an], b[bn == n ? i : i % bn]);
+}
+
+template <int OP>
+__global__ __launch_bounds__(BLOCK) void unary_kernel(const float* __restrict__ x,
+                                                      float* __restrict__ out, long n) {
+  const long n4 = n >> 2;
+  const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+  f32x4* o4 = reinterpret_cast<f32x4*>(out);
+  const long start = blockIdx.x * (long)BLOCK + threadIdx.x, step = (long)gridDim.x * BLOCK;
+  for (long i = start; i < n4; i += step) {
+    f32x4 v = x4[i], r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = una<OP>(v[j]);
+    o4[i] = r;
+  }
+  for (long i = (n4 << 2) + start; i < n; i += step) out[i] = una<OP>(x[i]);
+}
+
+template <int OP>
+__global__ __launch_bounds__(BLOCK) void compare_kernel(const float* __restrict__ a,
+                                                        const float* __restrict__ b,
+                                                        unsigned char* __restrict__ out, long n,
+                                                        long an, long bn) {
+  for (long i = blockIdx.x * (long)BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * BLOCK) {
+    const float x = a[an == n ? i : i % an], y = b[bn == n ? i : i % bn];
+    out[i] = OP == C_EQ ? x == y : OP == C_NE ? x != y : OP == C_LT ? x < y : x > y;
+  }
+}
+
+__global__ __launch_bounds__(BLOCK) void compare_i64_eq_kernel(const long* __restrict__ a,
+                                                               const long* __restrict__ b,
+                                                               unsigned char* __restrict__ out,
+                                                               long n) {
+  for (long i = blockIdx.x * (long)BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * BLOCK)
+    out[i] = a[i] == b[i];
+}
+
+// out = alpha * x + beta * y (y may be null when beta == 0)
+__global__ __launch_bounds__(BLOCK) void axpby_f32_kernel(float alpha, const float* __restrict__ x,
+                                                          float beta, const float* __restrict__ y,
+                                                          float* __restrict__ out, long n) {
+  const long n4 = n >> 2;
+  const long start = blockIdx.x * (long)BLOCK + threadIdx.x, step = (long)gridDim.x * BLOCK;
+  const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+  const f32x4* y4 = reinterpret_cast<const f32x4*>(y);
+  f32x4* o4 = reinterpret_cast<f32x4*>(out);
+  for (long i = start; i < n4; i += step) {
+    f32x4 r = x4[i] * alpha;
+    if (y) r += y4[i] * beta;
+    o4[i] = r;
+  }
+  for (long i = (n4 << 2) + start; i < n; i += step)
+    out[i] = alpha * x[i] + (y ? beta * y[i] : 0.f);
+}
+
+// bf16 axpby: 8 elements (16 B) per lane, fp32 math, round-to-nearest-even on the way out
+__global__ __launch_bounds__(BLOCK) void axpby_bf16_kernel(float alpha,
+                                                           const unsigned short* __restrict__ x,
+                                                           float beta,
+                                                           const unsigned short* __restrict__ y,
+                                                           unsigned short* __restrict__ out,
+                                                           long n) {
+  const long n8 = n >> 3;
+  const long start = blockIdx.x * (long)BLOCK + threadIdx.x, step = (long)gridDim.x * BLOCK;
+  const bf16x8* x8 = reinterpret_cast<const bf16x8*>(x);
+  const bf16x8* y8 = reinterpret_cast<const bf16x8*>(y);
+  bf16x8* o8 = reinterpret_cast<bf16x8*>(out);
+  for (long i = start; i < n8; i += step) {
+    bf16x8 xv = x8[i], yv = y ? y8[i] : xv, r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = alpha * dtf_bf16_to_f32((unsigned short)xv[j]);
+      if (y) v += beta * dtf_bf16_to_f32((unsigned short)yv[j]);
+      r[j] = (short)dtf_f32_to_bf16(v);
+    }
+    o8[i] = r;
+  }
+  for (long i = (n8 << 3) + start; i < n; i += step) {
+    float v = alpha * dtf_bf16_to_f32(x[i]);
+    if (y) v += beta * dtf_bf16_to_f32(y[i]);
+    out[i] = dtf_f32_to_bf16(v);
+  }
+}
+
+__global__ __launch_bounds__(BLOCK) void cast_f32_bf16_kernel(const float* __restrict__ x,
+                                                              unsigned short* __restrict__ out,
+                                                              long n) {
+  const long n4 = n >> 2;
+  const long start = blockIdx.x * (long)BLOCK + threadIdx.x, step = (long)gridDim.x * BLOCK;
+  const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+  bf16x4* o4 = reinterpret_cast<bf16x4*>(out);
+  for (long i = start; i < n4; i += step) {
+    f32x4 v = x4[i];
+    bf16x4 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = (short)dtf_f32_to_bf16(v[j]);
+    o4[i] = r;
+  }
+  for (long i = (n4 << 2) + start; i < n; i += step) out[i] = dtf_f32_to_bf16(x[i]);
+}
+
+__global__ __launch_bounds__(BLOCK) void cast_bf16_f32_kernel(const unsigned short* __restrict__ x,
+                                                              float* __restrict__ out, long n) {
+  const long n4 = n >> 2;
+  const long start = blockIdx.x * (long)BLOCK + threadIdx.x, step = (long)gridDim.x * BLOCK;
+  const bf16x4* x4 = reinterpret_cast<const bf16x4*>(x);
+  f32x4* o4 = reinterpret_cast<f32x4*>(out);
+  for (long i = start; i < n4; i += step) {
+    bf16x4 v = x4[i];
+    f32x4 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = dtf_bf16_to_f32((unsigned short)v[j]);
+    o4[i] = r;
+  }
+  for (long i = (n4 << 2) + start; i < n; i += step) out[i] = dtf_bf16_to_f32(x[i]);
+}
+
+__global__ __launch_bounds__(BLOCK) void cast_u8_f32_kernel(const unsigned char* __restrict__ x,
+                                                            float* __restrict__ out, long n) {
+  for (long i = blockIdx.x * (long)BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * BLOCK)
+    out[i] = x[i] ? 1.f : 0.f;
+}
+
+__global__ __launch_bounds__(BLOCK) void fill_f32_kernel(float* __restrict__ out, float value,
+                                                         long n) {
+  for (long i = blockIdx.x * (long)BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * BLOCK)
+    out[i] = value;
+}
+
+// out[r, c] = x[r, c] * s[r]
+__global__ __launch_bounds__(BLOCK) void row_scale_kernel(const float* __restrict__ x,
+                                                          const float* __restrict__ s,
+                                                          float* __restrict__ out, long rows,
+                                                          long cols) {
+  const long n = rows * cols;
+  for (long i = blockIdx.x * (long)BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * BLOCK)
+    out[i] = x[i] * s[i / cols];
+}
+
+bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+}  // namespace
+
+#define DTF_BIN_CASE(OP)                                                                        \
+  case OP:                                                                                      \
+    if (vec)                                                                                    \
+      hipLaunchKernelGGL((binary_vec_kernel<OP>), dim3(grid_for(n / 4, 1)), dim3(BLOCK), 0,     \
+                         stream, (const f32x4*)a, (const f32x4*)b, (f32x4*)out, n / 4);         \
+    else                                                                                        \
+      hipLaunchKernelGGL((binary_bcast_kernel<OP>), dim3(grid_for(n, 1)), dim3(BLOCK), 0,       \
+                         stream, a, b, out, n, an, bn);                                         \
+    break;
+
+// out[i] = op(a[i % an], b[i % bn]) for i < n
+DTF_API int dtf_binary_f32(int op, const float* a, const float* b, float* out, long n, long an,
+                           long bn, hipStream_t stream) {
+  if (n <= 0) return DTF_OK;
+  if (!a || !b || !out || an <= 0 || bn <= 0) return DTF_ERR_BAD_ARG;
+  const bool vec = an == n && bn == n && (n % 4 == 0) && aligned16(a) && aligned16(b) &&
+                   aligned16(out);
+  switch (op) {
+    DTF_BIN_CASE(B_ADD) DTF_BIN_CASE(B_SUB) DTF_BIN_CASE(B_MUL) DTF_BIN_CASE(B_DIV)
+    DTF_BIN_CASE(B_MAX) DTF_BIN_CASE(B_MIN) DTF_BIN_CASE(B_POW) DTF_BIN_CASE(B_SIGMOID_GRAD)
+    DTF_BIN_CASE(B_TANH_GRAD) DTF_BIN_CASE(B_RELU_GRAD)
+    default: return DTF_ERR_UNSUPPORTED;
+  }
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
+#define DTF_UN_CASE(OP)                                                                    \
+  case OP:                                                                                 \
+    hipLaunchKernelGGL((unary_kernel<OP>), dim3(grid_for(n, 4)), dim3(BLOCK), 0, stream, x, \
+                       out, n);                                                            \
+    break;
+
+DTF_API int dtf_unary_f32(int op, const float* x, float* out, long n, hipStream_t stream) {
+  if (n <= 0) return DTF_OK;
+  if (!x || !out || !aligned16(x) || !aligned16(out)) return DTF_ERR_BAD_ARG;
+  switch (op) {
+    DTF_UN_CASE(U_NEG) DTF_UN_CASE(U_LOG) DTF_UN_CASE(U_EXP) DTF_UN_CASE(U_SQRT)
+    DTF_UN_CASE(U_SQUARE) DTF_UN_CASE(U_RECIP) DTF_UN_CASE(U_ABS) DTF_UN_CASE(U_SIGMOID)
+    DTF_UN_CASE(U_TANH) DTF_UN_CASE(U_RELU)
+    default: return DTF_ERR_UNSUPPORTED;
+  }
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
+#define DTF_CMP_CASE(OP)                                                                     \
+  case OP:                                                                                   \
+    hipLaunchKernelGGL((compare_kernel<OP>), dim3(grid_for(n, 1)), dim3(BLOCK), 0, stream, a, \
+                       b, out, n, an, bn);                                                   \
+    break;
+
+DTF_API int dtf_compare_f32(int op, const float* a, const float* b, unsigned char* out, long n,
+                            long an, long bn, hipStream_t stream) {
+  if (n <= 0) return DTF_OK;
+  if (!a || !b || !out || an <= 0 || bn <= 0) return DTF_ERR_BAD_ARG;
+  switch (op) {
+    DTF_CMP_CASE(C_EQ) DTF_CMP_CASE(C_NE) DTF_CMP_CASE(C_LT) DTF_CMP_CASE(C_GT)
+    default: return DTF_ERR_UNSUPPORTED;
+  }
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
+DTF_API int dtf_equal_i64(const long* a, const long* b, unsigned char* out, long n,
+                          hipStream_t stream) {
+  if (n <= 0) return DTF_OK;
+  if (!a || !b || !out) return DTF_ERR_BAD_ARG;
+  hipLaunchKernelGGL(compare_i64_eq_kernel, dim3(grid_for(n, 1)), dim3(BLOCK), 0, stream, a, b,
+                     out, n);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
+DTF_API int dtf_axpby_f32(float alpha, const float* x, float beta, const float* y, float* out,
+                          long n, hipStream_t stream) {
+  if (n <= 0) return DTF_OK;
+  if (!x || !out || !aligned16(x) || !aligned16(out) || (y && !aligned16(y)))
+    return DTF_ERR_BAD_ARG;
+  hipLaunchKernelGGL(axpby_f32_kernel, dim3(grid_for(n, 4)), dim3(BLOCK), 0, stream, alpha, x,
+                     beta, y, out, n);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
+DTF_API int dtf_axpby_bf16(float alpha, const void* x, float beta, const void* y, void* out,
+                           long n, hipStream_t stream) {
+  if (n <= 0) return DTF_OK;
+  if (!x || !out || !aligned16(x) || !aligned16(out) || (y && !aligned16(y)))
+    return DTF_ERR_BAD_ARG;
+  hipLaunchKernelGGL(axpby_bf16_kernel, dim3(grid_for(n, 8)), dim3(BLOCK), 0, stream, alpha,
+                     (const unsigned short*)x, beta, (const unsigned short*)y,
+                     (unsigned short*)out, n);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
+DTF_API int dtf_cast_f32_to_bf16(const float* x, void* out, long n, hipStream_t stream) {
+  if (n <= 0) return DTF_OK;
+  if (!x || !out || !aligned16(x) || ((uintptr_t)out & 7)) return DTF_ERR_BAD_ARG;
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n, 4)), dim3(BLOCK), 0, stream, x,
+                     (unsigned short*)out, n);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
+DTF_API int dtf_cast_bf16_to_f32(const void* x, float* out, long n, hipStream_t stream) {
+  if (n <= 0) return DTF_OK;
+  if (!x || !out || ((uintptr_t)x & 7) || !aligned16(out)) return DTF_ERR_BAD_ARG;
+  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid_for(n, 4)), dim3(BLOCK), 0, stream,
+                     (const unsigned short*)x, out, n);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
+DTF_API int dtf_cast_bool_to_f32(const unsigned char* x, float* out, long n, hipStream_t stream) {
+  if (n <= 0) return DTF_OK;
+  if (!x || !out) return DTF_ERR_BAD_ARG;
+  hipLaunchKernelGGL(cast_u8_f32_kernel, dim3(grid_for(n, 1)), dim3(BLOCK), 0, stream, x, out, n);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
+DTF_API int dtf_fill_f32(float* out, float value, long n, hipStream_t stream) {
+  if (n <= 0) return DTF_OK;
+  if (!out) return DTF_ERR_BAD_ARG;
+  hipLaunchKernelGGL(fill_f32_kernel, dim3(grid_for(n, 1)), dim3(BLOCK), 0, stream, out, value, n);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
+DTF_API int dtf_row_scale_f32(const float* x, const float* s, float* out, long rows, long cols,
+                              hipStream_t stream) {
+  if (rows <= 0 || cols <= 0) return DTF_OK;
+  if (!x || !s || !out) return DTF_ERR_BAD_ARG;
+  hipLaunchKernelGGL(row_scale_kernel, dim3(grid_for(rows * cols, 1)), dim3(BLOCK), 0, stream, x,
+                     s, out, rows, cols);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}

@@ -1,0 +1,267 @@
+// bf16 GEMM on the gfx950 matrix cores (fp32 accumulate): C[M,N] = A[M,K] * Bt[N,K]^T.
+//
+// This is the kernel behind the sharded-GEMM workloads (16384^3 bf16 and its per-rank
+// K-/M-shards). Both operands are K-contiguous ("NT"): A is [M,K] row-major and the right-hand
+// operand is held as Bt = B^T, [N,K] row-major -- the storage layout this framework gives a
+// bf16 matrix variable that is used as a matmul right-hand side.
+//
+// Fast path (dtf_gemm_bf16_nt, tile 256x256x64, 512 threads = 8 waves as 2(M) x 4(N)):
+//  * global -> LDS by LDS-DMA (global_load_lds_dwordx4): no VGPR staging, two LDS buffers
+//    (2 x 64 KiB), the loads of K-tile t+1 are in flight while the MFMAs of tile t run; one
+//    barrier per K-tile.
+//  * LDS image: the tile is cut into 16-row x 64-k blocks of 2 KiB; inside a block the 16-byte
+//    chunk (row r, k-chunk c) sits at chunk index (r/8)*64 + c*8 + r%8. One LDS-DMA
+//    wave-instruction therefore fetches 8 rows x 128 B (whole cache lines), and a fragment
+//    read -- lane l takes row l&15, k-chunk 4s + (l>>4) -- touches 16 distinct 16-byte slots
+//    of the 256-byte bank row in every 16-lane ds_read_b128 group: conflict-free without
+//    padding (which LDS-DMA's lane-linear destination could not express anyway).
+//  * MFMA v_mfma_f32_16x16x32_bf16 with the operands swapped (Bt fragment as the instruction's
+//    A operand, A fragment as its B operand): the accumulator then holds, per lane, four
+//    consecutive n of one row m, so the epilogue issues 8-byte (bf16) / 16-byte (fp32) row
+//    stores instead of 2-byte column scatters.
+//  * workgroup id -> tile: XCD-aware remap (contiguous chunk of the tile grid per XCD L2) and
+//    a grouped walk (8 tile-rows deep) so the ~32 tiles resident on an XCD share A/B panels.
+//  * M and N edges are handled by clamping source rows (out-of-range rows are computed and
+//    dropped at the store); K must be a multiple of 64.
+//
+// Generic path (dtf_gemm_bf16_generic): 64x64 tile, register-staged, fully predicated; any
+// shape/stride, NN/NT/TN; used for ragged problems and as an in-library cross-check.
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void global_void;
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int NTHREADS = 512;
+constexpr int TILE_BYTES = BM * BK * 2;          // 32 KiB per operand tile
+constexpr int BUF_BYTES = 2 * TILE_BYTES;        // A + B
+constexpr int WM = 128, WN = 64;                 // per-wave output
+constexpr int MT = WM / 16, NT = WN / 16;        // 8 x 4 MFMA tiles per wave
+
+// byte offset inside an operand tile of the 16-byte chunk (row, kc): see the header comment
+__device__ __forceinline__ int chunk_off(int row, int kc) {
+  return (row >> 4) * 2048 + ((((row >> 3) & 1) * 64) + kc * 8 + (row & 7)) * 16;
+}
+
+// Issue this wave's share of one operand tile: 4 LDS-DMA instructions of 1 KiB each.
+// Piece c (0..31) covers rows 8c..8c+7, all 8 k-chunks; lane i -> (row 8c + i%8, chunk i/8).
+__device__ __forceinline__ void stage_tile(const unsigned short* __restrict__ X, long ld, int row0,
+                                           int max_row, int k0, char* lds_tile, int wave,
+                                           int lane) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int piece = wave * 4 + j;
+    int row = row0 + piece * 8 + (lane & 7);
+    row = row < max_row ? row : max_row;          // clamp: edge tiles re-read the last row
+    const unsigned short* src = X + (long)row * ld + k0 + (lane >> 3) * 8;
+    __builtin_amdgcn_global_load_lds((global_void*)src, (lds_void*)(lds_tile + piece * 1024), 16,
+                                     0, 0);
+  }
+}
+
+template <bool OUT_F32>
+__global__ __launch_bounds__(NTHREADS) void gemm_bf16_nt_kernel(
+    const unsigned short* __restrict__ A, const unsigned short* __restrict__ Bt,
+    void* __restrict__ C, int M, int N, int K, long lda, long ldb, long ldc, int tiles_m,
+    int tiles_n, float alpha) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (A tile | B tile)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  // XCD-aware, grouped tile walk
+  const int ntiles = tiles_m * tiles_n;
+  const int id = dtf_xcd_remap(blockIdx.x, ntiles);
+  constexpr int GROUP = 8;
+  const int per_group = GROUP * tiles_n;
+  const int g = id / per_group;
+  const int first_m = g * GROUP;
+  const int gsize = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
+  const int tm = first_m + (id % per_group) % gsize;
+  const int tn = (id % per_group) / gsize;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nkt = K / BK;
+  stage_tile(A, lda, m0, M - 1, 0, smem, wave, lane);
+  stage_tile(Bt, ldb, n0, N - 1, 0, smem + TILE_BYTES, wave, lane);
+
+  const int frow = lane & 15, fq = lane >> 4;
+  for (int kt = 0; kt < nkt; ++kt) {
+    // every wave's LDS-DMA for tile kt has landed (hipcc drains vmcnt before the barrier) and
+    // every wave is done reading the buffer tile kt+1 is about to overwrite
+    __syncthreads();
+    char* cur = smem + (kt & 1) * BUF_BYTES;
+    if (kt + 1 < nkt) {
+      char* nxt = smem + ((kt + 1) & 1) * BUF_BYTES;
+      stage_tile(A, lda, m0, M - 1, (kt + 1) * BK, nxt, wave, lane);
+      stage_tile(Bt, ldb, n0, N - 1, (kt + 1) * BK, nxt + TILE_BYTES, wave, lane);
+    }
+    const char* as = cur;
+    const char* bs = cur + TILE_BYTES;
+#pragma unroll
+    for (int s = 0; s < BK / 32; ++s) {
+      bf16x8 af[MT], bf[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        bf[j] = *reinterpret_cast<const bf16x8*>(bs + chunk_off(wc * WN + j * 16 + frow, 4 * s + fq));
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+        af[i] = *reinterpret_cast<const bf16x8*>(as + chunk_off(wr * WM + i * 16 + frow, 4 * s + fq));
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // swapped-operand accumulator: lane holds C[m = frow][n = 4*fq + r], r = 0..3
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int row = m0 + wr * WM + i * 16 + frow;
+    if (row >= M) continue;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int col = n0 + wc * WN + j * 16 + 4 * fq;
+      if (col >= N) continue;
+      f32x4 v = acc[i][j] * alpha;
+      if (OUT_F32) {
+        float* dst = reinterpret_cast<float*>(C) + (long)row * ldc + col;
+        if (col + 3 < N) *reinterpret_cast<f32x4*>(dst) = v;
+        else for (int r = 0; r < 4 && col + r < N; ++r) dst[r] = v[r];
+      } else {
+        unsigned short* dst = reinterpret_cast<unsigned short*>(C) + (long)row * ldc + col;
+        if (col + 3 < N) {
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (short)dtf_f32_to_bf16(v[r]);
+          *reinterpret_cast<bf16x4*>(dst) = o;
+        } else {
+          for (int r = 0; r < 4 && col + r < N; ++r) dst[r] = dtf_f32_to_bf16(v[r]);
+        }
+      }
+    }
+  }
+}
+
+// ---- generic, fully predicated bf16 GEMM (any shape, NN / NT / TN / TT via strides) -------------
+// C[m,n] = alpha * sum_k A(m,k) * B(k,n), A(m,k) = A[m*a_rs + k*a_cs], B(k,n) = B[k*b_rs + n*b_cs]
+constexpr int GB = 64, GK = 32;
+template <bool OUT_F32>
+__global__ __launch_bounds__(256) void gemm_bf16_generic_kernel(
+    const unsigned short* __restrict__ A, const unsigned short* __restrict__ B,
+    void* __restrict__ C, int M, int N, int K, long a_rs, long a_cs, long b_rs, long b_cs,
+    long ldc, float alpha) {
+  // As[m][k], Bs[n][k] with 80-byte rows (64 B data + 16 B pad: conflict-free b128 reads)
+  __shared__ __attribute__((aligned(16))) unsigned short As[GB][GK + 8];
+  __shared__ __attribute__((aligned(16))) unsigned short Bs[GB][GK + 8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;       // 2x2 waves, 32x32 each
+  const int m0 = blockIdx.y * GB, n0 = blockIdx.x * GB;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int frow = lane & 15, fq = lane >> 4;
+  for (int k0 = 0; k0 < K; k0 += GK) {
+    // 64 x 32 elements per operand, 256 threads -> 8 elements each
+    for (int e = tid; e < GB * GK; e += 256) {
+      const int r = e / GK, k = e % GK;
+      const int gm = m0 + r, gn = n0 + r, gk = k0 + k;
+      As[r][k] = (gm < M && gk < K) ? A[gm * a_rs + gk * a_cs] : (unsigned short)0;
+      Bs[r][k] = (gn < N && gk < K) ? B[gk * b_rs + gn * b_cs] : (unsigned short)0;
+    }
+    __syncthreads();
+    bf16x8 af[2], bf[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      af[i] = *reinterpret_cast<const bf16x8*>(&As[wr * 32 + i * 16 + frow][fq * 8]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      bf[j] = *reinterpret_cast<const bf16x8*>(&Bs[wc * 32 + j * 16 + frow][fq * 8]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = m0 + wr * 32 + i * 16 + frow;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int col = n0 + wc * 32 + j * 16 + 4 * fq + r;
+        if (row < M && col < N) {
+          const float v = acc[i][j][r] * alpha;
+          if (OUT_F32) reinterpret_cast<float*>(C)[(long)row * ldc + col] = v;
+          else reinterpret_cast<unsigned short*>(C)[(long)row * ldc + col] = dtf_f32_to_bf16(v);
+        }
+      }
+    }
+}
+
+}  // namespace
+
+// C[M,N] (bf16, or fp32 when out_f32) = alpha * A[M,K] * Bt[N,K]^T. Requirements of the fast
+// kernel: K % 64 == 0, lda/ldb % 8 == 0, 16-byte aligned A/Bt, ldc % 4 == 0 and 16-byte
+// (fp32) / 8-byte (bf16) aligned C. Returns DTF_ERR_UNSUPPORTED otherwise (callers then use
+// dtf_gemm_bf16_generic).
+DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int N, int K, long lda,
+                             long ldb, long ldc, float alpha, int out_f32, hipStream_t stream) {
+  if (!A || !Bt || !C || M <= 0 || N <= 0 || K <= 0) return DTF_ERR_BAD_ARG;
+  if (lda < K || ldb < K || ldc < N) return DTF_ERR_BAD_ARG;
+  if (K % BK || lda % 8 || ldb % 8 || ldc % 4 || ((uintptr_t)A & 15) || ((uintptr_t)Bt & 15) ||
+      ((uintptr_t)C & (out_f32 ? 15 : 7)))
+    return DTF_ERR_UNSUPPORTED;
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  const size_t lds = 2 * BUF_BYTES;   // 128 KiB
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<true>,
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<false>,
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  dim3 grid(tiles_m * tiles_n), block(NTHREADS);
+  if (out_f32)
+    hipLaunchKernelGGL(gemm_bf16_nt_kernel<true>, grid, block, lds, stream,
+                       (const unsigned short*)A, (const unsigned short*)Bt, C, M, N, K, lda, ldb,
+                       ldc, tiles_m, tiles_n, alpha);
+  else
+    hipLaunchKernelGGL(gemm_bf16_nt_kernel<false>, grid, block, lds, stream,
+                       (const unsigned short*)A, (const unsigned short*)Bt, C, M, N, K, lda, ldb,
+                       ldc, tiles_m, tiles_n, alpha);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
+// Any-shape bf16 GEMM: A(m,k) at A[m*a_rs + k*a_cs], B(k,n) at B[k*b_rs + n*b_cs].
+DTF_API int dtf_gemm_bf16_generic(const void* A, const void* B, void* C, int M, int N, int K,
+                                  long a_rs, long a_cs, long b_rs, long b_cs, long ldc, float alpha,
+                                  int out_f32, hipStream_t stream) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || ldc < N) return DTF_ERR_BAD_ARG;
+  dim3 grid((N + GB - 1) / GB, (M + GB - 1) / GB), block(256);
+  if (out_f32)
+    hipLaunchKernelGGL(gemm_bf16_generic_kernel<true>, grid, block, 0, stream,
+                       (const unsigned short*)A, (const unsigned short*)B, C, M, N, K, a_rs, a_cs,
+                       b_rs, b_cs, ldc, alpha);
+  else
+    hipLaunchKernelGGL(gemm_bf16_generic_kernel<false>, grid, block, 0, stream,
+                       (const unsigned short*)A, (const unsigned short*)B, C, M, N, K, a_rs, a_cs,
+                       b_rs, b_cs, ldc, alpha);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}

@@ -1,0 +1,204 @@
+// fp32 GEMM on the gfx950 matrix cores: C = act(op(A) * op(B) + bias).
+//
+// gfx950 has no TF32/xf32 path, but it has an exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) that
+// runs at the vector-FMA rate while leaving the VALU free, so the kernel is built on it.
+// This is the kernel behind tf.matmul in the reference graphs: the 1000x1000x1000 product
+// (tf_distributed_1000Matrix.py:48), the MLP layers x*W1 [B,784]x[784,100] and a2*W2
+// [B,100]x[100,10] (tf_distributed.py:62,64) and their NT / TN gradient products.
+//
+// Structure: 256 threads = 4 waves in a 2x2 grid over a BMxBN block tile (128x128 for large
+// problems, 64x64 when that is what it takes to put a workgroup on every CU), BK = 16.
+// Both operand tiles are staged K-major in LDS (As[k][m], Bs[k][n]) so the MFMA fragment read
+// -- lane l takes A[m = l&31][k = l>>5], B[k = l>>5][n = l&31] -- is 32 consecutive words per
+// half-wave: conflict-free ds_read_b32. An operand that is K-contiguous in memory is
+// transposed on its way into LDS (row stride BT+2 keeps those scattered writes
+// conflict-free); one that is M/N-contiguous is copied with 16-byte stores. Global loads for
+// tile k+1 are issued before the MFMAs of tile k and written to the other LDS buffer after
+// them: one barrier per K-tile. Shapes need no alignment: edge tiles are predicated
+// (1000 = 7*128 + 104, K = 784 / 100 / 10 all occur in the reference).
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 16;
+constexpr int NTHREADS = 256;
+
+template <int BT, bool KCONTIG>
+struct Loader {
+  static constexpr int LD = KCONTIG ? BT + 2 : BT;
+  static constexpr int PER_THREAD = (BT * BK / 4) / NTHREADS;
+  static_assert(PER_THREAD >= 1, "tile too small for 256 threads");
+
+  // X(t, k) = X[t * ld + k] when KCONTIG, X[k * ld + t] otherwise
+  __device__ static void fetch(f32x4 (&regs)[PER_THREAD], const float* __restrict__ X, long ld,
+                               int t0, int k0, int T, int K, bool vec_ok, int tid) {
+#pragma unroll
+    for (int i = 0; i < PER_THREAD; ++i) {
+      const int idx = tid + i * NTHREADS;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (KCONTIG) {
+        const int t = idx >> 2, k4 = idx & 3;
+        const int gt = t0 + t, gk = k0 + 4 * k4;
+        if (gt < T && gk < K) {
+          const float* p = X + (long)gt * ld + gk;
+          if (vec_ok && gk + 3 < K) {
+            v = *reinterpret_cast<const f32x4*>(p);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (gk + j < K) v[j] = p[j];
+          }
+        }
+      } else {
+        constexpr int V = BT / 4;
+        const int k = idx / V, t4 = idx % V;
+        const int gk = k0 + k, gt = t0 + 4 * t4;
+        if (gk < K && gt < T) {
+          const float* p = X + (long)gk * ld + gt;
+          if (vec_ok && gt + 3 < T) {
+            v = *reinterpret_cast<const f32x4*>(p);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (gt + j < T) v[j] = p[j];
+          }
+        }
+      }
+      regs[i] = v;
+    }
+  }
+
+  __device__ static void stash(const f32x4 (&regs)[PER_THREAD], float* __restrict__ Xs, int tid) {
+#pragma unroll
+    for (int i = 0; i < PER_THREAD; ++i) {
+      const int idx = tid + i * NTHREADS;
+      if (KCONTIG) {
+        const int t = idx >> 2, k4 = idx & 3;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Xs[(4 * k4 + j) * LD + t] = regs[i][j];
+      } else {
+        constexpr int V = BT / 4;
+        const int k = idx / V, t4 = idx % V;
+        *reinterpret_cast<f32x4*>(&Xs[k * LD + 4 * t4]) = regs[i];
+      }
+    }
+  }
+};
+
+template <int BM, int BN, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(
+    const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
+    const float* __restrict__ bias, int M, int N, int K, long lda, long ldb, long ldc,
+    int a_vec, int b_vec, int act, int tiles_n, int ntiles) {
+  using LA = Loader<BM, A_KC>;
+  using LB = Loader<BN, B_KC>;
+  constexpr int WM = BM / 2, WN = BN / 2;     // per-wave tile
+  constexpr int TM = WM / 32, TN = WN / 32;   // 32x32 MFMA tiles per wave
+  __shared__ __attribute__((aligned(16))) float smem[2 * BK * (LA::LD + LB::LD)];
+  constexpr int A_BUF = BK * LA::LD, B_BUF = BK * LB::LD;   // floats per buffer
+  float* const As = smem;                                   // As[buf][k][m]
+  float* const Bs = smem + 2 * A_BUF;                       // Bs[buf][k][n]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int tile = dtf_xcd_remap(blockIdx.x, ntiles);
+  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 ra[LA::PER_THREAD], rb[LB::PER_THREAD];
+  const int nkt = (K + BK - 1) / BK;
+  LA::fetch(ra, A, lda, m0, 0, M, K, a_vec != 0, tid);
+  LB::fetch(rb, B, ldb, n0, 0, N, K, b_vec != 0, tid);
+  LA::stash(ra, As, tid);
+  LB::stash(rb, Bs, tid);
+  __syncthreads();
+
+  const int lrow = lane & 31, lk = lane >> 5;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < nkt;
+    if (more) {
+      LA::fetch(ra, A, lda, m0, (kt + 1) * BK, M, K, a_vec != 0, tid);
+      LB::fetch(rb, B, ldb, n0, (kt + 1) * BK, N, K, b_vec != 0, tid);
+    }
+    const float* as = As + cur * A_BUF + wr * WM + lrow;
+    const float* bs = Bs + cur * B_BUF + wc * WN + lrow;
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = as[(2 * kk + lk) * LA::LD + 32 * i];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = bs[(2 * kk + lk) * LB::LD + 32 * j];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      LA::stash(ra, As + (cur ^ 1) * A_BUF, tid);
+      LB::stash(rb, Bs + (cur ^ 1) * B_BUF, tid);
+    }
+    __syncthreads();
+  }
+
+  // C/D fragment: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wc * WN + 32 * j + lrow;
+      if (col >= N) continue;
+      const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wr * WM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (row < M) C[(long)row * ldc + col] = dtf_apply_act(acc[i][j][r] + bv, act);
+      }
+    }
+}
+
+template <int BM, int BN>
+int launch(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
+           long lda, long ldb, long ldc, int trans_a, int trans_b, int act, hipStream_t stream) {
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  const int ntiles = tiles_m * tiles_n;
+  const int a_vec = (lda % 4 == 0) && ((uintptr_t)A % 16 == 0);
+  const int b_vec = (ldb % 4 == 0) && ((uintptr_t)B % 16 == 0);
+  dim3 grid(ntiles), block(NTHREADS);
+  // op(A)(m,k): stored [M,K] -> K-contiguous; stored [K,M] (trans_a) -> M-contiguous
+#define DTF_GEMM_CASE(AKC, BKC)                                                               \
+  hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, AKC, BKC>), grid, block, 0, stream, A, B, C,    \
+                     bias, M, N, K, lda, ldb, ldc, a_vec, b_vec, act, tiles_n, ntiles)
+  if (!trans_a && !trans_b) DTF_GEMM_CASE(true, false);
+  else if (!trans_a && trans_b) DTF_GEMM_CASE(true, true);
+  else if (trans_a && !trans_b) DTF_GEMM_CASE(false, false);
+  else DTF_GEMM_CASE(false, true);
+#undef DTF_GEMM_CASE
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
+}  // namespace
+
+// C[M,N] = act(op(A) * op(B) + bias[N]).  A is stored [M,K] (lda >= K), or [K,M] (lda >= M) when
+// trans_a; B is stored [K,N] (ldb >= N), or [N,K] (ldb >= K) when trans_b. bias may be null.
+DTF_API int dtf_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N,
+                         int K, long lda, long ldb, long ldc, int trans_a, int trans_b, int act,
+                         hipStream_t stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return DTF_ERR_BAD_ARG;
+  if (lda < (trans_a ? M : K) || ldb < (trans_b ? K : N) || ldc < N) return DTF_ERR_BAD_ARG;
+  const long big_tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
+  if (big_tiles >= 192)
+    return launch<128, 128>(A, B, C, bias, M, N, K, lda, ldb, ldc, trans_a, trans_b, act, stream);
+  return launch<64, 64>(A, B, C, bias, M, N, K, lda, ldb, ldc, trans_a, trans_b, act, stream);
+}

@@ -1,0 +1,263 @@
+// Reductions and the fused MLP-gradient column reductions.
+//
+// * row reductions ([R,C] -> [R]: sum / mean / max, argmax): one wave per row, butterfly
+//   shuffles across the 64 lanes (tf.reduce_sum(axis=[1]), tf.argmax(., 1) --
+//   tf_distributed.py:70,80);
+// * full reductions ([n] -> scalar, tf.reduce_mean -- tf_distributed.py:70,81): blocks write
+//   partials to a caller-provided workspace, the last kernel folds them in a fixed order, so
+//   the result is bitwise reproducible run to run (no float atomics);
+// * column reductions ([R,C] -> [C]) with an elementwise prologue: plain sum (bias gradient),
+//   sigmoid backward (dz = da*a*(1-a), db = colsum dz) and softmax-cross-entropy backward
+//   (dz = (y*sum(labels) - labels) * dloss/R, db = colsum dz). A workgroup owns 64 columns and
+//   walks the rows with 4 row-groups of 64 lanes, so no cross-workgroup combine is needed.
+#include "common.h"
+
+namespace {
+
+constexpr int BLOCK = 256;
+
+enum RowOp { R_SUM = 0, R_MEAN = 1, R_MAX = 2 };
+
+template <int OP>
+__global__ __launch_bounds__(BLOCK) void reduce_rows_kernel(const float* __restrict__ x,
+                                                            float* __restrict__ out, long rows,
+                                                            long cols) {
+  const int lane = threadIdx.x & 63;
+  const long wave = (blockIdx.x * (long)BLOCK + threadIdx.x) >> 6;
+  const long nwaves = ((long)gridDim.x * BLOCK) >> 6;
+  for (long r = wave; r < rows; r += nwaves) {
+    const float* row = x + r * cols;
+    float acc = OP == R_MAX ? -INFINITY : 0.f;
+    for (long c = lane; c < cols; c += 64) acc = OP == R_MAX ? fmaxf(acc, row[c]) : acc + row[c];
+    acc = OP == R_MAX ? dtf_wave_max(acc) : dtf_wave_sum(acc);
+    if (lane == 0) out[r] = OP == R_MEAN ? acc / (float)cols : acc;
+  }
+}
+
+// first index of the row maximum, as int64 (ties -> lowest index, like numpy/torch)
+__global__ __launch_bounds__(BLOCK) void argmax_rows_kernel(const float* __restrict__ x,
+                                                            long* __restrict__ out, long rows,
+                                                            long cols) {
+  const int lane = threadIdx.x & 63;
+  const long wave = (blockIdx.x * (long)BLOCK + threadIdx.x) >> 6;
+  const long nwaves = ((long)gridDim.x * BLOCK) >> 6;
+  for (long r = wave; r < rows; r += nwaves) {
+    const float* row = x + r * cols;
+    float best = -INFINITY;
+    long idx = cols;
+    for (long c = lane; c < cols; c += 64) {
+      const float v = row[c];
+      if (v > best || (v == best && c < idx)) { best = v; idx = c; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ob = __shfl_xor(best, off, 64);
+      const long oi = __shfl_xor(idx, off, 64);
+      if (ob > best || (ob == best && oi < idx)) { best = ob; idx = oi; }
+    }
+    if (lane == 0) out[r] = idx;
+  }
+}
+
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+  v = dtf_wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  float t = 0.f;
+  if (threadIdx.x == 0)
+    for (int w = 0; w < BLOCK / 64; ++w) t += sh[w];
+  return t;   // valid on thread 0
+}
+
+// stage 1: partial[b] = sum of this block's grid-stride slice
+__global__ __launch_bounds__(BLOCK) void reduce_all_stage1(const float* __restrict__ x,
+                                                           float* __restrict__ partial, long n) {
+  __shared__ float sh[BLOCK / 64];
+  float acc = 0.f;
+  for (long i = blockIdx.x * (long)BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * BLOCK)
+    acc += x[i];
+  const float t = block_sum(acc, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+// stage 2: out = scale * sum(partial[0..m))
+__global__ __launch_bounds__(BLOCK) void reduce_all_stage2(const float* __restrict__ partial,
+                                                           float* __restrict__ out, int m,
+                                                           float scale) {
+  __shared__ float sh[BLOCK / 64];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < m; i += BLOCK) acc += partial[i];
+  const float t = block_sum(acc, sh);
+  if (threadIdx.x == 0) out[0] = t * scale;
+}
+
+enum ColMode { COL_SUM = 0, COL_SIGMOID_GRAD = 1, COL_XENT_GRAD = 2 };
+
+// Workgroup b owns columns [64b, 64b+64); thread (g = tid>>6, l = tid&63) walks rows g, g+4, ...
+// MODE 0: p0 = x                      -> colsum[c] = sum_r x[r,c]
+// MODE 1: p0 = da, p1 = a             -> dz = da*a*(1-a) written to dz_out, colsum of dz
+// MODE 2: p0 = y, p1 = labels, p2 = dloss (scalar) -> dz = (y*rowsum(labels) - labels)*dloss/R
+//         (cols <= 64: one workgroup sees whole rows, so the label row-sum is a wave reduction)
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void reduce_cols_kernel(const float* __restrict__ p0,
+                                                            const float* __restrict__ p1,
+                                                            const float* __restrict__ p2,
+                                                            float* __restrict__ dz_out,
+                                                            float* __restrict__ colsum, long rows,
+                                                            long cols) {
+  __shared__ float sh[BLOCK];
+  const int l = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const long c = blockIdx.x * 64L + l;
+  const bool live = c < cols;
+  float scale = 1.f;
+  if (MODE == COL_XENT_GRAD) scale = p2[0] / (float)rows;
+  float acc = 0.f;
+  for (long r = g; r < rows; r += BLOCK / 64) {
+    float v = 0.f;
+    if (MODE == COL_SUM) {
+      if (live) v = p0[r * cols + c];
+    } else if (MODE == COL_SIGMOID_GRAD) {
+      if (live) {
+        const float a = p1[r * cols + c];
+        v = p0[r * cols + c] * a * (1.f - a);
+        dz_out[r * cols + c] = v;
+      }
+    } else {
+      const float lab = live ? p1[r * cols + c] : 0.f;
+      const float lsum = dtf_wave_sum(lab);
+      if (live) {
+        v = (p0[r * cols + c] * lsum - lab) * scale;
+        dz_out[r * cols + c] = v;
+      }
+    }
+    acc += v;
+  }
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  if (g == 0 && live && colsum) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < BLOCK / 64; ++k) t += sh[k * 64 + l];
+    colsum[c] = t;
+  }
+}
+
+// mean over rows of (argmax(y[r,:]) == argmax(labels[r,:])): one workgroup, lane per row
+__global__ __launch_bounds__(1024) void argmax_accuracy_kernel(const float* __restrict__ y,
+                                                               const float* __restrict__ labels,
+                                                               float* __restrict__ out, long rows,
+                                                               long cols) {
+  __shared__ float sh[16];
+  float hits = 0.f;
+  for (long r = threadIdx.x; r < rows; r += 1024) {
+    const float* yr = y + r * cols;
+    const float* lr = labels + r * cols;
+    long iy = 0, il = 0;
+    float by = yr[0], bl = lr[0];
+    for (long c = 1; c < cols; ++c) {
+      if (yr[c] > by) { by = yr[c]; iy = c; }
+      if (lr[c] > bl) { bl = lr[c]; il = c; }
+    }
+    hits += iy == il ? 1.f : 0.f;
+  }
+  hits = dtf_wave_sum(hits);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = hits;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < 16; ++w) t += sh[w];
+    out[0] = t / (float)rows;
+  }
+}
+
+int rows_grid(long rows) {
+  long blocks = (rows + 3) / 4;   // 4 waves per block, one row per wave
+  return (int)(blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks);
+}
+
+}  // namespace
+
+DTF_API int dtf_reduce_rows_f32(int op, const float* x, float* out, long rows, long cols,
+                                hipStream_t stream) {
+  if (rows <= 0) return DTF_OK;
+  if (!x || !out || cols <= 0) return DTF_ERR_BAD_ARG;
+  dim3 grid(rows_grid(rows)), block(BLOCK);
+  switch (op) {
+    case R_SUM: hipLaunchKernelGGL((reduce_rows_kernel<R_SUM>), grid, block, 0, stream, x, out, rows, cols); break;
+    case R_MEAN: hipLaunchKernelGGL((reduce_rows_kernel<R_MEAN>), grid, block, 0, stream, x, out, rows, cols); break;
+    case R_MAX: hipLaunchKernelGGL((reduce_rows_kernel<R_MAX>), grid, block, 0, stream, x, out, rows, cols); break;
+    default: return DTF_ERR_UNSUPPORTED;
+  }
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
+DTF_API int dtf_argmax_rows_f32(const float* x, long* out, long rows, long cols,
+                                hipStream_t stream) {
+  if (rows <= 0) return DTF_OK;
+  if (!x || !out || cols <= 0) return DTF_ERR_BAD_ARG;
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3(rows_grid(rows)), dim3(BLOCK), 0, stream, x, out,
+                     rows, cols);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
+// number of fp32 words of workspace dtf_reduce_all_f32 needs for n elements
+DTF_API int dtf_reduce_all_workspace(long n) {
+  long blocks = (n + BLOCK * 8L - 1) / (BLOCK * 8L);
+  return (int)(blocks < 1 ? 1 : blocks > 1024 ? 1024 : blocks);
+}
+
+// out[0] = scale * sum(x[0..n)); deterministic two-stage fold through `workspace`
+DTF_API int dtf_reduce_all_f32(const float* x, float* out, long n, float scale, float* workspace,
+                               hipStream_t stream) {
+  if (!x || !out || !workspace || n <= 0) return DTF_ERR_BAD_ARG;
+  const int blocks = dtf_reduce_all_workspace(n);
+  hipLaunchKernelGGL(reduce_all_stage1, dim3(blocks), dim3(BLOCK), 0, stream, x, workspace, n);
+  hipLaunchKernelGGL(reduce_all_stage2, dim3(1), dim3(BLOCK), 0, stream, workspace, out, blocks,
+                     scale);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
+DTF_API int dtf_reduce_cols_f32(const float* x, float* colsum, long rows, long cols,
+                                hipStream_t stream) {
+  if (!x || !colsum || rows <= 0 || cols <= 0) return DTF_ERR_BAD_ARG;
+  hipLaunchKernelGGL((reduce_cols_kernel<COL_SUM>), dim3((cols + 63) / 64), dim3(BLOCK), 0, stream,
+                     x, nullptr, nullptr, nullptr, colsum, rows, cols);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
+// dz = da * a * (1 - a); dbias[c] = sum_r dz[r, c] (dbias may be null)
+DTF_API int dtf_sigmoid_grad_bias_f32(const float* da, const float* a, float* dz, float* dbias,
+                                      long rows, long cols, hipStream_t stream) {
+  if (!da || !a || !dz || rows <= 0 || cols <= 0) return DTF_ERR_BAD_ARG;
+  hipLaunchKernelGGL((reduce_cols_kernel<COL_SIGMOID_GRAD>), dim3((cols + 63) / 64), dim3(BLOCK), 0,
+                     stream, da, a, nullptr, dz, dbias, rows, cols);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
+// dz = (y * rowsum(labels) - labels) * dloss / rows; dbias[c] = sum_r dz[r, c] (may be null).
+// Requires cols <= 64 (one workgroup sees whole rows).
+DTF_API int dtf_softmax_xent_grad_f32(const float* y, const float* labels, const float* dloss,
+                                      float* dz, float* dbias, long rows, long cols,
+                                      hipStream_t stream) {
+  if (!y || !labels || !dloss || !dz || rows <= 0 || cols <= 0) return DTF_ERR_BAD_ARG;
+  if (cols > 64) return DTF_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL((reduce_cols_kernel<COL_XENT_GRAD>), dim3(1), dim3(BLOCK), 0, stream, y,
+                     labels, dloss, dz, dbias, rows, cols);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
+DTF_API int dtf_argmax_accuracy_f32(const float* y, const float* labels, float* out, long rows,
+                                    long cols, hipStream_t stream) {
+  if (!y || !labels || !out || rows <= 0 || cols <= 0) return DTF_ERR_BAD_ARG;
+  hipLaunchKernelGGL(argmax_accuracy_kernel, dim3(1), dim3(1024), 0, stream, y, labels, out, rows,
+                     cols);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}

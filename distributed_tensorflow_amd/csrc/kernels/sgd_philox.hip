@@ -1,0 +1,287 @@
+// Optimizer update, random initialisation and partial-sum reduction kernels.
+//
+// * multi-tensor SGD: w -= lr * g for up to 16 tensors in ONE launch (the reference applies
+//   four ApplyGradientDescent ops plus a global_step increment per step,
+//   tf_distributed.py:75-76); scalar counters (global_step) are bumped by the same launch.
+// * Philox4x32-10 normal / uniform fill (tf.random_normal at tf_distributed.py:51-52 and
+//   tf_distributed_1000Matrix.py:43-44): counter-based, so element e of a stream depends only
+//   on (seed, op_seed, e) and any rank can generate any shard of a tensor independently.
+//   Bit-compatible (up to libm rounding) with ops/philox.py, which is the host oracle.
+// * reduce_partials: out = sum of up to 8 partial buffers (the local reduction step of a
+//   direct reduce-scatter over peer-mapped buffers, and of K-sharded GEMM partial sums).
+#include "common.h"
+
+namespace {
+
+constexpr int BLOCK = 256;
+
+struct SgdTensor {
+  float* w;
+  const float* g;
+  long n;
+  float lr;
+};
+constexpr int MAX_SGD_TENSORS = 16;
+constexpr int MAX_COUNTERS = 4;
+struct SgdArgs {
+  SgdTensor t[MAX_SGD_TENSORS];
+  float* counter[MAX_COUNTERS];
+  float delta[MAX_COUNTERS];
+  int num_tensors;
+  int num_counters;
+};
+
+// grid = (blocks_x, num_tensors): blockIdx.y selects the tensor
+__global__ __launch_bounds__(BLOCK) void multi_sgd_kernel(SgdArgs args) {
+  const SgdTensor t = args.t[blockIdx.y];
+  const long start = blockIdx.x * (long)BLOCK + threadIdx.x, step = (long)gridDim.x * BLOCK;
+  const bool vec = (((uintptr_t)t.w | (uintptr_t)t.g) & 15) == 0;
+  if (vec) {
+    const long n4 = t.n >> 2;
+    f32x4* w4 = reinterpret_cast<f32x4*>(t.w);
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(t.g);
+    for (long i = start; i < n4; i += step) w4[i] -= g4[i] * t.lr;
+    for (long i = (n4 << 2) + start; i < t.n; i += step) t.w[i] -= t.lr * t.g[i];
+  } else {
+    for (long i = start; i < t.n; i += step) t.w[i] -= t.lr * t.g[i];
+  }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < args.num_counters)
+    args.counter[threadIdx.x][0] += args.delta[threadIdx.x];
+}
+
+// ---- Philox4x32-10 -------------------------------------------------------------------------
+struct U4 { unsigned int x, y, z, w; };
+
+__device__ __forceinline__ U4 philox4x32_10(unsigned long block, unsigned int k0, unsigned int k1) {
+  unsigned int c0 = (unsigned int)block, c1 = (unsigned int)(block >> 32), c2 = 0u, c3 = 0u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long p0 = (unsigned long)0xD2511F53u * c0;
+    const unsigned long p1 = (unsigned long)0xCD9E8D57u * c2;
+    const unsigned int n0 = (unsigned int)(p1 >> 32) ^ c1 ^ k0;
+    const unsigned int n1 = (unsigned int)p1;
+    const unsigned int n2 = (unsigned int)(p0 >> 32) ^ c3 ^ k1;
+    const unsigned int n3 = (unsigned int)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return U4{c0, c1, c2, c3};
+}
+
+__device__ __forceinline__ float u01(unsigned int bits) {
+  return (float)(bits >> 8) * 5.9604644775390625e-08f + 2.98023223876953125e-08f;  // 2^-24, 2^-25
+}
+
+template <bool NORMAL, bool BF16_OUT>
+__global__ __launch_bounds__(BLOCK) void philox_fill_kernel(void* __restrict__ out_, long n,
+                                                            unsigned int seed,
+                                                            unsigned int op_seed, long offset,
+                                                            float a, float b) {
+  // NORMAL: value = a (mean) + b (stddev) * z;   uniform: value = a (min) + b (max - min) * u
+  const long first_block = offset >> 2;
+  const long nblocks = ((offset + n + 3) >> 2) - first_block;
+  for (long q = blockIdx.x * (long)BLOCK + threadIdx.x; q < nblocks;
+       q += (long)gridDim.x * BLOCK) {
+    const U4 r = philox4x32_10((unsigned long)(first_block + q), seed, op_seed);
+    float v[4];
+    const float u0 = u01(r.x), u1 = u01(r.y), u2 = u01(r.z), u3 = u01(r.w);
+    if (NORMAL) {
+      const float r0 = sqrtf(-2.f * logf(u0)), r1 = sqrtf(-2.f * logf(u2));
+      const float t0 = 6.283185307179586f * u1, t1 = 6.283185307179586f * u3;
+      v[0] = r0 * cosf(t0); v[1] = r0 * sinf(t0);
+      v[2] = r1 * cosf(t1); v[3] = r1 * sinf(t1);
+    } else {
+      v[0] = u0; v[1] = u1; v[2] = u2; v[3] = u3;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long e = ((first_block + q) << 2) + j - offset;   // index into out
+      if (e >= 0 && e < n) {
+        const float val = a + b * v[j];
+        if (BF16_OUT) reinterpret_cast<unsigned short*>(out_)[e] = dtf_f32_to_bf16(val);
+        else reinterpret_cast<float*>(out_)[e] = val;
+      }
+    }
+  }
+}
+
+// ---- partial-sum reduction -------------------------------------------------------------------
+constexpr int MAX_PARTIALS = 8;
+struct PartialArgs {
+  const void* src[MAX_PARTIALS];
+  int count;
+};
+
+__global__ __launch_bounds__(BLOCK) void reduce_partials_f32_kernel(PartialArgs args,
+                                                                    float* __restrict__ out,
+                                                                    long n, float scale) {
+  const long n4 = n >> 2;
+  const long start = blockIdx.x * (long)BLOCK + threadIdx.x, step = (long)gridDim.x * BLOCK;
+  for (long i = start; i < n4; i += step) {
+    f32x4 acc = reinterpret_cast<const f32x4*>(args.src[0])[i];
+    for (int p = 1; p < args.count; ++p) acc += reinterpret_cast<const f32x4*>(args.src[p])[i];
+    reinterpret_cast<f32x4*>(out)[i] = acc * scale;
+  }
+  for (long i = (n4 << 2) + start; i < n; i += step) {
+    float acc = 0.f;
+    for (int p = 0; p < args.count; ++p) acc += reinterpret_cast<const float*>(args.src[p])[i];
+    out[i] = acc * scale;
+  }
+}
+
+// bf16 partials, fp32 accumulation, bf16 result (halves the bytes a K-sharded GEMM moves)
+__global__ __launch_bounds__(BLOCK) void reduce_partials_bf16_kernel(PartialArgs args,
+                                                                     unsigned short* __restrict__ out,
+                                                                     long n, float scale) {
+  const long n8 = n >> 3;
+  const long start = blockIdx.x * (long)BLOCK + threadIdx.x, step = (long)gridDim.x * BLOCK;
+  for (long i = start; i < n8; i += step) {
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int p = 0; p < args.count; ++p) {
+      const bf16x8 v = reinterpret_cast<const bf16x8*>(args.src[p])[i];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += dtf_bf16_to_f32((unsigned short)v[j]);
+    }
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (short)dtf_f32_to_bf16(acc[j] * scale);
+    reinterpret_cast<bf16x8*>(out)[i] = r;
+  }
+  for (long i = (n8 << 3) + start; i < n; i += step) {
+    float acc = 0.f;
+    for (int p = 0; p < args.count; ++p)
+      acc += dtf_bf16_to_f32(reinterpret_cast<const unsigned short*>(args.src[p])[i]);
+    out[i] = dtf_f32_to_bf16(acc * scale);
+  }
+}
+
+// ---- gather of small fetched values ------------------------------------------------------------
+constexpr int MAX_PACK = 16;
+struct PackArgs {
+  const float* src[MAX_PACK];
+  int offset[MAX_PACK + 1];   // dst[offset[i] .. offset[i+1]) <- src[i]
+  int count;
+};
+
+// one workgroup: wave-strided copy of up to 16 tiny tensors into one contiguous staging buffer
+__global__ __launch_bounds__(BLOCK) void pack_f32_kernel(PackArgs args, float* __restrict__ dst) {
+  for (int i = 0; i < args.count; ++i) {
+    const int n = args.offset[i + 1] - args.offset[i];
+    for (int j = threadIdx.x; j < n; j += BLOCK) dst[args.offset[i] + j] = args.src[i][j];
+  }
+}
+
+int grid_for(long n, int per_thread) {
+  long blocks = (n + (long)BLOCK * per_thread - 1) / ((long)BLOCK * per_thread);
+  return (int)(blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks);
+}
+
+}  // namespace
+
+// w[i] -= lr[i] * g[i] for `count` (<= 16) tensors, counters[j][0] += deltas[j] for
+// `num_counters` (<= 4) scalars -- one launch.
+DTF_API int dtf_multi_sgd_f32(int count, float* const* w, const float* const* g, const long* n,
+                              const float* lr, int num_counters, float* const* counters,
+                              const float* deltas, hipStream_t stream) {
+  if (count < 0 || count > MAX_SGD_TENSORS || num_counters < 0 || num_counters > MAX_COUNTERS)
+    return DTF_ERR_BAD_ARG;
+  if (count == 0 && num_counters == 0) return DTF_OK;
+  SgdArgs args = {};
+  long max_n = 1;
+  for (int i = 0; i < count; ++i) {
+    if (!w[i] || !g[i] || n[i] < 0) return DTF_ERR_BAD_ARG;
+    args.t[i] = SgdTensor{w[i], g[i], n[i], lr[i]};
+    if (n[i] > max_n) max_n = n[i];
+  }
+  for (int j = 0; j < num_counters; ++j) {
+    if (!counters[j]) return DTF_ERR_BAD_ARG;
+    args.counter[j] = counters[j];
+    args.delta[j] = deltas[j];
+  }
+  args.num_tensors = count;
+  args.num_counters = num_counters;
+  if (count == 0)   // counters only: give the kernel one empty tensor to walk
+    args.t[0] = SgdTensor{args.counter[0], args.counter[0], 0, 0.f};
+  dim3 grid(grid_for(max_n, 4), count > 0 ? count : 1), block(BLOCK);
+  hipLaunchKernelGGL(multi_sgd_kernel, grid, block, 0, stream, args);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
+// out[i] = mean + stddev * N(0,1) for stream elements offset .. offset+n (bf16_out: 0/1)
+DTF_API int dtf_philox_normal(void* out, long n, unsigned int seed, unsigned int op_seed,
+                              long offset, float mean, float stddev, int bf16_out,
+                              hipStream_t stream) {
+  if (n <= 0) return DTF_OK;
+  if (!out || offset < 0) return DTF_ERR_BAD_ARG;
+  dim3 grid(grid_for((n + 3) / 4 + 1, 1)), block(BLOCK);
+  if (bf16_out)
+    hipLaunchKernelGGL((philox_fill_kernel<true, true>), grid, block, 0, stream, out, n, seed,
+                       op_seed, offset, mean, stddev);
+  else
+    hipLaunchKernelGGL((philox_fill_kernel<true, false>), grid, block, 0, stream, out, n, seed,
+                       op_seed, offset, mean, stddev);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
+DTF_API int dtf_philox_uniform(void* out, long n, unsigned int seed, unsigned int op_seed,
+                               long offset, float minval, float maxval, int bf16_out,
+                               hipStream_t stream) {
+  if (n <= 0) return DTF_OK;
+  if (!out || offset < 0) return DTF_ERR_BAD_ARG;
+  dim3 grid(grid_for((n + 3) / 4 + 1, 1)), block(BLOCK);
+  if (bf16_out)
+    hipLaunchKernelGGL((philox_fill_kernel<false, true>), grid, block, 0, stream, out, n, seed,
+                       op_seed, offset, minval, maxval - minval);
+  else
+    hipLaunchKernelGGL((philox_fill_kernel<false, false>), grid, block, 0, stream, out, n, seed,
+                       op_seed, offset, minval, maxval - minval);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
+// out = scale * sum_{p < count} src[p]   (count <= 8; dtype: 0 = fp32, 1 = bf16)
+DTF_API int dtf_reduce_partials(int count, const void* const* src, void* out, long n, float scale,
+                                int dtype, hipStream_t stream) {
+  if (count < 1 || count > MAX_PARTIALS || !out || n <= 0) return DTF_ERR_BAD_ARG;
+  PartialArgs args = {};
+  for (int p = 0; p < count; ++p) {
+    if (!src[p] || ((uintptr_t)src[p] & 15)) return DTF_ERR_BAD_ARG;
+    args.src[p] = src[p];
+  }
+  if ((uintptr_t)out & 15) return DTF_ERR_BAD_ARG;
+  args.count = count;
+  if (dtype == 0)
+    hipLaunchKernelGGL(reduce_partials_f32_kernel, dim3(grid_for(n, 4)), dim3(BLOCK), 0, stream,
+                       args, (float*)out, n, scale);
+  else if (dtype == 1)
+    hipLaunchKernelGGL(reduce_partials_bf16_kernel, dim3(grid_for(n, 8)), dim3(BLOCK), 0, stream,
+                       args, (unsigned short*)out, n, scale);
+  else
+    return DTF_ERR_UNSUPPORTED;
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
+// dst = concat(src[0][0..n0), src[1][0..n1), ...) for count <= 16 small fp32 buffers: the values
+// a step returns to the host (loss, step counter, accuracy) gathered by one launch so that
+// one device->host copy delivers all of them.
+DTF_API int dtf_pack_f32(int count, const float* const* src, const int* sizes, float* dst,
+                         hipStream_t stream) {
+  if (count < 1 || count > MAX_PACK || !dst) return DTF_ERR_BAD_ARG;
+  PackArgs args = {};
+  int off = 0;
+  for (int i = 0; i < count; ++i) {
+    if (!src[i] || sizes[i] < 0) return DTF_ERR_BAD_ARG;
+    args.src[i] = src[i];
+    args.offset[i] = off;
+    off += sizes[i];
+  }
+  args.offset[count] = off;
+  args.count = count;
+  hipLaunchKernelGGL(pack_f32_kernel, dim3(1), dim3(BLOCK), 0, stream, args, dst);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}

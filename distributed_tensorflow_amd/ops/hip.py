@@ -1,0 +1,574 @@
+"""ctypes binding of ``libdtf_hip.so`` -- the hand-written gfx950 kernel library.
+
+Each wrapper takes torch tensors that live on the GPU, checks on the host that their shapes,
+dtypes, contiguity and alignment match what the kernel and its launch grid assume (a kernel
+that indexes out of bounds can take the whole machine down, so nothing is launched on a
+mismatch), and enqueues the kernel on torch's *current* stream. Launchers never allocate or
+synchronise, so calls made while torch is capturing a HIP graph are captured.
+
+The library is built in-tree by ``build_native.py``. When a GPU is present and the library is
+missing, importing this module's users fails loudly rather than falling back to torch ops.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import List, Optional, Sequence
+
+import torch
+
+_HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_HERE, "lib", "libdtf_hip.so")
+
+ACT_NONE, ACT_SIGMOID, ACT_RELU, ACT_TANH = 0, 1, 2, 3
+ACTIVATIONS = {"none": ACT_NONE, "sigmoid": ACT_SIGMOID, "relu": ACT_RELU, "tanh": ACT_TANH}
+
+# op codes (must match csrc/kernels/elementwise.hip and reduce.hip)
+BINARY = {"add": 0, "sub": 1, "mul": 2, "div": 3, "max": 4, "min": 5, "pow": 6,
+          "sigmoid_grad": 7, "tanh_grad": 8, "relu_grad": 9}
+COMPARE = {"eq": 0, "ne": 1, "lt": 2, "gt": 3}
+UNARY = {"neg": 0, "log": 1, "exp": 2, "sqrt": 3, "square": 4, "recip": 5, "abs": 6,
+         "sigmoid": 7, "tanh": 8, "relu": 9}
+ROW_SUM, ROW_MEAN, ROW_MAX = 0, 1, 2
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+class HipKernelError(RuntimeError):
+    pass
+
+
+def library_present() -> bool:
+    return os.path.exists(LIB_PATH)
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not library_present():
+            raise HipKernelError(
+                "native kernel library %s is missing: run `python build_native.py` "
+                "(refusing to fall back to torch kernels on a GPU)" % LIB_PATH)
+        _lib = ctypes.CDLL(LIB_PATH)
+        _declare(_lib)
+    return _lib
+
+
+def _declare(L: ctypes.CDLL) -> None:
+    c = ctypes
+    P, I, LG, F, U = c.c_void_p, c.c_int, c.c_long, c.c_float, c.c_uint
+    sigs = {
+        "dtf_gemm_f32": [P, P, P, P, I, I, I, LG, LG, LG, I, I, I, P],
+        "dtf_gemm_bf16_nt": [P, P, P, I, I, I, LG, LG, LG, F, I, P],
+        "dtf_gemm_bf16_generic": [P, P, P, I, I, I, LG, LG, LG, LG, LG, F, I, P],
+        "dtf_binary_f32": [I, P, P, P, LG, LG, LG, P],
+        "dtf_unary_f32": [I, P, P, LG, P],
+        "dtf_compare_f32": [I, P, P, P, LG, LG, LG, P],
+        "dtf_equal_i64": [P, P, P, LG, P],
+        "dtf_axpby_f32": [F, P, F, P, P, LG, P],
+        "dtf_axpby_bf16": [F, P, F, P, P, LG, P],
+        "dtf_cast_f32_to_bf16": [P, P, LG, P],
+        "dtf_cast_bf16_to_f32": [P, P, LG, P],
+        "dtf_cast_bool_to_f32": [P, P, LG, P],
+        "dtf_fill_f32": [P, F, LG, P],
+        "dtf_row_scale_f32": [P, P, P, LG, LG, P],
+        "dtf_reduce_rows_f32": [I, P, P, LG, LG, P],
+        "dtf_argmax_rows_f32": [P, P, LG, LG, P],
+        "dtf_reduce_all_workspace": [LG],
+        "dtf_reduce_all_f32": [P, P, LG, F, P, P],
+        "dtf_reduce_cols_f32": [P, P, LG, LG, P],
+        "dtf_sigmoid_grad_bias_f32": [P, P, P, P, LG, LG, P],
+        "dtf_softmax_xent_grad_f32": [P, P, P, P, P, LG, LG, P],
+        "dtf_argmax_accuracy_f32": [P, P, P, LG, LG, P],
+        "dtf_softmax_rows_f32": [P, P, P, LG, LG, P],
+        "dtf_softmax_xent_workspace": [LG],
+        "dtf_softmax_xent_f32": [P, P, P, P, P, P, LG, LG, P],
+        "dtf_softmax_grad_f32": [P, P, P, LG, LG, P],
+        "dtf_multi_sgd_f32": [I, P, P, P, P, I, P, P, P],
+        "dtf_philox_normal": [P, LG, U, U, LG, F, F, I, P],
+        "dtf_philox_uniform": [P, LG, U, U, LG, F, F, I, P],
+        "dtf_reduce_partials": [I, P, P, LG, F, I, P],
+        "dtf_pack_f32": [I, P, P, P, P],
+    }
+    for name, argtypes in sigs.items():
+        fn = getattr(L, name)
+        fn.argtypes = argtypes
+        fn.restype = c.c_int
+
+
+# ---------------------------------------------------------------------------------------
+# helpers
+# ---------------------------------------------------------------------------------------
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _check(code: int, what: str) -> None:
+    if code != 0:
+        if code > 0:
+            raise HipKernelError("%s: HIP launch error %d" % (what, code))
+        raise HipKernelError("%s: rejected arguments (code %d)" % (what, code))
+
+
+def _req(t: torch.Tensor, dtype: torch.dtype, what: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or t.device.type != "cuda":
+        raise HipKernelError("%s: expected a GPU tensor" % what)
+    if t.dtype != dtype:
+        raise HipKernelError("%s: expected dtype %s, got %s" % (what, dtype, t.dtype))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _aligned(t: torch.Tensor) -> torch.Tensor:
+    """Kernels with 16-byte vector paths need a 16-byte aligned base."""
+    return t if t.data_ptr() % 16 == 0 else t.clone()
+
+
+# ---------------------------------------------------------------------------------------
+# GEMM
+# ---------------------------------------------------------------------------------------
+def gemm_f32(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool = False,
+             bias: Optional[torch.Tensor] = None, activation: int = ACT_NONE,
+             out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``act(op(a) @ op(b) + bias)`` on the fp32 MFMA kernel. ``a`` is [M,K] ([K,M] when
+    ``trans_a``), ``b`` is [K,N] ([N,K] when ``trans_b``)."""
+    a = _req(a, torch.float32, "gemm_f32 a")
+    b = _req(b, torch.float32, "gemm_f32 b")
+    if a.dim() != 2 or b.dim() != 2:
+        raise HipKernelError("gemm_f32: operands must be rank 2")
+    m, k = (a.shape[1], a.shape[0]) if trans_a else a.shape
+    k2, n = (b.shape[1], b.shape[0]) if trans_b else b.shape
+    if k != k2:
+        raise HipKernelError("gemm_f32: inner dimensions differ (%s vs %s)"
+                             % (tuple(a.shape), tuple(b.shape)))
+    if bias is not None:
+        bias = _req(bias, torch.float32, "gemm_f32 bias")
+        if bias.numel() != n:
+            raise HipKernelError("gemm_f32: bias has %d elements, N=%d" % (bias.numel(), n))
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    elif out.shape != (m, n) or out.dtype != torch.float32 or not out.is_contiguous():
+        raise HipKernelError("gemm_f32: bad out tensor")
+    if m == 0 or n == 0:
+        return out
+    if k == 0:
+        return out.zero_()
+    _check(lib().dtf_gemm_f32(a.data_ptr(), b.data_ptr(), out.data_ptr(), _ptr(bias), m, n, k,
+                              a.stride(0), b.stride(0), out.stride(0), int(trans_a), int(trans_b),
+                              int(activation), _stream()), "gemm_f32")
+    return out
+
+
+def gemm_bf16_nt(a: torch.Tensor, bt: torch.Tensor, out_dtype: torch.dtype = torch.bfloat16,
+                 alpha: float = 1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``alpha * a @ bt.T`` with a [M,K], bt [N,K] bf16 (both K-contiguous); fp32 accumulate;
+    result bf16 or fp32. Uses the 256x256x64 LDS-DMA kernel when the shape qualifies and the
+    predicated generic kernel otherwise."""
+    a = _req(a, torch.bfloat16, "gemm_bf16_nt a")
+    bt = _req(bt, torch.bfloat16, "gemm_bf16_nt bt")
+    if a.dim() != 2 or bt.dim() != 2 or a.shape[1] != bt.shape[1]:
+        raise HipKernelError("gemm_bf16_nt: need a [M,K] and bt [N,K], got %s and %s"
+                             % (tuple(a.shape), tuple(bt.shape)))
+    if out_dtype not in (torch.bfloat16, torch.float32):
+        raise HipKernelError("gemm_bf16_nt: out dtype must be bf16 or fp32")
+    m, k = a.shape
+    n = bt.shape[0]
+    if out is None:
+        out = torch.empty((m, n), dtype=out_dtype, device=a.device)
+    elif out.shape != (m, n) or out.dtype != out_dtype or out.stride(1) != 1:
+        raise HipKernelError("gemm_bf16_nt: bad out tensor")
+    if m == 0 or n == 0:
+        return out
+    if k == 0:
+        return out.zero_()
+    out_f32 = int(out_dtype == torch.float32)
+    code = lib().dtf_gemm_bf16_nt(a.data_ptr(), bt.data_ptr(), out.data_ptr(), m, n, k,
+                                  a.stride(0), bt.stride(0), out.stride(0), float(alpha), out_f32,
+                                  _stream())
+    if code == -2:    # shape/alignment outside the fast kernel's contract
+        code = lib().dtf_gemm_bf16_generic(a.data_ptr(), bt.data_ptr(), out.data_ptr(), m, n, k,
+                                           a.stride(0), 1, 1, bt.stride(0), out.stride(0),
+                                           float(alpha), out_f32, _stream())
+    _check(code, "gemm_bf16_nt")
+    return out
+
+
+def gemm_bf16(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool = False,
+              out_dtype: torch.dtype = torch.bfloat16, alpha: float = 1.0,
+              force_generic: bool = False) -> torch.Tensor:
+    """General bf16 matmul ``op(a) @ op(b)``. The NT case (``trans_b`` with K-contiguous
+    operands) takes the fast kernel; other layouts run the generic strided kernel."""
+    a = _req(a, torch.bfloat16, "gemm_bf16 a")
+    b = _req(b, torch.bfloat16, "gemm_bf16 b")
+    if not trans_a and trans_b and not force_generic:
+        return gemm_bf16_nt(a, b, out_dtype, alpha)
+    m, k = (a.shape[1], a.shape[0]) if trans_a else a.shape
+    k2, n = (b.shape[1], b.shape[0]) if trans_b else b.shape
+    if k != k2:
+        raise HipKernelError("gemm_bf16: inner dimensions differ")
+    out = torch.empty((m, n), dtype=out_dtype, device=a.device)
+    if m == 0 or n == 0:
+        return out
+    a_rs, a_cs = (1, a.stride(0)) if trans_a else (a.stride(0), 1)
+    b_rs, b_cs = (1, b.stride(0)) if trans_b else (b.stride(0), 1)
+    _check(lib().dtf_gemm_bf16_generic(a.data_ptr(), b.data_ptr(), out.data_ptr(), m, n, k, a_rs,
+                                       a_cs, b_rs, b_cs, out.stride(0), float(alpha),
+                                       int(out_dtype == torch.float32), _stream()), "gemm_bf16")
+    return out
+
+
+# ---------------------------------------------------------------------------------------
+# elementwise
+# ---------------------------------------------------------------------------------------
+def _bcast_numel(out_shape: torch.Size, t: torch.Tensor, what: str) -> int:
+    """``t`` may equal the output shape, be a trailing suffix of it, or be a scalar."""
+    if tuple(t.shape) == tuple(out_shape):
+        return t.numel()
+    squeezed = [d for d in t.shape]
+    while squeezed and squeezed[0] == 1:
+        squeezed.pop(0)
+    if tuple(squeezed) == tuple(out_shape[len(out_shape) - len(squeezed):]):
+        return t.numel()
+    raise HipKernelError("%s: broadcast of %s into %s is not a trailing-suffix broadcast"
+                         % (what, tuple(t.shape), tuple(out_shape)))
+
+
+def binary(op: str, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    a = _req(a, torch.float32, "binary a")
+    b = _req(b, torch.float32, "binary b")
+    out_shape = torch.broadcast_shapes(a.shape, b.shape)
+    an = _bcast_numel(out_shape, a, "binary a")
+    bn = _bcast_numel(out_shape, b, "binary b")
+    out = torch.empty(out_shape, dtype=torch.float32, device=a.device)
+    _check(lib().dtf_binary_f32(BINARY[op], a.data_ptr(), b.data_ptr(), out.data_ptr(),
+                                out.numel(), an, bn, _stream()), "binary " + op)
+    return out
+
+
+def compare(op: str, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    if a.dtype == torch.int64 and b.dtype == torch.int64 and op == "eq" and a.shape == b.shape:
+        a, b = a.contiguous(), b.contiguous()
+        out = torch.empty(a.shape, dtype=torch.bool, device=a.device)
+        _check(lib().dtf_equal_i64(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(),
+                                   _stream()), "equal_i64")
+        return out
+    a = _req(a, torch.float32, "compare a")
+    b = _req(b, torch.float32, "compare b")
+    out_shape = torch.broadcast_shapes(a.shape, b.shape)
+    an = _bcast_numel(out_shape, a, "compare a")
+    bn = _bcast_numel(out_shape, b, "compare b")
+    out = torch.empty(out_shape, dtype=torch.bool, device=a.device)
+    _check(lib().dtf_compare_f32(COMPARE[op], a.data_ptr(), b.data_ptr(), out.data_ptr(),
+                                 out.numel(), an, bn, _stream()), "compare " + op)
+    return out
+
+
+def unary(op: str, x: torch.Tensor) -> torch.Tensor:
+    x = _aligned(_req(x, torch.float32, "unary x"))
+    out = torch.empty_like(x)
+    _check(lib().dtf_unary_f32(UNARY[op], x.data_ptr(), out.data_ptr(), x.numel(), _stream()),
+           "unary " + op)
+    return out
+
+
+def axpby(alpha: float, x: torch.Tensor, beta: float = 0.0, y: Optional[torch.Tensor] = None,
+          out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``alpha*x + beta*y`` (fp32 or bf16; ``y`` optional)."""
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        raise HipKernelError("axpby: dtype must be fp32 or bf16")
+    x = _aligned(_req(x, x.dtype, "axpby x"))
+    if y is not None:
+        y = _aligned(_req(y, x.dtype, "axpby y"))
+        if y.shape != x.shape:
+            raise HipKernelError("axpby: shapes differ")
+    if out is None:
+        out = torch.empty_like(x)
+    elif out.shape != x.shape or out.dtype != x.dtype or not out.is_contiguous():
+        raise HipKernelError("axpby: bad out tensor")
+    fn = lib().dtf_axpby_f32 if x.dtype == torch.float32 else lib().dtf_axpby_bf16
+    _check(fn(float(alpha), x.data_ptr(), float(beta), _ptr(y), out.data_ptr(), x.numel(),
+              _stream()), "axpby")
+    return out
+
+
+def cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    if x.dtype == dtype:
+        return x
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    n = x.numel()
+    if x.dtype == torch.float32 and dtype == torch.bfloat16:
+        _check(lib().dtf_cast_f32_to_bf16(_aligned(x).data_ptr(), out.data_ptr(), n, _stream()),
+               "cast f32->bf16")
+    elif x.dtype == torch.bfloat16 and dtype == torch.float32:
+        _check(lib().dtf_cast_bf16_to_f32(x.data_ptr(), out.data_ptr(), n, _stream()),
+               "cast bf16->f32")
+    elif x.dtype == torch.bool and dtype == torch.float32:
+        _check(lib().dtf_cast_bool_to_f32(x.data_ptr(), out.data_ptr(), n, _stream()),
+               "cast bool->f32")
+    else:
+        raise HipKernelError("cast %s -> %s has no HIP kernel" % (x.dtype, dtype))
+    return out
+
+
+def fill(shape: Sequence[int], value: float, device) -> torch.Tensor:
+    out = torch.empty(tuple(shape), dtype=torch.float32, device=device)
+    _check(lib().dtf_fill_f32(out.data_ptr(), float(value), out.numel(), _stream()), "fill")
+    return out
+
+
+def row_scale(x: torch.Tensor, s: torch.Tensor) -> torch.Tensor:
+    x = _req(x, torch.float32, "row_scale x")
+    s = _req(s, torch.float32, "row_scale s")
+    if x.dim() != 2 or s.numel() != x.shape[0]:
+        raise HipKernelError("row_scale: need x [R,C] and s [R]")
+    out = torch.empty_like(x)
+    _check(lib().dtf_row_scale_f32(x.data_ptr(), s.data_ptr(), out.data_ptr(), x.shape[0],
+                                   x.shape[1], _stream()), "row_scale")
+    return out
+
+
+# ---------------------------------------------------------------------------------------
+# reductions / softmax / loss
+# ---------------------------------------------------------------------------------------
+def _as_rows(x: torch.Tensor) -> torch.Tensor:
+    return x.reshape(-1, x.shape[-1]) if x.dim() != 2 else x
+
+
+def reduce_rows(x: torch.Tensor, op: int) -> torch.Tensor:
+    x = _req(x, torch.float32, "reduce_rows x")
+    if x.dim() != 2:
+        raise HipKernelError("reduce_rows: rank-2 input required")
+    out = torch.empty((x.shape[0],), dtype=torch.float32, device=x.device)
+    _check(lib().dtf_reduce_rows_f32(op, x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1],
+                                     _stream()), "reduce_rows")
+    return out
+
+
+def argmax_rows(x: torch.Tensor) -> torch.Tensor:
+    x = _req(x, torch.float32, "argmax_rows x")
+    if x.dim() != 2 or x.shape[1] == 0:
+        raise HipKernelError("argmax_rows: rank-2 input with >=1 column required")
+    out = torch.empty((x.shape[0],), dtype=torch.int64, device=x.device)
+    _check(lib().dtf_argmax_rows_f32(x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1],
+                                     _stream()), "argmax_rows")
+    return out
+
+
+def reduce_all(x: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+    """``scale * sum(x)`` as a 0-d tensor; fixed-order (bitwise reproducible) fold."""
+    x = _req(x, torch.float32, "reduce_all x")
+    n = x.numel()
+    out = torch.empty((), dtype=torch.float32, device=x.device)
+    if n == 0:
+        return out.zero_()
+    ws = torch.empty((lib().dtf_reduce_all_workspace(n),), dtype=torch.float32, device=x.device)
+    _check(lib().dtf_reduce_all_f32(x.data_ptr(), out.data_ptr(), n, float(scale), ws.data_ptr(),
+                                    _stream()), "reduce_all")
+    return out
+
+
+def reduce_cols(x: torch.Tensor) -> torch.Tensor:
+    x = _req(x, torch.float32, "reduce_cols x")
+    if x.dim() != 2:
+        raise HipKernelError("reduce_cols: rank-2 input required")
+    out = torch.empty((x.shape[1],), dtype=torch.float32, device=x.device)
+    _check(lib().dtf_reduce_cols_f32(x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1],
+                                     _stream()), "reduce_cols")
+    return out
+
+
+def sigmoid_grad_bias(da: torch.Tensor, a: torch.Tensor, want_bias: bool = True):
+    da = _req(da, torch.float32, "sigmoid_grad_bias da")
+    a = _req(a, torch.float32, "sigmoid_grad_bias a")
+    if da.dim() != 2 or da.shape != a.shape:
+        raise HipKernelError("sigmoid_grad_bias: need matching rank-2 inputs")
+    dz = torch.empty_like(da)
+    db = torch.empty((da.shape[1],), dtype=torch.float32, device=da.device) if want_bias else None
+    _check(lib().dtf_sigmoid_grad_bias_f32(da.data_ptr(), a.data_ptr(), dz.data_ptr(), _ptr(db),
+                                           da.shape[0], da.shape[1], _stream()),
+           "sigmoid_grad_bias")
+    return dz, db
+
+
+def softmax_rows(x: torch.Tensor, log: bool = False) -> torch.Tensor:
+    x = _req(x, torch.float32, "softmax x")
+    x2 = _as_rows(x)
+    out = torch.empty_like(x2)
+    _check(lib().dtf_softmax_rows_f32(x2.data_ptr(), None if log else out.data_ptr(),
+                                      out.data_ptr() if log else None, x2.shape[0], x2.shape[1],
+                                      _stream()), "softmax_rows")
+    return out.view(x.shape)
+
+
+def softmax_grad(y: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    y = _req(y, torch.float32, "softmax_grad y")
+    dy = _req(dy, torch.float32, "softmax_grad dy")
+    if y.shape != dy.shape:
+        raise HipKernelError("softmax_grad: shapes differ")
+    y2, dy2 = _as_rows(y), _as_rows(dy)
+    dx = torch.empty_like(y2)
+    _check(lib().dtf_softmax_grad_f32(y2.data_ptr(), dy2.data_ptr(), dx.data_ptr(), y2.shape[0],
+                                      y2.shape[1], _stream()), "softmax_grad")
+    return dx.view(y.shape)
+
+
+def softmax_xent(logits: torch.Tensor, labels: torch.Tensor, want_softmax: bool = True,
+                 want_rows: bool = False, want_mean: bool = True):
+    """Fused softmax + cross-entropy. Returns ``(mean_loss, softmax, row_loss)`` with ``None``
+    for the parts not requested."""
+    logits = _req(logits, torch.float32, "softmax_xent logits")
+    labels = _req(labels, torch.float32, "softmax_xent labels")
+    if logits.dim() != 2 or logits.shape != labels.shape:
+        raise HipKernelError("softmax_xent: need matching rank-2 logits/labels")
+    r, c = logits.shape
+    dev = logits.device
+    y = torch.empty_like(logits) if want_softmax else None
+    rows = torch.empty((r,), dtype=torch.float32, device=dev) if want_rows else None
+    mean = torch.empty((), dtype=torch.float32, device=dev) if want_mean else None
+    ws = torch.empty((lib().dtf_softmax_xent_workspace(r),), dtype=torch.float32, device=dev) \
+        if want_mean else None
+    _check(lib().dtf_softmax_xent_f32(logits.data_ptr(), labels.data_ptr(), _ptr(y), _ptr(rows),
+                                      _ptr(mean), _ptr(ws), r, c, _stream()), "softmax_xent")
+    return mean, y, rows
+
+
+def softmax_xent_grad(y: torch.Tensor, labels: torch.Tensor, dloss: torch.Tensor,
+                      want_bias: bool = True):
+    """``dz = (y*rowsum(labels) - labels) * dloss / R`` and its column sum (C <= 64)."""
+    y = _req(y, torch.float32, "softmax_xent_grad y")
+    labels = _req(labels, torch.float32, "softmax_xent_grad labels")
+    dloss = _req(dloss, torch.float32, "softmax_xent_grad dloss")
+    if y.dim() != 2 or y.shape != labels.shape or dloss.numel() != 1:
+        raise HipKernelError("softmax_xent_grad: bad shapes")
+    r, c = y.shape
+    if c > 64:
+        dz = binary("sub", binary("mul", y, reduce_rows(labels, ROW_SUM).unsqueeze(1)
+                                  .expand_as(y).contiguous()), labels)
+        dz = binary("mul", dz, axpby(1.0 / r, dloss.reshape(1)))
+        return dz, (reduce_cols(dz) if want_bias else None)
+    dz = torch.empty_like(y)
+    db = torch.empty((c,), dtype=torch.float32, device=y.device) if want_bias else None
+    _check(lib().dtf_softmax_xent_grad_f32(y.data_ptr(), labels.data_ptr(), dloss.data_ptr(),
+                                           dz.data_ptr(), _ptr(db), r, c, _stream()),
+           "softmax_xent_grad")
+    return dz, db
+
+
+def argmax_accuracy(y: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+    y = _req(y, torch.float32, "argmax_accuracy y")
+    labels = _req(labels, torch.float32, "argmax_accuracy labels")
+    if y.dim() != 2 or y.shape != labels.shape or y.shape[1] == 0:
+        raise HipKernelError("argmax_accuracy: need matching rank-2 inputs")
+    out = torch.empty((), dtype=torch.float32, device=y.device)
+    _check(lib().dtf_argmax_accuracy_f32(y.data_ptr(), labels.data_ptr(), out.data_ptr(),
+                                         y.shape[0], y.shape[1], _stream()), "argmax_accuracy")
+    return out
+
+
+# ---------------------------------------------------------------------------------------
+# optimizer / rng / partial sums
+# ---------------------------------------------------------------------------------------
+def multi_sgd(params: Sequence[torch.Tensor], grads: Sequence[torch.Tensor],
+              lrs: Sequence[float], counters: Sequence[torch.Tensor] = (),
+              deltas: Sequence[float] = ()) -> None:
+    """In place ``p -= lr * g`` for every pair and ``counter += delta`` -- one launch per 16
+    tensors."""
+    if len(params) != len(grads) or len(params) != len(lrs) or len(counters) != len(deltas):
+        raise HipKernelError("multi_sgd: argument lists differ in length")
+    for p, g in zip(params, grads):
+        if p.dtype != torch.float32 or g.dtype != torch.float32 or not p.is_contiguous() \
+                or p.numel() != g.numel() or p.device.type != "cuda":
+            raise HipKernelError("multi_sgd: params/grads must be matching contiguous fp32 GPU "
+                                 "tensors")
+    for c in counters:
+        if c.dtype != torch.float32 or c.numel() != 1 or c.device.type != "cuda":
+            raise HipKernelError("multi_sgd: counters must be fp32 GPU scalars")
+    if len(counters) > 4:
+        raise HipKernelError("multi_sgd: at most 4 counters")
+    grads = [g if g.is_contiguous() else g.contiguous() for g in grads]
+    c = ctypes
+    first = True
+    for start in range(0, max(len(params), 1), 16):
+        ps, gs, ls = params[start:start + 16], grads[start:start + 16], lrs[start:start + 16]
+        n = len(ps)
+        w_arr = (c.c_void_p * max(n, 1))(*[p.data_ptr() for p in ps])
+        g_arr = (c.c_void_p * max(n, 1))(*[g.data_ptr() for g in gs])
+        n_arr = (c.c_long * max(n, 1))(*[p.numel() for p in ps])
+        lr_arr = (c.c_float * max(n, 1))(*[float(x) for x in ls])
+        nc = len(counters) if first else 0
+        c_arr = (c.c_void_p * max(nc, 1))(*[t.data_ptr() for t in counters][:nc])
+        d_arr = (c.c_float * max(nc, 1))(*[float(d) for d in deltas][:nc])
+        _check(lib().dtf_multi_sgd_f32(n, w_arr, g_arr, n_arr, lr_arr, nc, c_arr, d_arr,
+                                       _stream()), "multi_sgd")
+        first = False
+
+
+def philox_normal(shape: Sequence[int], seed: int, op_seed: int, mean: float = 0.0,
+                  stddev: float = 1.0, dtype: torch.dtype = torch.float32, device=None,
+                  offset: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise HipKernelError("philox_normal: dtype must be fp32 or bf16")
+    if out is None:
+        out = torch.empty(tuple(shape), dtype=dtype, device=device)
+    _check(lib().dtf_philox_normal(out.data_ptr(), out.numel(), seed & 0xFFFFFFFF,
+                                   op_seed & 0xFFFFFFFF, int(offset), float(mean), float(stddev),
+                                   int(dtype == torch.bfloat16), _stream()), "philox_normal")
+    return out
+
+
+def philox_uniform(shape: Sequence[int], seed: int, op_seed: int, minval: float = 0.0,
+                   maxval: float = 1.0, dtype: torch.dtype = torch.float32, device=None,
+                   offset: int = 0) -> torch.Tensor:
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise HipKernelError("philox_uniform: dtype must be fp32 or bf16")
+    out = torch.empty(tuple(shape), dtype=dtype, device=device)
+    _check(lib().dtf_philox_uniform(out.data_ptr(), out.numel(), seed & 0xFFFFFFFF,
+                                    op_seed & 0xFFFFFFFF, int(offset), float(minval),
+                                    float(maxval), int(dtype == torch.bfloat16), _stream()),
+           "philox_uniform")
+    return out
+
+
+def reduce_partials(parts: Sequence[torch.Tensor], scale: float = 1.0,
+                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``scale * sum(parts)`` for up to 8 same-shape fp32 / bf16 buffers (fp32 accumulate)."""
+    if not 1 <= len(parts) <= 8:
+        raise HipKernelError("reduce_partials: 1..8 buffers")
+    dt = parts[0].dtype
+    if dt not in (torch.float32, torch.bfloat16):
+        raise HipKernelError("reduce_partials: dtype must be fp32 or bf16")
+    parts = [_aligned(_req(p, dt, "reduce_partials part")) for p in parts]
+    if any(p.shape != parts[0].shape for p in parts):
+        raise HipKernelError("reduce_partials: shapes differ")
+    if out is None:
+        out = torch.empty_like(parts[0])
+    elif out.shape != parts[0].shape or out.dtype != dt or not out.is_contiguous():
+        raise HipKernelError("reduce_partials: bad out tensor")
+    arr = (ctypes.c_void_p * len(parts))(*[p.data_ptr() for p in parts])
+    _check(lib().dtf_reduce_partials(len(parts), arr, out.data_ptr(), out.numel(), float(scale),
+                                     int(dt == torch.bfloat16), _stream()), "reduce_partials")
+    return out
+
+
+def pack_f32(parts: Sequence[torch.Tensor], out: torch.Tensor) -> List[int]:
+    """Gather up to 16 small fp32 tensors into the head of ``out`` with one launch; returns
+    the offset of each part."""
+    if not 1 <= len(parts) <= 16:
+        raise HipKernelError("pack_f32: 1..16 parts")
+    parts = [_req(p, torch.float32, "pack_f32 part") for p in parts]
+    total = sum(p.numel() for p in parts)
+    if out.dtype != torch.float32 or out.numel() < total or not out.is_contiguous() \
+            or out.device.type != "cuda":
+        raise HipKernelError("pack_f32: bad out tensor")
+    src = (ctypes.c_void_p * len(parts))(*[p.data_ptr() for p in parts])
+    sizes = (ctypes.c_int * len(parts))(*[p.numel() for p in parts])
+    _check(lib().dtf_pack_f32(len(parts), src, sizes, out.data_ptr(), _stream()), "pack_f32")
+    offsets, off = [], 0
+    for p in parts:
+        offsets.append(off)
+        off += p.numel()
+    return offsets

@@ -391,6 +391,13 @@ def _dense_grad_sigmoid(op, inputs, ctx):
     return [dz, dz.sum(dim=0)]
 
 
+@ref_kernel("ArgmaxAccuracy")
+def _argmax_accuracy(op, inputs, ctx):
+    """(y, labels) -> mean(argmax(y, 1) == argmax(labels, 1)) as fp32."""
+    y, labels = inputs
+    return [(y.argmax(dim=1) == labels.argmax(dim=1)).to(torch.float32).mean()]
+
+
 @ref_kernel("BiasGrad")
 def _bias_grad(op, inputs, ctx):
     return [inputs[0].sum(dim=0)]

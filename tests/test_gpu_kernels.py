@@ -1,0 +1,246 @@
+"""HIP kernel numerics vs plain PyTorch fp32/fp64 references (runs on the MI355X box)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    from distributed_tensorflow_amd.ops import hip as h
+    h.lib()
+    return h
+
+
+def _ref_mm(a, b):
+    return (a.double().cpu() @ b.double().cpu())
+
+
+@pytest.mark.parametrize("m,n,k", [(1000, 1000, 1000), (100, 100, 784), (100, 10, 100),
+                                   (784, 100, 100), (10000, 100, 784), (4096, 4096, 512),
+                                   (33, 65, 17), (1, 1, 1), (257, 129, 1023)])
+def test_gemm_f32_nn(hip, m, n, k):
+    g = torch.Generator().manual_seed(m * 7 + n * 3 + k)
+    a = torch.randn(m, k, generator=g).cuda()
+    b = torch.randn(k, n, generator=g).cuda()
+    c = hip.gemm_f32(a, b)
+    ref = _ref_mm(a, b)
+    err = (c.double().cpu() - ref).abs().max().item()
+    assert err <= 2e-6 * k * 4 + 1e-5, err
+
+
+@pytest.mark.parametrize("ta,tb", [(False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("m,n,k", [(100, 10, 100), (784, 100, 100), (300, 200, 130),
+                                   (1000, 1000, 1000)])
+def test_gemm_f32_transposes(hip, ta, tb, m, n, k):
+    g = torch.Generator().manual_seed(11)
+    a = torch.randn(m, k, generator=g).cuda()
+    b = torch.randn(k, n, generator=g).cuda()
+    a_in = a.t().contiguous() if ta else a
+    b_in = b.t().contiguous() if tb else b
+    c = hip.gemm_f32(a_in, b_in, ta, tb)
+    err = (c.double().cpu() - _ref_mm(a, b)).abs().max().item()
+    assert err <= 1e-5 * k + 1e-5, err
+
+
+def test_gemm_f32_identity_asymmetric(hip):
+    """A = I with an asymmetric B catches a row/col swap in the C fragment write."""
+    n = 192
+    b = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251).cuda()
+    c = hip.gemm_f32(torch.eye(n).cuda(), b)
+    assert torch.equal(c, b)
+    c2 = hip.gemm_f32(b, torch.eye(n).cuda())
+    assert torch.equal(c2, b)
+
+
+def test_gemm_f32_exact_integers(hip):
+    a = torch.randint(-4, 5, (130, 70)).float().cuda()
+    b = torch.randint(-4, 5, (70, 90)).float().cuda()
+    assert torch.equal(hip.gemm_f32(a, b), (a.double() @ b.double()).float())
+
+
+@pytest.mark.parametrize("act", ["none", "sigmoid", "relu", "tanh"])
+def test_gemm_f32_bias_activation(hip, act):
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(100, 784, generator=g).cuda() * 0.1
+    w = torch.randn(784, 100, generator=g).cuda()
+    b = torch.randn(100, generator=g).cuda()
+    out = hip.gemm_f32(x, w, bias=b, activation=hip.ACTIVATIONS[act])
+    z = x.double() @ w.double() + b.double()
+    ref = {"none": z, "sigmoid": torch.sigmoid(z), "relu": torch.relu(z), "tanh": torch.tanh(z)}[act]
+    assert (out.double() - ref).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("m,n,k", [(256, 256, 64), (512, 768, 256), (1024, 1024, 1024),
+                                   (300, 520, 128), (2048, 256, 4096)])
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
+def test_gemm_bf16_nt_fast(hip, m, n, k, out_dtype):
+    g = torch.Generator().manual_seed(m + n + k)
+    a = torch.randn(m, k, generator=g).bfloat16().cuda()
+    bt = torch.randn(n, k, generator=g).bfloat16().cuda()
+    c = hip.gemm_bf16_nt(a, bt, out_dtype)
+    ref = a.double().cpu() @ bt.double().cpu().t()
+    tol = (0.02 if out_dtype == torch.bfloat16 else 1e-3) * (k ** 0.5) + 1e-3
+    err = (c.double().cpu() - ref).abs().max().item()
+    assert err < tol, (err, tol)
+
+
+def test_gemm_bf16_nt_exact_integers(hip):
+    """Exact small-integer data: any fragment-layout or staging bug shows as a wrong integer."""
+    g = torch.Generator().manual_seed(3)
+    a = torch.randint(-3, 4, (512, 256), generator=g).float()
+    bt = torch.randint(-3, 4, (768, 256), generator=g).float()
+    c = hip.gemm_bf16_nt(a.bfloat16().cuda(), bt.bfloat16().cuda(), torch.float32)
+    assert torch.equal(c.cpu(), a @ bt.t())
+
+
+def test_gemm_bf16_identity_asymmetric(hip):
+    n = 512
+    b = ((torch.arange(n * n).reshape(n, n) % 13) - 6).float()
+    eye = torch.eye(n)
+    c = hip.gemm_bf16_nt(eye.bfloat16().cuda(), b.t().contiguous().bfloat16().cuda(), torch.float32)
+    assert torch.equal(c.cpu(), b)
+    c2 = hip.gemm_bf16_nt(b.bfloat16().cuda(), eye.bfloat16().cuda(), torch.float32)
+    assert torch.equal(c2.cpu(), b)
+
+
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+def test_gemm_bf16_generic_layouts(hip, ta, tb):
+    g = torch.Generator().manual_seed(9)
+    m, n, k = 150, 70, 45
+    a = torch.randint(-3, 4, (m, k), generator=g).float()
+    b = torch.randint(-3, 4, (k, n), generator=g).float()
+    a_in = (a.t().contiguous() if ta else a).bfloat16().cuda()
+    b_in = (b.t().contiguous() if tb else b).bfloat16().cuda()
+    c = hip.gemm_bf16(a_in, b_in, ta, tb, torch.float32, force_generic=True)
+    assert torch.equal(c.cpu(), a @ b)
+
+
+def test_elementwise_and_broadcast(hip):
+    g = torch.Generator().manual_seed(1)
+    a = torch.randn(100, 100, generator=g).cuda()
+    b = torch.randn(100, generator=g).cuda()
+    assert torch.allclose(hip.binary("add", a, b), a + b)
+    assert torch.allclose(hip.binary("mul", a, a), a * a)
+    assert torch.allclose(hip.binary("sub", a, torch.tensor(2.0).cuda()), a - 2)
+    assert torch.allclose(hip.binary("div", a, a.abs() + 1), a / (a.abs() + 1))
+    y = torch.sigmoid(a)
+    assert torch.allclose(hip.binary("sigmoid_grad", y, a), a * y * (1 - y), atol=1e-6)
+    for name, fn in [("neg", torch.neg), ("exp", torch.exp), ("sigmoid", torch.sigmoid),
+                     ("tanh", torch.tanh), ("relu", torch.relu), ("square", torch.square),
+                     ("abs", torch.abs)]:
+        assert torch.allclose(hip.unary(name, a), fn(a), atol=1e-6, rtol=1e-5), name
+    pos = a.abs() + 0.1
+    assert torch.allclose(hip.unary("log", pos), torch.log(pos), atol=1e-6, rtol=1e-5)
+    assert torch.allclose(hip.unary("sqrt", pos), torch.sqrt(pos), atol=1e-6, rtol=1e-5)
+    odd = torch.randn(1001, generator=g).cuda()
+    assert torch.allclose(hip.unary("neg", odd), -odd)
+    assert torch.equal(hip.compare("eq", a, a.clone()), torch.ones_like(a, dtype=torch.bool))
+    assert torch.equal(hip.compare("gt", a, b), a > b)
+
+
+def test_axpby_cast_partials(hip):
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(1000, 37, generator=g).cuda()
+    y = torch.randn(1000, 37, generator=g).cuda()
+    assert torch.allclose(hip.axpby(2.0, x, -0.5, y), 2 * x - 0.5 * y, atol=1e-6)
+    assert torch.allclose(hip.axpby(3.0, x), 3 * x)
+    xb, yb = x.bfloat16(), y.bfloat16()
+    ref = (2 * xb.float() - 0.5 * yb.float()).bfloat16()
+    assert torch.equal(hip.axpby(2.0, xb, -0.5, yb), ref)
+    assert torch.equal(hip.cast(x, torch.bfloat16), x.bfloat16())
+    assert torch.equal(hip.cast(xb, torch.float32), xb.float())
+    parts = [torch.randn(4099, generator=g).cuda() for _ in range(5)]
+    assert torch.allclose(hip.reduce_partials(parts), sum(parts), atol=1e-5)
+    pb = [p.bfloat16() for p in parts]
+    refb = sum(p.float() for p in pb).bfloat16()
+    assert torch.equal(hip.reduce_partials(pb), refb)
+
+
+def test_reductions(hip):
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(10000, 10, generator=g).cuda()
+    assert torch.allclose(hip.reduce_rows(x, hip.ROW_SUM), x.sum(1), atol=1e-5)
+    assert torch.allclose(hip.reduce_rows(x, hip.ROW_MEAN), x.mean(1), atol=1e-6)
+    assert torch.allclose(hip.reduce_rows(x, hip.ROW_MAX), x.amax(1))
+    assert torch.equal(hip.argmax_rows(x), x.argmax(1))
+    assert torch.allclose(hip.reduce_cols(x), x.double().sum(0).float(), atol=1e-3)
+    big = torch.randn(3_000_001, generator=g).cuda()
+    assert abs(hip.reduce_all(big).item() - big.double().sum().item()) < 0.05
+    r1, r2 = hip.reduce_all(big), hip.reduce_all(big)
+    assert torch.equal(r1, r2)                      # fixed-order fold: bitwise reproducible
+    wide = torch.randn(64, 1000, generator=g).cuda()
+    assert torch.allclose(hip.reduce_rows(wide, hip.ROW_SUM), wide.sum(1), atol=1e-4)
+    assert torch.equal(hip.argmax_rows(wide), wide.argmax(1))
+
+
+@pytest.mark.parametrize("rows,cols", [(100, 10), (10000, 10), (7, 64), (33, 1000)])
+def test_softmax_xent(hip, rows, cols):
+    g = torch.Generator().manual_seed(rows + cols)
+    logits = (torch.randn(rows, cols, generator=g) * 3).cuda()
+    labels = torch.eye(cols)[torch.randint(0, cols, (rows,), generator=g)].cuda()
+    mean, y, per_row = hip.softmax_xent(logits, labels, want_rows=True)
+    ld = logits.double()
+    ref_y = torch.softmax(ld, 1)
+    ref_rows = -(labels.double() * torch.log_softmax(ld, 1)).sum(1)
+    assert torch.allclose(y.double(), ref_y, atol=1e-6)
+    assert torch.allclose(per_row.double(), ref_rows, atol=1e-5)
+    assert abs(mean.item() - ref_rows.mean().item()) < 1e-5
+    assert torch.allclose(hip.softmax_rows(logits).double(), ref_y, atol=1e-6)
+    assert torch.allclose(hip.softmax_rows(logits, log=True).double(), torch.log_softmax(ld, 1),
+                          atol=1e-5)
+    if cols <= 64:
+        dloss = torch.tensor(1.0).cuda()
+        dz, db = hip.softmax_xent_grad(y, labels, dloss)
+        ref_dz = (ref_y - labels.double()) / rows
+        assert torch.allclose(dz.double(), ref_dz, atol=1e-7)
+        assert torch.allclose(db.double(), ref_dz.sum(0), atol=1e-6)
+    dy = torch.randn(rows, cols, generator=g).cuda()
+    ref_dx = (dy.double() - (dy.double() * ref_y).sum(1, keepdim=True)) * ref_y
+    assert torch.allclose(hip.softmax_grad(y, dy).double(), ref_dx, atol=1e-5)
+
+
+def test_sigmoid_grad_bias_and_accuracy(hip):
+    g = torch.Generator().manual_seed(8)
+    da = torch.randn(100, 100, generator=g).cuda()
+    a = torch.sigmoid(torch.randn(100, 100, generator=g)).cuda()
+    dz, db = hip.sigmoid_grad_bias(da, a)
+    ref = da.double() * a.double() * (1 - a.double())
+    assert torch.allclose(dz.double(), ref, atol=1e-7)
+    assert torch.allclose(db.double(), ref.sum(0), atol=1e-5)
+    y = torch.randn(10000, 10, generator=g).cuda()
+    lab = torch.eye(10)[torch.randint(0, 10, (10000,), generator=g)].cuda()
+    ref_acc = (y.argmax(1) == lab.argmax(1)).float().mean().item()
+    assert abs(hip.argmax_accuracy(y, lab).item() - ref_acc) < 1e-6
+
+
+def test_multi_sgd(hip):
+    g = torch.Generator().manual_seed(6)
+    shapes = [(784, 100), (100,), (100, 10), (10,)] + [(17,)] * 15
+    ps = [torch.randn(*s, generator=g).cuda() for s in shapes]
+    gs = [torch.randn(*s, generator=g).cuda() for s in shapes]
+    ref = [p - 0.0005 * q for p, q in zip(ps, gs)]
+    step = torch.zeros((), device="cuda")
+    hip.multi_sgd(ps, gs, [0.0005] * len(ps), [step], [1.0])
+    for p, r in zip(ps, ref):
+        assert torch.allclose(p, r, atol=1e-7)
+    assert step.item() == 1.0
+
+
+def test_philox_matches_host_stream(hip):
+    from distributed_tensorflow_amd.ops import philox
+    n = 10007
+    dev = hip.philox_normal((n,), seed=1, op_seed=5, device="cuda").cpu().numpy()
+    host = philox.normal(n, 1, 5)
+    assert np.abs(dev - host).max() < 1e-4
+    assert abs(dev.mean()) < 0.05 and abs(dev.std() - 1) < 0.05
+    # any shard of the stream can be generated independently
+    shard = hip.philox_normal((1000,), seed=1, op_seed=5, device="cuda", offset=4321).cpu().numpy()
+    assert np.array_equal(shard, dev[4321:5321])
+    again = hip.philox_normal((n,), seed=1, op_seed=5, device="cuda").cpu().numpy()
+    assert np.array_equal(dev, again)
+    u = hip.philox_uniform((n,), seed=3, op_seed=9, minval=-1, maxval=1, device="cuda").cpu().numpy()
+    assert np.abs(u - (philox.uniform(n, 3, 9) * 2 - 1)).max() < 1e-6
+    assert u.min() > -1 and u.max() < 1

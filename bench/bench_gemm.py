@@ -35,6 +35,7 @@ def main() -> None:
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--no-torch", action="store_true")
+    ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     rows = []
@@ -45,7 +46,7 @@ def main() -> None:
             a = (torch.rand(m, k, device="cuda") * 2 - 1).bfloat16()
             bt = (torch.rand(n, k, device="cuda") * 2 - 1).bfloat16()
             out = torch.empty(m, n, device="cuda", dtype=torch.bfloat16)
-            ours = timeit(lambda: hip.gemm_bf16_nt(a, bt, torch.bfloat16, out=out), args.iters)
+            ours = timeit(lambda: hip.gemm_bf16_nt(a, bt, torch.bfloat16, out=out, variant=args.variant), args.iters)
             ref = None if args.no_torch else timeit(lambda: torch.matmul(a, bt.t()), args.iters)
             if n <= 4096:
                 err = (out.float() - a.float() @ bt.float().t()).abs().max().item()
@@ -58,7 +59,7 @@ def main() -> None:
             ours = timeit(lambda: hip.gemm_f32(a, b, out=out), args.iters)
             ref = None if args.no_torch else timeit(lambda: torch.matmul(a, b), args.iters)
             err = (out[:128].double() - a[:128].double() @ b.double()).abs().max().item()
-        row = {"dtype": args.dtype, "n": n, "ms": round(ours, 4),
+        row = {"dtype": args.dtype, "variant": args.variant, "n": n, "ms": round(ours, 4),
                "tflops": round(flops / ours / 1e9, 1), "max_err": err}
         if ref is not None:
             row["torch_ms"] = round(ref, 4)

@@ -152,6 +152,187 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_nt_kernel(
   }
 }
 
+// ---- quadrant-phased, group-staggered kernel ("ping-pong") -----------------------------------
+// Same tile, LDS image, MFMA and epilogue as the kernel above; what changes is the schedule.
+//  * A K-tile is four 16 KiB half-tiles (A rows 0-127 / 128-255, Bt rows 0-127 / 128-255). A
+//    wave's 128x64 output is interleaved so that all eight waves work on the SAME block
+//    quadrant at the same time: rows {wr*64 + [0,64)} and {128 + wr*64 + [0,64)}, columns
+//    {wc*32 + [0,32)} and {128 + wc*32 + [0,32)}. Quadrant (mh, nh) therefore reads only
+//    half-tiles A_mh and B_nh.
+//  * A K-tile is four phases, quadrants (0,0) (0,1) (1,1) (1,0): each phase keeps one
+//    operand's fragments in registers from the phase before (both Bt halves stay resident for
+//    the whole K-tile), so the phases read 12 / 4 / 8 / 0 fragments from LDS and each runs 16
+//    MFMAs. A half-tile's LDS slot is dead as soon as its fragments are in registers, which
+//    lets the LDS-DMA stream run six half-tiles (1.5 K-tiles) ahead in just two K-tile buffers:
+//    phase g issues half-tile g+6 and waits with a COUNTED s_waitcnt vmcnt(8) (four half-tiles
+//    stay in flight across every barrier; the loop never drains to zero).
+//  * Waves 4-7 (wr = 1; the partner of waves 0-3 on each SIMD) run one barrier behind waves
+//    0-3. Each phase is [LDS reads + DMA issue] barrier [16 MFMAs] barrier, so while one wave
+//    of a SIMD is in its MFMA segment its partner is in its load segment: the matrix pipe
+//    always has a feeder, and the loads of one group hide under the MFMAs of the other.
+//  * Hazards: a staged half-tile is read one full phase (two barriers) after the vmcnt that
+//    retired it, and a slot is restaged at least two phases after its last read.
+__device__ __forceinline__ void stage_half(const unsigned short* __restrict__ A,
+                                           const unsigned short* __restrict__ Bt, long lda,
+                                           long ldb, int m0, int n0, int M, int N, int h, int nkt,
+                                           int kind, int buf, char* smem, int wave, int lane) {
+  int t = h >> 2;
+  t = t < nkt ? t : nkt - 1;        // past the end: restage a dead slot with valid memory
+  const int k0 = t * BK;
+  const bool is_a = (kind == 0 || kind == 3);
+  const int half = (kind >= 2) ? 1 : 0;
+  const unsigned short* X = is_a ? A : Bt;
+  const long ld = is_a ? lda : ldb;
+  const int base_row = (is_a ? m0 : n0) + half * 128;
+  const int max_row = (is_a ? M : N) - 1;
+  char* dst = smem + buf * BUF_BYTES + (is_a ? 0 : TILE_BYTES) + half * (TILE_BYTES / 2);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int piece = wave * 2 + j;               // 16 pieces of 8 rows per half-tile
+    int row = base_row + piece * 8 + (lane & 7);
+    row = row < max_row ? row : max_row;
+    const unsigned short* src = X + (long)row * ld + k0 + (lane >> 3) * 8;
+    __builtin_amdgcn_global_load_lds((global_void*)src, (lds_void*)(dst + piece * 1024), 16, 0, 0);
+  }
+}
+
+template <bool OUT_F32>
+__global__ __launch_bounds__(NTHREADS) void gemm_bf16_nt_pp_kernel(
+    const unsigned short* __restrict__ A, const unsigned short* __restrict__ Bt,
+    void* __restrict__ C, int M, int N, int K, long lda, long ldb, long ldc, int tiles_m,
+    int tiles_n, float alpha) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  const int ntiles = tiles_m * tiles_n;
+  const int id = dtf_xcd_remap(blockIdx.x, ntiles);
+  constexpr int GROUP = 8;
+  const int per_group = GROUP * tiles_n;
+  const int grp = id / per_group;
+  const int first_m = grp * GROUP;
+  const int gsize = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
+  const int tm = first_m + (id % per_group) % gsize;
+  const int tn = (id % per_group) / gsize;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int nkt = K / BK;
+
+  f32x4 acc[2][2][4][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 af[4][2];        // [m-tile][k-step] of the current A half
+  bf16x8 bf[2][2][2];     // [n-half][n-tile][k-step]: both Bt halves stay resident
+
+  const int frow = lane & 15, fq = lane >> 4;
+  // per-lane part of chunk_off(); the wave-uniform / compile-time parts are added per read
+  const int lane_off = (((frow >> 3) * 64) + fq * 8 + (frow & 7)) * 16;
+  const int a_wave = (wr * 4) * 2048;                  // wave's first 16-row block in an A half
+  const int b_wave = TILE_BYTES + (wc * 2) * 2048;     // ... in a Bt half
+
+  // prologue: half-tiles 0..5 in flight, 0 and 1 landed and visible
+#pragma unroll
+  for (int h = 0; h < 6; ++h)
+    stage_half(A, Bt, lda, ldb, m0, n0, M, N, h, nkt, h & 3, (h >> 2) & 1, smem, wave, lane);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();          // waves 4-7 run one barrier behind
+
+#define DTF_READ_A(MH, BUFI)                                                                     \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) \
+      af[i][s2] = *reinterpret_cast<const bf16x8*>(smem + (BUFI) * BUF_BYTES + (MH) * 16384 +    \
+                                                   a_wave + i * 2048 + s2 * 512 + lane_off);
+#define DTF_READ_B(NH, BUFI)                                                                     \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) \
+      bf[NH][j][s2] = *reinterpret_cast<const bf16x8*>(smem + (BUFI) * BUF_BYTES + (NH) * 16384 + \
+                                                       b_wave + j * 2048 + s2 * 512 + lane_off);
+#define DTF_MFMA_QUAD(MH, NH)                                                                    \
+  _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) _Pragma("unroll") for (int i = 0; i < 4; ++i) \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[MH][NH][i][j] =                          \
+          __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[NH][j][s2], af[i][s2], acc[MH][NH][i][j],   \
+                                                  0, 0, 0);
+// phase P (0..7) of an iteration that starts at global phase g0: LDS reads, DMA issue of
+// half-tile g0+P+6, counted wait, barrier, 16 MFMAs, barrier
+#define DTF_PHASE(P, READS, MH, NH)                                                              \
+  {                                                                                              \
+    READS;                                                                                       \
+    stage_half(A, Bt, lda, ldb, m0, n0, M, N, g0 + (P) + 6, nkt, ((P) + 2) & 3,                  \
+               (((P) + 6) >> 2) & 1, smem, wave, lane);                                          \
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    __builtin_amdgcn_s_barrier();                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    __builtin_amdgcn_s_setprio(1);                                                               \
+    DTF_MFMA_QUAD(MH, NH)                                                                        \
+    __builtin_amdgcn_s_setprio(0);                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    __builtin_amdgcn_s_barrier();                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+  }
+
+  int g0 = 0;
+  for (int it = 0; it < nkt / 2; ++it, g0 += 8) {
+    DTF_PHASE(0, DTF_READ_B(0, 0) DTF_READ_A(0, 0), 0, 0)
+    DTF_PHASE(1, DTF_READ_B(1, 0), 0, 1)
+    DTF_PHASE(2, DTF_READ_A(1, 0), 1, 1)
+    DTF_PHASE(3, , 1, 0)
+    DTF_PHASE(4, DTF_READ_B(0, 1) DTF_READ_A(0, 1), 0, 0)
+    DTF_PHASE(5, DTF_READ_B(1, 1), 0, 1)
+    DTF_PHASE(6, DTF_READ_A(1, 1), 1, 1)
+    DTF_PHASE(7, , 1, 0)
+  }
+  if (nkt & 1) {   // odd K-tile count: the last K-tile has an even index -> buffer 0
+    DTF_PHASE(0, DTF_READ_B(0, 0) DTF_READ_A(0, 0), 0, 0)
+    DTF_PHASE(1, DTF_READ_B(1, 0), 0, 1)
+    DTF_PHASE(2, DTF_READ_A(1, 0), 1, 1)
+    DTF_PHASE(3, , 1, 0)
+  }
+#undef DTF_PHASE
+#undef DTF_MFMA_QUAD
+#undef DTF_READ_A
+#undef DTF_READ_B
+  if (wr == 0) __builtin_amdgcn_s_barrier();          // every wave has passed the same count
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // no LDS-DMA may outlive the workgroup
+
+  // epilogue: lane holds C[row = frow][col = 4*fq + r] of each 16x16 tile
+#pragma unroll
+  for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = m0 + mh * 128 + wr * 64 + i * 16 + frow;
+      if (row >= M) continue;
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int col = n0 + nh * 128 + wc * 32 + j * 16 + 4 * fq;
+          if (col >= N) continue;
+          f32x4 v = acc[mh][nh][i][j] * alpha;
+          if (OUT_F32) {
+            float* dst = reinterpret_cast<float*>(C) + (long)row * ldc + col;
+            if (col + 3 < N) *reinterpret_cast<f32x4*>(dst) = v;
+            else for (int r = 0; r < 4 && col + r < N; ++r) dst[r] = v[r];
+          } else {
+            unsigned short* dst = reinterpret_cast<unsigned short*>(C) + (long)row * ldc + col;
+            if (col + 3 < N) {
+              bf16x4 o;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) o[r] = (short)dtf_f32_to_bf16(v[r]);
+              *reinterpret_cast<bf16x4*>(dst) = o;
+            } else {
+              for (int r = 0; r < 4 && col + r < N; ++r) dst[r] = dtf_f32_to_bf16(v[r]);
+            }
+          }
+        }
+    }
+}
+
 // ---- generic, fully predicated bf16 GEMM (any shape, NN / NT / TN / TT via strides) -------------
 // C[m,n] = alpha * sum_k A(m,k) * B(k,n), A(m,k) = A[m*a_rs + k*a_cs], B(k,n) = B[k*b_rs + n*b_cs]
 constexpr int GB = 64, GK = 32;
@@ -218,8 +399,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_generic_kernel(
 // kernel: K % 64 == 0, lda/ldb % 8 == 0, 16-byte aligned A/Bt, ldc % 4 == 0 and 16-byte
 // (fp32) / 8-byte (bf16) aligned C. Returns DTF_ERR_UNSUPPORTED otherwise (callers then use
 // dtf_gemm_bf16_generic).
+// variant: 0 = default (ping-pong schedule), 1 = two-phase double-buffer, 2 = ping-pong.
 DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int N, int K, long lda,
-                             long ldb, long ldc, float alpha, int out_f32, hipStream_t stream) {
+                             long ldb, long ldc, float alpha, int out_f32, int variant,
+                             hipStream_t stream) {
   if (!A || !Bt || !C || M <= 0 || N <= 0 || K <= 0) return DTF_ERR_BAD_ARG;
   if (lda < K || ldb < K || ldc < N) return DTF_ERR_BAD_ARG;
   if (K % BK || lda % 8 || ldb % 8 || ldc % 4 || ((uintptr_t)A & 15) || ((uintptr_t)Bt & 15) ||
@@ -233,9 +416,25 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<false>,
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)gemm_bf16_nt_pp_kernel<true>,
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)gemm_bf16_nt_pp_kernel<false>,
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   dim3 grid(tiles_m * tiles_n), block(NTHREADS);
+  if (variant != 1) {
+    if (out_f32)
+      hipLaunchKernelGGL(gemm_bf16_nt_pp_kernel<true>, grid, block, lds, stream,
+                         (const unsigned short*)A, (const unsigned short*)Bt, C, M, N, K, lda, ldb,
+                         ldc, tiles_m, tiles_n, alpha);
+    else
+      hipLaunchKernelGGL(gemm_bf16_nt_pp_kernel<false>, grid, block, lds, stream,
+                         (const unsigned short*)A, (const unsigned short*)Bt, C, M, N, K, lda, ldb,
+                         ldc, tiles_m, tiles_n, alpha);
+    DTF_LAUNCH_CHECK();
+    return DTF_OK;
+  }
   if (out_f32)
     hipLaunchKernelGGL(gemm_bf16_nt_kernel<true>, grid, block, lds, stream,
                        (const unsigned short*)A, (const unsigned short*)Bt, C, M, N, K, lda, ldb,

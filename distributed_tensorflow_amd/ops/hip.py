@@ -59,7 +59,7 @@ def _declare(L: ctypes.CDLL) -> None:
     P, I, LG, F, U = c.c_void_p, c.c_int, c.c_long, c.c_float, c.c_uint
     sigs = {
         "dtf_gemm_f32": [P, P, P, P, I, I, I, LG, LG, LG, I, I, I, P],
-        "dtf_gemm_bf16_nt": [P, P, P, I, I, I, LG, LG, LG, F, I, P],
+        "dtf_gemm_bf16_nt": [P, P, P, I, I, I, LG, LG, LG, F, I, I, P],
         "dtf_gemm_bf16_generic": [P, P, P, I, I, I, LG, LG, LG, LG, LG, F, I, P],
         "dtf_binary_f32": [I, P, P, P, LG, LG, LG, P],
         "dtf_unary_f32": [I, P, P, LG, P],
@@ -163,7 +163,8 @@ def gemm_f32(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: b
 
 
 def gemm_bf16_nt(a: torch.Tensor, bt: torch.Tensor, out_dtype: torch.dtype = torch.bfloat16,
-                 alpha: float = 1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 alpha: float = 1.0, out: Optional[torch.Tensor] = None,
+                 variant: int = 0) -> torch.Tensor:
     """``alpha * a @ bt.T`` with a [M,K], bt [N,K] bf16 (both K-contiguous); fp32 accumulate;
     result bf16 or fp32. Uses the 256x256x64 LDS-DMA kernel when the shape qualifies and the
     predicated generic kernel otherwise."""
@@ -187,7 +188,7 @@ def gemm_bf16_nt(a: torch.Tensor, bt: torch.Tensor, out_dtype: torch.dtype = tor
     out_f32 = int(out_dtype == torch.float32)
     code = lib().dtf_gemm_bf16_nt(a.data_ptr(), bt.data_ptr(), out.data_ptr(), m, n, k,
                                   a.stride(0), bt.stride(0), out.stride(0), float(alpha), out_f32,
-                                  _stream())
+                                  int(variant), _stream())
     if code == -2:    # shape/alignment outside the fast kernel's contract
         code = lib().dtf_gemm_bf16_generic(a.data_ptr(), bt.data_ptr(), out.data_ptr(), m, n, k,
                                            a.stride(0), 1, 1, bt.stride(0), out.stride(0),

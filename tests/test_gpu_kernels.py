@@ -73,37 +73,48 @@ def test_gemm_f32_bias_activation(hip, act):
     assert (out.double() - ref).abs().max().item() < 2e-5
 
 
+@pytest.mark.parametrize("variant", [1, 2])
 @pytest.mark.parametrize("m,n,k", [(256, 256, 64), (512, 768, 256), (1024, 1024, 1024),
-                                   (300, 520, 128), (2048, 256, 4096)])
+                                   (300, 520, 128), (2048, 256, 4096), (256, 512, 192),
+                                   (1, 1, 64), (257, 255, 320)])
 @pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
-def test_gemm_bf16_nt_fast(hip, m, n, k, out_dtype):
+def test_gemm_bf16_nt_fast(hip, m, n, k, out_dtype, variant):
     g = torch.Generator().manual_seed(m + n + k)
     a = torch.randn(m, k, generator=g).bfloat16().cuda()
     bt = torch.randn(n, k, generator=g).bfloat16().cuda()
-    c = hip.gemm_bf16_nt(a, bt, out_dtype)
+    c = hip.gemm_bf16_nt(a, bt, out_dtype, variant=variant)
     ref = a.double().cpu() @ bt.double().cpu().t()
     tol = (0.02 if out_dtype == torch.bfloat16 else 1e-3) * (k ** 0.5) + 1e-3
     err = (c.double().cpu() - ref).abs().max().item()
     assert err < tol, (err, tol)
 
 
-def test_gemm_bf16_nt_exact_integers(hip):
-    """Exact small-integer data: any fragment-layout or staging bug shows as a wrong integer."""
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("m,n,k", [(512, 768, 256), (768, 512, 1344), (4096, 4096, 2048)])
+def test_gemm_bf16_nt_exact_integers(hip, variant, m, n, k):
+    """Exact small-integer data: any fragment-layout, staging or pipeline-hazard bug shows as
+    a wrong integer (every output element is checked, bit for bit)."""
     g = torch.Generator().manual_seed(3)
-    a = torch.randint(-3, 4, (512, 256), generator=g).float()
-    bt = torch.randint(-3, 4, (768, 256), generator=g).float()
-    c = hip.gemm_bf16_nt(a.bfloat16().cuda(), bt.bfloat16().cuda(), torch.float32)
-    assert torch.equal(c.cpu(), a @ bt.t())
+    a = torch.randint(-3, 4, (m, k), generator=g).float()
+    bt = torch.randint(-3, 4, (n, k), generator=g).float()
+    ref = (a.cuda() @ bt.cuda().t())                 # exact in fp32: |sum| < 2^24
+    for _ in range(3):                               # repeated launches: race screen
+        c = hip.gemm_bf16_nt(a.bfloat16().cuda(), bt.bfloat16().cuda(), torch.float32,
+                             variant=variant)
+        assert torch.equal(c, ref)
 
 
 def test_gemm_bf16_identity_asymmetric(hip):
     n = 512
     b = ((torch.arange(n * n).reshape(n, n) % 13) - 6).float()
     eye = torch.eye(n)
-    c = hip.gemm_bf16_nt(eye.bfloat16().cuda(), b.t().contiguous().bfloat16().cuda(), torch.float32)
-    assert torch.equal(c.cpu(), b)
-    c2 = hip.gemm_bf16_nt(b.bfloat16().cuda(), eye.bfloat16().cuda(), torch.float32)
-    assert torch.equal(c2.cpu(), b)
+    for variant in (1, 2):
+        c = hip.gemm_bf16_nt(eye.bfloat16().cuda(), b.t().contiguous().bfloat16().cuda(),
+                             torch.float32, variant=variant)
+        assert torch.equal(c.cpu(), b)
+        c2 = hip.gemm_bf16_nt(b.bfloat16().cuda(), eye.bfloat16().cuda(), torch.float32,
+                              variant=variant)
+        assert torch.equal(c2.cpu(), b)
 
 
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])

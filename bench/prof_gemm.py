@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Tiny driver for rocprofv3: run one GEMM kernel variant a few times and exit."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from distributed_tensorflow_amd.ops import hip  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--n", type=int, default=8192)
+ap.add_argument("--dtype", default="bf16")
+ap.add_argument("--variant", type=int, default=0)
+ap.add_argument("--iters", type=int, default=5)
+args = ap.parse_args()
+n = args.n
+if args.dtype == "bf16":
+    a = (torch.rand(n, n, device="cuda") * 2 - 1).bfloat16()
+    bt = (torch.rand(n, n, device="cuda") * 2 - 1).bfloat16()
+    out = torch.empty(n, n, device="cuda", dtype=torch.bfloat16)
+    for _ in range(args.iters):
+        hip.gemm_bf16_nt(a, bt, torch.bfloat16, out=out, variant=args.variant)
+else:
+    a = torch.rand(n, n, device="cuda") * 2 - 1
+    b = torch.rand(n, n, device="cuda") * 2 - 1
+    out = torch.empty(n, n, device="cuda")
+    for _ in range(args.iters):
+        hip.gemm_f32(a, b, out=out)
+torch.cuda.synchronize()
+print("done")

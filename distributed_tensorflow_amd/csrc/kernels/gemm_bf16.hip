@@ -9,12 +9,16 @@
 //  * global -> LDS by LDS-DMA (global_load_lds_dwordx4): no VGPR staging, two LDS buffers
 //    (2 x 64 KiB), the loads of K-tile t+1 are in flight while the MFMAs of tile t run; one
 //    barrier per K-tile.
-//  * LDS image: the tile is cut into 16-row x 64-k blocks of 2 KiB; inside a block the 16-byte
-//    chunk (row r, k-chunk c) sits at chunk index (r/8)*64 + c*8 + r%8. One LDS-DMA
-//    wave-instruction therefore fetches 8 rows x 128 B (whole cache lines), and a fragment
-//    read -- lane l takes row l&15, k-chunk 4s + (l>>4) -- touches 16 distinct 16-byte slots
-//    of the 256-byte bank row in every 16-lane ds_read_b128 group: conflict-free without
-//    padding (which LDS-DMA's lane-linear destination could not express anyway).
+//  * LDS image: row-major tile rows of 128 B (64 k), with the eight 16-byte chunks of row r
+//    XOR-permuted: chunk c sits at position c ^ ((r >> 1) & 7). LDS-DMA writes lane-linearly
+//    (wave base + lane * 16), so the permutation is applied to each lane's global SOURCE
+//    address: lane i of a 1 KiB piece fetches row i/8, chunk (i%8) ^ swizzle -- consecutive
+//    lanes read consecutive-or-permuted chunks of one 128-byte line, so every quad of lanes
+//    stays inside one 64-byte segment (an earlier image that put consecutive lanes on
+//    consecutive ROWS was conflict-free too but cost ~4x the address-coalescer time per
+//    instruction and capped the kernel at 1.15 PF). A fragment read -- lane l takes row l&15,
+//    chunk 4s + (l>>4) -- then hits 16 distinct 16-byte slots of the 256-byte bank row in
+//    every 16-lane ds_read_b128 group: conflict-free (SQ_LDS_BANK_CONFLICT = 0).
 //  * MFMA v_mfma_f32_16x16x32_bf16 with the operands swapped (Bt fragment as the instruction's
 //    A operand, A fragment as its B operand): the accumulator then holds, per lane, four
 //    consecutive n of one row m, so the epilogue issues 8-byte (bf16) / 16-byte (fp32) row
@@ -42,20 +46,23 @@ constexpr int MT = WM / 16, NT = WN / 16;        // 8 x 4 MFMA tiles per wave
 
 // byte offset inside an operand tile of the 16-byte chunk (row, kc): see the header comment
 __device__ __forceinline__ int chunk_off(int row, int kc) {
-  return (row >> 4) * 2048 + ((((row >> 3) & 1) * 64) + kc * 8 + (row & 7)) * 16;
+  return row * 128 + ((kc ^ ((row >> 1) & 7)) << 4);
 }
 
 // Issue this wave's share of one operand tile: 4 LDS-DMA instructions of 1 KiB each.
-// Piece c (0..31) covers rows 8c..8c+7, all 8 k-chunks; lane i -> (row 8c + i%8, chunk i/8).
+// Piece c (0..31) covers rows 8c..8c+7; lane i lands at byte 16*i of the piece, i.e. row
+// 8c + i/8, position i%8, and therefore fetches chunk (i%8) ^ swizzle(row) of that row.
 __device__ __forceinline__ void stage_tile(const unsigned short* __restrict__ X, long ld, int row0,
                                            int max_row, int k0, char* lds_tile, int wave,
                                            int lane) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int piece = wave * 4 + j;
-    int row = row0 + piece * 8 + (lane & 7);
+    const int trow = piece * 8 + (lane >> 3);     // tile-relative row
+    int row = row0 + trow;
     row = row < max_row ? row : max_row;          // clamp: edge tiles re-read the last row
-    const unsigned short* src = X + (long)row * ld + k0 + (lane >> 3) * 8;
+    const int kc = (lane & 7) ^ ((trow >> 1) & 7);
+    const unsigned short* src = X + (long)row * ld + k0 + kc * 8;
     __builtin_amdgcn_global_load_lds((global_void*)src, (lds_void*)(lds_tile + piece * 1024), 16,
                                      0, 0);
   }
@@ -189,9 +196,11 @@ __device__ __forceinline__ void stage_half(const unsigned short* __restrict__ A,
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int piece = wave * 2 + j;               // 16 pieces of 8 rows per half-tile
-    int row = base_row + piece * 8 + (lane & 7);
+    const int trow = piece * 8 + (lane >> 3);     // row inside the half-tile (128 = 0 mod 16)
+    int row = base_row + trow;
     row = row < max_row ? row : max_row;
-    const unsigned short* src = X + (long)row * ld + k0 + (lane >> 3) * 8;
+    const int kc = (lane & 7) ^ ((trow >> 1) & 7);
+    const unsigned short* src = X + (long)row * ld + k0 + kc * 8;
     __builtin_amdgcn_global_load_lds((global_void*)src, (lds_void*)(dst + piece * 1024), 16, 0, 0);
   }
 }
@@ -200,7 +209,9 @@ template <bool OUT_F32>
 __global__ __launch_bounds__(NTHREADS) void gemm_bf16_nt_pp_kernel(
     const unsigned short* __restrict__ A, const unsigned short* __restrict__ Bt,
     void* __restrict__ C, int M, int N, int K, long lda, long ldb, long ldc, int tiles_m,
-    int tiles_n, float alpha) {
+    int tiles_n, float alpha, int dbg) {
+  // dbg (timing experiments only; results are wrong when set): bit 0 = issue no LDS-DMA in the
+  // K-loop, bit 1 = always stage K-tile 0 (every load an L2 hit), bit 2 = skip the counted wait
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -231,8 +242,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_nt_pp_kernel(
   bf16x8 bf[2][2][2];     // [n-half][n-tile][k-step]: both Bt halves stay resident
 
   const int frow = lane & 15, fq = lane >> 4;
-  // per-lane part of chunk_off(); the wave-uniform / compile-time parts are added per read
-  const int lane_off = (((frow >> 3) * 64) + fq * 8 + (frow & 7)) * 16;
+  // per-lane part of chunk_off() for k-step 0 / 1 (the XOR makes them differ by +-64 B); the
+  // wave-uniform and compile-time parts are added per read
+  const int lane_off0 = chunk_off(frow, fq), lane_off1 = chunk_off(frow, 4 + fq);
   const int a_wave = (wr * 4) * 2048;                  // wave's first 16-row block in an A half
   const int b_wave = TILE_BYTES + (wc * 2) * 2048;     // ... in a Bt half
 
@@ -247,11 +259,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_nt_pp_kernel(
 #define DTF_READ_A(MH, BUFI)                                                                     \
   _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) \
       af[i][s2] = *reinterpret_cast<const bf16x8*>(smem + (BUFI) * BUF_BYTES + (MH) * 16384 +    \
-                                                   a_wave + i * 2048 + s2 * 512 + lane_off);
+                                                   a_wave + i * 2048 +                          \
+                                                   (s2 ? lane_off1 : lane_off0));
 #define DTF_READ_B(NH, BUFI)                                                                     \
   _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) \
       bf[NH][j][s2] = *reinterpret_cast<const bf16x8*>(smem + (BUFI) * BUF_BYTES + (NH) * 16384 + \
-                                                       b_wave + j * 2048 + s2 * 512 + lane_off);
+                                                       b_wave + j * 2048 +                      \
+                                                       (s2 ? lane_off1 : lane_off0));
 #define DTF_MFMA_QUAD(MH, NH)                                                                    \
   _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) _Pragma("unroll") for (int i = 0; i < 4; ++i) \
       _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[MH][NH][i][j] =                          \
@@ -262,9 +276,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_nt_pp_kernel(
 #define DTF_PHASE(P, READS, MH, NH)                                                              \
   {                                                                                              \
     READS;                                                                                       \
-    stage_half(A, Bt, lda, ldb, m0, n0, M, N, g0 + (P) + 6, nkt, ((P) + 2) & 3,                  \
-               (((P) + 6) >> 2) & 1, smem, wave, lane);                                          \
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                             \
+    if (!(dbg & 1))                                                                              \
+      stage_half(A, Bt, lda, ldb, m0, n0, M, N, (dbg & 2) ? 0 : g0 + (P) + 6, nkt,               \
+                 ((P) + 2) & 3, (((P) + 6) >> 2) & 1, smem, wave, lane);                         \
+    if (!(dbg & 4)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                             \
     __builtin_amdgcn_sched_barrier(0);                                                           \
     __builtin_amdgcn_s_barrier();                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                           \
@@ -399,7 +414,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_generic_kernel(
 // kernel: K % 64 == 0, lda/ldb % 8 == 0, 16-byte aligned A/Bt, ldc % 4 == 0 and 16-byte
 // (fp32) / 8-byte (bf16) aligned C. Returns DTF_ERR_UNSUPPORTED otherwise (callers then use
 // dtf_gemm_bf16_generic).
-// variant: 0 = default (ping-pong schedule), 1 = two-phase double-buffer, 2 = ping-pong.
+// variant & 15: 0 = default (ping-pong schedule), 1 = two-phase double-buffer, 2 = ping-pong;
+// variant >> 4: timing-experiment bits of the ping-pong kernel (0 in production).
 DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int N, int K, long lda,
                              long ldb, long ldc, float alpha, int out_f32, int variant,
                              hipStream_t stream) {
@@ -423,15 +439,15 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
     attr_set = true;
   }
   dim3 grid(tiles_m * tiles_n), block(NTHREADS);
-  if (variant != 1) {
+  if ((variant & 15) != 1) {
     if (out_f32)
       hipLaunchKernelGGL(gemm_bf16_nt_pp_kernel<true>, grid, block, lds, stream,
                          (const unsigned short*)A, (const unsigned short*)Bt, C, M, N, K, lda, ldb,
-                         ldc, tiles_m, tiles_n, alpha);
+                         ldc, tiles_m, tiles_n, alpha, variant >> 4);
     else
       hipLaunchKernelGGL(gemm_bf16_nt_pp_kernel<false>, grid, block, lds, stream,
                          (const unsigned short*)A, (const unsigned short*)Bt, C, M, N, K, lda, ldb,
-                         ldc, tiles_m, tiles_n, alpha);
+                         ldc, tiles_m, tiles_n, alpha, variant >> 4);
     DTF_LAUNCH_CHECK();
     return DTF_OK;
   }

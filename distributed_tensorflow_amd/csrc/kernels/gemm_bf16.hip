@@ -205,13 +205,15 @@ __device__ __forceinline__ void stage_half(const unsigned short* __restrict__ A,
   }
 }
 
-template <bool OUT_F32>
+template <bool OUT_F32, int DBG>
 __global__ __launch_bounds__(NTHREADS) void gemm_bf16_nt_pp_kernel(
     const unsigned short* __restrict__ A, const unsigned short* __restrict__ Bt,
     void* __restrict__ C, int M, int N, int K, long lda, long ldb, long ldc, int tiles_m,
-    int tiles_n, float alpha, int dbg) {
-  // dbg (timing experiments only; results are wrong when set): bit 0 = issue no LDS-DMA in the
-  // K-loop, bit 1 = always stage K-tile 0 (every load an L2 hit), bit 2 = skip the counted wait
+    int tiles_n, float alpha) {
+  // DBG (timing experiments only, built with -DDTF_GEMM_EXPERIMENTS; results are wrong when
+  // set): bit 0 = issue no LDS-DMA in the K-loop, bit 1 = always stage K-tile 0 (every load an
+  // L2 hit), bit 2 = skip the counted wait
+  constexpr int dbg = DBG;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -432,22 +434,37 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<false>,
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipFuncSetAttribute((const void*)gemm_bf16_nt_pp_kernel<true>,
+    hipFuncSetAttribute((const void*)gemm_bf16_nt_pp_kernel<true, 0>,
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipFuncSetAttribute((const void*)gemm_bf16_nt_pp_kernel<false>,
+    hipFuncSetAttribute((const void*)gemm_bf16_nt_pp_kernel<false, 0>,
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+#ifdef DTF_GEMM_EXPERIMENTS
+    hipFuncSetAttribute((const void*)gemm_bf16_nt_pp_kernel<false, 1>,
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)gemm_bf16_nt_pp_kernel<false, 2>,
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)gemm_bf16_nt_pp_kernel<false, 4>,
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+#endif
     attr_set = true;
   }
   dim3 grid(tiles_m * tiles_n), block(NTHREADS);
   if ((variant & 15) != 1) {
-    if (out_f32)
-      hipLaunchKernelGGL(gemm_bf16_nt_pp_kernel<true>, grid, block, lds, stream,
-                         (const unsigned short*)A, (const unsigned short*)Bt, C, M, N, K, lda, ldb,
-                         ldc, tiles_m, tiles_n, alpha, variant >> 4);
-    else
-      hipLaunchKernelGGL(gemm_bf16_nt_pp_kernel<false>, grid, block, lds, stream,
-                         (const unsigned short*)A, (const unsigned short*)Bt, C, M, N, K, lda, ldb,
-                         ldc, tiles_m, tiles_n, alpha, variant >> 4);
+#define DTF_PP_LAUNCH(F32, DBGV)                                                                  \
+  hipLaunchKernelGGL((gemm_bf16_nt_pp_kernel<F32, DBGV>), grid, block, lds, stream,               \
+                     (const unsigned short*)A, (const unsigned short*)Bt, C, M, N, K, lda, ldb,   \
+                     ldc, tiles_m, tiles_n, alpha)
+    const int dbg = variant >> 4;
+    if (dbg == 0) {
+      if (out_f32) DTF_PP_LAUNCH(true, 0); else DTF_PP_LAUNCH(false, 0);
+    }
+#ifdef DTF_GEMM_EXPERIMENTS
+    else if (dbg == 1) DTF_PP_LAUNCH(false, 1);
+    else if (dbg == 2) DTF_PP_LAUNCH(false, 2);
+    else if (dbg == 4) DTF_PP_LAUNCH(false, 4);
+#endif
+    else return DTF_ERR_UNSUPPORTED;
+#undef DTF_PP_LAUNCH
     DTF_LAUNCH_CHECK();
     return DTF_OK;
   }

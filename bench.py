@@ -1,0 +1,155 @@
+#!/usr/bin/env python3
+"""Headline benchmark: sharded GEMM TFLOP/s (whole job) and step latency on N MI355X.
+
+Workload: ``C = A @ B`` with A, B 16384 x 16384 bf16 (synthetic: counter-based Philox
+U(-1,1) generated in place on each rank), fp32 accumulation on the hand-written MFMA kernel,
+result bf16 materialised in full on every rank. One *step* = one complete product including
+its collectives -- the analogue of one ``sess.run(C)`` of the reference's matmul script
+(``tf_distributed_1000Matrix.py:48,74``), at the 16384^3 bf16 size of the sharded-GEMM
+configuration. Total work is fixed as N grows (strong scaling).
+
+    python bench.py                       # 1 GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line. ``--strategy auto`` (default) times the full-result strategies
+(row-sharded A + all-gather of C; K-sharded operands + all-reduce of partial sums) during
+warm-up and runs the faster one; the choice is reported in ``config.parallelism``.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from distributed_tensorflow_amd.parallel.comm import SingleComm, TorchDistComm  # noqa: E402
+from distributed_tensorflow_amd.parallel.sharded_matmul import ShardedMatmul  # noqa: E402
+
+DTYPES = {"bf16": torch.bfloat16, "fp32": torch.float32}
+FULL_RESULT_STRATEGIES = ("m_shard_allgather", "k_shard_allreduce")
+
+
+def timed_steps(engine: ShardedMatmul, comm, steps: int) -> float:
+    """Wall seconds for ``steps`` steps, bracketed by barrier + device sync on both sides."""
+    comm.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        engine.step()
+    torch.cuda.synchronize()
+    comm.barrier()
+    return time.perf_counter() - t0
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--m", type=int, default=16384)
+    ap.add_argument("--n", type=int, default=16384)
+    ap.add_argument("--k", type=int, default=16384)
+    ap.add_argument("--dtype", default="bf16", choices=sorted(DTYPES))
+    ap.add_argument("--strategy", default="auto")
+    ap.add_argument("--panels", type=int, default=None)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no GPU visible)")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    use_dist = world > 1 or os.environ.get("DTF_FORCE_DIST") == "1"   # world-1 RCCL smoke
+    comm = TorchDistComm(device=device) if use_dist else SingleComm(device)
+    rank = comm.rank
+    if world != args.gpus and rank == 0:
+        print("note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world),
+              file=sys.stderr)
+
+    dtype = DTYPES[args.dtype]
+
+    def make(strategy: str) -> ShardedMatmul:
+        eng = ShardedMatmul(args.m, args.n, args.k, comm, dtype=dtype, strategy=strategy,
+                            panels=args.panels, seed=1, device=device)
+        eng.init_operands()
+        return eng
+
+    if world == 1:
+        strategy = "replicated" if args.strategy == "auto" else args.strategy
+        engine = make(strategy)
+        for _ in range(args.warmup):
+            engine.step()
+    elif args.strategy != "auto":
+        strategy = args.strategy
+        engine = make(strategy)
+        for _ in range(args.warmup):
+            engine.step()
+    else:
+        # measured choice, inside the (untimed) warm-up: run each candidate, keep the faster
+        best = None
+        probe = max(2, args.warmup)
+        for cand in FULL_RESULT_STRATEGIES:
+            eng = make(cand)
+            eng.step()                                   # first-touch / communicator setup
+            secs = timed_steps(eng, comm, probe)
+            t = torch.tensor([secs], device=device)
+            comm.all_reduce(t, "max")
+            if best is None or t.item() < best[0]:
+                best = (t.item(), cand, eng)
+            else:
+                del eng
+                torch.cuda.empty_cache()
+        _, strategy, engine = best
+
+    elapsed = timed_steps(engine, comm, args.steps)
+    if world > 1:
+        t = torch.tensor([elapsed], device=device)
+        comm.all_reduce(t, "max")
+        elapsed = t.item()
+
+    ms_per_step = elapsed * 1e3 / args.steps
+    tflops = engine.flops_per_step / (ms_per_step * 1e-3) / 1e12
+    if rank == 0:
+        par = {"replicated": "single_gpu" if world == 1 else "replicated%d" % world,
+               "m_shard": "m_shard%d" % world,
+               "m_shard_allgather": "m_shard%d+allgather" % world,
+               "k_shard_allreduce": "k_shard%d+allreduce" % world,
+               "k_shard_reduce_scatter": "k_shard%d+reduce_scatter" % world,
+               "summa_2d": "summa2d_%d" % world}[strategy]
+        print(json.dumps({
+            "metric": "sharded_gemm_tflops",
+            "value": round(tflops, 2),
+            "unit": "TFLOP/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic (Philox U(-1,1) operands generated on device, random init)",
+            "config": {"model": "gemm_%dx%dx%d_%s" % (args.m, args.n, args.k, args.dtype),
+                       "global_batch": args.m, "seq_len": args.k,
+                       "m": args.m, "n": args.n, "k": args.k,
+                       "parallelism": par, "panels": engine.panels,
+                       "result": "full C on every rank" if strategy in
+                       ("replicated", "m_shard_allgather", "k_shard_allreduce")
+                       else "C left sharded"},
+        }), flush=True)
+    comm.close()
+
+
+if __name__ == "__main__":
+    main()

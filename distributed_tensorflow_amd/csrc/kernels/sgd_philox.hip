@@ -106,6 +106,36 @@ __global__ __launch_bounds__(BLOCK) void philox_fill_kernel(void* __restrict__ o
   }
 }
 
+// 2-D window of a stream laid out as a [*, global_cols] matrix: out[i, j] is stream element
+// (row0 + i) * global_cols + col0 + j. This is how a rank materialises its shard of a global
+// random matrix (row block, column block or 2-D block) without generating the rest.
+template <bool NORMAL, bool BF16_OUT>
+__global__ __launch_bounds__(BLOCK) void philox_fill_2d_kernel(void* __restrict__ out_, long rows,
+                                                               long cols, long ld_out,
+                                                               unsigned int seed,
+                                                               unsigned int op_seed, long row0,
+                                                               long col0, long global_cols,
+                                                               float a, float b) {
+  const long n = rows * cols;
+  for (long t = blockIdx.x * (long)BLOCK + threadIdx.x; t < n; t += (long)gridDim.x * BLOCK) {
+    const long i = t / cols, j = t % cols;
+    const long e = (row0 + i) * global_cols + col0 + j;
+    const U4 r = philox4x32_10((unsigned long)(e >> 2), seed, op_seed);
+    const int lane = (int)(e & 3);
+    float v;
+    if (NORMAL) {
+      const float ua = u01(lane < 2 ? r.x : r.z), ub = u01(lane < 2 ? r.y : r.w);
+      const float rad = sqrtf(-2.f * logf(ua)), th = 6.283185307179586f * ub;
+      v = (lane & 1) ? rad * sinf(th) : rad * cosf(th);
+    } else {
+      v = u01(lane == 0 ? r.x : lane == 1 ? r.y : lane == 2 ? r.z : r.w);
+    }
+    const float val = a + b * v;
+    if (BF16_OUT) reinterpret_cast<unsigned short*>(out_)[i * ld_out + j] = dtf_f32_to_bf16(val);
+    else reinterpret_cast<float*>(out_)[i * ld_out + j] = val;
+  }
+}
+
 // ---- partial-sum reduction -------------------------------------------------------------------
 constexpr int MAX_PARTIALS = 8;
 struct PartialArgs {
@@ -282,6 +312,27 @@ DTF_API int dtf_pack_f32(int count, const float* const* src, const int* sizes, f
   args.offset[count] = off;
   args.count = count;
   hipLaunchKernelGGL(pack_f32_kernel, dim3(1), dim3(BLOCK), 0, stream, args, dst);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
+// out[i*ld_out + j] = a + b * g(stream element (row0+i)*global_cols + col0 + j), g = N(0,1) when
+// normal else U(0,1). dtype: bf16_out 0/1.
+DTF_API int dtf_philox_fill_2d(void* out, long rows, long cols, long ld_out, unsigned int seed,
+                               unsigned int op_seed, long row0, long col0, long global_cols,
+                               float a, float b, int normal, int bf16_out, hipStream_t stream) {
+  if (rows <= 0 || cols <= 0) return DTF_OK;
+  if (!out || ld_out < cols || row0 < 0 || col0 < 0 || global_cols < col0 + cols)
+    return DTF_ERR_BAD_ARG;
+  dim3 grid(grid_for(rows * cols, 4)), block(BLOCK);
+#define DTF_FILL2D(NRM, BF)                                                                      \
+  hipLaunchKernelGGL((philox_fill_2d_kernel<NRM, BF>), grid, block, 0, stream, out, rows, cols,  \
+                     ld_out, seed, op_seed, row0, col0, global_cols, a, b)
+  if (normal && bf16_out) DTF_FILL2D(true, true);
+  else if (normal) DTF_FILL2D(true, false);
+  else if (bf16_out) DTF_FILL2D(false, true);
+  else DTF_FILL2D(false, false);
+#undef DTF_FILL2D
   DTF_LAUNCH_CHECK();
   return DTF_OK;
 }

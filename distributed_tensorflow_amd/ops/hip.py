@@ -89,6 +89,7 @@ def _declare(L: ctypes.CDLL) -> None:
         "dtf_philox_uniform": [P, LG, U, U, LG, F, F, I, P],
         "dtf_reduce_partials": [I, P, P, LG, F, I, P],
         "dtf_pack_f32": [I, P, P, P, P],
+        "dtf_philox_fill_2d": [P, LG, LG, LG, U, U, LG, LG, LG, F, F, I, I, P],
     }
     for name, argtypes in sigs.items():
         fn = getattr(L, name)
@@ -573,3 +574,22 @@ def pack_f32(parts: Sequence[torch.Tensor], out: torch.Tensor) -> List[int]:
         offsets.append(off)
         off += p.numel()
     return offsets
+
+
+def philox_window(rows: int, cols: int, seed: int, op_seed: int, row0: int, col0: int,
+                  global_cols: int, dtype: torch.dtype = torch.float32, device=None,
+                  normal: bool = True, a: float = 0.0, b: float = 1.0) -> torch.Tensor:
+    """The ``[rows, cols]`` window at ``(row0, col0)`` of a global random matrix with
+    ``global_cols`` columns whose element ``(i, j)`` is stream element ``i*global_cols + j``:
+    a rank's shard of a global matrix, generated locally. Values are ``a + b * g`` with ``g``
+    N(0,1) (``normal``) or U(0,1)."""
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise HipKernelError("philox_window: dtype must be fp32 or bf16")
+    if row0 < 0 or col0 < 0 or col0 + cols > global_cols:
+        raise HipKernelError("philox_window: window outside the global matrix")
+    out = torch.empty((rows, cols), dtype=dtype, device=device)
+    _check(lib().dtf_philox_fill_2d(out.data_ptr(), rows, cols, out.stride(0) if rows else cols,
+                                    seed & 0xFFFFFFFF, op_seed & 0xFFFFFFFF, row0, col0,
+                                    global_cols, float(a), float(b), int(normal),
+                                    int(dtype == torch.bfloat16), _stream()), "philox_window")
+    return out

@@ -71,3 +71,24 @@ def normal(n: int, seed: int, op_seed: int, offset: int = 0) -> np.ndarray:
     flat = out.reshape(-1)
     start = offset - first * 4
     return flat[start:start + n]
+
+
+def window(rows: int, cols: int, seed: int, op_seed: int, row0: int, col0: int,
+           global_cols: int, normal_dist: bool = True) -> np.ndarray:
+    """Host version of the 2-D window generator: element (i, j) of the result is stream
+    element ``(row0 + i) * global_cols + col0 + j`` (N(0,1) or U(0,1))."""
+    idx = ((np.arange(rows, dtype=np.uint64)[:, None] + np.uint64(row0)) * np.uint64(global_cols)
+           + np.arange(cols, dtype=np.uint64)[None, :] + np.uint64(col0)).reshape(-1)
+    bits = philox4x32(idx >> np.uint64(2), seed, op_seed)
+    u = _uniform01(bits)
+    lane = (idx & np.uint64(3)).astype(np.int64)
+    sel = np.arange(idx.size)
+    if not normal_dist:
+        return u[sel, lane].reshape(rows, cols)
+    pair = (lane >> 1) * 2
+    ua, ub = u[sel, pair], u[sel, pair + 1]
+    rad = np.sqrt(np.float32(-2.0) * np.log(ua), dtype=np.float32)
+    theta = _TWO_PI * ub
+    out = np.where(lane & 1, rad * np.sin(theta, dtype=np.float32),
+                   rad * np.cos(theta, dtype=np.float32))
+    return out.astype(np.float32).reshape(rows, cols)

@@ -119,6 +119,28 @@ class ExecContext:
     def var_is_initialized(self, var_op) -> bool:
         return self._store(var_op).is_initialized(var_op.name)
 
+    def uninitialized(self, var_ops) -> List[str]:
+        """Names of the given variables that hold no value, one query per owning store."""
+        groups: Dict[int, Tuple[Any, List[str]]] = {}
+        for v in var_ops:
+            st = self._store(v)
+            groups.setdefault(id(st), (st, []))[1].append(v.name)
+        missing: List[str] = []
+        for st, names in groups.values():
+            missing.extend(st.uninitialized(names))
+        order = {v.name: i for i, v in enumerate(var_ops)}
+        return sorted(missing, key=lambda n: order.get(n, 0))
+
+    # -- gradient synchronisation hooks (synchronous strategies) --------------------------
+    def reduce_gradients(self, grads):
+        rt = self.session._runtime
+        return list(grads) if rt is None else rt.reduce_gradients(grads)
+
+    def sharded_sgd(self, var_ops, grads, lrs) -> bool:
+        rt = self.session._runtime
+        fn = getattr(rt, "sharded_sgd_step", None)
+        return bool(fn and fn([v.name for v in var_ops], grads, lrs))
+
 
 # ---------------------------------------------------------------------------------------
 # plans

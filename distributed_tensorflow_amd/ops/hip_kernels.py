@@ -333,6 +333,10 @@ def _multi_apply_sgd(op, inputs, ctx):
     variables, other dtypes) goes through the store interface."""
     var_ops = op.attrs["var_ops"]
     lrs = op.attrs["learning_rates"]
+    if ctx.sharded_sgd(var_ops, list(inputs), lrs):      # reduce-scatter / owner update / gather
+        inputs, var_ops, lrs = [], [], []
+    else:
+        inputs = ctx.reduce_gradients(list(inputs))      # no-op without a synchronous runtime
     local_p, local_g, local_lr, rest = [], [], [], []
     for var_op, lr, g in zip(var_ops, lrs, inputs):
         store = ctx.session._store_for(var_op)
@@ -372,7 +376,7 @@ def _apply_sgd(op, inputs, ctx):
     store = ctx.session._store_for(var_op)
     fast = getattr(store, "local_tensor", None)
     p = fast(var_op.name) if fast is not None else None
-    g = inputs[1]
+    g = ctx.reduce_gradients([inputs[1]])[0]
     if p is not None and p.dtype == _f32 and g.dtype == _f32 and p.is_cuda:
         hip.multi_sgd([p], [g], [op.attrs["learning_rate"]])
         store.update_count += 1

@@ -122,7 +122,8 @@ def _assign_sub(op, inputs, ctx):
 
 @ref_kernel("ApplyGradientDescent", stateful=True)
 def _apply_sgd(op, inputs, ctx):
-    return [ctx.var_apply_sgd(op.inputs[0].op, op.attrs["learning_rate"], inputs[1])]
+    grad = ctx.reduce_gradients([inputs[1]])[0]
+    return [ctx.var_apply_sgd(op.inputs[0].op, op.attrs["learning_rate"], grad)]
 
 
 @ref_kernel("IsVariableInitialized", stateful=True)
@@ -132,8 +133,7 @@ def _is_var_init(op, inputs, ctx):
 
 @ref_kernel("ReportUninitializedVariables", stateful=True, host_only=True)
 def _report_uninit(op, inputs, ctx):
-    missing = [n.encode() for t, n in zip(op.inputs, op.attrs["names"])
-               if not ctx.var_is_initialized(t.op)]
+    missing = [n.encode() for n in ctx.uninitialized([t.op for t in op.inputs])]
     return [np.array(missing, dtype=object)]
 
 
@@ -407,8 +407,9 @@ def _bias_grad(op, inputs, ctx):
 def _multi_apply_sgd(op, inputs, ctx):
     var_ops = op.attrs["var_ops"]
     lrs = op.attrs["learning_rates"]
-    for var_op, lr, g in zip(var_ops, lrs, inputs):
-        ctx.var_apply_sgd(var_op, lr, g)
+    if not ctx.sharded_sgd(var_ops, list(inputs), lrs):
+        for var_op, lr, g in zip(var_ops, lrs, ctx.reduce_gradients(list(inputs))):
+            ctx.var_apply_sgd(var_op, lr, g)
     for var_op, delta in op.attrs.get("counter_increments", []):
         ctx.var_assign_add(var_op, torch.tensor(delta, dtype=var_op.outputs[0].dtype.torch,
                                                 device=ctx.device))

@@ -1,0 +1,252 @@
+"""Cluster runtimes: how a session's variables and gradients move between tasks.
+
+The reference has exactly one distribution strategy -- asynchronous data-parallel training
+with between-graph replication and one parameter server (``tf_distributed.py:33-36,75-76``) --
+implemented by TensorFlow's placer, graph partitioner and gRPC rendezvous. A *runtime* here is
+the equivalent of those pieces for one task: it decides which store owns each variable
+(from the variable's ``/job:ps/task:K`` placement), brackets every ``Session.run`` with the
+transfers that placement implies, and synchronises gradients when the strategy is
+synchronous.
+
+* ``PsRuntime``         -- ``strategy="ps_async"``: variables live in ps tasks reached over TCP;
+  per step one PULL and one APPLY per ps task; updates are asynchronous and lock-free exactly
+  as in the reference. Runs without a GPU.
+* ``CollectiveRuntime`` -- ``strategy="allreduce_sync"`` / ``"reduce_scatter_sync"``: one process
+  per GPU, no ps processes. Variable pull/push become collectives over xGMI (RCCL):
+  ``allreduce_sync`` keeps every variable replicated and all-reduces one flat gradient bucket
+  per step; ``reduce_scatter_sync`` keeps the parameter-server idea of a single owner per
+  parameter shard -- gradients are reduce-scattered to the owners, each owner applies SGD to
+  its shard, and the updated shards are all-gathered (= broadcast from every owner).
+  Semantic difference from the reference, by construction: updates are bulk-synchronous.
+  Gradients are *summed* across workers (each worker's batch-mean gradient applied with the
+  same learning rate, as the asynchronous ps would apply them one by one) unless
+  ``grad_aggregation="mean"``; ``global_step`` advances by one per synchronous step.
+* ``LocalRuntime``      -- a server with no peers (``Server.create_local_server``).
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, List, Optional, Sequence
+
+import torch
+
+from ..client.variable_store import LocalVariableStore
+from ..framework.device import DeviceSpec
+from .comm import Communicator, SingleComm
+
+
+class LocalRuntime:
+    strategy = "local"
+    capturable = True
+
+    def __init__(self, device: torch.device):
+        self.device = torch.device(device)
+        self.local_store = LocalVariableStore(self.device)
+        self.is_chief = True
+        self.comm: Communicator = SingleComm(self.device)
+
+    def store_for_device(self, device: str):
+        return self.local_store
+
+    def begin_step(self, plan) -> Any:
+        return None
+
+    def end_step(self, plan, token) -> None:
+        pass
+
+    def reduce_gradients(self, grads: Sequence[torch.Tensor]) -> List[torch.Tensor]:
+        return list(grads)
+
+    def after_init(self, session, var_names: Sequence[str]) -> None:
+        pass
+
+    def wait_ready(self, timeout_s: Optional[float] = None) -> None:
+        pass
+
+    def all_stores(self) -> List[Any]:
+        return [self.local_store]
+
+    def shutdown(self) -> None:
+        pass
+
+
+class PsRuntime(LocalRuntime):
+    """Worker-side runtime of the asynchronous parameter-server strategy."""
+
+    strategy = "ps_async"
+    capturable = False      # every step talks to the ps over TCP
+
+    def __init__(self, cluster, job_name: str, task_index: int, device: torch.device,
+                 connect_timeout_s: float = 60.0):
+        super().__init__(device)
+        from .ps_transport import RemoteVariableStore
+        self.cluster = cluster
+        self.job_name, self.task_index = job_name, task_index
+        self.is_chief = job_name == "worker" and task_index == 0
+        self._remote: Dict[int, RemoteVariableStore] = {}
+        self._timeout = connect_timeout_s
+        self._ps_job = "ps"
+
+    def _ps_store(self, task: int):
+        if task not in self._remote:
+            from .ps_transport import RemoteVariableStore
+            addr = self.cluster.task_address(self._ps_job, task)
+            self._remote[task] = RemoteVariableStore(addr, self.device, self._timeout)
+        return self._remote[task]
+
+    def store_for_device(self, device: str):
+        spec = DeviceSpec.from_string(device)
+        if spec.job == self._ps_job and self._ps_job in self.cluster.jobs:
+            return self._ps_store(spec.task or 0)
+        return self.local_store
+
+    def begin_step(self, plan) -> Any:
+        by_store: Dict[int, List[str]] = {}
+        for var_op in plan.var_ops:
+            spec = DeviceSpec.from_string(var_op.device)
+            if spec.job == self._ps_job and self._ps_job in self.cluster.jobs:
+                by_store.setdefault(spec.task or 0, []).append(var_op.name)
+        for task, names in by_store.items():
+            self._ps_store(task).begin_step(names)       # one PULL per ps task
+        return list(self._remote.values())
+
+    def end_step(self, plan, token) -> None:
+        for store in (token or []):
+            store.end_step()                              # one APPLY per ps task
+
+    def all_stores(self) -> List[Any]:
+        tasks = self.cluster.task_indices(self._ps_job) if self._ps_job in self.cluster.jobs \
+            else []
+        return [self._ps_store(t) for t in tasks] + [self.local_store]
+
+    def shutdown(self) -> None:
+        for store in self._remote.values():
+            store.close()
+
+    def report_done(self) -> None:
+        """This worker is finished: every ps task exits ``join()`` once all workers said so."""
+        from .ps_transport import UnavailableError
+        for t in self.cluster.task_indices(self._ps_job):
+            try:
+                self._ps_store(t).report_done(self.task_index)
+            except UnavailableError:
+                pass
+
+    def shutdown_parameter_servers(self) -> None:
+        """Ask every ps task to leave ``join()`` (the reference has no such path: its ps
+        blocks forever and has to be killed, ``tf_distributed.py:31``)."""
+        for t in self.cluster.task_indices(self._ps_job):
+            self._ps_store(t).shutdown_server()
+
+
+class CollectiveRuntime(LocalRuntime):
+    """Synchronous data parallelism over a communicator (RCCL on GPUs, gloo on CPUs)."""
+
+    capturable = False      # collectives are issued eagerly between kernel launches
+
+    def __init__(self, comm: Communicator, device: torch.device,
+                 strategy: str = "allreduce_sync", grad_aggregation: str = "sum"):
+        super().__init__(device)
+        if strategy not in ("allreduce_sync", "reduce_scatter_sync"):
+            raise ValueError("unknown collective strategy %r" % strategy)
+        if grad_aggregation not in ("sum", "mean"):
+            raise ValueError("grad_aggregation must be 'sum' or 'mean'")
+        self.comm = comm
+        self.strategy = strategy
+        self.grad_aggregation = grad_aggregation
+        self.is_chief = comm.rank == 0
+        self._flat_params: Optional[torch.Tensor] = None
+        self._flat_grads: Optional[torch.Tensor] = None
+        self._layout: List[Any] = []       # (name, offset, numel, shape)
+        self.bytes_reduced = 0
+
+    # -- initial state: chief's values -> everyone (one broadcast of one flat buffer) ------
+    def after_init(self, session, var_names: Sequence[str]) -> None:
+        store = self.local_store
+        names = [n for n in var_names]
+        present = self.comm.broadcast_object(
+            [(n, tuple(store.read(n).shape), str(store.read(n).dtype)) for n in names]
+            if self.is_chief else None, src=0)
+        f32 = [(n, shape) for n, shape, dt in present if dt == "torch.float32"]
+        other = [(n, shape, dt) for n, shape, dt in present if dt != "torch.float32"]
+        w = self.comm.world_size
+        total = sum(int(torch.Size(s).numel()) for _, s in f32)
+        padded = ((total + w - 1) // w) * w if total else 0
+        flat = torch.zeros(padded, dtype=torch.float32, device=self.device)
+        off = 0
+        self._layout = []
+        for n, shape in f32:
+            numel = int(torch.Size(shape).numel())
+            if self.is_chief:
+                flat[off:off + numel].copy_(store.read(n).reshape(-1))
+            self._layout.append((n, off, numel, shape))
+            off += numel
+        if padded:
+            self.comm.broadcast(flat, src=0)
+        for n, o, numel, shape in self._layout:
+            store.adopt(n, flat[o:o + numel].view(shape))    # variables are views of the arena
+        for n, shape, dt in other:
+            t = store.read(n).clone() if self.is_chief else \
+                torch.empty(shape, dtype=getattr(torch, dt.split(".")[-1]), device=self.device)
+            self.comm.broadcast(t, src=0)
+            store.assign(n, t)
+        self._flat_params = flat
+        self._flat_grads = torch.zeros_like(flat)
+        self.comm.barrier()
+
+    def wait_ready(self, timeout_s: Optional[float] = None) -> None:
+        self.comm.barrier()
+
+    # -- gradient synchronisation --------------------------------------------------------
+    def reduce_gradients(self, grads: Sequence[torch.Tensor]) -> List[torch.Tensor]:
+        """All-reduce a list of gradients as ONE flat bucket; returns reduced views."""
+        grads = list(grads)
+        if self.comm.world_size == 1 or not grads:
+            return grads
+        total = sum(g.numel() for g in grads)
+        bucket = self._flat_grads[:total] if (self._flat_grads is not None
+                                              and self._flat_grads.numel() >= total
+                                              and grads[0].dtype == torch.float32) \
+            else torch.empty(total, dtype=grads[0].dtype, device=grads[0].device)
+        off = 0
+        for g in grads:
+            bucket[off:off + g.numel()].copy_(g.reshape(-1))
+            off += g.numel()
+        self.comm.all_reduce(bucket, "avg" if self.grad_aggregation == "mean" else "sum")
+        self.bytes_reduced += bucket.numel() * bucket.element_size()
+        out, off = [], 0
+        for g in grads:
+            out.append(bucket[off:off + g.numel()].view(g.shape))
+            off += g.numel()
+        return out
+
+    def sharded_sgd_step(self, names: Sequence[str], grads: Sequence[torch.Tensor],
+                         lrs: Sequence[float]) -> bool:
+        """``reduce_scatter_sync``: reduce-scatter the flat gradient to the shard owners, apply
+        SGD on the owned shard only, all-gather the updated parameters. Returns False when the
+        request does not cover the flat arena (caller then falls back to all-reduce)."""
+        if self.strategy != "reduce_scatter_sync" or self._flat_params is None:
+            return False
+        by_name = {n: (g, lr) for n, g, lr in zip(names, grads, lrs)}
+        if set(by_name) != {n for n, _, _, _ in self._layout} or len(set(lrs)) != 1:
+            return False
+        flat_g, flat_p = self._flat_grads, self._flat_params
+        flat_g.zero_()
+        for n, off, numel, _ in self._layout:
+            flat_g[off:off + numel].copy_(by_name[n][0].reshape(-1))
+        w, r = self.comm.world_size, self.comm.rank
+        shard = flat_p.numel() // w
+        g_shard = torch.empty(shard, dtype=torch.float32, device=self.device)
+        self.comm.reduce_scatter(g_shard, flat_g,
+                                 "avg" if self.grad_aggregation == "mean" else "sum")
+        p_shard = flat_p[r * shard:(r + 1) * shard]
+        if self.device.type == "cuda":
+            from ..ops import hip
+            hip.multi_sgd([p_shard], [g_shard], [lrs[0]])
+        else:
+            p_shard.add_(g_shard, alpha=-float(lrs[0]))
+        self.comm.all_gather(flat_p, p_shard.clone())
+        self.bytes_reduced += flat_g.numel() * 4
+        return True
+
+    def shutdown(self) -> None:
+        pass

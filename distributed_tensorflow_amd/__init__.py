@@ -27,7 +27,7 @@ from .framework.ops import (abs, add, add_n, argmax, axpby, cast, constant,  # n
                             identity, less, log, matmul, maximum, minimum, multiply, negative,
                             no_op, not_equal, ones, ones_like, placeholder, pow,
                             random_normal, random_uniform, reciprocal, reduce_max,
-                            reduce_mean, reduce_sum, reshape, scale, sigmoid, sqrt, square,
+                            reduce_mean, reduce_sum, reshape, scale, sigmoid, sign, sqrt, square,
                             stop_gradient, subtract, tanh, transpose, truncated_normal, zeros,
                             zeros_like)
 from .framework.variables import (Variable, constant_initializer, get_variable,  # noqa: F401

@@ -89,6 +89,9 @@ class _FlagValues:
                 values[name[2:]] = False
             else:
                 rest.append(arg)
+        # a parse starts from the defaults; only values assigned explicitly survive it
+        for name in [n for n in self._values if not self.__dict__.get("_frozen_" + n)]:
+            del self._values[name]
         for name, val in values.items():
             if not self.__dict__.get("_frozen_" + name):  # explicit assignment wins
                 self._values[name] = val

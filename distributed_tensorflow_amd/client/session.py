@@ -197,6 +197,7 @@ class Session:
         self.config = config or ConfigProto()
         self.target = target or ""
         self._closed = False
+        self._close_hooks: List[Any] = []
         self._plans: Dict[Tuple, ExecutionPlan] = {}
         self._lock = threading.RLock()
         self.device = torch.device(self.config.device) if self.config.device \
@@ -240,9 +241,17 @@ class Session:
         finally:
             stack.pop()
 
+    def add_close_hook(self, fn) -> None:
+        """``fn(session)`` runs at the start of ``close()`` while the session is still usable
+        (the Supervisor's final checkpoint hangs here)."""
+        self._close_hooks.append(fn)
+
     def close(self) -> None:
         if self._closed:
             return
+        hooks, self._close_hooks = self._close_hooks, []
+        for fn in hooks:
+            fn(self)
         self._closed = True
         for plan in self._plans.values():
             plan.graphs.clear()
@@ -397,7 +406,8 @@ class Session:
             arr = np.asarray(value)
             if t.dtype.numpy is not None and arr.dtype != np.dtype(t.dtype.numpy):
                 arr = arr.astype(t.dtype.numpy)
-            out = torch.from_numpy(np.ascontiguousarray(arr))
+            # (np.ascontiguousarray would turn a 0-d value into shape (1,))
+            out = torch.from_numpy(arr if arr.flags.c_contiguous else arr.copy())
             if t.dtype.numpy is None:
                 out = out.to(t.dtype.torch)
             out = out.to(self.device, non_blocking=False)

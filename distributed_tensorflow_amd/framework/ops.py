@@ -286,6 +286,10 @@ def abs(x, name=None) -> Tensor:  # noqa: A001
     return _unary("Abs", x, name)
 
 
+def sign(x, name=None) -> Tensor:
+    return _unary("Sign", x, name)
+
+
 def sigmoid(x, name=None) -> Tensor:
     return _unary("Sigmoid", x, name)
 
@@ -565,6 +569,27 @@ def _square_grad(op, g):
     return (multiply(scale(g, 2.0), op.inputs[0]),)
 
 
+@gradient("Abs")
+def _abs_grad(op, g):
+    return (multiply(g, sign(op.inputs[0])),)
+
+
+@gradient("Maximum")
+def _maximum_grad(op, g):
+    x, y = op.inputs
+    x_wins = subtract(ones_like(g), cast(less(x, y), g.dtype))     # 1 where x >= y
+    return (_unbroadcast(multiply(g, x_wins), x, y),
+            _unbroadcast(multiply(g, subtract(ones_like(g), x_wins)), y, x))
+
+
+@gradient("Minimum")
+def _minimum_grad(op, g):
+    x, y = op.inputs
+    x_wins = subtract(ones_like(g), cast(greater(x, y), g.dtype))  # 1 where x <= y
+    return (_unbroadcast(multiply(g, x_wins), x, y),
+            _unbroadcast(multiply(g, subtract(ones_like(g), x_wins)), y, x))
+
+
 @gradient("Reciprocal")
 def _recip_grad(op, g):
     y = op.outputs[0]
@@ -674,14 +699,15 @@ def _sum_to_shape_grad(op, g):
 # python operator overloads
 # ---------------------------------------------------------------------------------------
 def _install_overloads() -> None:
-    Tensor.__add__ = lambda s, o: add(s, o)
-    Tensor.__radd__ = lambda s, o: add(o, s)
-    Tensor.__sub__ = lambda s, o: subtract(s, o)
-    Tensor.__rsub__ = lambda s, o: subtract(o, s)
-    Tensor.__mul__ = lambda s, o: multiply(s, o)
-    Tensor.__rmul__ = lambda s, o: multiply(o, s)
-    Tensor.__truediv__ = lambda s, o: divide(s, o)
-    Tensor.__rtruediv__ = lambda s, o: divide(o, s)
+    # default op names of the overloads are lower-case ("mul", "add"), as in TF1 graphs
+    Tensor.__add__ = lambda s, o: add(s, o, name="add")
+    Tensor.__radd__ = lambda s, o: add(o, s, name="add")
+    Tensor.__sub__ = lambda s, o: subtract(s, o, name="sub")
+    Tensor.__rsub__ = lambda s, o: subtract(o, s, name="sub")
+    Tensor.__mul__ = lambda s, o: multiply(s, o, name="mul")
+    Tensor.__rmul__ = lambda s, o: multiply(o, s, name="mul")
+    Tensor.__truediv__ = lambda s, o: divide(s, o, name="truediv")
+    Tensor.__rtruediv__ = lambda s, o: divide(o, s, name="truediv")
     Tensor.__neg__ = lambda s: negative(s)
     Tensor.__matmul__ = lambda s, o: matmul(s, o)
     Tensor.__pow__ = lambda s, o: pow(s, o)

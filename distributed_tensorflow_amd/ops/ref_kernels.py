@@ -34,7 +34,9 @@ def _const(op, inputs, ctx):
     if cached is None:
         dt = op.attrs["dtype"]
         value = op.attrs["value"]
-        cached = torch.as_tensor(np.ascontiguousarray(value)).to(device=ctx.device, dtype=dt.torch)
+        value = np.asarray(value)
+        cached = torch.as_tensor(value if value.flags.c_contiguous else value.copy()).to(
+            device=ctx.device, dtype=dt.torch)
         ctx.const_cache[op] = cached
     return [cached]
 
@@ -173,6 +175,7 @@ ref_kernel("Sqrt")(_un(torch.sqrt))
 ref_kernel("Square")(_un(torch.square))
 ref_kernel("Reciprocal")(_un(torch.reciprocal))
 ref_kernel("Abs")(_un(torch.abs))
+ref_kernel("Sign")(_un(torch.sign))
 ref_kernel("Sigmoid")(_un(torch.sigmoid))
 ref_kernel("Tanh")(_un(torch.tanh))
 ref_kernel("Relu")(_un(torch.relu))

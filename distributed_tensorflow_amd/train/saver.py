@@ -214,10 +214,15 @@ class Saver:
         self._max_to_keep = max_to_keep
         self._sharded = sharded
         self._kept: List[str] = []
-        get_default_graph().add_to_collection(GraphKeys.SAVERS, self)
+        # the graph is bound at construction: save() may run on a service thread whose
+        # default-graph stack is not the one the model was built under
+        self._graph = get_default_graph()
+        self._graph.add_to_collection(GraphKeys.SAVERS, self)
 
     def _variables(self) -> List[Variable]:
-        return self._var_list if self._var_list is not None else global_variables()
+        if self._var_list is not None:
+            return self._var_list
+        return self._graph.get_collection(GraphKeys.GLOBAL_VARIABLES)
 
     @property
     def last_checkpoints(self) -> List[str]:

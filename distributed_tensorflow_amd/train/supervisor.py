@@ -197,6 +197,7 @@ class Supervisor:
         self._init_feed_dict = init_feed_dict
         self._init_fn = init_fn
         self._coord = Coordinator()
+        self._save_lock = threading.Lock()
         self._save_path = os.path.join(logdir, checkpoint_basename) if logdir else None
         self._summary_writer = None
         self._started_threads: List[threading.Thread] = []
@@ -294,7 +295,10 @@ class Supervisor:
         threads = []
         if self._saver is not None and self._save_model_secs:
             threads.append(_Looper(self._coord, self._save_model_secs, "sv-checkpoint",
-                                   lambda: self._checkpoint(sess), run_at_stop=True))
+                                   lambda: self._checkpoint(sess)))
+            # final checkpoint: taken when the session closes (the reference's
+            # `with sv.prepare_or_wait_for_session(...) as sess:` closes it before sv.stop())
+            sess.add_close_hook(self._final_checkpoint)
         if self._summary_op is not None and self._save_summaries_secs and self._summary_writer:
             threads.append(_Looper(self._coord, self._save_summaries_secs, "sv-summary",
                                    lambda: self._write_summary(sess)))
@@ -312,8 +316,15 @@ class Supervisor:
         return int(np.asarray(sess.run(self._global_step)).item())
 
     def _checkpoint(self, sess: Session) -> None:
-        if self._saver is not None and self._save_path:
-            self._saver.save(sess, self._save_path, global_step=self._step_value(sess))
+        if self._saver is not None and self._save_path and not sess._closed:
+            with self._save_lock:
+                self._saver.save(sess, self._save_path, global_step=self._step_value(sess))
+
+    def _final_checkpoint(self, sess: Session) -> None:
+        try:
+            self._checkpoint(sess)
+        except Exception:  # noqa: BLE001 -- the cluster may already be gone at shutdown
+            pass
 
     def _write_summary(self, sess: Session) -> None:
         # summaries that need fed placeholders cannot be computed by a background thread;
@@ -386,23 +397,19 @@ class Supervisor:
             finally:
                 try:
                     self.stop()
-                except RuntimeError:
-                    pass
+                except (RuntimeError, UnavailableError, CommError, FailedPreconditionError):
+                    pass            # a service thread hit the same outage
                 sess.close()
 
 
 class _Looper(threading.Thread):
-    def __init__(self, coord: Coordinator, interval: float, name: str, fn: Callable[[], None],
-                 run_at_stop: bool = False):
+    def __init__(self, coord: Coordinator, interval: float, name: str, fn: Callable[[], None]):
         super().__init__(name=name, daemon=True)
         self._coord, self._interval, self._fn = coord, interval, fn
-        self._run_at_stop = run_at_stop
 
     def run(self) -> None:
         with self._coord.stop_on_exception():
             while not self._coord.wait_for_stop(self._interval):
-                self._fn()
-            if self._run_at_stop:
                 self._fn()
 
 

@@ -1,0 +1,381 @@
+"""T1 (single process, several "tasks"): communicators, parameter-server transport,
+Supervisor chief/non-chief protocol, async vs sync update semantics, failure injection."""
+import threading
+import time
+
+import numpy as np
+import pytest
+import torch
+
+import distributed_tensorflow_amd as tf
+from distributed_tensorflow_amd.models import mnist_mlp
+from distributed_tensorflow_amd.parallel.comm import CommError, LoopbackComm, SingleComm
+from distributed_tensorflow_amd.parallel.ps_transport import (PsService, RemoteVariableStore,
+                                                              UnavailableError)
+from distributed_tensorflow_amd.parallel.sharded_matmul import STRATEGIES, ShardedMatmul
+from distributed_tensorflow_amd.train.server import _free_port
+
+
+def run_ranks(world, fn, timeout_s=20.0):
+    comms = LoopbackComm.create_world(world, timeout_s=timeout_s)
+    out, errs = [None] * world, []
+
+    def body(r):
+        try:
+            out[r] = fn(comms[r])
+        except BaseException as e:  # noqa: BLE001
+            errs.append(e)
+
+    threads = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    [t.start() for t in threads]
+    [t.join(60) for t in threads]
+    if errs:
+        raise errs[0]
+    return out
+
+
+def test_loopback_collectives():
+    def fn(c):
+        r, w = c.rank, c.world_size
+        t = torch.full((6,), float(r + 1))
+        c.all_reduce(t)
+        assert torch.equal(t, torch.full((6,), 10.0))
+        b = torch.arange(4.0) if r == 2 else torch.zeros(4)
+        c.broadcast(b, src=2)
+        assert torch.equal(b, torch.arange(4.0))
+        full = torch.arange(8.0) * (r + 1)
+        out = torch.empty(2)
+        c.reduce_scatter(out, full)
+        assert torch.equal(out, torch.arange(8.0)[2 * r:2 * r + 2] * 10)
+        gathered = torch.empty(w, 3)
+        c.all_gather(gathered, torch.full((3,), float(r)))
+        assert torch.equal(gathered[:, 0], torch.arange(4.0))
+        m = torch.tensor([float(r)])
+        c.all_reduce(m, "max")
+        assert m.item() == 3.0
+        a = torch.tensor([float(r)])
+        c.all_reduce(a, "avg")
+        assert a.item() == 1.5
+        assert c.broadcast_object({"rank": r}, src=1) == {"rank": 1}
+        assert c.all_gather_object(r * r) == [0, 1, 4, 9]
+        sub = c.split(color=r % 2)                       # {0,2} and {1,3}
+        assert sub.world_size == 2 and sub.rank == r // 2
+        s = torch.tensor([float(r)])
+        sub.all_reduce(s)
+        assert s.item() == (2.0 if r % 2 == 0 else 4.0)
+        c.barrier()
+        return True
+
+    assert run_ranks(4, fn) == [True] * 4
+
+
+def test_loopback_fault_injection_detects_dead_and_slow_ranks():
+    comms = LoopbackComm.create_world(2, timeout_s=0.5)
+    comms[1].kill()
+    with pytest.raises(CommError, match="died"):
+        comms[0].all_reduce(torch.ones(1))
+    comms = LoopbackComm.create_world(2, timeout_s=0.3)
+    with pytest.raises(CommError, match="timed out"):
+        comms[0].barrier()                                # rank 1 never arrives
+    single = SingleComm()
+    t = torch.ones(3)
+    single.all_reduce(t)
+    single.barrier()
+    assert torch.equal(t, torch.ones(3)) and single.split(0).world_size == 1
+
+
+@pytest.mark.parametrize("strategy", STRATEGIES)
+@pytest.mark.parametrize("world", [1, 2, 4])
+def test_sharded_matmul_strategies_match_reference(strategy, world):
+    if strategy == "summa_2d" and world == 2:
+        pytest.skip("SUMMA needs a square grid")
+
+    def fn(c):
+        sm = ShardedMatmul(64, 48, 32, c, dtype=torch.float32, strategy=strategy,
+                           panels=None if strategy == "summa_2d" else 2)
+        sm.step()
+        got = sm.result_dense().double()
+        ref = sm.reference(sm.rows_of_result(), sm.cols_of_result())
+        return (got - ref).abs().max().item()
+
+    assert max(run_ranks(world, fn)) < 1e-5
+
+
+def test_sharded_matmul_is_world_size_invariant():
+    def fn(c):
+        sm = ShardedMatmul(32, 32, 64, c, dtype=torch.float32, strategy="k_shard_allreduce")
+        return sm.step().clone()
+
+    one = run_ranks(1, fn)[0]
+    four = run_ranks(4, fn)
+    for c in four:
+        assert torch.allclose(c, one, atol=1e-5)
+    with pytest.raises(ValueError):
+        ShardedMatmul(30, 32, 64, LoopbackComm.create_world(4)[0], strategy="m_shard")
+    with pytest.raises(ValueError):
+        ShardedMatmul(32, 32, 64, strategy="bogus")
+
+
+# -- parameter-server transport -----------------------------------------------------------------
+@pytest.fixture
+def ps_service():
+    svc = PsService("127.0.0.1", 0)
+    svc.start()
+    yield svc
+    svc.stop()
+
+
+def test_ps_transport_pull_apply_semantics(ps_service):
+    addr = "127.0.0.1:%d" % ps_service.port
+    a, b = RemoteVariableStore(addr), RemoteVariableStore(addr)
+    assert a.uninitialized(["w", "step"]) == ["w", "step"]
+    a.assign("w", torch.ones(4, 3))
+    a.assign("step", torch.tensor(0.0))
+    assert b.is_initialized("w") and b.uninitialized(["w", "x"]) == ["x"]
+    with pytest.raises(tf.FailedPreconditionError):
+        b.read("x")
+    # two workers read the same weights, push different gradients: the ps applies both
+    a.begin_step(["w", "step"])
+    b.begin_step(["w", "step"])
+    a.apply_sgd("w", 0.5, torch.full((4, 3), 2.0))
+    a.assign_add("step", torch.tensor(1.0))
+    b.apply_sgd("w", 0.5, torch.full((4, 3), 4.0))
+    b.assign_add("step", torch.tensor(1.0))
+    assert torch.equal(a.read("w"), torch.ones(4, 3))          # snapshot semantics within a step
+    a.end_step()
+    b.end_step()
+    a.begin_step(["w", "step"])
+    assert torch.equal(a.read("w"), torch.full((4, 3), 1.0 - 1.0 - 2.0))
+    assert a.read("step").item() == 2.0                        # one increment per applied gradient
+    assert ps_service.store.update_count == 2 and a.ping() == 2
+    assert sorted(a.names()) == ["step", "w"]
+    assert a.bytes_pulled > 0 and a.bytes_pushed == 4 * 3 * 4 + 4
+    state = b.state_dict()
+    assert torch.equal(state["w"], a.read("w"))
+    a.close()
+    b.close()
+
+
+def test_ps_client_unavailable_and_done_protocol():
+    with pytest.raises(UnavailableError):
+        RemoteVariableStore("127.0.0.1:%d" % _free_port(), connect_timeout_s=0.3).names()
+    svc = PsService("127.0.0.1", 0, expected_workers=2)
+    svc.start()
+    addr = "127.0.0.1:%d" % svc.port
+    w0, w1 = RemoteVariableStore(addr), RemoteVariableStore(addr)
+    assert w0.report_done(0) == 1 and not svc.stopped
+    assert w1.report_done(1) == 2 and svc.wait(2.0)            # all workers done -> join() returns
+    svc.stop()
+
+
+# -- whole jobs in one process: 1 ps + 2 workers (threads), reference training script flow ------
+def _cluster(num_workers=2):
+    return tf.train.ClusterSpec({"ps": ["127.0.0.1:%d" % _free_port()],
+                                 "worker": ["127.0.0.1:%d" % _free_port()
+                                            for _ in range(num_workers)]})
+
+
+def _worker_job(cluster, task, steps, results, protocol="grpc", comm=None, strategy=None,
+                lr=0.05, logdir=None, start_delay=0.0):
+    time.sleep(start_delay)
+    g = tf.Graph()
+    with g.as_default():
+        config = tf.ConfigProto(device="cpu", strategy=strategy)
+        server = tf.train.Server(cluster, job_name="worker", task_index=task, protocol=protocol,
+                                 config=config, comm=comm)
+        with tf.device(tf.train.replica_device_setter(
+                worker_device="/job:worker/task:%d" % task, cluster=cluster)):
+            m = mnist_mlp.build_model(learning_rate=lr, seed=1)
+        sv = tf.train.Supervisor(is_chief=(task == 0), global_step=m.global_step,
+                                 init_op=m.init_op, logdir=logdir, recovery_wait_secs=0.05,
+                                 save_model_secs=0.2, summary_op=None)
+        rng = np.random.RandomState(100 + task)
+        from distributed_tensorflow_amd.data.mnist import synthetic_mnist
+        images, labels = synthetic_mnist(600, seed=task)
+        onehot = np.eye(10, dtype=np.float32)[labels]
+        costs = []
+        with sv.prepare_or_wait_for_session(server.target, config=config) as sess:
+            for i in range(steps):
+                idx = rng.randint(0, 600, 50)
+                _, c, step = sess.run([m.train_op, m.loss, m.global_step],
+                                      {m.x: images[idx], m.y_: onehot[idx]})
+                costs.append(float(c))
+            final = {k: sess.run(v) for k, v in
+                     (("w1", m.w1), ("b2", m.b2), ("step", m.global_step))}
+            placement = (m.w1.device, m.x.device, m.train_op.device)
+            types = {s.node.type for p in sess._plans.values() for s in p.steps}
+        sv.stop()
+        results[task] = dict(costs=costs, final=final, placement=placement, types=types,
+                             runtime=server.runtime)
+        server.stop()
+
+
+def test_async_parameter_server_job_one_ps_two_workers():
+    cluster = _cluster(2)
+    ps = tf.train.Server(cluster, job_name="ps", task_index=0)
+    assert ps.target.startswith("grpc://127.0.0.1:")
+    results = {}
+    threads = [threading.Thread(target=_worker_job, args=(cluster, t, 40, results),
+                                kwargs=dict(start_delay=0.3 * t)) for t in (1, 0)]
+    [t.start() for t in threads]      # the non-chief starts first and has to wait for the chief
+    [t.join(120) for t in threads]
+    assert set(results) == {0, 1}
+    for t in (0, 1):
+        r = results[t]
+        assert r["placement"] == ("/job:ps/task:0", "/job:worker/task:%d" % t, "/job:ps/task:0")
+        assert np.mean(r["costs"][-5:]) < np.mean(r["costs"][:5])          # it learns
+        assert "MultiApplySGD" in r["types"]
+    # state lives in the ps only: both workers read the same final variables from it
+    store = ps.runtime.local_store
+    assert store.read("global_step").item() == 80.0                         # every update counted
+    assert store.update_count == 80 * 4
+    last = max(results, key=lambda t: results[t]["final"]["step"])
+    assert np.allclose(results[last]["final"]["w1"], store.read("weights/Variable").numpy())
+    assert results[0]["runtime"].local_store.names() == []                  # nothing stored locally
+    ps.stop()
+
+
+@pytest.mark.parametrize("strategy", ["allreduce_sync", "reduce_scatter_sync"])
+def test_sync_collective_job_keeps_replicas_identical(strategy):
+    world = 2
+    cluster = tf.train.ClusterSpec({"ps": ["127.0.0.1:%d" % _free_port()],
+                                    "worker": ["127.0.0.1:%d" % _free_port()
+                                               for _ in range(world)]})
+    comms = LoopbackComm.create_world(world, timeout_s=30)
+    results = {}
+    threads = [threading.Thread(target=_worker_job, args=(cluster, t, 25, results),
+                                kwargs=dict(protocol="rccl", comm=comms[t], strategy=strategy))
+               for t in range(world)]
+    [t.start() for t in threads]
+    [t.join(120) for t in threads]
+    assert set(results) == {0, 1}
+    a, b = results[0]["final"], results[1]["final"]
+    assert np.array_equal(a["w1"], b["w1"]) and np.array_equal(a["b2"], b["b2"])   # bitwise
+    assert a["step"] == b["step"] == 25.0                # one increment per synchronous step
+    assert results[0]["costs"] != results[1]["costs"]    # different data on each worker
+    assert np.mean(results[0]["costs"][-5:]) < np.mean(results[0]["costs"][:5])
+    assert results[0]["runtime"].bytes_reduced > 0
+
+
+def test_sync_sum_of_gradients_equals_sequential_application():
+    """allreduce_sync with sum aggregation == applying both workers' gradients (computed at the
+    same weights) one after the other with the same learning rate."""
+    world = 2
+    cluster = tf.train.ClusterSpec({"worker": ["127.0.0.1:%d" % _free_port()
+                                               for _ in range(world)]})
+    comms = LoopbackComm.create_world(world, timeout_s=30)
+    results = {}
+    threads = [threading.Thread(target=_worker_job, args=(cluster, t, 1, results),
+                                kwargs=dict(protocol="rccl", comm=comms[t],
+                                            strategy="allreduce_sync"))
+               for t in range(world)]
+    [t.start() for t in threads]
+    [t.join(60) for t in threads]
+    # oracle: single process, same init, gradient of each worker's batch at the initial weights
+    from distributed_tensorflow_amd.data.mnist import synthetic_mnist
+    g = tf.Graph()
+    with g.as_default():
+        m = mnist_mlp.build_model(learning_rate=0.05, seed=1)
+        grads = tf.gradients(m.loss, [m.w1._variable])
+        with tf.Session(config=tf.ConfigProto(device="cpu")) as sess:
+            sess.run(m.init_op)
+            w0 = sess.run(m.w1)
+            total = np.zeros_like(w0)
+            for task in range(world):
+                rng = np.random.RandomState(100 + task)
+                images, labels = synthetic_mnist(600, seed=task)
+                idx = rng.randint(0, 600, 50)
+                total += sess.run(grads[0], {m.x: images[idx],
+                                             m.y_: np.eye(10, dtype=np.float32)[labels][idx]})
+    assert np.allclose(results[0]["final"]["w1"], w0 - 0.05 * total, atol=1e-6)
+
+
+def test_supervisor_checkpoints_and_recovers(tmp_path):
+    logdir = str(tmp_path / "sv")
+    cluster = tf.train.ClusterSpec({"worker": ["127.0.0.1:%d" % _free_port()]})
+    results = {}
+    _worker_job(cluster, 0, 30, results, protocol="grpc", logdir=logdir)
+    ckpt = tf.train.latest_checkpoint(logdir)
+    assert ckpt is not None and ckpt.endswith("model.ckpt-30")        # saved again at stop()
+    # a new job with the same logdir resumes from the checkpoint instead of re-initialising
+    results2 = {}
+    _worker_job(cluster, 0, 5, results2, protocol="grpc", logdir=logdir)
+    assert results2[0]["final"]["step"] == 35.0
+    events = [f for f in (tmp_path / "sv").iterdir() if f.name.startswith("events.out")]
+    assert events
+
+
+def test_non_chief_times_out_without_chief():
+    cluster = _cluster(2)
+    ps = tf.train.Server(cluster, job_name="ps", task_index=0)
+    g = tf.Graph()
+    with g.as_default():
+        server = tf.train.Server(cluster, job_name="worker", task_index=1,
+                                 config=tf.ConfigProto(device="cpu"))
+        with tf.device(tf.train.replica_device_setter(cluster=cluster)):
+            m = mnist_mlp.build_model()
+        sv = tf.train.Supervisor(is_chief=False, global_step=m.global_step, init_op=m.init_op,
+                                 recovery_wait_secs=0.05)
+        with pytest.raises(TimeoutError, match="not ready"):
+            sv.prepare_or_wait_for_session(server.target, max_wait_secs=0.3)
+        server.stop()
+    ps.stop()
+
+
+def test_run_with_recovery_after_ps_restart(tmp_path):
+    """The ps dies mid-job: the chief rebuilds its session, restores the last checkpoint into the
+    restarted ps and carries on."""
+    port = _free_port()
+    cluster = tf.train.ClusterSpec({"ps": ["127.0.0.1:%d" % port],
+                                    "worker": ["127.0.0.1:%d" % _free_port()]})
+    ps = tf.train.Server(cluster, job_name="ps", task_index=0)
+    logdir = str(tmp_path / "rec")
+    g = tf.Graph()
+    with g.as_default():
+        server = tf.train.Server(cluster, job_name="worker", task_index=0,
+                                 config=tf.ConfigProto(device="cpu"))
+        with tf.device(tf.train.replica_device_setter(cluster=cluster)):
+            step = tf.train.get_or_create_global_step()
+            w = tf.Variable(tf.zeros([4]), name="w")
+            train = tf.group(w.assign_add(tf.ones([4])), step.assign_add(1.0))
+        sv = tf.train.Supervisor(is_chief=True, global_step=step, logdir=logdir,
+                                 save_model_secs=0.05, recovery_wait_secs=0.05, summary_op=None)
+        state = {"n": 0, "killed": False, "ps": ps}
+
+        def step_fn(sess):
+            sess.run(train)
+            state["n"] += 1
+            if state["n"] == 10 and not state["killed"]:
+                time.sleep(0.3)                       # let a checkpoint land
+                state["ps"].stop()                    # ps crashes ...
+                state["killed"] = True
+                state["ps"] = tf.train.Server(cluster, job_name="ps", task_index=0)   # ... restarts empty
+            return state["n"] < 20
+
+        restarts = sv.run_with_recovery(server.target, step_fn)
+        assert restarts == 1
+        final = state["ps"].runtime.local_store.read("global_step").item()
+        assert 10 <= final <= 21                      # resumed from a checkpoint, not from zero
+        server.stop()
+    state["ps"].stop()
+
+
+def test_local_server_and_server_validation():
+    s = tf.train.Server.create_local_server()
+    assert s.target.startswith("local://")
+    with tf.Session(s.target) as sess:
+        assert sess.run(tf.constant(3.0) * 2) == 6.0
+    s.stop()
+    c = tf.train.ClusterSpec({"ps": ["a:1"], "worker": ["b:1", "c:1"]})
+    with pytest.raises(ValueError):
+        tf.train.Server(c, job_name="evaluator", task_index=0, start=False)
+    with pytest.raises(ValueError):
+        tf.train.Server(c, job_name="worker", task_index=5, start=False)
+    with pytest.raises(ValueError):
+        tf.train.Server(c, start=False)                       # ambiguous job
+    with pytest.raises(ValueError):
+        tf.train.Server(c, job_name="worker", task_index=0, protocol="mpi", start=False)
+    with pytest.raises(ValueError):
+        tf.Session("grpc://nowhere:1")
+    sd = tf.train.Server(c, job_name="worker", task_index=1, start=False).server_def
+    assert sd.job_name == "worker" and sd.task_index == 1 and sd.SerializeToString()

@@ -304,12 +304,44 @@ class RemoteVariableStore:
                  connect_timeout_s: float = 60.0):
         self.client = PsClient(address, connect_timeout_s)
         self.device = torch.device(device)
-        self._cache: Dict[str, torch.Tensor] = {}
-        self._sgd: List[Tuple[str, float, np.ndarray]] = []
-        self._add: List[Tuple[str, np.ndarray]] = []
+        # step state is per thread: the training loop and the Supervisor's service threads
+        # (checkpoint, summaries) run steps through the same store concurrently
+        self._tls = threading.local()
         self.update_count = 0
         self.bytes_pulled = 0
         self.bytes_pushed = 0
+
+    @property
+    def _cache(self) -> Dict[str, torch.Tensor]:
+        try:
+            return self._tls.cache
+        except AttributeError:
+            self._tls.cache = {}
+            return self._tls.cache
+
+    @property
+    def _sgd(self) -> List[Tuple[str, float, np.ndarray]]:
+        try:
+            return self._tls.sgd
+        except AttributeError:
+            self._tls.sgd = []
+            return self._tls.sgd
+
+    @_sgd.setter
+    def _sgd(self, value) -> None:
+        self._tls.sgd = value
+
+    @property
+    def _add(self) -> List[Tuple[str, np.ndarray]]:
+        try:
+            return self._tls.add
+        except AttributeError:
+            self._tls.add = []
+            return self._tls.add
+
+    @_add.setter
+    def _add(self, value) -> None:
+        self._tls.add = value
 
     # -- step bracket --------------------------------------------------------------------
     def begin_step(self, names: Sequence[str]) -> None:

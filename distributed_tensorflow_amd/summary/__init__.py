@@ -9,7 +9,7 @@ A scalar summary is a *host* op: the session fetches the scalar together with th
 fetched values in the step's single device->host copy and encodes the ``Summary`` protobuf on
 the CPU, so summaries add no GPU kernel.
 
-Event files are ``events.out.tfevents.<unix_ts>.<hostname>``; records are TFRecord framed
+Event files are ``events.out.tfevents.<unix_ts>.<hostname>.<pid>.<serial>``; records are TFRecord framed
 (``u64 length | u32 masked_crc32c(length) | payload | u32 masked_crc32c(payload)``) ``Event``
 protobufs; the first record carries ``file_version = "brain.Event:2"``.
 """
@@ -201,12 +201,18 @@ class EventFileWriter:
     """Asynchronous writer: ``add_event`` enqueues, a daemon thread frames and writes, and
     the file is flushed every ``flush_secs``."""
 
+    _serial = 0
+
     def __init__(self, logdir: str, max_queue: int = 10, flush_secs: float = 120.0,
                  filename_suffix: str = ""):
         self._logdir = str(logdir)
         os.makedirs(self._logdir, exist_ok=True)
-        fname = "events.out.tfevents.%010d.%s%s" % (time.time(), socket.gethostname(),
-                                                    filename_suffix)
+        # several tasks of one node share a log directory (the reference's tasks each had a
+        # host of their own): pid + per-process counter keep their files apart
+        EventFileWriter._serial += 1
+        fname = "events.out.tfevents.%010d.%s.%d.%d%s" % (
+            time.time(), socket.gethostname(), os.getpid(), EventFileWriter._serial,
+            filename_suffix)
         self.path = os.path.join(self._logdir, fname)
         lib = native.load()
         self._file = _NativeEventsFile(lib, self.path) if lib is not None \

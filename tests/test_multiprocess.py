@@ -1,0 +1,123 @@
+"""T2: real multi-process jobs on localhost (CPU): the three example scripts as 1 ps + 2 workers
+over the TCP parameter-server transport, the same script as 2 gloo ranks with collective
+strategies, and a torch.distributed (gloo) run of the communicator / sharded-matmul layer."""
+import json
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+from distributed_tensorflow_amd import launch
+from distributed_tensorflow_amd.summary import read_events
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EX = os.path.join(ROOT, "examples")
+
+
+def _run_launcher(args, timeout=240):
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    proc = subprocess.run([sys.executable, "-m", "distributed_tensorflow_amd.launch"] + args,
+                          cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                          text=True, timeout=timeout)
+    return proc.returncode, proc.stdout
+
+
+def test_launcher_plans_cluster_and_commands():
+    cluster, tasks = launch.plan_tasks(3, 2, "grpc", ports=[1, 2, 3, 4, 5])
+    assert cluster == {"ps": ["127.0.0.1:1", "127.0.0.1:2"],
+                       "worker": ["127.0.0.1:3", "127.0.0.1:4", "127.0.0.1:5"]}
+    assert tasks == [("ps", 0), ("ps", 1), ("worker", 0), ("worker", 1), ("worker", 2)]
+    cmd = launch.child_command("s.py", ["--x=1"], cluster, "worker", 1, "grpc", None)
+    assert "--job_name=worker" in cmd and "--task_index=1" in cmd and "--shutdown_ps" in cmd
+    assert cmd[-1] == "--x=1"
+    assert "--shutdown_ps" not in launch.child_command("s.py", [], cluster, "ps", 0, "grpc", None)
+    cluster, tasks = launch.plan_tasks(2, 1, "rccl", ports=[7, 8])
+    assert "ps" not in cluster and tasks == [("worker", 0), ("worker", 1)]
+    env = launch.child_env(cluster, "worker", 1, "rccl")
+    assert env["RANK"] == "1" and env["WORLD_SIZE"] == "2" and env["MASTER_ADDR"] == "127.0.0.1"
+    assert env["MASTER_PORT"] == "7" and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    with pytest.raises(ValueError):
+        launch.plan_tasks(0, 1, "grpc")
+
+
+@pytest.mark.parametrize("script", ["tf_distributed.py", "tf_distributed_worker.py"])
+def test_mnist_example_one_ps_two_workers(script, tmp_path):
+    logs = str(tmp_path / "logs")
+    rc, out = _run_launcher(["--num_workers", "2", "--timeout", "200", os.path.join(EX, script),
+                             "--", "--max_steps", "120", "--device", "cpu", "--logs_path", logs,
+                             "--data_dir", str(tmp_path / "nodata")])
+    assert rc == 0, out
+    for w in (0, 1):
+        assert "[worker:%d] Variables initialized ..." % w in out
+        assert "[worker:%d] done" % w in out
+        assert re.search(r"\[worker:%d\] Test-Accuracy: \d+\.\d\d" % w, out)
+        assert re.search(r"\[worker:%d\] Final Cost: \d+\.\d{4}" % w, out)
+    # the reference's progress line (tf_distributed.py:118-122), printed every 100 local steps
+    m = re.search(r"Step: (\d+),\s+Epoch:\s+(\d+),\s+Batch:\s+(\d+) of\s+(\d+),\s+Cost: (\d+\.\d{4}),"
+                  r"\s+AvgTime:\s*(\d+\.\d\d)ms", out)
+    assert m, out
+    assert int(m.group(4)) == 550                 # 55000 / 100 batches per epoch
+    # both workers advanced the shared global_step: someone saw a step beyond its own count
+    steps = [int(s) for s in re.findall(r"Step: (\d+),", out)]
+    assert max(steps) > 100
+    events = []
+    for fname in os.listdir(logs):
+        events += list(read_events(os.path.join(logs, fname)))
+    tags = {v[0] for e in events for v in e.get("summary", [])}
+    assert {"cost", "accuracy"} <= tags
+
+
+def test_matmul_example_one_ps_two_workers(tmp_path):
+    rc, out = _run_launcher(["--num_workers", "2", "--timeout", "200",
+                             os.path.join(EX, "tf_distributed_1000Matrix.py"), "--",
+                             "--max_steps", "101", "--device", "cpu",
+                             "--logs_path", str(tmp_path / "logs")])
+    assert rc == 0, out
+    assert out.count("done") == 2
+    assert re.search(r"AvgTime:\s*\d+\.\d\dms", out) and re.search(r"GFLOPS: \d+\.\d", out)
+    # A and B live on the ps: both workers computed the same product
+    costs = re.findall(r"Final Cost: (-?\d+\.\d{4})", out)
+    assert len(costs) == 2 and costs[0] == costs[1]
+
+
+@pytest.mark.parametrize("strategy", ["allreduce_sync", "reduce_scatter_sync"])
+def test_mnist_example_two_collective_ranks(strategy, tmp_path):
+    rc, out = _run_launcher(["--num_workers", "2", "--protocol", "rccl", "--strategy", strategy,
+                             "--timeout", "200", os.path.join(EX, "tf_distributed.py"), "--",
+                             "--max_steps", "40", "--device", "cpu",
+                             "--logs_path", str(tmp_path / "logs"),
+                             "--data_dir", str(tmp_path / "nodata")])
+    assert rc == 0, out
+    acc = re.findall(r"Test-Accuracy: (\d+\.\d\d)", out)
+    assert len(acc) == 2 and acc[0] == acc[1]       # replicas stay identical
+
+
+@pytest.mark.parametrize("strategy", ["allreduce_sync", "reduce_scatter_sync"])
+def test_gloo_two_process_comm_matmul_and_training(strategy, tmp_path):
+    from distributed_tensorflow_amd.train.server import _free_port
+    env = dict(os.environ, PYTHONPATH=ROOT, DTF_STRATEGY=strategy, OMP_NUM_THREADS="2",
+               DTF_RESULT_DIR=str(tmp_path))
+    proc = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+         "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+         os.path.join(ROOT, "tests", "helpers", "gloo_worker.py")],
+        cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+        timeout=240)
+    assert proc.returncode == 0, proc.stdout
+    results = []
+    for r in (0, 1):
+        with open(str(tmp_path / ("rank%d.json" % r))) as fh:
+            results.append(json.load(fh))
+    assert [r["rank"] for r in results] == [0, 1]
+    for r in results:
+        assert r["world"] == 2 and r["allreduce"] == 3.0
+        assert r["all_gather"] == [0.0, 0.0, 1.0, 1.0]
+        assert r["bcast_obj"] == {"x": 7}
+        lo = 4 * r["rank"]
+        assert r["reduce_scatter"] == [3.0 * (lo + i) for i in range(4)]
+        assert max(r["matmul_err"].values()) < 1e-3
+        assert r["loss_last"] < 0.05 * r["loss_first"]
+        assert r["step"] == 60.0
+    assert results[0]["w"] == results[1]["w"]        # bit-identical replicas

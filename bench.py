@@ -35,7 +35,7 @@ if ROOT not in sys.path:
 from distributed_tensorflow_amd.parallel.comm import SingleComm, TorchDistComm  # noqa: E402
 from distributed_tensorflow_amd.parallel.sharded_matmul import ShardedMatmul  # noqa: E402
 
-DTYPES = {"bf16": torch.bfloat16, "fp32": torch.float32}
+DTYPES = {"bf16": torch.bfloat16, "fp32": torch.float32, "fp8": torch.float8_e4m3fn}
 FULL_RESULT_STRATEGIES = ("m_shard_allgather", "k_shard_allreduce")
 
 
@@ -90,8 +90,10 @@ def main() -> None:
         engine = make(strategy)
         for _ in range(args.warmup):
             engine.step()
-    elif args.strategy != "auto":
-        strategy = args.strategy
+    elif args.strategy != "auto" or args.dtype == "fp8":
+        # fp8 is the 2-D sharded configuration (65536^2 sized for 288 GB HBM): SUMMA on the
+        # P x Q grid, C left 2-D sharded
+        strategy = "summa_2d" if args.strategy == "auto" else args.strategy
         engine = make(strategy)
         for _ in range(args.warmup):
             engine.step()

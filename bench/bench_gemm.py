@@ -32,7 +32,7 @@ def timeit(fn, iters: int, warmup: int = 3) -> float:
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--sizes", default="1024,2048,4096,8192,16384")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8"])
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--no-torch", action="store_true")
     ap.add_argument("--variant", type=int, default=0)
@@ -52,6 +52,20 @@ def main() -> None:
                 err = (out.float() - a.float() @ bt.float().t()).abs().max().item()
             else:
                 err = (out[:256].float() - a[:256].float() @ bt.float().t()).abs().max().item()
+        elif args.dtype == "fp8":
+            a = hip.philox_window(m, k, 1, 1, 0, 0, k, torch.float8_e4m3fn, "cuda", False, -1.0, 2.0)
+            bt = hip.philox_window(n, k, 1, 2, 0, 0, k, torch.float8_e4m3fn, "cuda", False, -1.0, 2.0)
+            out = torch.empty(m, n, device="cuda", dtype=torch.bfloat16)
+            ours = timeit(lambda: hip.gemm_fp8_nt(a, bt, torch.bfloat16, out=out), args.iters)
+            ref = None
+            if not args.no_torch and hasattr(torch, "_scaled_mm"):
+                one = torch.ones((), device="cuda")
+                try:
+                    ref = timeit(lambda: torch._scaled_mm(a, bt.t(), scale_a=one, scale_b=one,
+                                                          out_dtype=torch.bfloat16), args.iters)
+                except Exception as e:  # noqa: BLE001 -- reference only
+                    print("torch._scaled_mm unavailable: %s" % str(e)[:100], file=sys.stderr)
+            err = (out[:256].float() - a[:256].float() @ bt.float().t()).abs().max().item()
         else:
             a = torch.rand(m, k, device="cuda") * 2 - 1
             b = torch.rand(k, n, device="cuda") * 2 - 1

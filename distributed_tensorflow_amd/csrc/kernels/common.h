@@ -31,6 +31,8 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) short bf16x8;   // 8 bf16 in 4 VGPRs
 typedef __attribute__((ext_vector_type(4))) short bf16x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(8))) int i32x8;      // 32 fp8 in 8 VGPRs
 
 __device__ __forceinline__ float dtf_apply_act(float v, int act) {
   switch (act) {
@@ -51,6 +53,33 @@ __device__ __forceinline__ unsigned short dtf_f32_to_bf16(float f) {
   if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
   u += 0x7fffu + ((u >> 16) & 1u);
   return (unsigned short)(u >> 16);
+}
+
+// f32 -> OCP fp8 e4m3fn (bias 7, 3 mantissa bits, no infinities, max 448), round-to-nearest-
+// even, SATURATING: |f| beyond 448 becomes +-448 (0x7e), never NaN. NaN -> 0x7f.
+__device__ __forceinline__ unsigned char dtf_f32_to_e4m3(float f) {
+  const unsigned int u = __float_as_uint(f);
+  const unsigned int sign = (u >> 24) & 0x80u;
+  unsigned int a = u & 0x7fffffffu;
+  if (a > 0x7f800000u) return (unsigned char)(sign | 0x7fu);
+  if (a < 0x3c800000u) {                       // |f| < 2^-6: subnormal grid, step 2^-9
+    const float q = rintf(__uint_as_float(a) * 512.0f);   // 0..8 (8 = the smallest normal)
+    return (unsigned char)(sign | (unsigned int)q);
+  }
+  a += 0x7ffffu + ((a >> 20) & 1u);            // RNE at mantissa bit 20
+  a &= ~0xfffffu;
+  const int e = (int)(a >> 23) - 127 + 7;
+  const unsigned int m = (a >> 20) & 7u;
+  if (e > 15 || (e == 15 && m == 7u)) return (unsigned char)(sign | 0x7eu);
+  return (unsigned char)(sign | ((unsigned int)e << 3) | m);
+}
+
+__device__ __forceinline__ float dtf_e4m3_to_f32(unsigned char b) {
+  const unsigned int sign = ((unsigned int)b & 0x80u) << 24;
+  const unsigned int e = (b >> 3) & 15u, m = b & 7u;
+  if (e == 15u && m == 7u) return __uint_as_float(sign | 0x7fc00000u);
+  if (e == 0u) return __uint_as_float(sign | __float_as_uint((float)m * 0.001953125f));
+  return __uint_as_float(sign | ((e + 120u) << 23) | (m << 20));
 }
 
 // wave64 all-lane sum / max via butterfly shuffles

@@ -189,6 +189,49 @@ __global__ __launch_bounds__(BLOCK) void cast_bf16_f32_kernel(const unsigned sho
   for (long i = (n4 << 2) + start; i < n; i += step) out[i] = dtf_bf16_to_f32(x[i]);
 }
 
+// quantise to OCP fp8 e4m3: out = e4m3(clamp(x * scale, +-448)); 4 elements -> one 32-bit store
+// through v_cvt_pk_fp8_f32 (round-to-nearest-even). SRC_BF16 selects the source type.
+template <bool SRC_BF16>
+__global__ __launch_bounds__(BLOCK) void cast_to_fp8_kernel(const void* __restrict__ x_,
+                                                            unsigned char* __restrict__ out,
+                                                            long n, float scale) {
+  const long n4 = n >> 2;
+  const long start = blockIdx.x * (long)BLOCK + threadIdx.x, step = (long)gridDim.x * BLOCK;
+  for (long i = start; i < n4; i += step) {
+    f32x4 v;
+    if (SRC_BF16) {
+      const bf16x4 h = reinterpret_cast<const bf16x4*>(x_)[i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = dtf_bf16_to_f32((unsigned short)h[j]);
+    } else {
+      v = reinterpret_cast<const f32x4*>(x_)[i];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = __builtin_amdgcn_fmed3f(v[j] * scale, -448.f, 448.f);
+    int packed = 0;
+    packed = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], packed, false);
+    packed = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], packed, true);
+    reinterpret_cast<int*>(out)[i] = packed;
+  }
+  for (long i = (n4 << 2) + start; i < n; i += step) {
+    const float f = SRC_BF16 ? dtf_bf16_to_f32(reinterpret_cast<const unsigned short*>(x_)[i])
+                             : reinterpret_cast<const float*>(x_)[i];
+    out[i] = dtf_f32_to_e4m3(f * scale);
+  }
+}
+
+// dequantise: out = f32/bf16(e4m3(x)) * scale
+template <bool DST_BF16>
+__global__ __launch_bounds__(BLOCK) void cast_from_fp8_kernel(const unsigned char* __restrict__ x,
+                                                              void* __restrict__ out_, long n,
+                                                              float scale) {
+  for (long i = blockIdx.x * (long)BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * BLOCK) {
+    const float f = dtf_e4m3_to_f32(x[i]) * scale;
+    if (DST_BF16) reinterpret_cast<unsigned short*>(out_)[i] = dtf_f32_to_bf16(f);
+    else reinterpret_cast<float*>(out_)[i] = f;
+  }
+}
+
 __global__ __launch_bounds__(BLOCK) void cast_u8_f32_kernel(const unsigned char* __restrict__ x,
                                                             float* __restrict__ out, long n) {
   for (long i = blockIdx.x * (long)BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * BLOCK)
@@ -326,6 +369,36 @@ DTF_API int dtf_cast_bf16_to_f32(const void* x, float* out, long n, hipStream_t 
   if (!x || !out || ((uintptr_t)x & 7) || !aligned16(out)) return DTF_ERR_BAD_ARG;
   hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid_for(n, 4)), dim3(BLOCK), 0, stream,
                      (const unsigned short*)x, out, n);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
+// src_kind / dst_kind: 0 = fp32, 1 = bf16
+DTF_API int dtf_cast_to_fp8(const void* x, int src_kind, void* out, long n, float scale,
+                            hipStream_t stream) {
+  if (n <= 0) return DTF_OK;
+  if (!x || !out || !aligned16(x) || ((uintptr_t)out & 3) || src_kind < 0 || src_kind > 1)
+    return DTF_ERR_BAD_ARG;
+  if (src_kind == 1)
+    hipLaunchKernelGGL(cast_to_fp8_kernel<true>, dim3(grid_for(n, 4)), dim3(BLOCK), 0, stream, x,
+                       (unsigned char*)out, n, scale);
+  else
+    hipLaunchKernelGGL(cast_to_fp8_kernel<false>, dim3(grid_for(n, 4)), dim3(BLOCK), 0, stream, x,
+                       (unsigned char*)out, n, scale);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
+DTF_API int dtf_cast_from_fp8(const void* x, void* out, int dst_kind, long n, float scale,
+                              hipStream_t stream) {
+  if (n <= 0) return DTF_OK;
+  if (!x || !out || dst_kind < 0 || dst_kind > 1) return DTF_ERR_BAD_ARG;
+  if (dst_kind == 1)
+    hipLaunchKernelGGL(cast_from_fp8_kernel<true>, dim3(grid_for(n, 1)), dim3(BLOCK), 0, stream,
+                       (const unsigned char*)x, out, n, scale);
+  else
+    hipLaunchKernelGGL(cast_from_fp8_kernel<false>, dim3(grid_for(n, 1)), dim3(BLOCK), 0, stream,
+                       (const unsigned char*)x, out, n, scale);
   DTF_LAUNCH_CHECK();
   return DTF_OK;
 }

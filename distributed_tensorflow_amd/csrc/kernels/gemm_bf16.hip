@@ -179,17 +179,20 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_nt_kernel(
 //    always has a feeder, and the loads of one group hide under the MFMAs of the other.
 //  * Hazards: a staged half-tile is read one full phase (two barriers) after the vmcnt that
 //    retired it, and a slot is restaged at least two phases after its last read.
-__device__ __forceinline__ void stage_half(const unsigned short* __restrict__ A,
-                                           const unsigned short* __restrict__ Bt, long lda,
+// ESIZE = bytes per element (2: bf16, 1: fp8); a K-tile is always 128 bytes of k per row, and
+// lda / ldb are in elements.
+template <int ESIZE>
+__device__ __forceinline__ void stage_half(const char* __restrict__ A,
+                                           const char* __restrict__ Bt, long lda,
                                            long ldb, int m0, int n0, int M, int N, int h, int nkt,
                                            int kind, int buf, char* smem, int wave, int lane) {
   int t = h >> 2;
   t = t < nkt ? t : nkt - 1;        // past the end: restage a dead slot with valid memory
-  const int k0 = t * BK;
+  const long k0 = (long)t * 128;    // bytes
   const bool is_a = (kind == 0 || kind == 3);
   const int half = (kind >= 2) ? 1 : 0;
-  const unsigned short* X = is_a ? A : Bt;
-  const long ld = is_a ? lda : ldb;
+  const char* X = is_a ? A : Bt;
+  const long ld = (is_a ? lda : ldb) * ESIZE;
   const int base_row = (is_a ? m0 : n0) + half * 128;
   const int max_row = (is_a ? M : N) - 1;
   char* dst = smem + buf * BUF_BYTES + (is_a ? 0 : TILE_BYTES) + half * (TILE_BYTES / 2);
@@ -200,16 +203,26 @@ __device__ __forceinline__ void stage_half(const unsigned short* __restrict__ A,
     int row = base_row + trow;
     row = row < max_row ? row : max_row;
     const int kc = (lane & 7) ^ ((trow >> 1) & 7);
-    const unsigned short* src = X + (long)row * ld + k0 + kc * 8;
+    const char* src = X + (long)row * ld + k0 + kc * 16;
     __builtin_amdgcn_global_load_lds((global_void*)src, (lds_void*)(dst + piece * 1024), 16, 0, 0);
   }
 }
 
-template <bool OUT_F32, int DBG>
-__global__ __launch_bounds__(NTHREADS) void gemm_bf16_nt_pp_kernel(
-    const unsigned short* __restrict__ A, const unsigned short* __restrict__ Bt,
+// FP8 = false: bf16 operands, K-tile 64, two v_mfma_f32_16x16x32_bf16 per output tile and K-tile.
+// FP8 = true : OCP e4m3 operands, K-tile 128 (the same 128 bytes per row, so the LDS image, the
+//   DMA stream and the fragment reads are byte-for-byte those of the bf16 kernel); the two
+//   16-byte fragment reads of a lane (k bytes 16q..16q+15 and 64+16q..64+16q+15, q = lane>>4)
+//   form the 32-byte operand of ONE v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales
+//   (E8M0 0x7f). A and Bt lanes of the same q hold the same k set, which is all the
+//   instruction's k-assignment requires of a full-K reduction. That MFMA takes twice the
+//   cycles of the bf16 one at 4x the k, so a K-tile costs the same matrix-pipe time and the
+//   same bytes as in bf16 while doing twice the flops.
+template <bool OUT_F32, int DBG, bool FP8>
+__global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
+    const char* __restrict__ A, const char* __restrict__ Bt,
     void* __restrict__ C, int M, int N, int K, long lda, long ldb, long ldc, int tiles_m,
-    int tiles_n, float alpha) {
+    int tiles_n, float alpha, float beta) {
+  constexpr int ESIZE = FP8 ? 1 : 2;
   // DBG (timing experiments only, built with -DDTF_GEMM_EXPERIMENTS; results are wrong when
   // set): bit 0 = issue no LDS-DMA in the K-loop, bit 1 = always stage K-tile 0 (every load an
   // L2 hit), bit 2 = skip the counted wait
@@ -229,7 +242,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_nt_pp_kernel(
   const int tm = first_m + (id % per_group) % gsize;
   const int tn = (id % per_group) / gsize;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int nkt = K / BK;
+  const int nkt = K / (128 / ESIZE);
 
   f32x4 acc[2][2][4][2];
 #pragma unroll
@@ -240,8 +253,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_nt_pp_kernel(
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  bf16x8 af[4][2];        // [m-tile][k-step] of the current A half
-  bf16x8 bf[2][2][2];     // [n-half][n-tile][k-step]: both Bt halves stay resident
+  i32x4 af[4][2];         // [m-tile][16-byte k-chunk] of the current A half
+  i32x4 bf[2][2][2];      // [n-half][n-tile][k-chunk]: both Bt halves stay resident
 
   const int frow = lane & 15, fq = lane >> 4;
   // per-lane part of chunk_off() for k-step 0 / 1 (the XOR makes them differ by +-64 B); the
@@ -253,34 +266,44 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_nt_pp_kernel(
   // prologue: half-tiles 0..5 in flight, 0 and 1 landed and visible
 #pragma unroll
   for (int h = 0; h < 6; ++h)
-    stage_half(A, Bt, lda, ldb, m0, n0, M, N, h, nkt, h & 3, (h >> 2) & 1, smem, wave, lane);
+    stage_half<ESIZE>(A, Bt, lda, ldb, m0, n0, M, N, h, nkt, h & 3, (h >> 2) & 1, smem, wave,
+                      lane);
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();          // waves 4-7 run one barrier behind
 
 #define DTF_READ_A(MH, BUFI)                                                                     \
   _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) \
-      af[i][s2] = *reinterpret_cast<const bf16x8*>(smem + (BUFI) * BUF_BYTES + (MH) * 16384 +    \
-                                                   a_wave + i * 2048 +                          \
-                                                   (s2 ? lane_off1 : lane_off0));
+      af[i][s2] = *reinterpret_cast<const i32x4*>(smem + (BUFI) * BUF_BYTES + (MH) * 16384 +     \
+                                                  a_wave + i * 2048 +                           \
+                                                  (s2 ? lane_off1 : lane_off0));
 #define DTF_READ_B(NH, BUFI)                                                                     \
   _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) \
-      bf[NH][j][s2] = *reinterpret_cast<const bf16x8*>(smem + (BUFI) * BUF_BYTES + (NH) * 16384 + \
-                                                       b_wave + j * 2048 +                      \
-                                                       (s2 ? lane_off1 : lane_off0));
+      bf[NH][j][s2] = *reinterpret_cast<const i32x4*>(smem + (BUFI) * BUF_BYTES + (NH) * 16384 + \
+                                                      b_wave + j * 2048 +                       \
+                                                      (s2 ? lane_off1 : lane_off0));
 #define DTF_MFMA_QUAD(MH, NH)                                                                    \
-  _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) _Pragma("unroll") for (int i = 0; i < 4; ++i) \
-      _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[MH][NH][i][j] =                          \
-          __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[NH][j][s2], af[i][s2], acc[MH][NH][i][j],   \
-                                                  0, 0, 0);
+  if constexpr (FP8) {                                                                           \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)  \
+        acc[MH][NH][i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(                    \
+            __builtin_shufflevector(bf[NH][j][0], bf[NH][j][1], 0, 1, 2, 3, 4, 5, 6, 7),         \
+            __builtin_shufflevector(af[i][0], af[i][1], 0, 1, 2, 3, 4, 5, 6, 7),                 \
+            acc[MH][NH][i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);                              \
+  } else {                                                                                       \
+    _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) _Pragma("unroll") for (int i = 0; i < 4;    \
+                                                                            ++i)                 \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[MH][NH][i][j] =                        \
+            __builtin_amdgcn_mfma_f32_16x16x32_bf16((bf16x8)bf[NH][j][s2], (bf16x8)af[i][s2],    \
+                                                    acc[MH][NH][i][j], 0, 0, 0);                 \
+  }
 // phase P (0..7) of an iteration that starts at global phase g0: LDS reads, DMA issue of
 // half-tile g0+P+6, counted wait, barrier, 16 MFMAs, barrier
 #define DTF_PHASE(P, READS, MH, NH)                                                              \
   {                                                                                              \
     READS;                                                                                       \
     if (!(dbg & 1))                                                                              \
-      stage_half(A, Bt, lda, ldb, m0, n0, M, N, (dbg & 2) ? 0 : g0 + (P) + 6, nkt,               \
-                 ((P) + 2) & 3, (((P) + 6) >> 2) & 1, smem, wave, lane);                         \
+      stage_half<ESIZE>(A, Bt, lda, ldb, m0, n0, M, N, (dbg & 2) ? 0 : g0 + (P) + 6, nkt,        \
+                        ((P) + 2) & 3, (((P) + 6) >> 2) & 1, smem, wave, lane);                  \
     if (!(dbg & 4)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                             \
     __builtin_amdgcn_sched_barrier(0);                                                           \
     __builtin_amdgcn_s_barrier();                                                                \
@@ -333,10 +356,18 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_nt_pp_kernel(
           f32x4 v = acc[mh][nh][i][j] * alpha;
           if (OUT_F32) {
             float* dst = reinterpret_cast<float*>(C) + (long)row * ldc + col;
-            if (col + 3 < N) *reinterpret_cast<f32x4*>(dst) = v;
-            else for (int r = 0; r < 4 && col + r < N; ++r) dst[r] = v[r];
+            if (col + 3 < N) {
+              if (beta != 0.f) v += *reinterpret_cast<const f32x4*>(dst) * beta;
+              *reinterpret_cast<f32x4*>(dst) = v;
+            } else {
+              for (int r = 0; r < 4 && col + r < N; ++r)
+                dst[r] = beta != 0.f ? v[r] + beta * dst[r] : v[r];
+            }
           } else {
             unsigned short* dst = reinterpret_cast<unsigned short*>(C) + (long)row * ldc + col;
+            if (beta != 0.f) {
+              for (int r = 0; r < 4 && col + r < N; ++r) v[r] += beta * dtf_bf16_to_f32(dst[r]);
+            }
             if (col + 3 < N) {
               bf16x4 o;
 #pragma unroll
@@ -357,7 +388,7 @@ template <bool OUT_F32>
 __global__ __launch_bounds__(256) void gemm_bf16_generic_kernel(
     const unsigned short* __restrict__ A, const unsigned short* __restrict__ B,
     void* __restrict__ C, int M, int N, int K, long a_rs, long a_cs, long b_rs, long b_cs,
-    long ldc, float alpha) {
+    long ldc, float alpha, float beta) {
   // As[m][k], Bs[n][k] with 80-byte rows (64 B data + 16 B pad: conflict-free b128 reads)
   __shared__ __attribute__((aligned(16))) unsigned short As[GB][GK + 8];
   __shared__ __attribute__((aligned(16))) unsigned short Bs[GB][GK + 8];
@@ -402,9 +433,80 @@ __global__ __launch_bounds__(256) void gemm_bf16_generic_kernel(
       for (int r = 0; r < 4; ++r) {
         const int col = n0 + wc * 32 + j * 16 + 4 * fq + r;
         if (row < M && col < N) {
-          const float v = acc[i][j][r] * alpha;
-          if (OUT_F32) reinterpret_cast<float*>(C)[(long)row * ldc + col] = v;
-          else reinterpret_cast<unsigned short*>(C)[(long)row * ldc + col] = dtf_f32_to_bf16(v);
+          float v = acc[i][j][r] * alpha;
+          if (OUT_F32) {
+            float* dst = reinterpret_cast<float*>(C) + (long)row * ldc + col;
+            if (beta != 0.f) v += beta * *dst;
+            *dst = v;
+          } else {
+            unsigned short* dst = reinterpret_cast<unsigned short*>(C) + (long)row * ldc + col;
+            if (beta != 0.f) v += beta * dtf_bf16_to_f32(*dst);
+            *dst = dtf_f32_to_bf16(v);
+          }
+        }
+      }
+    }
+}
+
+// ---- generic, fully predicated fp8 (e4m3) GEMM: v_mfma_f32_16x16x32_fp8_fp8, any shape/stride --
+template <bool OUT_F32>
+__global__ __launch_bounds__(256) void gemm_fp8_generic_kernel(
+    const unsigned char* __restrict__ A, const unsigned char* __restrict__ B,
+    void* __restrict__ C, int M, int N, int K, long a_rs, long a_cs, long b_rs, long b_cs,
+    long ldc, float alpha, float beta) {
+  // As[m][k], Bs[n][k] with 40-byte rows (32 B data + 8 B pad, keeps the 8-byte reads aligned)
+  __shared__ __attribute__((aligned(16))) unsigned char As[GB][GK + 8];
+  __shared__ __attribute__((aligned(16))) unsigned char Bs[GB][GK + 8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int m0 = blockIdx.y * GB, n0 = blockIdx.x * GB;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int frow = lane & 15, fq = lane >> 4;
+  for (int k0 = 0; k0 < K; k0 += GK) {
+    for (int e = tid; e < GB * GK; e += 256) {
+      const int r = e / GK, k = e % GK;
+      const int gm = m0 + r, gn = n0 + r, gk = k0 + k;
+      As[r][k] = (gm < M && gk < K) ? A[gm * a_rs + gk * a_cs] : (unsigned char)0;
+      Bs[r][k] = (gn < N && gk < K) ? B[gk * b_rs + gn * b_cs] : (unsigned char)0;
+    }
+    __syncthreads();
+    long af[2], bf[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      af[i] = *reinterpret_cast<const long*>(&As[wr * 32 + i * 16 + frow][fq * 8]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      bf[j] = *reinterpret_cast<const long*>(&Bs[wc * 32 + j * 16 + frow][fq * 8]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(bf[j], af[i], acc[i][j], 0, 0, 0);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = m0 + wr * 32 + i * 16 + frow;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int col = n0 + wc * 32 + j * 16 + 4 * fq + r;
+        if (row < M && col < N) {
+          float v = acc[i][j][r] * alpha;
+          if (OUT_F32) {
+            float* dst = reinterpret_cast<float*>(C) + (long)row * ldc + col;
+            if (beta != 0.f) v += beta * *dst;
+            *dst = v;
+          } else {
+            unsigned short* dst = reinterpret_cast<unsigned short*>(C) + (long)row * ldc + col;
+            if (beta != 0.f) v += beta * dtf_bf16_to_f32(*dst);
+            *dst = dtf_f32_to_bf16(v);
+          }
         }
       }
     }
@@ -418,9 +520,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_generic_kernel(
 // dtf_gemm_bf16_generic).
 // variant & 15: 0 = default (ping-pong schedule), 1 = two-phase double-buffer, 2 = ping-pong;
 // variant >> 4: timing-experiment bits of the ping-pong kernel (0 in production).
+template <typename KernelT>
+static void dtf_allow_lds(KernelT kernel, size_t lds) {
+  hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
 DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int N, int K, long lda,
-                             long ldb, long ldc, float alpha, int out_f32, int variant,
-                             hipStream_t stream) {
+                             long ldb, long ldc, float alpha, float beta, int out_f32,
+                             int variant, hipStream_t stream) {
   if (!A || !Bt || !C || M <= 0 || N <= 0 || K <= 0) return DTF_ERR_BAD_ARG;
   if (lda < K || ldb < K || ldc < N) return DTF_ERR_BAD_ARG;
   if (K % BK || lda % 8 || ldb % 8 || ldc % 4 || ((uintptr_t)A & 15) || ((uintptr_t)Bt & 15) ||
@@ -430,30 +537,24 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
   const size_t lds = 2 * BUF_BYTES;   // 128 KiB
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<true>,
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<false>,
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipFuncSetAttribute((const void*)gemm_bf16_nt_pp_kernel<true, 0>,
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipFuncSetAttribute((const void*)gemm_bf16_nt_pp_kernel<false, 0>,
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dtf_allow_lds(gemm_bf16_nt_kernel<true>, lds);
+    dtf_allow_lds(gemm_bf16_nt_kernel<false>, lds);
+    dtf_allow_lds(gemm_nt_pp_kernel<true, 0, false>, lds);
+    dtf_allow_lds(gemm_nt_pp_kernel<false, 0, false>, lds);
 #ifdef DTF_GEMM_EXPERIMENTS
-    hipFuncSetAttribute((const void*)gemm_bf16_nt_pp_kernel<false, 1>,
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipFuncSetAttribute((const void*)gemm_bf16_nt_pp_kernel<false, 2>,
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipFuncSetAttribute((const void*)gemm_bf16_nt_pp_kernel<false, 4>,
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dtf_allow_lds(gemm_nt_pp_kernel<false, 1, false>, lds);
+    dtf_allow_lds(gemm_nt_pp_kernel<false, 2, false>, lds);
+    dtf_allow_lds(gemm_nt_pp_kernel<false, 4, false>, lds);
 #endif
     attr_set = true;
   }
   dim3 grid(tiles_m * tiles_n), block(NTHREADS);
+  if ((variant & 15) == 1 && beta != 0.f) return DTF_ERR_UNSUPPORTED;
   if ((variant & 15) != 1) {
 #define DTF_PP_LAUNCH(F32, DBGV)                                                                  \
-  hipLaunchKernelGGL((gemm_bf16_nt_pp_kernel<F32, DBGV>), grid, block, lds, stream,               \
-                     (const unsigned short*)A, (const unsigned short*)Bt, C, M, N, K, lda, ldb,   \
-                     ldc, tiles_m, tiles_n, alpha)
+  hipLaunchKernelGGL((gemm_nt_pp_kernel<F32, DBGV, false>), grid, block, lds, stream,             \
+                     (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tiles_m,         \
+                     tiles_n, alpha, beta)
     const int dbg = variant >> 4;
     if (dbg == 0) {
       if (out_f32) DTF_PP_LAUNCH(true, 0); else DTF_PP_LAUNCH(false, 0);
@@ -480,20 +581,70 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
   return DTF_OK;
 }
 
+// fp8 (OCP e4m3fn) operands: C[M,N] (bf16 or fp32) = alpha * A[M,K] * Bt[N,K]^T, fp32
+// accumulate; alpha carries the product of the operands' per-tensor dequantisation scales.
+// Fast kernel contract: K % 128 == 0, lda/ldb % 16 == 0, 16-byte aligned A/Bt, C as for bf16.
+DTF_API int dtf_gemm_fp8_nt(const void* A, const void* Bt, void* C, int M, int N, int K, long lda,
+                            long ldb, long ldc, float alpha, float beta, int out_f32,
+                            hipStream_t stream) {
+  if (!A || !Bt || !C || M <= 0 || N <= 0 || K <= 0) return DTF_ERR_BAD_ARG;
+  if (lda < K || ldb < K || ldc < N) return DTF_ERR_BAD_ARG;
+  if (K % 128 || lda % 16 || ldb % 16 || ldc % 4 || ((uintptr_t)A & 15) || ((uintptr_t)Bt & 15) ||
+      ((uintptr_t)C & (out_f32 ? 15 : 7)))
+    return DTF_ERR_UNSUPPORTED;
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  const size_t lds = 2 * BUF_BYTES;
+  static bool attr_set = false;
+  if (!attr_set) {
+    dtf_allow_lds(gemm_nt_pp_kernel<true, 0, true>, lds);
+    dtf_allow_lds(gemm_nt_pp_kernel<false, 0, true>, lds);
+    attr_set = true;
+  }
+  dim3 grid(tiles_m * tiles_n), block(NTHREADS);
+  if (out_f32)
+    hipLaunchKernelGGL((gemm_nt_pp_kernel<true, 0, true>), grid, block, lds, stream,
+                       (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tiles_m,
+                       tiles_n, alpha, beta);
+  else
+    hipLaunchKernelGGL((gemm_nt_pp_kernel<false, 0, true>), grid, block, lds, stream,
+                       (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tiles_m,
+                       tiles_n, alpha, beta);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
 // Any-shape bf16 GEMM: A(m,k) at A[m*a_rs + k*a_cs], B(k,n) at B[k*b_rs + n*b_cs].
 DTF_API int dtf_gemm_bf16_generic(const void* A, const void* B, void* C, int M, int N, int K,
                                   long a_rs, long a_cs, long b_rs, long b_cs, long ldc, float alpha,
-                                  int out_f32, hipStream_t stream) {
+                                  float beta, int out_f32, hipStream_t stream) {
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || ldc < N) return DTF_ERR_BAD_ARG;
   dim3 grid((N + GB - 1) / GB, (M + GB - 1) / GB), block(256);
   if (out_f32)
     hipLaunchKernelGGL(gemm_bf16_generic_kernel<true>, grid, block, 0, stream,
                        (const unsigned short*)A, (const unsigned short*)B, C, M, N, K, a_rs, a_cs,
-                       b_rs, b_cs, ldc, alpha);
+                       b_rs, b_cs, ldc, alpha, beta);
   else
     hipLaunchKernelGGL(gemm_bf16_generic_kernel<false>, grid, block, 0, stream,
                        (const unsigned short*)A, (const unsigned short*)B, C, M, N, K, a_rs, a_cs,
-                       b_rs, b_cs, ldc, alpha);
+                       b_rs, b_cs, ldc, alpha, beta);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
+// Any-shape fp8 (e4m3) GEMM, same addressing convention as dtf_gemm_bf16_generic.
+DTF_API int dtf_gemm_fp8_generic(const void* A, const void* B, void* C, int M, int N, int K,
+                                 long a_rs, long a_cs, long b_rs, long b_cs, long ldc, float alpha,
+                                 float beta, int out_f32, hipStream_t stream) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || ldc < N) return DTF_ERR_BAD_ARG;
+  dim3 grid((N + GB - 1) / GB, (M + GB - 1) / GB), block(256);
+  if (out_f32)
+    hipLaunchKernelGGL(gemm_fp8_generic_kernel<true>, grid, block, 0, stream,
+                       (const unsigned char*)A, (const unsigned char*)B, C, M, N, K, a_rs, a_cs,
+                       b_rs, b_cs, ldc, alpha, beta);
+  else
+    hipLaunchKernelGGL(gemm_fp8_generic_kernel<false>, grid, block, 0, stream,
+                       (const unsigned char*)A, (const unsigned char*)B, C, M, N, K, a_rs, a_cs,
+                       b_rs, b_cs, ldc, alpha, beta);
   DTF_LAUNCH_CHECK();
   return DTF_OK;
 }

@@ -109,7 +109,8 @@ __global__ __launch_bounds__(BLOCK) void philox_fill_kernel(void* __restrict__ o
 // 2-D window of a stream laid out as a [*, global_cols] matrix: out[i, j] is stream element
 // (row0 + i) * global_cols + col0 + j. This is how a rank materialises its shard of a global
 // random matrix (row block, column block or 2-D block) without generating the rest.
-template <bool NORMAL, bool BF16_OUT>
+// OUT: 0 = fp32, 1 = bf16, 2 = fp8 e4m3 (saturating)
+template <bool NORMAL, int OUT>
 __global__ __launch_bounds__(BLOCK) void philox_fill_2d_kernel(void* __restrict__ out_, long rows,
                                                                long cols, long ld_out,
                                                                unsigned int seed,
@@ -131,7 +132,9 @@ __global__ __launch_bounds__(BLOCK) void philox_fill_2d_kernel(void* __restrict_
       v = u01(lane == 0 ? r.x : lane == 1 ? r.y : lane == 2 ? r.z : r.w);
     }
     const float val = a + b * v;
-    if (BF16_OUT) reinterpret_cast<unsigned short*>(out_)[i * ld_out + j] = dtf_f32_to_bf16(val);
+    if (OUT == 2) reinterpret_cast<unsigned char*>(out_)[i * ld_out + j] = dtf_f32_to_e4m3(val);
+    else if (OUT == 1)
+      reinterpret_cast<unsigned short*>(out_)[i * ld_out + j] = dtf_f32_to_bf16(val);
     else reinterpret_cast<float*>(out_)[i * ld_out + j] = val;
   }
 }
@@ -317,10 +320,11 @@ DTF_API int dtf_pack_f32(int count, const float* const* src, const int* sizes, f
 }
 
 // out[i*ld_out + j] = a + b * g(stream element (row0+i)*global_cols + col0 + j), g = N(0,1) when
-// normal else U(0,1). dtype: bf16_out 0/1.
+// normal else U(0,1). out_kind: 0 = fp32, 1 = bf16, 2 = fp8 e4m3.
 DTF_API int dtf_philox_fill_2d(void* out, long rows, long cols, long ld_out, unsigned int seed,
                                unsigned int op_seed, long row0, long col0, long global_cols,
-                               float a, float b, int normal, int bf16_out, hipStream_t stream) {
+                               float a, float b, int normal, int out_kind, hipStream_t stream) {
+  if (out_kind < 0 || out_kind > 2) return DTF_ERR_BAD_ARG;
   if (rows <= 0 || cols <= 0) return DTF_OK;
   if (!out || ld_out < cols || row0 < 0 || col0 < 0 || global_cols < col0 + cols)
     return DTF_ERR_BAD_ARG;
@@ -328,10 +332,15 @@ DTF_API int dtf_philox_fill_2d(void* out, long rows, long cols, long ld_out, uns
 #define DTF_FILL2D(NRM, BF)                                                                      \
   hipLaunchKernelGGL((philox_fill_2d_kernel<NRM, BF>), grid, block, 0, stream, out, rows, cols,  \
                      ld_out, seed, op_seed, row0, col0, global_cols, a, b)
-  if (normal && bf16_out) DTF_FILL2D(true, true);
-  else if (normal) DTF_FILL2D(true, false);
-  else if (bf16_out) DTF_FILL2D(false, true);
-  else DTF_FILL2D(false, false);
+  if (normal) {
+    if (out_kind == 2) DTF_FILL2D(true, 2);
+    else if (out_kind == 1) DTF_FILL2D(true, 1);
+    else DTF_FILL2D(true, 0);
+  } else {
+    if (out_kind == 2) DTF_FILL2D(false, 2);
+    else if (out_kind == 1) DTF_FILL2D(false, 1);
+    else DTF_FILL2D(false, 0);
+  }
 #undef DTF_FILL2D
   DTF_LAUNCH_CHECK();
   return DTF_OK;

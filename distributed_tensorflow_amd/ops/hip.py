@@ -59,8 +59,12 @@ def _declare(L: ctypes.CDLL) -> None:
     P, I, LG, F, U = c.c_void_p, c.c_int, c.c_long, c.c_float, c.c_uint
     sigs = {
         "dtf_gemm_f32": [P, P, P, P, I, I, I, LG, LG, LG, I, I, I, P],
-        "dtf_gemm_bf16_nt": [P, P, P, I, I, I, LG, LG, LG, F, I, I, P],
-        "dtf_gemm_bf16_generic": [P, P, P, I, I, I, LG, LG, LG, LG, LG, F, I, P],
+        "dtf_gemm_bf16_nt": [P, P, P, I, I, I, LG, LG, LG, F, F, I, I, P],
+        "dtf_gemm_bf16_generic": [P, P, P, I, I, I, LG, LG, LG, LG, LG, F, F, I, P],
+        "dtf_gemm_fp8_nt": [P, P, P, I, I, I, LG, LG, LG, F, F, I, P],
+        "dtf_gemm_fp8_generic": [P, P, P, I, I, I, LG, LG, LG, LG, LG, F, F, I, P],
+        "dtf_cast_to_fp8": [P, I, P, LG, F, P],
+        "dtf_cast_from_fp8": [P, P, I, LG, F, P],
         "dtf_binary_f32": [I, P, P, P, LG, LG, LG, P],
         "dtf_unary_f32": [I, P, P, LG, P],
         "dtf_compare_f32": [I, P, P, P, LG, LG, LG, P],
@@ -165,10 +169,10 @@ def gemm_f32(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: b
 
 def gemm_bf16_nt(a: torch.Tensor, bt: torch.Tensor, out_dtype: torch.dtype = torch.bfloat16,
                  alpha: float = 1.0, out: Optional[torch.Tensor] = None,
-                 variant: int = 0) -> torch.Tensor:
-    """``alpha * a @ bt.T`` with a [M,K], bt [N,K] bf16 (both K-contiguous); fp32 accumulate;
-    result bf16 or fp32. Uses the 256x256x64 LDS-DMA kernel when the shape qualifies and the
-    predicated generic kernel otherwise."""
+                 variant: int = 0, beta: float = 0.0) -> torch.Tensor:
+    """``alpha * a @ bt.T (+ beta * out)`` with a [M,K], bt [N,K] bf16 (both K-contiguous); fp32
+    accumulate; result bf16 or fp32. Uses the 256x256x64 LDS-DMA kernel when the shape
+    qualifies and the predicated generic kernel otherwise."""
     a = _req(a, torch.bfloat16, "gemm_bf16_nt a")
     bt = _req(bt, torch.bfloat16, "gemm_bf16_nt bt")
     if a.dim() != 2 or bt.dim() != 2 or a.shape[1] != bt.shape[1]:
@@ -178,6 +182,8 @@ def gemm_bf16_nt(a: torch.Tensor, bt: torch.Tensor, out_dtype: torch.dtype = tor
         raise HipKernelError("gemm_bf16_nt: out dtype must be bf16 or fp32")
     m, k = a.shape
     n = bt.shape[0]
+    if beta != 0.0 and out is None:
+        raise HipKernelError("gemm_bf16_nt: beta needs an out tensor to accumulate into")
     if out is None:
         out = torch.empty((m, n), dtype=out_dtype, device=a.device)
     elif out.shape != (m, n) or out.dtype != out_dtype or out.stride(1) != 1:
@@ -185,16 +191,84 @@ def gemm_bf16_nt(a: torch.Tensor, bt: torch.Tensor, out_dtype: torch.dtype = tor
     if m == 0 or n == 0:
         return out
     if k == 0:
-        return out.zero_()
+        return out.mul_(beta) if beta != 0.0 else out.zero_()
     out_f32 = int(out_dtype == torch.float32)
     code = lib().dtf_gemm_bf16_nt(a.data_ptr(), bt.data_ptr(), out.data_ptr(), m, n, k,
-                                  a.stride(0), bt.stride(0), out.stride(0), float(alpha), out_f32,
-                                  int(variant), _stream())
+                                  a.stride(0), bt.stride(0), out.stride(0), float(alpha),
+                                  float(beta), out_f32, int(variant), _stream())
     if code == -2:    # shape/alignment outside the fast kernel's contract
         code = lib().dtf_gemm_bf16_generic(a.data_ptr(), bt.data_ptr(), out.data_ptr(), m, n, k,
                                            a.stride(0), 1, 1, bt.stride(0), out.stride(0),
-                                           float(alpha), out_f32, _stream())
+                                           float(alpha), float(beta), out_f32, _stream())
     _check(code, "gemm_bf16_nt")
+    return out
+
+
+FP8 = torch.float8_e4m3fn
+FP8_MAX = 448.0
+
+
+def gemm_fp8_nt(a: torch.Tensor, bt: torch.Tensor, out_dtype: torch.dtype = torch.bfloat16,
+                alpha: float = 1.0, out: Optional[torch.Tensor] = None,
+                force_generic: bool = False, beta: float = 0.0) -> torch.Tensor:
+    """``alpha * a @ bt.T (+ beta * out)`` with a [M,K], bt [N,K] in OCP fp8 e4m3 (both K-contiguous), fp32
+    accumulate, bf16 or fp32 result. ``alpha`` is where the product of the operands'
+    dequantisation scales goes. Shapes the 256x256x128 block-scaled-MFMA kernel cannot take run
+    on the predicated generic kernel."""
+    a = _req(a, FP8, "gemm_fp8_nt a")
+    bt = _req(bt, FP8, "gemm_fp8_nt bt")
+    if a.dim() != 2 or bt.dim() != 2 or a.shape[1] != bt.shape[1]:
+        raise HipKernelError("gemm_fp8_nt: need a [M,K] and bt [N,K], got %s and %s"
+                             % (tuple(a.shape), tuple(bt.shape)))
+    if out_dtype not in (torch.bfloat16, torch.float32):
+        raise HipKernelError("gemm_fp8_nt: out dtype must be bf16 or fp32")
+    m, k = a.shape
+    n = bt.shape[0]
+    if beta != 0.0 and out is None:
+        raise HipKernelError("gemm_fp8_nt: beta needs an out tensor to accumulate into")
+    if out is None:
+        out = torch.empty((m, n), dtype=out_dtype, device=a.device)
+    elif out.shape != (m, n) or out.dtype != out_dtype or out.stride(1) != 1:
+        raise HipKernelError("gemm_fp8_nt: bad out tensor")
+    if m == 0 or n == 0:
+        return out
+    if k == 0:
+        return out.mul_(beta) if beta != 0.0 else out.zero_()
+    out_f32 = int(out_dtype == torch.float32)
+    code = -2 if force_generic else lib().dtf_gemm_fp8_nt(
+        a.data_ptr(), bt.data_ptr(), out.data_ptr(), m, n, k, a.stride(0), bt.stride(0),
+        out.stride(0), float(alpha), float(beta), out_f32, _stream())
+    if code == -2:
+        code = lib().dtf_gemm_fp8_generic(a.data_ptr(), bt.data_ptr(), out.data_ptr(), m, n, k,
+                                          a.stride(0), 1, 1, bt.stride(0), out.stride(0),
+                                          float(alpha), float(beta), out_f32, _stream())
+    _check(code, "gemm_fp8_nt")
+    return out
+
+
+def quantize_fp8(x: torch.Tensor, scale: Optional[float] = None):
+    """Per-tensor fp8 quantisation: returns ``(q, inv_scale)`` with ``q = e4m3(x * scale)``
+    (saturating at +-448) and ``x ~= q * inv_scale``. ``scale`` defaults to ``448 / max|x|``."""
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        raise HipKernelError("quantize_fp8: source must be fp32 or bf16")
+    x = _aligned(_req(x, x.dtype, "quantize_fp8 x"))
+    if scale is None:
+        amax = float(x.abs().amax().item()) if x.numel() else 0.0
+        scale = FP8_MAX / amax if amax > 0 else 1.0
+    out = torch.empty(x.shape, dtype=FP8, device=x.device)
+    _check(lib().dtf_cast_to_fp8(x.data_ptr(), int(x.dtype == torch.bfloat16), out.data_ptr(),
+                                 x.numel(), float(scale), _stream()), "quantize_fp8")
+    return out, 1.0 / float(scale)
+
+
+def dequantize_fp8(q: torch.Tensor, inv_scale: float = 1.0,
+                   dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    q = _req(q, FP8, "dequantize_fp8 q")
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise HipKernelError("dequantize_fp8: target must be fp32 or bf16")
+    out = torch.empty(q.shape, dtype=dtype, device=q.device)
+    _check(lib().dtf_cast_from_fp8(q.data_ptr(), out.data_ptr(), int(dtype == torch.bfloat16),
+                                   q.numel(), float(inv_scale), _stream()), "dequantize_fp8")
     return out
 
 
@@ -217,7 +291,7 @@ def gemm_bf16(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: 
     a_rs, a_cs = (1, a.stride(0)) if trans_a else (a.stride(0), 1)
     b_rs, b_cs = (1, b.stride(0)) if trans_b else (b.stride(0), 1)
     _check(lib().dtf_gemm_bf16_generic(a.data_ptr(), b.data_ptr(), out.data_ptr(), m, n, k, a_rs,
-                                       a_cs, b_rs, b_cs, out.stride(0), float(alpha),
+                                       a_cs, b_rs, b_cs, out.stride(0), float(alpha), 0.0,
                                        int(out_dtype == torch.float32), _stream()), "gemm_bf16")
     return out
 
@@ -583,13 +657,14 @@ def philox_window(rows: int, cols: int, seed: int, op_seed: int, row0: int, col0
     ``global_cols`` columns whose element ``(i, j)`` is stream element ``i*global_cols + j``:
     a rank's shard of a global matrix, generated locally. Values are ``a + b * g`` with ``g``
     N(0,1) (``normal``) or U(0,1)."""
-    if dtype not in (torch.float32, torch.bfloat16):
-        raise HipKernelError("philox_window: dtype must be fp32 or bf16")
+    kinds = {torch.float32: 0, torch.bfloat16: 1, torch.float8_e4m3fn: 2}
+    if dtype not in kinds:
+        raise HipKernelError("philox_window: dtype must be fp32, bf16 or fp8 e4m3")
     if row0 < 0 or col0 < 0 or col0 + cols > global_cols:
         raise HipKernelError("philox_window: window outside the global matrix")
     out = torch.empty((rows, cols), dtype=dtype, device=device)
     _check(lib().dtf_philox_fill_2d(out.data_ptr(), rows, cols, out.stride(0) if rows else cols,
                                     seed & 0xFFFFFFFF, op_seed & 0xFFFFFFFF, row0, col0,
                                     global_cols, float(a), float(b), int(normal),
-                                    int(dtype == torch.bfloat16), _stream()), "philox_window")
+                                    kinds[dtype], _stream()), "philox_window")
     return out

@@ -167,8 +167,15 @@ class TorchDistComm(Communicator):
             return group_rank
         return self._dist.get_global_rank(self._group, group_rank)
 
+    @staticmethod
+    def _bytes_view(t: torch.Tensor) -> torch.Tensor:
+        """Pure data movement of 1-byte float types goes over the wire as uint8 (not every
+        backend build knows the fp8 dtypes)."""
+        return t.view(torch.uint8) if t.element_size() == 1 and t.is_floating_point() else t
+
     def broadcast(self, tensor, src=0, async_op=False):
         src = self._global(src)
+        tensor = self._bytes_view(tensor)
         return self._wrap(lambda: self._dist.broadcast(tensor, src=src, group=self._group,
                                                        async_op=async_op), async_op)
 

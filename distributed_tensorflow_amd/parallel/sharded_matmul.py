@@ -17,6 +17,17 @@ strategy                   A / B shard per rank   communication     result
 ``summa_2d``               2-D block / 2-D block  row/col broadcast 2-D block of C
 =========================  =====================  ================  ==========================
 
+``summa_2d`` runs on a P x Q process grid (the most square factorisation of the world size:
+8 ranks -> 2 x 4). K is cut into L = lcm(P, Q) panels; A's block (i, j) holds the L/Q panels of
+grid column j, Bt's block the L/P panels of grid row i, each stored contiguously. Step l
+broadcasts A's panel along grid rows and B's panel along grid columns -- two collectives on
+disjoint xGMI links -- and the product of panel l runs while the broadcasts of panel l+1 are in
+flight (two receive buffers per operand). The fp32 accumulation across panels happens in the
+GEMM epilogue (``beta = 1``), not in a separate add.
+
+Operand dtypes: fp32 (exact MFMA), bf16, and OCP fp8 e4m3 (block-scaled MFMA with unit scales;
+results in bf16, or fp32 for ``summa_2d``).
+
 xGMI is a point-to-point mesh (7 links of ~153 GB/s per GPU), so the bytes a strategy moves
 decide everything: for 16384^3 bf16 on 8 GPUs a rank computes for ~0.75 ms, an all-gather of C
 moves 448 MiB into each rank and an all-reduce of fp32 partial sums twice 896 MiB. Every
@@ -68,10 +79,12 @@ class ShardedMatmul:
         self.rank, self.world = self.comm.rank, self.comm.world_size
         self.device = torch.device(device) if device is not None else self.comm.device
         self.dtype = dtype
+        # fp8 operands produce bf16 results (fp32 accumulate inside the kernel)
+        self.out_dtype = torch.bfloat16 if dtype == torch.float8_e4m3fn else dtype
         self.strategy = strategy
         self.seed = seed
         self.distribution = distribution
-        self.reduce_dtype = reduce_dtype or dtype
+        self.reduce_dtype = reduce_dtype or self.out_dtype
         self.on_gpu = self.device.type == "cuda"
         if self.on_gpu:
             from ..ops import hip
@@ -79,13 +92,15 @@ class ShardedMatmul:
             hip.lib()
         w = self.world
         if strategy == "summa_2d":
-            q = int(round(math.sqrt(w)))
-            if q * q != w:
-                raise ValueError("summa_2d needs a square number of ranks, got %d" % w)
-            self.grid = q
-            self.pr, self.pc = divmod(self.rank, q)
-            self.row_comm = self.comm.split(self.pr, self.pc)
-            self.col_comm = self.comm.split(self.pc, self.pr)
+            p_rows = max(d for d in range(1, int(math.isqrt(w)) + 1) if w % d == 0)
+            self.grid_rows, self.grid_cols = p_rows, w // p_rows
+            self.k_panels = math.lcm(self.grid_rows, self.grid_cols)
+            if self.k % self.k_panels:
+                raise ValueError("K=%d must be divisible by lcm(grid)=%d"
+                                 % (self.k, self.k_panels))
+            self.pr, self.pc = divmod(self.rank, self.grid_cols)
+            self.row_comm = self.comm.split(self.pr, self.pc)     # ranks of my grid row
+            self.col_comm = self.comm.split(self.pc, self.pr)     # ranks of my grid column
         if strategy in ("m_shard", "m_shard_allgather", "k_shard_reduce_scatter") \
                 and self.m % w:
             raise ValueError("M=%d must be divisible by the world size %d" % (self.m, w))
@@ -112,7 +127,7 @@ class ShardedMatmul:
         op_seed = 1 if which == "a" else 2
         normal = self.distribution == "normal"
         a, b = (0.0, 1.0) if normal else (-1.0, 2.0)     # N(0,1) or U(-1,1)
-        if self.on_gpu and self.dtype in (torch.float32, torch.bfloat16):
+        if self.on_gpu:
             return self._hip.philox_window(rows, cols, self.seed, op_seed, row0, col0,
                                            global_cols, self.dtype, self.device, normal, a, b)
         host = philox.window(rows, cols, self.seed, op_seed, row0, col0, global_cols, normal)
@@ -132,28 +147,37 @@ class ShardedMatmul:
             kl = k // w
             self.a = self._window("a", m, kl, 0, r * kl, k)
             self.bt = self._window("b", n, kl, 0, r * kl, k)
-        else:   # summa_2d: A block (pr, pc) of [M,K], Bt block (pc, pr): rows of N, cols of K
-            q = self.grid
-            m0, ml = _split(m, q, self.pr)
-            n0, nl = _split(n, q, self.pc)
-            ka0, kal = _split(k, q, self.pc)     # A(pr, pc) holds K block pc
-            kb0, kbl = _split(k, q, self.pr)     # B(pr, pc) holds K block pr
-            self.a = self._window("a", ml, kal, m0, ka0, k)
-            self.bt = self._window("b", nl, kbl, n0, kb0, k)
+        else:
+            # summa_2d: rank (pr, pc) owns rows M_pr of A for the K panels of grid column pc and
+            # rows N_pc of Bt for the K panels of grid row pr; one contiguous tensor per panel
+            P, Q, L = self.grid_rows, self.grid_cols, self.k_panels
+            m0, ml = _split(m, P, self.pr)
+            n0, nl = _split(n, Q, self.pc)
+            kp = k // L
+            self.a_panels = {l: self._window("a", ml, kp, m0, l * kp, k)
+                             for l in range(L) if l * Q // L == self.pc}
+            self.b_panels = {l: self._window("b", nl, kp, n0, l * kp, k)
+                             for l in range(L) if l * P // L == self.pr}
+            self.a = next(iter(self.a_panels.values()))
+            self.bt = next(iter(self.b_panels.values()))
         self._alloc_result()
 
     def _alloc_result(self) -> None:
         m, n, w = self.m, self.n, self.world
         s = self.strategy
-        dev, dt = self.device, self.dtype
+        dev, dt = self.device, self.out_dtype
         if s in ("replicated", "m_shard_allgather", "k_shard_allreduce"):
             self.c = torch.empty((m, n), dtype=dt, device=dev)
         elif s in ("m_shard", "k_shard_reduce_scatter"):
             self.c = torch.empty((m // w, n), dtype=dt, device=dev)
         else:
-            _, ml = _split(m, self.grid, self.pr)
-            _, nl = _split(n, self.grid, self.pc)
+            _, ml = _split(m, self.grid_rows, self.pr)
+            _, nl = _split(n, self.grid_cols, self.pc)
+            kp = self.k // self.k_panels
             self.c = torch.empty((ml, nl), dtype=torch.float32, device=dev)
+            # two receive buffers per operand: panel l+1 lands while panel l is multiplied
+            self._a_recv = [torch.empty((ml, kp), dtype=self.dtype, device=dev) for _ in (0, 1)]
+            self._b_recv = [torch.empty((nl, kp), dtype=self.dtype, device=dev) for _ in (0, 1)]
         if s == "k_shard_reduce_scatter" or (s == "k_shard_allreduce"
                                              and self.reduce_dtype != dt):
             self._partial = torch.empty((m, n), dtype=self.reduce_dtype, device=dev)
@@ -161,17 +185,29 @@ class ShardedMatmul:
             self._local = torch.empty((m // w, n), dtype=dt, device=dev)
 
     # -- local product -------------------------------------------------------------------
-    def _gemm(self, a: torch.Tensor, bt: torch.Tensor, out: torch.Tensor) -> None:
-        """out = a @ bt^T (a [m,k], bt [n,k]) on the hand-written kernels (GPU) or torch (CPU)."""
+    def _gemm(self, a: torch.Tensor, bt: torch.Tensor, out: torch.Tensor,
+              accumulate: bool = False) -> None:
+        """out (+)= a @ bt^T (a [m,k], bt [n,k]) on the hand-written kernels (GPU) or torch
+        (CPU)."""
         if self.on_gpu:
+            beta = 1.0 if accumulate else 0.0
             if a.dtype == torch.bfloat16:
-                self._hip.gemm_bf16_nt(a, bt, out.dtype, out=out)
+                self._hip.gemm_bf16_nt(a, bt, out.dtype, out=out, beta=beta)
+            elif a.dtype == torch.float8_e4m3fn:
+                self._hip.gemm_fp8_nt(a, bt, out.dtype, out=out, beta=beta)
             elif a.dtype == torch.float32:
-                self._hip.gemm_f32(a, bt, trans_b=True, out=out)
+                if accumulate:
+                    out.add_(self._hip.gemm_f32(a, bt, trans_b=True))
+                else:
+                    self._hip.gemm_f32(a, bt, trans_b=True, out=out)
             else:
                 raise TypeError("unsupported GEMM dtype %s" % a.dtype)
         else:
-            out.copy_((a.float() @ bt.float().t()).to(out.dtype))
+            prod = a.float() @ bt.float().t()
+            if accumulate:
+                out.add_(prod.to(out.dtype))
+            else:
+                out.copy_(prod.to(out.dtype))
 
     # -- one step ------------------------------------------------------------------------
     def step(self) -> torch.Tensor:
@@ -243,23 +279,30 @@ class ShardedMatmul:
         return self.c
 
     def _step_summa(self) -> torch.Tensor:
-        """SUMMA on a q x q grid: for each K block l, A(:, l) is broadcast along grid rows and
-        B(l, :) along grid columns, and every rank accumulates its C block in fp32."""
-        q = self.grid
-        self.c.zero_()
-        _, ml = _split(self.m, q, self.pr)
-        _, nl = _split(self.n, q, self.pc)
-        tmp = torch.empty_like(self.c)
-        for l in range(q):
-            _, kl = _split(self.k, q, l)
-            a_blk = self.a if self.pc == l else torch.empty((ml, kl), dtype=self.dtype,
-                                                           device=self.device)
-            b_blk = self.bt if self.pr == l else torch.empty((nl, kl), dtype=self.dtype,
-                                                            device=self.device)
-            self.row_comm.broadcast(a_blk, src=l)
-            self.col_comm.broadcast(b_blk, src=l)
-            self._gemm(a_blk, b_blk, tmp)
-            self.c.add_(tmp)
+        """SUMMA on the P x Q grid: for K panel l, A's panel is broadcast along grid rows from
+        grid column ``l*Q/L`` and Bt's panel along grid columns from grid row ``l*P/L``; every
+        rank accumulates its C block in fp32. The broadcasts of panel l+1 are issued before
+        the product of panel l so the links and the matrix cores work at the same time."""
+        P, Q, L = self.grid_rows, self.grid_cols, self.k_panels
+
+        def issue(l: int):
+            a_src, b_src = l * Q // L, l * P // L
+            a_blk = self.a_panels[l] if self.pc == a_src else self._a_recv[l & 1]
+            b_blk = self.b_panels[l] if self.pr == b_src else self._b_recv[l & 1]
+            wa = self.row_comm.broadcast(a_blk, src=a_src, async_op=True) if Q > 1 else None
+            wb = self.col_comm.broadcast(b_blk, src=b_src, async_op=True) if P > 1 else None
+            return a_blk, b_blk, wa, wb
+
+        nxt = issue(0)
+        for l in range(L):
+            a_blk, b_blk, wa, wb = nxt
+            if wa is not None:
+                wa.wait()
+            if wb is not None:
+                wb.wait()
+            if l + 1 < L:
+                nxt = issue(l + 1)
+            self._gemm(a_blk, b_blk, self.c, accumulate=(l > 0))
         return self.c
 
     # -- checking ------------------------------------------------------------------------
@@ -284,12 +327,12 @@ class ShardedMatmul:
             rows = self.m // p
             per = rows // w
             return np.concatenate([i * rows + r * per + np.arange(per) for i in range(p)])
-        m0, ml = _split(self.m, self.grid, self.pr)
+        m0, ml = _split(self.m, self.grid_rows, self.pr)
         return np.arange(ml) + m0
 
     def cols_of_result(self) -> np.ndarray:
         if self.strategy == "summa_2d":
-            n0, nl = _split(self.n, self.grid, self.pc)
+            n0, nl = _split(self.n, self.grid_cols, self.pc)
             return np.arange(nl) + n0
         return np.arange(self.n)
 
@@ -304,4 +347,6 @@ class ShardedMatmul:
                            for j in cols])
         at = (torch.from_numpy(a_rows) * b + a).to(self.dtype).double()
         bt = (torch.from_numpy(b_rows) * b + a).to(self.dtype).double()
+        # (torch's fp8 cast rounds to nearest even like the device fill; U(-1,1) and N(0,1)
+        # samples are far below the e4m3 saturation point, where the two would differ)
         return at @ bt.t()

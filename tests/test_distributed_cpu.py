@@ -85,12 +85,10 @@ def test_loopback_fault_injection_detects_dead_and_slow_ranks():
 
 
 @pytest.mark.parametrize("strategy", STRATEGIES)
-@pytest.mark.parametrize("world", [1, 2, 4])
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
 def test_sharded_matmul_strategies_match_reference(strategy, world):
-    if strategy == "summa_2d" and world == 2:
-        pytest.skip("SUMMA needs a square grid")
-
     def fn(c):
+        # world 8 runs SUMMA on a 2 x 4 grid (K cut into lcm = 4 panels), world 2 on 1 x 2
         sm = ShardedMatmul(64, 48, 32, c, dtype=torch.float32, strategy=strategy,
                            panels=None if strategy == "summa_2d" else 2)
         sm.step()
@@ -99,6 +97,21 @@ def test_sharded_matmul_strategies_match_reference(strategy, world):
         return (got - ref).abs().max().item()
 
     assert max(run_ranks(world, fn)) < 1e-5
+
+
+@pytest.mark.parametrize("strategy", ["m_shard_allgather", "summa_2d"])
+def test_sharded_matmul_fp8_operands(strategy):
+    """fp8 e4m3 operands (bf16 / fp32 results): the CPU path multiplies the dequantised values,
+    so it pins the operand generation, the sharding and the collectives of the fp8 config."""
+    def fn(c):
+        sm = ShardedMatmul(32, 32, 64, c, dtype=torch.float8_e4m3fn, strategy=strategy)
+        sm.step()
+        assert sm.a.dtype == torch.float8_e4m3fn
+        got = sm.result_dense().double()
+        ref = sm.reference(sm.rows_of_result(), sm.cols_of_result())
+        return (got - ref).abs().max().item()
+
+    assert max(run_ranks(4, fn)) < (0.06 if strategy == "m_shard_allgather" else 1e-4)
 
 
 def test_sharded_matmul_is_world_size_invariant():

@@ -255,3 +255,98 @@ def test_philox_matches_host_stream(hip):
     u = hip.philox_uniform((n,), seed=3, op_seed=9, minval=-1, maxval=1, device="cuda").cpu().numpy()
     assert np.abs(u - (philox.uniform(n, 3, 9) * 2 - 1)).max() < 1e-6
     assert u.min() > -1 and u.max() < 1
+
+
+# -- fp8 (OCP e4m3) ----------------------------------------------------------------------------
+FP8 = torch.float8_e4m3fn
+
+
+@pytest.mark.parametrize("generic", [False, True])
+@pytest.mark.parametrize("m,n,k", [(256, 256, 128), (512, 768, 256), (768, 512, 1408),
+                                   (300, 520, 384), (4096, 4096, 2048), (1, 1, 128)])
+def test_gemm_fp8_nt_exact_integers(hip, m, n, k, generic):
+    """Small integers are exact in e4m3 and their products exact in the fp32 accumulator, so the
+    block-scaled MFMA path (unit scales, k split over two 16-byte chunks per lane) must match
+    bit for bit; so must the non-scaled MFMA of the generic kernel."""
+    g = torch.Generator().manual_seed(m + k)
+    a = torch.randint(-3, 4, (m, k), generator=g).float()
+    bt = torch.randint(-3, 4, (n, k), generator=g).float()
+    ref = a.cuda() @ bt.cuda().t()
+    for _ in range(2):
+        c = hip.gemm_fp8_nt(a.to(FP8).cuda(), bt.to(FP8).cuda(), torch.float32,
+                            force_generic=generic)
+        assert torch.equal(c, ref)
+
+
+def test_gemm_fp8_identity_asymmetric_and_ragged(hip):
+    n = 512
+    b = ((torch.arange(n * n).reshape(n, n) % 13) - 6).float()
+    eye = torch.eye(n)
+    c = hip.gemm_fp8_nt(eye.to(FP8).cuda(), b.t().contiguous().to(FP8).cuda(), torch.float32)
+    assert torch.equal(c.cpu(), b)
+    c2 = hip.gemm_fp8_nt(b.to(FP8).cuda(), eye.to(FP8).cuda(), torch.float32)
+    assert torch.equal(c2.cpu(), b)
+    # K not a multiple of 128 -> generic kernel through the same entry point
+    a = torch.randint(-3, 4, (70, 45)).float()
+    bt = torch.randint(-3, 4, (33, 45)).float()
+    c3 = hip.gemm_fp8_nt(a.to(FP8).cuda(), bt.to(FP8).cuda(), torch.float32)
+    assert torch.equal(c3.cpu(), a @ bt.t())
+
+
+def test_gemm_fp8_random_scaled_and_beta(hip):
+    g = torch.Generator().manual_seed(4)
+    m, n, k = 512, 384, 1024
+    a = torch.randn(m, k, generator=g).cuda()
+    bt = torch.randn(n, k, generator=g).cuda()
+    qa, sa = hip.quantize_fp8(a)
+    qb, sb = hip.quantize_fp8(bt)
+    # reference from the dequantised operands: isolates the GEMM from the quantisation error
+    ref = (qa.float().double() * sa) @ (qb.float().double() * sb).t()
+    c = hip.gemm_fp8_nt(qa, qb, torch.float32, alpha=sa * sb)
+    assert (c.double() - ref).abs().max().item() < 1e-3
+    cb = hip.gemm_fp8_nt(qa, qb, torch.bfloat16, alpha=sa * sb)
+    assert (cb.double() - ref).abs().max().item() < 0.02 * (k ** 0.5)
+    # quantisation error itself stays at the e4m3 level (2^-4 relative per element)
+    full = a.double() @ bt.double().t()
+    assert ((c.double() - full).norm() / full.norm()).item() < 0.06
+    # beta: accumulate into an existing fp32 result
+    acc = c.clone()
+    hip.gemm_fp8_nt(qa, qb, torch.float32, alpha=sa * sb, out=acc, beta=1.0)
+    assert torch.allclose(acc, 2 * c, rtol=1e-6, atol=1e-5)
+    a16, b16 = a.bfloat16(), bt.bfloat16()
+    base = hip.gemm_bf16_nt(a16, b16, torch.float32)
+    acc = base.clone()
+    hip.gemm_bf16_nt(a16, b16, torch.float32, out=acc, beta=0.5)
+    assert torch.allclose(acc, 1.5 * base, rtol=1e-6, atol=1e-4)
+
+
+def test_fp8_quantize_dequantize_and_philox(hip):
+    x = torch.cat([torch.linspace(-500, 500, 4001), torch.tensor([0.0, 1e-4, 2 ** -9, 2 ** -10,
+                                                                  0.0009765625 * 1.5, 447.9, 464.0])]).cuda()
+    q, inv = hip.quantize_fp8(x, scale=1.0)
+    ref = x.clamp(-448, 448).to(FP8)                  # torch: round-to-nearest-even e4m3fn
+    assert torch.equal(q.view(torch.uint8), ref.view(torch.uint8))
+    back = hip.dequantize_fp8(q, inv)
+    assert torch.equal(back, ref.float())
+    qb, _ = hip.quantize_fp8(x.bfloat16(), scale=1.0)
+    assert torch.equal(qb.view(torch.uint8), x.bfloat16().float().clamp(-448, 448).to(FP8).view(torch.uint8))
+    assert torch.equal(hip.dequantize_fp8(q, 2.0, torch.bfloat16), (ref.float() * 2).bfloat16())
+    # device-side software rounding (used by the Philox fill) against torch's cast
+    w32 = hip.philox_window(64, 256, 7, 1, 3, 5, 1024, torch.float32, "cuda", True, 0.0, 1.0)
+    w8 = hip.philox_window(64, 256, 7, 1, 3, 5, 1024, FP8, "cuda", True, 0.0, 1.0)
+    assert torch.equal(w8.view(torch.uint8), w32.to(FP8).view(torch.uint8))
+    big = hip.philox_window(8, 256, 7, 1, 0, 0, 256, FP8, "cuda", True, 0.0, 300.0)
+    assert big.float().abs().max().item() == 448.0 and not big.float().isnan().any()
+
+
+def test_sharded_matmul_fp8_single_gpu(hip):
+    from distributed_tensorflow_amd.parallel.sharded_matmul import ShardedMatmul
+    sm = ShardedMatmul(512, 512, 1024, dtype=FP8, strategy="replicated", device=torch.device("cuda"))
+    c = sm.step()
+    assert c.dtype == torch.bfloat16
+    rows, cols = np.arange(0, 512, 37), np.arange(0, 512, 41)
+    ref = sm.reference(rows, cols)
+    got = c.double().cpu()[rows][:, cols]
+    assert (got - ref).abs().max().item() < 0.25          # bf16 rounding of |c| up to ~32
+    s2 = ShardedMatmul(512, 512, 1024, dtype=FP8, strategy="summa_2d", device=torch.device("cuda"))
+    assert (s2.step().double().cpu()[rows][:, cols] - ref).abs().max().item() < 1e-3

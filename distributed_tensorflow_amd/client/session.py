@@ -211,6 +211,8 @@ class Session:
             if self.config.device is None:
                 self.device = self._runtime.device
         if self.device.type == "cuda":
+            if self.device.index is None:       # "cuda" = this process's current GPU
+                self.device = torch.device("cuda", torch.cuda.current_device())
             torch.cuda.set_device(self.device)
             from ..ops import hip_kernels  # noqa: F401  (registers HIP kernels; fails loudly)
         self._local_store = (self._runtime.local_store if self._runtime is not None
@@ -418,6 +420,26 @@ class Session:
                                  % (tuple(out.shape), t.name, t.shape))
         return out.contiguous()
 
+    def _prep_feed(self, t: Tensor, value: Any):
+        """Feed value for the HIP-graph path: a device tensor is used as is; host data becomes
+        a contiguous ndarray of the placeholder's dtype that ``_run_captured`` stages through
+        pinned memory (one asynchronous H2D copy straight into the graph's input buffer)."""
+        if isinstance(value, torch.Tensor):
+            if value.device.type == "cuda" or t.dtype.numpy is None:
+                return self._to_device(t, value)
+            value = value.detach().numpy()
+        if t.dtype.numpy is None:
+            return self._to_device(t, value)
+        arr = np.asarray(value)
+        if arr.dtype != np.dtype(t.dtype.numpy):
+            arr = arr.astype(t.dtype.numpy)
+        if t.shape is not None:
+            if len(t.shape) != arr.ndim or any(
+                    d is not None and d != s for d, s in zip(t.shape, arr.shape)):
+                raise ValueError("Cannot feed value of shape %s for Tensor %r, which has shape %s"
+                                 % (tuple(arr.shape), t.name, t.shape))
+        return arr
+
     def _run_steps(self, steps: Sequence[_Step], vals: List[Any], trace=None) -> None:
         ctx = self._ctx
         for s in steps:
@@ -469,12 +491,13 @@ class Session:
 
         token = self._begin_step(plan)
         try:
-            feeds = [self._to_device(t, v) for t, v in fed_pairs]
             use_graph = (self.device.type == "cuda" and self.config.hip_graphs
                          and plan.capturable and trace is None and plan.runs >= 1)
             if use_graph:
-                slot_vals = self._run_captured(plan, feeds)
+                slot_vals = self._run_captured(plan, [self._prep_feed(t, v)
+                                                      for t, v in fed_pairs])
             else:
+                feeds = [self._to_device(t, v) for t, v in fed_pairs]
                 vals: List[Any] = [None] * plan.num_slots
                 for (_, sl), v in zip(plan.feed_slots, feeds):
                     vals[sl] = v
@@ -513,15 +536,34 @@ class Session:
             self._runtime.end_step(plan, token)
 
     # -- HIP-graph path --------------------------------------------------------------------
-    def _run_captured(self, plan: ExecutionPlan, feeds: List[torch.Tensor]):
-        sig = tuple((tuple(f.shape), f.dtype) for f in feeds)
+    def _run_captured(self, plan: ExecutionPlan, feeds: List[Any]):
+        sig = tuple((tuple(f.shape), str(f.dtype)) for f in feeds)
         cap = plan.graphs.get(sig)
         if cap is None:
-            cap = self._capture(plan, feeds)
+            dev_feeds = [f if isinstance(f, torch.Tensor) else
+                         torch.from_numpy(np.ascontiguousarray(f).reshape(f.shape)).to(self.device)
+                         for f in feeds]
+            cap = self._capture(plan, dev_feeds)
             plan.graphs[sig] = cap
             self.stats["captures"] += 1
-        for static, f in zip(cap.static_feeds, feeds):
-            static.copy_(f, non_blocking=True)
+        if cap.h2d_done is not None:
+            cap.h2d_done.synchronize()       # last step's copies have left the pinned buffers
+        staged = False
+        for i, (static, f) in enumerate(zip(cap.static_feeds, feeds)):
+            if isinstance(f, torch.Tensor):
+                static.copy_(f, non_blocking=True)
+                continue
+            pin = cap.pinned[i]
+            if pin is None:
+                pin = cap.pinned[i] = torch.empty(static.shape, dtype=static.dtype,
+                                                  pin_memory=True)
+            np.copyto(pin.numpy(), f)
+            static.copy_(pin, non_blocking=True)
+            staged = True
+        if staged:
+            if cap.h2d_done is None:
+                cap.h2d_done = torch.cuda.Event()
+            cap.h2d_done.record()
         cap.graph.replay()
         self.stats["graph_replays"] += 1
         out: Dict[int, Any] = {}
@@ -538,6 +580,8 @@ class Session:
     def _capture(self, plan: ExecutionPlan, feeds: List[torch.Tensor]) -> _CapturedStep:
         cap = _CapturedStep()
         cap.static_feeds = [torch.empty_like(f) for f in feeds]
+        cap.pinned = [None] * len(feeds)
+        cap.h2d_done = None
         for static, f in zip(cap.static_feeds, feeds):
             static.copy_(f)
         # small fp32 results (loss, step, accuracy ...) are packed into one pinned buffer by

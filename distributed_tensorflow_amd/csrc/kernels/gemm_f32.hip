@@ -16,6 +16,14 @@
 // tile k+1 are issued before the MFMAs of tile k and written to the other LDS buffer after
 // them: one barrier per K-tile. Shapes need no alignment: edge tiles are predicated
 // (1000 = 7*128 + 104, K = 784 / 100 / 10 all occur in the reference).
+//
+// Split-K: the exact-fp32 MFMA retires 32x32x2 per 64 cycles per wave, so a product with few
+// output tiles and a long K (the MLP's x*W1: 100x100 outputs, K = 784 -- four 64x64 tiles)
+// leaves the chip idle and takes 392 serial MFMAs per wave. Such problems are cut along K into
+// `splits` workgroups per tile; each writes its partial tile to a workspace plane, takes a ticket
+// from a per-tile counter, and the workgroup that draws the last ticket sums the planes in split
+// order (deterministic), applies bias + activation and writes C. The counter is reset by that
+// workgroup, so the same workspace serves every launch (and every HIP-graph replay) on a stream.
 #include "common.h"
 
 namespace {
@@ -89,7 +97,8 @@ template <int BM, int BN, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
     const float* __restrict__ bias, int M, int N, int K, long lda, long ldb, long ldc,
-    int a_vec, int b_vec, int act, int tiles_n, int ntiles) {
+    int a_vec, int b_vec, int act, int tiles_n, int ntiles, int splits, int kchunk,
+    float* __restrict__ partial, int* __restrict__ counters) {
   using LA = Loader<BM, A_KC>;
   using LB = Loader<BN, B_KC>;
   constexpr int WM = BM / 2, WN = BN / 2;     // per-wave tile
@@ -102,8 +111,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  const int tile = dtf_xcd_remap(blockIdx.x, ntiles);
+  const int split = blockIdx.x / ntiles;
+  const int tile = dtf_xcd_remap(blockIdx.x % ntiles, ntiles);
   const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+  const int k_begin = split * kchunk;                 // kchunk is a multiple of BK
+  const int k_end = (k_begin + kchunk < K) ? k_begin + kchunk : K;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -114,9 +126,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   f32x4 ra[LA::PER_THREAD], rb[LB::PER_THREAD];
-  const int nkt = (K + BK - 1) / BK;
-  LA::fetch(ra, A, lda, m0, 0, M, K, a_vec != 0, tid);
-  LB::fetch(rb, B, ldb, n0, 0, N, K, b_vec != 0, tid);
+  const int nkt = (k_end - k_begin + BK - 1) / BK;
+  LA::fetch(ra, A, lda, m0, k_begin, M, k_end, a_vec != 0, tid);
+  LB::fetch(rb, B, ldb, n0, k_begin, N, k_end, b_vec != 0, tid);
   LA::stash(ra, As, tid);
   LB::stash(rb, Bs, tid);
   __syncthreads();
@@ -126,8 +138,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(
     const int cur = kt & 1;
     const bool more = kt + 1 < nkt;
     if (more) {
-      LA::fetch(ra, A, lda, m0, (kt + 1) * BK, M, K, a_vec != 0, tid);
-      LB::fetch(rb, B, ldb, n0, (kt + 1) * BK, N, K, b_vec != 0, tid);
+      LA::fetch(ra, A, lda, m0, k_begin + (kt + 1) * BK, M, k_end, a_vec != 0, tid);
+      LB::fetch(rb, B, ldb, n0, k_begin + (kt + 1) * BK, N, k_end, b_vec != 0, tid);
     }
     const float* as = As + cur * A_BUF + wr * WM + lrow;
     const float* bs = Bs + cur * B_BUF + wc * WN + lrow;
@@ -152,6 +164,47 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(
   }
 
   // C/D fragment: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  if (splits > 1) {
+    const long plane = (long)M * N;
+    float* const mine = partial + split * plane;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wc * WN + 32 * j + lrow;
+        if (col >= N) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wr * WM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk;
+          if (row < M) mine[(long)row * N + col] = acc[i][j][r];
+        }
+      }
+    __shared__ int ticket;
+    __threadfence();                       // this workgroup's plane is visible device-wide ...
+    __syncthreads();
+    if (tid == 0) ticket = atomicAdd(&counters[tile], 1);   // ... before its ticket is
+    __syncthreads();
+    if (ticket != splits - 1) return;
+    __threadfence();                       // last ticket: every other plane of the tile landed
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wc * WN + 32 * j + lrow;
+        if (col >= N) continue;
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wr * WM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk;
+          if (row >= M) continue;
+          float v = 0.f;
+          for (int sp = 0; sp < splits; ++sp) v += partial[sp * plane + (long)row * N + col];
+          C[(long)row * ldc + col] = dtf_apply_act(v + bv, act);
+        }
+      }
+    if (tid == 0) counters[tile] = 0;      // ready for the next launch on this stream
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -169,16 +222,18 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(
 
 template <int BM, int BN>
 int launch(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
-           long lda, long ldb, long ldc, int trans_a, int trans_b, int act, hipStream_t stream) {
+           long lda, long ldb, long ldc, int trans_a, int trans_b, int act, int splits,
+           int kchunk, float* partial, int* counters, hipStream_t stream) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const int ntiles = tiles_m * tiles_n;
   const int a_vec = (lda % 4 == 0) && ((uintptr_t)A % 16 == 0);
   const int b_vec = (ldb % 4 == 0) && ((uintptr_t)B % 16 == 0);
-  dim3 grid(ntiles), block(NTHREADS);
+  dim3 grid(ntiles * splits), block(NTHREADS);
   // op(A)(m,k): stored [M,K] -> K-contiguous; stored [K,M] (trans_a) -> M-contiguous
 #define DTF_GEMM_CASE(AKC, BKC)                                                               \
   hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, AKC, BKC>), grid, block, 0, stream, A, B, C,    \
-                     bias, M, N, K, lda, ldb, ldc, a_vec, b_vec, act, tiles_n, ntiles)
+                     bias, M, N, K, lda, ldb, ldc, a_vec, b_vec, act, tiles_n, ntiles, splits,  \
+                     kchunk, partial, counters)
   if (!trans_a && !trans_b) DTF_GEMM_CASE(true, false);
   else if (!trans_a && trans_b) DTF_GEMM_CASE(true, true);
   else if (trans_a && !trans_b) DTF_GEMM_CASE(false, false);
@@ -190,15 +245,43 @@ int launch(const float* A, const float* B, float* C, const float* bias, int M, i
 
 }  // namespace
 
+// Split-K plan for an M x N x K product: number of K splits (1 = none) and the K extent of one
+// split. Splitting pays when the 64x64 tile grid cannot fill the chip and K is long enough to
+// give every split at least four K-tiles.
+constexpr int DTF_SPLITK_MAX_TILES = 1024;   // counters the workspace must provide
+
+DTF_API int dtf_gemm_f32_splits(int M, int N, int K, int* kchunk_out) {
+  const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
+  int splits = 1, kchunk = K;
+  if (tiles <= 64 && K >= 256 && tiles <= DTF_SPLITK_MAX_TILES) {
+    int want = (int)(256 / tiles);
+    if (want > 32) want = 32;
+    int chunk = ((K + want - 1) / want + 15) / 16 * 16;
+    if (chunk < 64) chunk = 64;
+    splits = (K + chunk - 1) / chunk;
+    kchunk = chunk;
+    if (splits <= 1) { splits = 1; kchunk = K; }
+  }
+  if (kchunk_out) *kchunk_out = kchunk;
+  return splits;
+}
+
 // C[M,N] = act(op(A) * op(B) + bias[N]).  A is stored [M,K] (lda >= K), or [K,M] (lda >= M) when
 // trans_a; B is stored [K,N] (ldb >= N), or [N,K] (ldb >= K) when trans_b. bias may be null.
+// partial / counters: split-K workspace (splits * M * N floats; DTF_SPLITK_MAX_TILES zeroed
+// ints). With either null the product runs unsplit.
 DTF_API int dtf_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N,
                          int K, long lda, long ldb, long ldc, int trans_a, int trans_b, int act,
-                         hipStream_t stream) {
+                         float* partial, int* counters, hipStream_t stream) {
   if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return DTF_ERR_BAD_ARG;
   if (lda < (trans_a ? M : K) || ldb < (trans_b ? K : N) || ldc < N) return DTF_ERR_BAD_ARG;
   const long big_tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
   if (big_tiles >= 192)
-    return launch<128, 128>(A, B, C, bias, M, N, K, lda, ldb, ldc, trans_a, trans_b, act, stream);
-  return launch<64, 64>(A, B, C, bias, M, N, K, lda, ldb, ldc, trans_a, trans_b, act, stream);
+    return launch<128, 128>(A, B, C, bias, M, N, K, lda, ldb, ldc, trans_a, trans_b, act, 1, K,
+                            nullptr, nullptr, stream);
+  int kchunk = K;
+  int splits = (partial && counters) ? dtf_gemm_f32_splits(M, N, K, &kchunk) : 1;
+  if (splits == 1) kchunk = ((K + BK - 1) / BK) * BK;
+  return launch<64, 64>(A, B, C, bias, M, N, K, lda, ldb, ldc, trans_a, trans_b, act, splits,
+                        kchunk, partial, counters, stream);
 }

@@ -94,51 +94,79 @@ __global__ __launch_bounds__(BLOCK) void reduce_all_stage2(const float* __restri
 
 enum ColMode { COL_SUM = 0, COL_SIGMOID_GRAD = 1, COL_XENT_GRAD = 2 };
 
-// Workgroup b owns columns [64b, 64b+64); thread (g = tid>>6, l = tid&63) walks rows g, g+4, ...
+// Workgroup b owns columns [64b, 64b+64); thread (g = tid>>6, l = tid&63) walks rows g, g+G, ...
+// with G = blockDim/64 row groups (16 for short matrices such as a 100-row batch, so a thread's
+// serial chain of dependent-latency loads is a handful of rows, four of them in flight at once).
 // MODE 0: p0 = x                      -> colsum[c] = sum_r x[r,c]
 // MODE 1: p0 = da, p1 = a             -> dz = da*a*(1-a) written to dz_out, colsum of dz
 // MODE 2: p0 = y, p1 = labels, p2 = dloss (scalar) -> dz = (y*rowsum(labels) - labels)*dloss/R
 //         (cols <= 64: one workgroup sees whole rows, so the label row-sum is a wave reduction)
+// Sums are folded in a fixed order: deterministic for a given launch shape.
+constexpr int COLS_BLOCK = 1024;
+
 template <int MODE>
-__global__ __launch_bounds__(BLOCK) void reduce_cols_kernel(const float* __restrict__ p0,
-                                                            const float* __restrict__ p1,
-                                                            const float* __restrict__ p2,
-                                                            float* __restrict__ dz_out,
-                                                            float* __restrict__ colsum, long rows,
-                                                            long cols) {
-  __shared__ float sh[BLOCK];
+__global__ __launch_bounds__(COLS_BLOCK) void reduce_cols_kernel(const float* __restrict__ p0,
+                                                                 const float* __restrict__ p1,
+                                                                 const float* __restrict__ p2,
+                                                                 float* __restrict__ dz_out,
+                                                                 float* __restrict__ colsum,
+                                                                 long rows, long cols) {
+  __shared__ float sh[COLS_BLOCK];
   const int l = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int groups = blockDim.x >> 6;
   const long c = blockIdx.x * 64L + l;
   const bool live = c < cols;
   float scale = 1.f;
   if (MODE == COL_XENT_GRAD) scale = p2[0] / (float)rows;
   float acc = 0.f;
-  for (long r = g; r < rows; r += BLOCK / 64) {
-    float v = 0.f;
-    if (MODE == COL_SUM) {
-      if (live) v = p0[r * cols + c];
-    } else if (MODE == COL_SIGMOID_GRAD) {
-      if (live) {
-        const float a = p1[r * cols + c];
-        v = p0[r * cols + c] * a * (1.f - a);
-        dz_out[r * cols + c] = v;
-      }
-    } else {
+  if (MODE == COL_XENT_GRAD) {
+    for (long r = g; r < rows; r += groups) {
       const float lab = live ? p1[r * cols + c] : 0.f;
       const float lsum = dtf_wave_sum(lab);
       if (live) {
-        v = (p0[r * cols + c] * lsum - lab) * scale;
+        const float v = (p0[r * cols + c] * lsum - lab) * scale;
         dz_out[r * cols + c] = v;
+        acc += v;
       }
     }
-    acc += v;
+  } else if (live) {
+    long r = g;
+    for (; r + 3L * groups < rows; r += 4L * groups) {      // four independent rows in flight
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long idx = (r + (long)u * groups) * cols + c;
+        if (MODE == COL_SUM) {
+          v[u] = p0[idx];
+        } else {
+          const float a = p1[idx];
+          v[u] = p0[idx] * a * (1.f - a);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (MODE == COL_SIGMOID_GRAD) dz_out[(r + (long)u * groups) * cols + c] = v[u];
+        acc += v[u];
+      }
+    }
+    for (; r < rows; r += groups) {
+      const long idx = r * cols + c;
+      float v;
+      if (MODE == COL_SUM) {
+        v = p0[idx];
+      } else {
+        const float a = p1[idx];
+        v = p0[idx] * a * (1.f - a);
+        dz_out[idx] = v;
+      }
+      acc += v;
+    }
   }
   sh[threadIdx.x] = acc;
   __syncthreads();
   if (g == 0 && live && colsum) {
     float t = 0.f;
-#pragma unroll
-    for (int k = 0; k < BLOCK / 64; ++k) t += sh[k * 64 + l];
+    for (int k = 0; k < groups; ++k) t += sh[k * 64 + l];
     colsum[c] = t;
   }
 }
@@ -169,6 +197,13 @@ __global__ __launch_bounds__(1024) void argmax_accuracy_kernel(const float* __re
     for (int w = 0; w < 16; ++w) t += sh[w];
     out[0] = t / (float)rows;
   }
+}
+
+// threads of a reduce_cols workgroup: one 64-lane row group per 4 rows, 4..16 groups
+int cols_threads(long rows) {
+  long groups = (rows + 3) / 4;
+  groups = groups < 4 ? 4 : groups > 16 ? 16 : groups;
+  return (int)groups * 64;
 }
 
 int rows_grid(long rows) {
@@ -224,8 +259,9 @@ DTF_API int dtf_reduce_all_f32(const float* x, float* out, long n, float scale, 
 DTF_API int dtf_reduce_cols_f32(const float* x, float* colsum, long rows, long cols,
                                 hipStream_t stream) {
   if (!x || !colsum || rows <= 0 || cols <= 0) return DTF_ERR_BAD_ARG;
-  hipLaunchKernelGGL((reduce_cols_kernel<COL_SUM>), dim3((cols + 63) / 64), dim3(BLOCK), 0, stream,
-                     x, nullptr, nullptr, nullptr, colsum, rows, cols);
+  hipLaunchKernelGGL((reduce_cols_kernel<COL_SUM>), dim3((cols + 63) / 64),
+                     dim3(cols_threads(rows)), 0, stream, x, nullptr, nullptr, nullptr, colsum, rows,
+                     cols);
   DTF_LAUNCH_CHECK();
   return DTF_OK;
 }
@@ -234,8 +270,8 @@ DTF_API int dtf_reduce_cols_f32(const float* x, float* colsum, long rows, long c
 DTF_API int dtf_sigmoid_grad_bias_f32(const float* da, const float* a, float* dz, float* dbias,
                                       long rows, long cols, hipStream_t stream) {
   if (!da || !a || !dz || rows <= 0 || cols <= 0) return DTF_ERR_BAD_ARG;
-  hipLaunchKernelGGL((reduce_cols_kernel<COL_SIGMOID_GRAD>), dim3((cols + 63) / 64), dim3(BLOCK), 0,
-                     stream, da, a, nullptr, dz, dbias, rows, cols);
+  hipLaunchKernelGGL((reduce_cols_kernel<COL_SIGMOID_GRAD>), dim3((cols + 63) / 64),
+                     dim3(cols_threads(rows)), 0, stream, da, a, nullptr, dz, dbias, rows, cols);
   DTF_LAUNCH_CHECK();
   return DTF_OK;
 }
@@ -247,8 +283,8 @@ DTF_API int dtf_softmax_xent_grad_f32(const float* y, const float* labels, const
                                       hipStream_t stream) {
   if (!y || !labels || !dloss || !dz || rows <= 0 || cols <= 0) return DTF_ERR_BAD_ARG;
   if (cols > 64) return DTF_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((reduce_cols_kernel<COL_XENT_GRAD>), dim3(1), dim3(BLOCK), 0, stream, y,
-                     labels, dloss, dz, dbias, rows, cols);
+  hipLaunchKernelGGL((reduce_cols_kernel<COL_XENT_GRAD>), dim3(1), dim3(cols_threads(rows)), 0,
+                     stream, y, labels, dloss, dz, dbias, rows, cols);
   DTF_LAUNCH_CHECK();
   return DTF_OK;
 }

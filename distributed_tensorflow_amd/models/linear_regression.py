@@ -1,0 +1,76 @@
+"""Linear regression trained with plain SGD -- the smallest between-graph-replicated model.
+
+``y = x W + b`` with a mean-squared-error loss. Under ``replica_device_setter`` the two
+parameters are placed on the ps job; with the ``reduce_scatter_sync`` runtime that ownership
+becomes shards of one flat arena: gradients are reduce-scattered to the owners, each owner
+applies ``w -= lr * g`` to its shard and the shards are all-gathered (the broadcast of the
+updated parameters), i.e. the parameter-server step of ``tf_distributed.py:33-36,75-76``
+expressed as collectives.
+
+Synthetic data: ``x ~ N(0, 1)`` and ``y = x W* + b* + noise`` with a fixed ground truth drawn
+from a counter-based stream, so every worker can generate its own batches and convergence to
+``W*`` is checkable.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Optional, Tuple
+
+import numpy as np
+
+from ..framework import dtypes
+from ..framework import ops as F
+from ..framework.graph import get_default_graph, name_scope, set_random_seed
+from ..framework.variables import (Variable, constant_initializer, get_variable,
+                                   global_variables_initializer)
+from ..ops import philox
+from ..train.optimizer import GradientDescentOptimizer
+
+
+def build_model(features: int = 1024, outputs: int = 1, learning_rate: float = 0.05,
+                seed: Optional[int] = 1) -> SimpleNamespace:
+    global_step = get_variable("global_step", [], initializer=constant_initializer(0),
+                               trainable=False)
+    with name_scope("input"):
+        x = F.placeholder(dtypes.float32, shape=[None, features], name="x-input")
+        y_ = F.placeholder(dtypes.float32, shape=[None, outputs], name="y-input")
+    set_random_seed(seed)
+    with name_scope("weights"):
+        w = Variable(F.zeros([features, outputs]))
+    with name_scope("biases"):
+        b = Variable(F.zeros([outputs]))
+    with name_scope("model"):
+        y = F.add(F.matmul(x, w), b)
+    with name_scope("loss"):
+        loss = F.reduce_mean(F.square(y - y_))
+    with name_scope("train"):
+        optimizer = GradientDescentOptimizer(learning_rate)
+        train_op = optimizer.minimize(loss, global_step=global_step)
+    init_op = global_variables_initializer()
+    return SimpleNamespace(graph=get_default_graph(), global_step=global_step, x=x, y_=y_, w=w,
+                           b=b, y=y, loss=loss, train_op=train_op, init_op=init_op,
+                           optimizer=optimizer, features=features, outputs=outputs)
+
+
+def ground_truth(features: int, outputs: int, seed: int = 7) -> Tuple[np.ndarray, np.ndarray]:
+    """The fixed ``(W*, b*)`` every worker regresses towards."""
+    w = philox.window(features, outputs, seed, 11, 0, 0, outputs, True).astype(np.float32)
+    b = philox.window(1, outputs, seed, 12, 0, 0, outputs, True).astype(np.float32)[0]
+    return w / np.sqrt(features), b
+
+
+class SyntheticRegressionData:
+    """Per-worker batch stream: worker ``task`` draws from its own counter range."""
+
+    def __init__(self, features: int, outputs: int, task: int = 0, noise: float = 0.01,
+                 seed: int = 7):
+        self.features, self.outputs, self.noise = features, outputs, noise
+        self.w, self.b = ground_truth(features, outputs, seed)
+        self._rng = np.random.RandomState(seed * 1000 + task)
+
+    def next_batch(self, batch_size: int) -> Tuple[np.ndarray, np.ndarray]:
+        x = self._rng.standard_normal((batch_size, self.features)).astype(np.float32)
+        y = x @ self.w + self.b
+        if self.noise:
+            y = y + self.noise * self._rng.standard_normal(y.shape).astype(np.float32)
+        return x, y.astype(np.float32)

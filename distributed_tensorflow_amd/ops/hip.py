@@ -58,7 +58,8 @@ def _declare(L: ctypes.CDLL) -> None:
     c = ctypes
     P, I, LG, F, U = c.c_void_p, c.c_int, c.c_long, c.c_float, c.c_uint
     sigs = {
-        "dtf_gemm_f32": [P, P, P, P, I, I, I, LG, LG, LG, I, I, I, P],
+        "dtf_gemm_f32": [P, P, P, P, I, I, I, LG, LG, LG, I, I, I, P, P, P],
+        "dtf_gemm_f32_splits": [I, I, I, P],
         "dtf_gemm_bf16_nt": [P, P, P, I, I, I, LG, LG, LG, F, F, I, I, P],
         "dtf_gemm_bf16_generic": [P, P, P, I, I, I, LG, LG, LG, LG, LG, F, F, I, P],
         "dtf_gemm_fp8_nt": [P, P, P, I, I, I, LG, LG, LG, F, F, I, P],
@@ -83,6 +84,7 @@ def _declare(L: ctypes.CDLL) -> None:
         "dtf_reduce_cols_f32": [P, P, LG, LG, P],
         "dtf_sigmoid_grad_bias_f32": [P, P, P, P, LG, LG, P],
         "dtf_softmax_xent_grad_f32": [P, P, P, P, P, LG, LG, P],
+        "dtf_xent_grad_narrow_f32": [P, P, P, P, P, LG, LG, P],
         "dtf_argmax_accuracy_f32": [P, P, P, LG, LG, P],
         "dtf_softmax_rows_f32": [P, P, P, LG, LG, P],
         "dtf_softmax_xent_workspace": [LG],
@@ -135,6 +137,17 @@ def _aligned(t: torch.Tensor) -> torch.Tensor:
 # ---------------------------------------------------------------------------------------
 # GEMM
 # ---------------------------------------------------------------------------------------
+_SPLITK_COUNTERS: dict = {}
+
+
+def _splitk_counters(device: torch.device) -> torch.Tensor:
+    key = (device.type, device.index)
+    t = _SPLITK_COUNTERS.get(key)
+    if t is None:
+        t = _SPLITK_COUNTERS[key] = torch.zeros(1024, dtype=torch.int32, device=device)
+    return t
+
+
 def gemm_f32(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool = False,
              bias: Optional[torch.Tensor] = None, activation: int = ACT_NONE,
              out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -161,9 +174,17 @@ def gemm_f32(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: b
         return out
     if k == 0:
         return out.zero_()
-    _check(lib().dtf_gemm_f32(a.data_ptr(), b.data_ptr(), out.data_ptr(), _ptr(bias), m, n, k,
-                              a.stride(0), b.stride(0), out.stride(0), int(trans_a), int(trans_b),
-                              int(activation), _stream()), "gemm_f32")
+    L = lib()
+    partial = counters = None
+    splits = L.dtf_gemm_f32_splits(m, n, k, None)
+    if splits > 1:
+        # split-K workspace: one plane per split (caching allocator; graph-capturable) and the
+        # per-device ticket counters, zeroed once and reset by the kernel itself
+        partial = torch.empty(splits * m * n, dtype=torch.float32, device=a.device)
+        counters = _splitk_counters(a.device)
+    _check(L.dtf_gemm_f32(a.data_ptr(), b.data_ptr(), out.data_ptr(), _ptr(bias), m, n, k,
+                          a.stride(0), b.stride(0), out.stride(0), int(trans_a), int(trans_b),
+                          int(activation), _ptr(partial), _ptr(counters), _stream()), "gemm_f32")
     return out
 
 
@@ -528,9 +549,9 @@ def softmax_xent_grad(y: torch.Tensor, labels: torch.Tensor, dloss: torch.Tensor
         return dz, (reduce_cols(dz) if want_bias else None)
     dz = torch.empty_like(y)
     db = torch.empty((c,), dtype=torch.float32, device=y.device) if want_bias else None
-    _check(lib().dtf_softmax_xent_grad_f32(y.data_ptr(), labels.data_ptr(), dloss.data_ptr(),
-                                           dz.data_ptr(), _ptr(db), r, c, _stream()),
-           "softmax_xent_grad")
+    fn = lib().dtf_xent_grad_narrow_f32 if c <= 32 else lib().dtf_softmax_xent_grad_f32
+    _check(fn(y.data_ptr(), labels.data_ptr(), dloss.data_ptr(), dz.data_ptr(), _ptr(db), r, c,
+              _stream()), "softmax_xent_grad")
     return dz, db
 
 

@@ -126,6 +126,9 @@ class Server:
         self.runtime = None
         self.device = torch.device(config.device) if config is not None and \
             getattr(config, "device", None) else _default_device(job_name)
+        if self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))
+                                       % max(1, torch.cuda.device_count()))
         if start:
             self.start()
 

@@ -63,6 +63,8 @@ def define_flags(default_job=DEFAULT_JOB, default_epochs=DEFAULT_EPOCHS):
     tf.app.flags.DEFINE_string("checkpoint_dir", "", "Supervisor logdir (enables checkpoints)")
     tf.app.flags.DEFINE_boolean("shutdown_ps", False, "report completion so the ps exits once all workers are done")
     tf.app.flags.DEFINE_string("device", "", "torch device of this task (default: auto)")
+    tf.app.flags.DEFINE_boolean("device_data", True, "keep the data set resident in GPU memory "
+                                "(GPU tasks only) so feeds are device-to-device copies")
     return tf.app.flags.FLAGS
 
 
@@ -107,6 +109,12 @@ def main(argv=None, default_num_workers=DEFAULT_NUM_WORKERS):
                              init_op=model.init_op, logdir=FLAGS.checkpoint_dir or None,
                              summary_op=None, recovery_wait_secs=1.0)
 
+    test_images, test_labels = mnist.test.images, mnist.test.labels
+    if FLAGS.device_data and server.device.type == "cuda":
+        mnist.train.to_device(server.device)
+        mnist.test.to_device(server.device)
+        test_images, test_labels = mnist.test.device_images, mnist.test.device_labels
+
     begin_time = time.time()
     frequency = 100
     local_step = 0
@@ -133,7 +141,7 @@ def main(argv=None, default_num_workers=DEFAULT_NUM_WORKERS):
                     done = True
                     break
             print("Test-Accuracy: %2.2f" % sess.run(
-                model.accuracy, feed_dict={model.x: mnist.test.images, model.y_: mnist.test.labels}))
+                model.accuracy, feed_dict={model.x: test_images, model.y_: test_labels}))
             print("Total Time: %3.2fs" % float(time.time() - begin_time))
             print("Final Cost: %.4f" % cost)
             if done:

@@ -352,3 +352,92 @@ def test_sharded_matmul_fp8_single_gpu(hip):
     assert (got - ref).abs().max().item() < 0.25          # bf16 rounding of |c| up to ~32
     s2 = ShardedMatmul(512, 512, 1024, dtype=FP8, strategy="summa_2d", device=torch.device("cuda"))
     assert (s2.step().double().cpu()[rows][:, cols] - ref).abs().max().item() < 1e-3
+
+
+# -- small-shape paths of the training step ------------------------------------------------------
+@pytest.mark.parametrize("m,n,k,ta,tb", [(100, 100, 784, False, False), (100, 10, 1000, False, False),
+                                          (64, 64, 4096, False, True), (100, 100, 784, True, False),
+                                          (130, 70, 300, True, True), (1000, 1000, 1000, False, False)])
+def test_gemm_f32_split_k(hip, m, n, k, ta, tb):
+    """Few output tiles + long K take the split-K path (ticketed last-workgroup reduction):
+    exact on integer data, bit-identical across repeated launches, bias + activation applied
+    once, after the reduction."""
+    g = torch.Generator().manual_seed(k)
+    a = torch.randint(-3, 4, (m, k), generator=g).float().cuda()
+    b = torch.randint(-3, 4, (k, n), generator=g).float().cuda()
+    a_in = a.t().contiguous() if ta else a
+    b_in = b.t().contiguous() if tb else b
+    ref = a @ b
+    outs = [hip.gemm_f32(a_in, b_in, ta, tb) for _ in range(4)]
+    for o in outs:
+        assert torch.equal(o, ref)
+    bias = torch.arange(n, dtype=torch.float32).cuda()
+    x = torch.randn(m, k, generator=g).cuda() * 0.05
+    x_in = x.t().contiguous() if ta else x
+    out = hip.gemm_f32(x_in, b_in, ta, tb, bias=bias, activation=hip.ACTIVATIONS["sigmoid"])
+    refz = torch.sigmoid(x.double() @ b.double() + bias.double())
+    assert (out.double() - refz).abs().max().item() < 1e-5
+    again = hip.gemm_f32(x_in, b_in, ta, tb, bias=bias, activation=hip.ACTIVATIONS["sigmoid"])
+    assert torch.equal(out, again)
+
+
+@pytest.mark.parametrize("rows,cols", [(100, 10), (1, 3), (1000, 16), (5000, 10), (300, 32), (2049, 17)])
+def test_softmax_xent_narrow_rows(hip, rows, cols):
+    g = torch.Generator().manual_seed(rows + cols)
+    logits = (torch.randn(rows, cols, generator=g) * 3).cuda()
+    labels = torch.softmax(torch.randn(rows, cols, generator=g), 1).cuda()
+    y, row_loss, mean = hip.softmax_xent(logits, labels)
+    ref_y = torch.softmax(logits.double(), 1)
+    ref_rows = -(labels.double() * torch.log_softmax(logits.double(), 1)).sum(1)
+    assert (y.double() - ref_y).abs().max().item() < 1e-6
+    assert (row_loss.double() - ref_rows).abs().max().item() < 1e-5
+    assert abs(mean.item() - ref_rows.mean().item()) < 1e-5
+    dloss = torch.tensor([0.7]).cuda()
+    dz, db = hip.softmax_xent_grad(y, labels, dloss)
+    ref_dz = (ref_y * labels.double().sum(1, keepdim=True) - labels.double()) * 0.7 / rows
+    assert (dz.double() - ref_dz).abs().max().item() < 1e-6
+    assert (db.double() - ref_dz.sum(0)).abs().max().item() < 1e-5
+    dz2, db2 = hip.softmax_xent_grad(y, labels, dloss)
+    assert torch.equal(dz, dz2) and torch.equal(db, db2)
+
+
+@pytest.mark.parametrize("rows,cols", [(100, 100), (100, 10), (3, 70), (1000, 100), (10000, 64)])
+def test_reduce_cols_and_sigmoid_grad_shapes(hip, rows, cols):
+    g = torch.Generator().manual_seed(rows * 3 + cols)
+    x = torch.randn(rows, cols, generator=g).cuda()
+    assert (hip.reduce_cols(x).double() - x.double().sum(0)).abs().max().item() < 1e-3
+    a = torch.sigmoid(torch.randn(rows, cols, generator=g)).cuda()
+    dz, db = hip.sigmoid_grad_bias(x, a)
+    ref = x.double() * a.double() * (1 - a.double())
+    assert (dz.double() - ref).abs().max().item() < 1e-6
+    assert (db.double() - ref.sum(0)).abs().max().item() < 1e-3
+
+
+def test_session_graph_replay_with_host_and_device_feeds(hip):
+    """The HIP-graph path stages numpy feeds through pinned memory and takes device tensors
+    as they are; both must give the eager result, step after step."""
+    import distributed_tensorflow_amd as tf
+    from distributed_tensorflow_amd.models import mnist_mlp
+    rng = np.random.RandomState(1)
+    batches = [(rng.rand(100, 784).astype(np.float32),
+                np.eye(10, dtype=np.float32)[rng.randint(0, 10, 100)]) for _ in range(6)]
+    results = {}
+    for mode in ("eager", "graph_host", "graph_device"):
+        g = tf.Graph()
+        with g.as_default():
+            model = mnist_mlp.build_model(seed=1)
+            cfg = tf.ConfigProto(device="cuda", hip_graphs=(mode != "eager"))
+            with tf.Session(config=cfg) as sess:
+                sess.run(model.init_op)
+                losses = []
+                for bx, by in batches:
+                    if mode == "graph_device":
+                        bx, by = torch.from_numpy(bx).cuda(), torch.from_numpy(by).cuda()
+                    _, l, s, st = sess.run([model.train_op, model.loss, model.summary_op,
+                                            model.global_step], {model.x: bx, model.y_: by})
+                    losses.append(float(l))
+                results[mode] = (losses, sess.run(model.w2), dict(sess.stats))
+    assert results["graph_host"][2]["graph_replays"] >= 4
+    for mode in ("graph_host", "graph_device"):
+        assert np.allclose(results[mode][0], results["eager"][0], rtol=1e-6)
+        assert np.allclose(results[mode][1], results["eager"][1], rtol=1e-6, atol=1e-7)

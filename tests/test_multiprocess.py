@@ -121,3 +121,13 @@ def test_gloo_two_process_comm_matmul_and_training(strategy, tmp_path):
         assert r["loss_last"] < 0.05 * r["loss_first"]
         assert r["step"] == 60.0
     assert results[0]["w"] == results[1]["w"]        # bit-identical replicas
+
+
+def test_linear_regression_reduce_scatter_converges():
+    rc, out = _run_launcher(["--num_workers", "2", "--protocol", "rccl", "--strategy",
+                             "reduce_scatter_sync", "--timeout", "200",
+                             os.path.join(EX, "linear_regression.py"), "--",
+                             "--max_steps", "300", "--device", "cpu", "--features", "64"])
+    assert rc == 0, out
+    errs = [float(e) for e in re.findall(r"Weight-Error: (\d+\.\d+)", out)]
+    assert len(errs) == 2 and errs[0] == errs[1] and errs[0] < 0.01

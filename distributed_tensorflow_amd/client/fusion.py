@@ -12,6 +12,9 @@ pruned subgraph before execution:
   logits gradient and the bias gradient);
 * ``SigmoidGrad`` + the bias-gradient column sum      -> ``DenseGradSigmoid``;
 * ``reduce_mean(cast(equal(argmax(y,1), argmax(y_,1))))``  -> ``ArgmaxAccuracy``;
+* a linear output layer + softmax cross-entropy + their whole backward (logits gradient, weight
+  and bias gradients, the gradient into -- and through -- a preceding sigmoid layer, and the
+  accuracy of the same predictions) -> ``ClassifierHeadTrain``, one kernel for small heads;
 * every ``ApplyGradientDescent`` (+ the ``global_step`` increment) -> one ``MultiApplySGD``.
 
 Rewrites are expressed as *tensor replacements* (``original tensor -> output k of a fused
@@ -148,6 +151,56 @@ def _match_accuracy(mean_op: Operation):
     return srcs[0], srcs[1]
 
 
+_HEAD_MAX_HIDDEN, _HEAD_MAX_CLASSES = 128, 16
+
+
+def _match_head(dense, logits, dlogits_t, emit_bias, grad_map, alive, fed, rw, consumers):
+    """The pieces around a fused softmax cross-entropy that make it a whole classifier head:
+    ``logits = FusedDense(a, W, b)`` without activation, ``dW = MatMul(a, dlogits, transpose_a)``
+    and ``da = MatMul(dlogits, W, transpose_b)``; when ``a`` is itself the output of a sigmoid
+    ``FusedDense`` whose ``DenseGradSigmoid`` consumes exactly ``da``, that node is absorbed too.
+    Returns ``(a, W, dW, da, (dz_prev, db_prev) | None)`` or ``None``."""
+    if dense is None or not emit_bias or dense.attrs["activation"] != "none":
+        return None
+    a_t, w_t, _ = dense.inputs
+    if logits in fed:
+        return None
+    if w_t.shape is None or len(w_t.shape) != 2 or None in w_t.shape:
+        return None
+    if w_t.shape[0] > _HEAD_MAX_HIDDEN or w_t.shape[1] > _HEAD_MAX_CLASSES:
+        return None
+    dw_t, da_t = grad_map.get(w_t), grad_map.get(a_t)
+    if dw_t is None or da_t is None or dw_t.op not in alive or da_t.op not in alive:
+        return None
+    dw_op, da_op = dw_t.op, da_t.op
+    if dw_op.type != "MatMul" or da_op.type != "MatMul":
+        return None
+    if not (dw_op.attrs["transpose_a"] and not dw_op.attrs["transpose_b"]
+            and dw_op.inputs[0] is a_t and dw_op.inputs[1] is dlogits_t):
+        return None
+    if not (da_op.attrs["transpose_b"] and not da_op.attrs["transpose_a"]
+            and da_op.inputs[0] is dlogits_t and da_op.inputs[1] is w_t):
+        return None
+    # dlogits itself must have no other reader than dW, da and the bias gradient
+    for c in consumers.get(dlogits_t, []):
+        if c in alive and c is not dw_op and c is not da_op and c.type != "SumToShapeOf":
+            return None
+    sig = None
+    mapped = rw.tensor_map.get(a_t)
+    if mapped is not None and getattr(mapped.op, "type", "") == "FusedDense" \
+            and mapped.op.attrs["activation"] == "sigmoid":
+        z_prev = mapped.op.attrs["_pre_activation"]
+        b_prev = mapped.op.attrs["_bias"]
+        dz_prev, db_prev = grad_map.get(z_prev), grad_map.get(b_prev)
+        if dz_prev is not None and db_prev is not None:
+            g = rw.tensor_map.get(dz_prev)
+            if g is not None and getattr(g.op, "type", "") == "DenseGradSigmoid" \
+                    and g.op.inputs[0] is da_t and rw.tensor_map.get(db_prev) is g.op.outputs[1] \
+                    and all(c is dz_prev.op for c in consumers.get(da_t, []) if c in alive):
+                sig = (dz_prev, db_prev)
+    return a_t, w_t, dw_t, da_t, sig
+
+
 def build_rewrite(graph: Graph, ops: Sequence[Operation], fed: Set[Tensor],
                   fetched: Set[Tensor] = frozenset()) -> Rewrite:
     """Find fusable patterns among ``ops`` (the pruned, topologically ordered subgraph)."""
@@ -234,6 +287,51 @@ def build_rewrite(graph: Graph, ops: Sequence[Operation], fed: Set[Tensor],
             rw.tensor_map[dlogits_t] = gnode.outputs[0]
             if emit_bias:
                 rw.tensor_map[db_t] = gnode.outputs[1]
+
+            # -- whole classifier head: dense + xent forward and backward in one node --------
+            head = _match_head(dense, logits, dlogits_t, emit_bias, grad_map, alive, fed, rw,
+                               consumers)
+            if head is not None:
+                a_t, w_t, dw_t, da_t, sig = head
+                outs = [(loss_t.dtype, loss_t.shape), (soft_t.dtype, soft_t.shape),
+                        (dw_t.dtype, dw_t.shape), (db_t.dtype, db_t.shape)]
+                prev_dz = prev_db = None
+                if sig is not None:
+                    prev_dz, prev_db = sig
+                    outs += [(prev_dz.dtype, prev_dz.shape), (prev_db.dtype, prev_db.shape)]
+                else:
+                    outs.append((da_t.dtype, da_t.shape))
+                acc_op = None
+                for cand in ops:
+                    acc_hit = _match_accuracy(cand) if cand.type == "Mean" else None
+                    if acc_hit is not None and acc_hit[0] is soft_t and acc_hit[1] is labels:
+                        acc_op = cand
+                        outs.append((cand.outputs[0].dtype, cand.outputs[0].shape))
+                        break
+                # d(loss) seeded by gradients() is ones_like(loss): a constant, and one that
+                # would make the merged node depend on its own output
+                head_inputs = [a_t, w_t, bias_t, labels]
+                dloss_const = None
+                if dloss_t.op.type == "OnesLike" and dloss_t.op.inputs[0] is loss_t:
+                    dloss_const = 1.0
+                else:
+                    head_inputs.append(dloss_t)
+                hnode = FusedNode(graph, "ClassifierHeadTrain", op.name + "/fused_head",
+                                  head_inputs, outs,
+                                  {"sigmoid_input": sig is not None,
+                                   "emit_accuracy": acc_op is not None,
+                                   "dloss_const": dloss_const}, device=op.device)
+                rw.tensor_map[loss_t] = hnode.outputs[0]
+                rw.tensor_map[soft_t] = hnode.outputs[1]
+                rw.tensor_map[dw_t] = hnode.outputs[2]
+                rw.tensor_map[db_t] = hnode.outputs[3]
+                if sig is not None:
+                    rw.tensor_map[prev_dz] = hnode.outputs[4]
+                    rw.tensor_map[prev_db] = hnode.outputs[5]
+                else:
+                    rw.tensor_map[da_t] = hnode.outputs[4]
+                if acc_op is not None:
+                    rw.tensor_map[acc_op.outputs[0]] = hnode.outputs[len(outs) - 1]
 
     # -- metric: argmax-compare-mean --------------------------------------------------------
     for op in ops:

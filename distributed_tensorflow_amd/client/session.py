@@ -178,7 +178,9 @@ class _CapturedStep:
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.static_feeds: List[torch.Tensor] = []
         self.host_buf: Optional[torch.Tensor] = None      # pinned staging for packed scalars
-        self.layout: List[Tuple[int, int, torch.Size, torch.dtype]] = []
+        self.host_np = None                               # numpy view of host_buf
+        self.host_words = 0
+        self.layout: List[Tuple[int, int, tuple, int]] = []   # (slot, offset, shape, numel)
         self.slot_values: List[Any] = []
 
 
@@ -569,9 +571,9 @@ class Session:
         out: Dict[int, Any] = {}
         if cap.host_buf is not None:
             torch.cuda.current_stream(self.device).synchronize()
-            for slot_idx, off, shape, _dt in cap.layout:
-                n = int(np.prod(shape)) if len(shape) else 1
-                out[slot_idx] = cap.host_buf[off:off + n].view(shape).clone()
+            snap = cap.host_np[:cap.host_words].copy()      # one copy out of the pinned buffer
+            for slot_idx, off, shape, n in cap.layout:
+                out[slot_idx] = snap[off:off + n].reshape(shape) if shape else snap[off]
         for sl in list(plan.fetch_slots) + plan.host_input_slots:
             if sl is not None and sl not in out:
                 out[sl] = cap.slot_values[sl]
@@ -612,7 +614,10 @@ class Session:
                 hip.pack_f32([p[4] for p in packed], stage)      # one gather launch
                 host_buf[:off].copy_(stage, non_blocking=True)   # one device->host copy
                 cap.host_buf = host_buf
-                cap.layout = [(sl, o, shape, dt) for sl, o, shape, dt, _ in packed]
+                cap.host_np = host_buf.numpy()
+                cap.host_words = off
+                cap.layout = [(sl, o, tuple(shape), int(v.numel()))
+                              for sl, o, shape, _dt, v in packed]
         cap.graph = graph
         cap.slot_values = vals
         return cap

@@ -171,9 +171,9 @@ __global__ __launch_bounds__(1024) void xent_grad_narrow_kernel(
   }
   __syncthreads();
   if (threadIdx.x < cols) {
+    const int nwaves = blockDim.x >> 6;
     float t = 0.f;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) t += sh[k][threadIdx.x];
+    for (int k = 0; k < nwaves; ++k) t += sh[k][threadIdx.x];
     dbias[threadIdx.x] = t;
   }
 }

@@ -58,7 +58,7 @@ def _declare(L: ctypes.CDLL) -> None:
     c = ctypes
     P, I, LG, F, U = c.c_void_p, c.c_int, c.c_long, c.c_float, c.c_uint
     sigs = {
-        "dtf_gemm_f32": [P, P, P, P, I, I, I, LG, LG, LG, I, I, I, P, P, P],
+        "dtf_gemm_f32": [P, P, P, P, I, I, I, LG, LG, LG, I, I, I, P, P],
         "dtf_gemm_f32_splits": [I, I, I, P],
         "dtf_gemm_bf16_nt": [P, P, P, I, I, I, LG, LG, LG, F, F, I, I, P],
         "dtf_gemm_bf16_generic": [P, P, P, I, I, I, LG, LG, LG, LG, LG, F, F, I, P],
@@ -85,6 +85,8 @@ def _declare(L: ctypes.CDLL) -> None:
         "dtf_sigmoid_grad_bias_f32": [P, P, P, P, LG, LG, P],
         "dtf_softmax_xent_grad_f32": [P, P, P, P, P, LG, LG, P],
         "dtf_xent_grad_narrow_f32": [P, P, P, P, P, LG, LG, P],
+        "dtf_mlp_head_supported": [LG, LG, LG],
+        "dtf_mlp_head_train": [P, P, P, P, P, P, P, P, P, P, P, P, LG, LG, LG, I, P],
         "dtf_argmax_accuracy_f32": [P, P, P, LG, LG, P],
         "dtf_softmax_rows_f32": [P, P, P, LG, LG, P],
         "dtf_softmax_xent_workspace": [LG],
@@ -137,17 +139,6 @@ def _aligned(t: torch.Tensor) -> torch.Tensor:
 # ---------------------------------------------------------------------------------------
 # GEMM
 # ---------------------------------------------------------------------------------------
-_SPLITK_COUNTERS: dict = {}
-
-
-def _splitk_counters(device: torch.device) -> torch.Tensor:
-    key = (device.type, device.index)
-    t = _SPLITK_COUNTERS.get(key)
-    if t is None:
-        t = _SPLITK_COUNTERS[key] = torch.zeros(1024, dtype=torch.int32, device=device)
-    return t
-
-
 def gemm_f32(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool = False,
              bias: Optional[torch.Tensor] = None, activation: int = ACT_NONE,
              out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -175,16 +166,14 @@ def gemm_f32(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: b
     if k == 0:
         return out.zero_()
     L = lib()
-    partial = counters = None
+    partial = None
     splits = L.dtf_gemm_f32_splits(m, n, k, None)
     if splits > 1:
-        # split-K workspace: one plane per split (caching allocator; graph-capturable) and the
-        # per-device ticket counters, zeroed once and reset by the kernel itself
+        # split-K workspace: one plane per split (caching allocator; graph-capturable)
         partial = torch.empty(splits * m * n, dtype=torch.float32, device=a.device)
-        counters = _splitk_counters(a.device)
     _check(L.dtf_gemm_f32(a.data_ptr(), b.data_ptr(), out.data_ptr(), _ptr(bias), m, n, k,
                           a.stride(0), b.stride(0), out.stride(0), int(trans_a), int(trans_b),
-                          int(activation), _ptr(partial), _ptr(counters), _stream()), "gemm_f32")
+                          int(activation), _ptr(partial), _stream()), "gemm_f32")
     return out
 
 
@@ -553,6 +542,48 @@ def softmax_xent_grad(y: torch.Tensor, labels: torch.Tensor, dloss: torch.Tensor
     _check(fn(y.data_ptr(), labels.data_ptr(), dloss.data_ptr(), dz.data_ptr(), _ptr(db), r, c,
               _stream()), "softmax_xent_grad")
     return dz, db
+
+
+def mlp_head_supported(b: int, h: int, c: int) -> bool:
+    return bool(lib().dtf_mlp_head_supported(b, h, c))
+
+
+def mlp_head_train(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, labels: torch.Tensor,
+                   dloss: torch.Tensor, sigmoid_input: bool, want_accuracy: bool):
+    """One-launch forward + backward of a small softmax head (B <= 128, H <= 128, C <= 16).
+    Returns ``(loss, y, dw, db, da_or_dz_prev, db_prev_or_None, accuracy_or_None)``."""
+    a = _req(a, torch.float32, "mlp_head a")
+    w = _req(w, torch.float32, "mlp_head w")
+    bias = _req(bias, torch.float32, "mlp_head bias")
+    labels = _req(labels, torch.float32, "mlp_head labels")
+    dloss = _req(dloss, torch.float32, "mlp_head dloss")
+    if a.dim() != 2 or w.dim() != 2 or a.shape[1] != w.shape[0] or bias.numel() != w.shape[1] \
+            or tuple(labels.shape) != (a.shape[0], w.shape[1]) or dloss.numel() != 1:
+        raise HipKernelError("mlp_head_train: inconsistent shapes a%s w%s bias%s labels%s"
+                             % (tuple(a.shape), tuple(w.shape), tuple(bias.shape),
+                                tuple(labels.shape)))
+    b, h = a.shape
+    c = w.shape[1]
+    dev = a.device
+    buf = torch.empty(2 + b * c + h * c + c + b * h + h, dtype=torch.float32, device=dev)
+    off = 0
+
+    def take(n, shape):
+        nonlocal off
+        t = buf[off:off + n].view(shape)
+        off += n
+        return t
+
+    loss, acc = take(1, ()), take(1, ())
+    y, dw, db = take(b * c, (b, c)), take(h * c, (h, c)), take(c, (c,))
+    da, dbp = take(b * h, (b, h)), take(h, (h,))
+    _check(lib().dtf_mlp_head_train(a.data_ptr(), w.data_ptr(), bias.data_ptr(),
+                                    labels.data_ptr(), dloss.data_ptr(), loss.data_ptr(),
+                                    y.data_ptr(), dw.data_ptr(), db.data_ptr(), da.data_ptr(),
+                                    dbp.data_ptr() if sigmoid_input else None,
+                                    acc.data_ptr() if want_accuracy else None,
+                                    b, h, c, int(sigmoid_input), _stream()), "mlp_head_train")
+    return loss, y, dw, db, da, (dbp if sigmoid_input else None), (acc if want_accuracy else None)
 
 
 def argmax_accuracy(y: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:

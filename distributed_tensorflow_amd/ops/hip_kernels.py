@@ -60,7 +60,15 @@ def _random_uniform(op, inputs, ctx):
 def _fill(op, inputs, ctx):
     if op.attrs["dtype"].torch != _f32:
         return _ref("Fill")(op, inputs, ctx)
-    return [hip.fill(op.attrs["shape"], op.attrs["value"], ctx.device)]
+    # a small constant fill (the 1.0 seeding backprop, zero biases) is materialised once per
+    # session; consumers never write into their inputs (Assign copies into the store)
+    cached = ctx.const_cache.get(op)
+    if cached is not None:
+        return [cached]
+    out = hip.fill(op.attrs["shape"], op.attrs["value"], ctx.device)
+    if out.numel() <= 65536 and not torch.cuda.is_current_stream_capturing():
+        ctx.const_cache[op] = out
+    return [out]
 
 
 @hip_kernel("OnesLike")
@@ -316,6 +324,44 @@ def _dense_grad_sigmoid(op, inputs, ctx):
         return _ref("DenseGradSigmoid")(op, inputs, ctx)
     dz, db = hip.sigmoid_grad_bias(da, a)
     return [dz, db]
+
+
+@hip_kernel("ClassifierHeadTrain")
+def _classifier_head_train(op, inputs, ctx):
+    a, w, b, labels = inputs[:4]
+    if len(inputs) > 4:
+        dloss = inputs[4]
+    else:
+        key = ("scalar", float(op.attrs["dloss_const"]))
+        dloss = ctx.const_cache.get(key)
+        if dloss is None:
+            dloss = hip.fill((), float(op.attrs["dloss_const"]), ctx.device)
+            if not torch.cuda.is_current_stream_capturing():
+                ctx.const_cache[key] = dloss
+    if not _is_f32(a, w, b, labels, dloss) or a.dim() != 2:
+        return _ref("ClassifierHeadTrain")(op, inputs, ctx)
+    sig = bool(op.attrs.get("sigmoid_input"))
+    want_acc = bool(op.attrs.get("emit_accuracy"))
+    if hip.mlp_head_supported(a.shape[0], a.shape[1], w.shape[1]):
+        loss, y, dw, db, da, dbp, acc = hip.mlp_head_train(a, w, b, labels, dloss, sig, want_acc)
+    else:
+        # batch or layer too large for the one-workgroup kernel: the same math as a chain of
+        # the general kernels
+        z = hip.gemm_f32(a, w, bias=b)
+        loss, y, _ = hip.softmax_xent(z, labels)
+        dz, db = hip.softmax_xent_grad(y, labels, dloss, True)
+        dw = hip.gemm_f32(a, dz, trans_a=True)
+        da = hip.gemm_f32(dz, w, trans_b=True)
+        dbp = None
+        if sig:
+            da, dbp = hip.sigmoid_grad_bias(da, a)
+        acc = hip.argmax_accuracy(y, labels) if want_acc else None
+    outs = [loss, y, dw, db, da]
+    if sig:
+        outs.append(dbp)
+    if want_acc:
+        outs.append(acc)
+    return outs
 
 
 @hip_kernel("ArgmaxAccuracy")

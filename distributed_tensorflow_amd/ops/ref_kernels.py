@@ -401,6 +401,32 @@ def _argmax_accuracy(op, inputs, ctx):
     return [(y.argmax(dim=1) == labels.argmax(dim=1)).to(torch.float32).mean()]
 
 
+@ref_kernel("ClassifierHeadTrain")
+def _classifier_head_train(op, inputs, ctx):
+    """(a, W, b, labels[, dloss]) -> (loss, softmax, dW, db, da | dz_prev[, db_prev][, accuracy]);
+    without the fifth input d(loss) is the constant ``dloss_const``.
+
+    Forward and backward of ``softmax(a W + b)`` under the mean cross-entropy in one node; with
+    ``sigmoid_input`` the gradient is carried through the sigmoid that produced ``a``
+    (``dz_prev = da * a * (1 - a)`` and its column sum ``db_prev``)."""
+    a, w, b, labels = inputs[:4]
+    dloss = inputs[4] if len(inputs) > 4 else op.attrs["dloss_const"]
+    logp = torch.log_softmax(a @ w + b, dim=-1)
+    y = torch.exp(logp)
+    loss = -(labels * logp).sum(dim=-1).mean()
+    dz = (y * labels.sum(dim=-1, keepdim=True) - labels) * (dloss / a.shape[0])
+    outs = [loss, y, a.t() @ dz, dz.sum(dim=0)]
+    da = dz @ w.t()
+    if op.attrs.get("sigmoid_input"):
+        dzp = da * a * (1 - a)
+        outs += [dzp, dzp.sum(dim=0)]
+    else:
+        outs.append(da)
+    if op.attrs.get("emit_accuracy"):
+        outs.append((y.argmax(dim=1) == labels.argmax(dim=1)).to(torch.float32).mean())
+    return outs
+
+
 @ref_kernel("BiasGrad")
 def _bias_grad(op, inputs, ctx):
     return [inputs[0].sum(dim=0)]

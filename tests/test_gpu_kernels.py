@@ -386,7 +386,7 @@ def test_softmax_xent_narrow_rows(hip, rows, cols):
     g = torch.Generator().manual_seed(rows + cols)
     logits = (torch.randn(rows, cols, generator=g) * 3).cuda()
     labels = torch.softmax(torch.randn(rows, cols, generator=g), 1).cuda()
-    y, row_loss, mean = hip.softmax_xent(logits, labels)
+    mean, y, row_loss = hip.softmax_xent(logits, labels, want_rows=True)
     ref_y = torch.softmax(logits.double(), 1)
     ref_rows = -(labels.double() * torch.log_softmax(logits.double(), 1)).sum(1)
     assert (y.double() - ref_y).abs().max().item() < 1e-6
@@ -441,3 +441,36 @@ def test_session_graph_replay_with_host_and_device_feeds(hip):
     for mode in ("graph_host", "graph_device"):
         assert np.allclose(results[mode][0], results["eager"][0], rtol=1e-6)
         assert np.allclose(results[mode][1], results["eager"][1], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("b,h,c,sig", [(100, 100, 10, True), (128, 128, 16, True), (1, 1, 1, False),
+                                       (37, 64, 3, False), (100, 100, 10, False)])
+def test_mlp_head_train_kernel(hip, b, h, c, sig):
+    g = torch.Generator().manual_seed(b + h + c)
+    a = torch.sigmoid(torch.randn(b, h, generator=g)).cuda()
+    w = torch.randn(h, c, generator=g).cuda()
+    bias = torch.randn(c, generator=g).cuda()
+    labels = torch.eye(c)[torch.randint(0, c, (b,), generator=g)].cuda()
+    dloss = torch.tensor([1.3]).cuda()
+    loss, y, dw, db, da, dbp, acc = hip.mlp_head_train(a, w, bias, labels, dloss, sig, True)
+    A, W, Bv, L = a.double(), w.double(), bias.double(), labels.double()
+    logp = torch.log_softmax(A @ W + Bv, 1)
+    ry = logp.exp()
+    rloss = -(L * logp).sum(1).mean()
+    rdz = (ry * L.sum(1, keepdim=True) - L) * 1.3 / b
+    rda = rdz @ W.t()
+    assert abs(loss.item() - rloss.item()) < 1e-5
+    assert (y.double() - ry).abs().max().item() < 1e-6
+    assert (dw.double() - A.t() @ rdz).abs().max().item() < 1e-6
+    assert (db.double() - rdz.sum(0)).abs().max().item() < 1e-6
+    if sig:
+        rdzp = rda * A * (1 - A)
+        assert (da.double() - rdzp).abs().max().item() < 1e-6
+        assert (dbp.double() - rdzp.sum(0)).abs().max().item() < 1e-6
+    else:
+        assert dbp is None and (da.double() - rda).abs().max().item() < 1e-6
+    racc = (ry.argmax(1) == L.argmax(1)).double().mean().item()
+    assert abs(acc.item() - racc) < 1e-6
+    again = hip.mlp_head_train(a, w, bias, labels, dloss, sig, True)
+    assert torch.equal(again[2], dw) and torch.equal(again[0], loss)
+    assert not hip.mlp_head_supported(129, 100, 10) and not hip.mlp_head_supported(100, 100, 17)

@@ -180,6 +180,13 @@ def test_fused_and_unfused_plans_agree_bitwise_on_cpu():
             hist = [sess.run([m.train_op, m.loss, m.global_step, m.accuracy],
                              {m.x: bx, m.y_: by})[1:] for _ in range(4)]
             outs.append((hist, sess.run(m.w2)))
+            if fuse:
+                # the whole step is four compute nodes: layer 1, the classifier head (layer 2 +
+                # loss + every gradient but dW1 + accuracy), dW1, and one multi-tensor SGD
+                plan = [p for p in sess._plans.values() if any(
+                    st.node.type == "MultiApplySGD" for st in p.steps)][0]
+                types = [st.node.type for st in plan.steps if st.node.type != "VariableV2"]
+                assert types == ["FusedDense", "ClassifierHeadTrain", "MatMul", "MultiApplySGD"]
     for (l0, s0, a0), (l1, s1, a1) in zip(outs[0][0], outs[1][0]):
         assert abs(l0 - l1) < 1e-5 and s0 == s1 and a0 == a1
     assert np.allclose(outs[0][1], outs[1][1], atol=1e-6)

@@ -373,6 +373,51 @@ DTF_API int dtf_cast_bf16_to_f32(const void* x, float* out, long n, hipStream_t 
   return DTF_OK;
 }
 
+// out[c, r] = x[r, c] for any 1/2/4-byte element type: 64x64 tiles through LDS (row pitch 65
+// elements, so the transposed read walks consecutive banks), coalesced on both sides.
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ x,
+                                                        T* __restrict__ out, long rows, long cols,
+                                                        long ldx, long ldo) {
+  __shared__ T tile[64][65];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;       // 64 x 4
+  const long r0 = blockIdx.y * 64L, c0 = blockIdx.x * 64L;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const long r = r0 + ty + 4 * i, c = c0 + tx;
+    if (r < rows && c < cols) tile[ty + 4 * i][tx] = x[r * ldx + c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const long c = c0 + ty + 4 * i, r = r0 + tx;
+    if (c < cols && r < rows) out[c * ldo + r] = tile[tx][ty + 4 * i];
+  }
+}
+
+// elem_size in {1, 2, 4}; x is [rows, cols] with row pitch ldx, out is [cols, rows] with ldo
+DTF_API int dtf_transpose(const void* x, void* out, long rows, long cols, long ldx, long ldo,
+                          int elem_size, hipStream_t stream) {
+  if (rows <= 0 || cols <= 0) return DTF_OK;
+  if (!x || !out || ldx < cols || ldo < rows) return DTF_ERR_BAD_ARG;
+  dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64)), block(256);
+  if (grid.y > 65535) return DTF_ERR_UNSUPPORTED;
+  switch (elem_size) {
+    case 1: hipLaunchKernelGGL(transpose_kernel<unsigned char>, grid, block, 0, stream,
+                               (const unsigned char*)x, (unsigned char*)out, rows, cols, ldx, ldo);
+      break;
+    case 2: hipLaunchKernelGGL(transpose_kernel<unsigned short>, grid, block, 0, stream,
+                               (const unsigned short*)x, (unsigned short*)out, rows, cols, ldx, ldo);
+      break;
+    case 4: hipLaunchKernelGGL(transpose_kernel<float>, grid, block, 0, stream, (const float*)x,
+                               (float*)out, rows, cols, ldx, ldo);
+      break;
+    default: return DTF_ERR_UNSUPPORTED;
+  }
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
 // src_kind / dst_kind: 0 = fp32, 1 = bf16
 DTF_API int dtf_cast_to_fp8(const void* x, int src_kind, void* out, long n, float scale,
                             hipStream_t stream) {

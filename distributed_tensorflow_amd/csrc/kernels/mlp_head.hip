@@ -49,7 +49,8 @@ __global__ __launch_bounds__(HT) void mlp_head_kernel(HeadArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int B = p.B, H = p.H, C = p.C;
 
-  for (int e = tid; e < B * H; e += HT) a_s[(e / H) * A_LD + (e % H)] = p.a[e];
+  for (int rr = wave; rr < B; rr += HT / 64)      // wave per row, lanes along H: coalesced
+    for (int h = lane; h < H; h += 64) a_s[rr * A_LD + h] = p.a[rr * H + h];
   for (int e = tid; e < H * HC; e += HT) {      // columns >= C are zero: the unrolled
     const int h = e / HC, c = e % HC;           // products below run over all HC columns
     w_s[e] = c < C ? p.w[h * C + c] : 0.f;
@@ -62,10 +63,18 @@ __global__ __launch_bounds__(HT) void mlp_head_kernel(HeadArgs p) {
 #pragma unroll
   for (int c = 0; c < HC; ++c) z[c] = 0.f;
   if (r < B) {
+#pragma unroll 2
     for (int h = part; h < H; h += 8) {
       const float av = a_s[r * A_LD + h];
+      const f32x4* wrow = reinterpret_cast<const f32x4*>(w_s + h * HC);
 #pragma unroll
-      for (int c = 0; c < HC; ++c) z[c] += av * w_s[h * HC + c];
+      for (int q = 0; q < HC / 4; ++q) {
+        const f32x4 wv = wrow[q];
+        z[4 * q] += av * wv[0];
+        z[4 * q + 1] += av * wv[1];
+        z[4 * q + 2] += av * wv[2];
+        z[4 * q + 3] += av * wv[3];
+      }
     }
   }
 #pragma unroll
@@ -128,9 +137,16 @@ __global__ __launch_bounds__(HT) void mlp_head_kernel(HeadArgs p) {
   // ---- phase 2: dW, db --------------------------------------------------------------------
   for (int e = tid; e < H * C; e += HT) {
     const int h = e / C, c = e % C;
-    float acc = 0.f;
-    for (int rr = 0; rr < B; ++rr) acc += a_s[rr * A_LD + h] * dz_s[rr * HC + c];
-    p.dw[e] = acc;
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;   // four loads in flight per operand
+    int rr = 0;
+    for (; rr + 3 < B; rr += 4) {
+      acc0 += a_s[rr * A_LD + h] * dz_s[rr * HC + c];
+      acc1 += a_s[(rr + 1) * A_LD + h] * dz_s[(rr + 1) * HC + c];
+      acc2 += a_s[(rr + 2) * A_LD + h] * dz_s[(rr + 2) * HC + c];
+      acc3 += a_s[(rr + 3) * A_LD + h] * dz_s[(rr + 3) * HC + c];
+    }
+    for (; rr < B; ++rr) acc0 += a_s[rr * A_LD + h] * dz_s[rr * HC + c];
+    p.dw[e] = (acc0 + acc1) + (acc2 + acc3);
   }
   if (tid < C) {
     float acc = 0.f;
@@ -140,17 +156,28 @@ __global__ __launch_bounds__(HT) void mlp_head_kernel(HeadArgs p) {
   __syncthreads();                              // dW is done reading a_s before it is rewritten
 
   // ---- phase 3: da = dz W^T (optionally through the sigmoid of the previous layer) -----------
-  for (int e = tid; e < B * H; e += HT) {
-    const int rr = e / H, h = e % H;
-    float acc = 0.f;
+  // wave per row, lanes along H; a lane's W row(s) stay in registers across all its rows
+  for (int h = lane; h < H; h += 64) {
+    float wr[HC];
 #pragma unroll
-    for (int c = 0; c < HC; ++c) acc += dz_s[rr * HC + c] * w_s[h * HC + c];
-    if (p.sig_grad) {
-      const float av = a_s[rr * A_LD + h];
-      acc = acc * av * (1.f - av);
-      a_s[rr * A_LD + h] = acc;
+    for (int c = 0; c < HC; ++c) wr[c] = w_s[h * HC + c];
+#pragma unroll 2
+    for (int rr = wave; rr < B; rr += HT / 64) {
+      const f32x4* dzr = reinterpret_cast<const f32x4*>(dz_s + rr * HC);   // broadcast reads
+      float acc = 0.f;
+#pragma unroll
+      for (int q = 0; q < HC / 4; ++q) {
+        const f32x4 d = dzr[q];
+        acc += d[0] * wr[4 * q] + d[1] * wr[4 * q + 1] + d[2] * wr[4 * q + 2] +
+               d[3] * wr[4 * q + 3];
+      }
+      if (p.sig_grad) {
+        const float av = a_s[rr * A_LD + h];
+        acc = acc * av * (1.f - av);
+        a_s[rr * A_LD + h] = acc;
+      }
+      p.da[rr * H + h] = acc;
     }
-    p.da[e] = acc;
   }
   if (!p.sig_grad || !p.db_prev) return;
   __syncthreads();
@@ -159,8 +186,10 @@ __global__ __launch_bounds__(HT) void mlp_head_kernel(HeadArgs p) {
   {
     const int h = tid & 127, g = tid >> 7;
     float acc = 0.f;
-    if (h < H)
+    if (h < H) {
+#pragma unroll 4
       for (int rr = g; rr < B; rr += 8) acc += a_s[rr * A_LD + h];
+    }
     red[tid] = acc;
     __syncthreads();
     if (tid < H) {

@@ -65,6 +65,7 @@ def _declare(L: ctypes.CDLL) -> None:
         "dtf_gemm_fp8_nt": [P, P, P, I, I, I, LG, LG, LG, F, F, I, P],
         "dtf_gemm_fp8_generic": [P, P, P, I, I, I, LG, LG, LG, LG, LG, F, F, I, P],
         "dtf_cast_to_fp8": [P, I, P, LG, F, P],
+        "dtf_transpose": [P, P, LG, LG, LG, LG, I, P],
         "dtf_cast_from_fp8": [P, P, I, LG, F, P],
         "dtf_binary_f32": [I, P, P, P, LG, LG, LG, P],
         "dtf_unary_f32": [I, P, P, LG, P],
@@ -282,15 +283,39 @@ def dequantize_fp8(q: torch.Tensor, inv_scale: float = 1.0,
     return out
 
 
+def transpose2d(x: torch.Tensor) -> torch.Tensor:
+    """Materialised transpose of a rank-2 tensor of 1-, 2- or 4-byte elements."""
+    if not isinstance(x, torch.Tensor) or x.device.type != "cuda" or x.dim() != 2:
+        raise HipKernelError("transpose2d: expected a rank-2 GPU tensor")
+    if x.element_size() not in (1, 2, 4):
+        raise HipKernelError("transpose2d: unsupported element size %d" % x.element_size())
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    rows, cols = x.shape
+    out = torch.empty((cols, rows), dtype=x.dtype, device=x.device)
+    _check(lib().dtf_transpose(x.data_ptr(), out.data_ptr(), rows, cols, x.stride(0),
+                               max(1, rows), x.element_size(), _stream()), "transpose2d")
+    return out
+
+
 def gemm_bf16(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool = False,
               out_dtype: torch.dtype = torch.bfloat16, alpha: float = 1.0,
               force_generic: bool = False) -> torch.Tensor:
     """General bf16 matmul ``op(a) @ op(b)``. The NT case (``trans_b`` with K-contiguous
-    operands) takes the fast kernel; other layouts run the generic strided kernel."""
+    operands) is the fast kernel's native layout; for the other layouts a large product
+    re-lays the offending operand out with one tiled transpose pass (memory-bound: ~3 % of the
+    GEMM at 16384^3) and runs the same kernel, a small one runs the generic strided kernel."""
     a = _req(a, torch.bfloat16, "gemm_bf16 a")
     b = _req(b, torch.bfloat16, "gemm_bf16 b")
     if not trans_a and trans_b and not force_generic:
         return gemm_bf16_nt(a, b, out_dtype, alpha)
+    if not force_generic and a.dim() == 2 and b.dim() == 2:
+        m_, k_ = (a.shape[1], a.shape[0]) if trans_a else a.shape
+        n_ = b.shape[0] if trans_b else b.shape[1]
+        if k_ % 64 == 0 and 2.0 * m_ * n_ * k_ >= 2.0 * 512 ** 3:
+            a_kc = transpose2d(a) if trans_a else a          # [M, K]
+            bt_kc = b if trans_b else transpose2d(b)         # [N, K]
+            return gemm_bf16_nt(a_kc, bt_kc, out_dtype, alpha)
     m, k = (a.shape[1], a.shape[0]) if trans_a else a.shape
     k2, n = (b.shape[1], b.shape[0]) if trans_b else b.shape
     if k != k2:

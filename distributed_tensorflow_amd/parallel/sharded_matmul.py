@@ -108,8 +108,15 @@ class ShardedMatmul:
             raise ValueError("K=%d must be divisible by the world size %d" % (self.k, w))
         rows_local = self.m // w if strategy.startswith("m_shard") else self.m
         if panels is None:
-            panels = 1 if w == 1 or strategy in ("replicated", "m_shard", "summa_2d") \
-                else max(1, min(8, rows_local // 256))
+            # a panel's product must still fill the chip: at least one 256x256 output tile per
+            # CU (256 of them), otherwise the pipelining costs more MFMA time than the overlap
+            # hides. 16384 columns -> panels of >= 1024 rows (8 ranks: 2 panels of the 2048-row
+            # shard; 2 ranks: 8 panels of the 8192-row shard).
+            panels = 1
+            if w > 1 and strategy not in ("replicated", "m_shard", "summa_2d"):
+                col_tiles = max(1, (self.n + 255) // 256)
+                min_rows = 256 * max(1, (256 + col_tiles - 1) // col_tiles)
+                panels = max(1, min(8, rows_local // min_rows))
         self.panels = max(1, int(panels))
         while rows_local % self.panels or (strategy == "k_shard_reduce_scatter"
                                            and (self.m // self.panels) % w):

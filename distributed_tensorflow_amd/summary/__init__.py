@@ -147,8 +147,15 @@ def merge_all(key: str = GraphKeys.SUMMARIES, scope: Optional[str] = None) -> Op
 
 @ref_kernel("ScalarSummary", host_only=True)
 def _scalar_summary_kernel(op, inputs, ctx):
-    value = np.asarray(inputs[0]).reshape(-1)[0]
-    return [encode_scalar_summary(op.attrs["tag"], float(value))]
+    # runs every training step: everything but the 4 value bytes is fixed per op, so the
+    # message is a cached prefix + struct.pack (identical bytes to encode_scalar_summary)
+    prefix = op.attrs.get("_wire_prefix")
+    if prefix is None:
+        whole = encode_scalar_summary(op.attrs["tag"], 0.0)
+        prefix = op.attrs["_wire_prefix"] = whole[:-4]
+    v = inputs[0]
+    value = float(v) if isinstance(v, (float, np.floating)) else float(np.asarray(v).reshape(-1)[0])
+    return [prefix + struct.pack("<f", value)]
 
 
 @ref_kernel("MergeSummary", host_only=True)

@@ -474,3 +474,22 @@ def test_mlp_head_train_kernel(hip, b, h, c, sig):
     again = hip.mlp_head_train(a, w, bias, labels, dloss, sig, True)
     assert torch.equal(again[2], dw) and torch.equal(again[0], loss)
     assert not hip.mlp_head_supported(129, 100, 10) and not hip.mlp_head_supported(100, 100, 17)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.uint8])
+@pytest.mark.parametrize("rows,cols", [(64, 64), (100, 37), (1000, 1000), (1, 513), (4096, 130)])
+def test_transpose2d(hip, dtype, rows, cols):
+    x = (torch.arange(rows * cols).reshape(rows, cols) % 251).to(dtype).cuda()
+    assert torch.equal(hip.transpose2d(x), x.t().contiguous())
+
+
+@pytest.mark.parametrize("ta,tb", [(False, False), (True, False), (True, True)])
+def test_gemm_bf16_large_non_nt_layouts_use_fast_kernel(hip, ta, tb):
+    g = torch.Generator().manual_seed(12)
+    m, n, k = 768, 512, 1024
+    a = torch.randint(-3, 4, (m, k), generator=g).float()
+    b = torch.randint(-3, 4, (k, n), generator=g).float()
+    a_in = (a.t().contiguous() if ta else a).bfloat16().cuda()
+    b_in = (b.t().contiguous() if tb else b).bfloat16().cuda()
+    c = hip.gemm_bf16(a_in, b_in, ta, tb, torch.float32)
+    assert torch.equal(c.cpu(), a @ b)

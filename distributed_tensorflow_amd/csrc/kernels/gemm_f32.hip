@@ -256,20 +256,38 @@ int launch(const float* A, const float* B, float* C, const float* bias, int M, i
 
 }  // namespace
 
-// Split-K plan for an M x N x K product: number of K splits (1 = none) and the K extent of one
-// split. Splitting pays when the 64x64 tile grid cannot fill the chip and K is long enough to
-// give every split at least four K-tiles.
+// Block tile for an M x N x K product, from measurements on MI355X: the 128x128 tile (2x2 MFMA
+// tiles per wave, half the LDS reads per flop) wins from ~4096^2 outputs on (122 TF at 4096^3);
+// below that the 64x64 tile keeps more workgroups per CU in flight and is faster (2048^3: 98 vs
+// 85 TF; 1536^3 with split-K 4: 87 vs 47 TF).
+DTF_API int dtf_gemm_f32_tile(int M, int N, int K) {
+  const long big_tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
+  return big_tiles >= 512 ? 128 : 64;
+}
+
+// Split-K plan: number of K splits (1 = none). A 64x64-tile grid of up to ~1000 workgroups gains
+// from up to 4 splits (four resident workgroups per CU hide each other's load latency: 1000^3
+// 41 -> 33 us); tiny grids (the MLP's 100x100 outputs with K = 784) take as many splits as give
+// every CU a workgroup, each split keeping at least four K-tiles.
 DTF_API int dtf_gemm_f32_splits(int M, int N, int K, int* kchunk_out) {
-  const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
   int splits = 1, kchunk = K;
-  if (tiles <= 64 && K >= 256) {
-    int want = (int)(256 / tiles);
-    if (want > 32) want = 32;
-    int chunk = ((K + want - 1) / want + 15) / 16 * 16;
-    if (chunk < 64) chunk = 64;
-    splits = (K + chunk - 1) / chunk;
-    kchunk = chunk;
-    if (splits <= 1) { splits = 1; kchunk = K; }
+  if (dtf_gemm_f32_tile(M, N, K) == 64 && K >= 256) {
+    const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
+    int want = 1;
+    if (tiles <= 64) {
+      want = (int)(256 / tiles);
+      if (want > 32) want = 32;
+    } else if (tiles < 1024) {
+      want = (int)((1024 + tiles - 1) / tiles);
+      if (want > 4) want = 4;
+    }
+    if (want > 1) {
+      int chunk = ((K + want - 1) / want + 15) / 16 * 16;
+      if (chunk < 64) chunk = 64;
+      splits = (K + chunk - 1) / chunk;
+      kchunk = chunk;
+      if (splits <= 1) { splits = 1; kchunk = K; }
+    }
   }
   if (kchunk_out) *kchunk_out = kchunk;
   return splits;
@@ -277,20 +295,25 @@ DTF_API int dtf_gemm_f32_splits(int M, int N, int K, int* kchunk_out) {
 
 // C[M,N] = act(op(A) * op(B) + bias[N]).  A is stored [M,K] (lda >= K), or [K,M] (lda >= M) when
 // trans_a; B is stored [K,N] (ldb >= N), or [N,K] (ldb >= K) when trans_b. bias may be null.
-// partial: split-K workspace of dtf_gemm_f32_splits() * M * N floats; with null the product
-// runs unsplit.
+// partial: split-K workspace of `splits` * M * N floats, `splits` being what
+// dtf_gemm_f32_splits() returned (or the caller's own choice); splits <= 1 or a null workspace
+// runs the product unsplit.
 DTF_API int dtf_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N,
                          int K, long lda, long ldb, long ldc, int trans_a, int trans_b, int act,
-                         float* partial, hipStream_t stream) {
+                         float* partial, int splits, int tile, hipStream_t stream) {
   if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return DTF_ERR_BAD_ARG;
   if (lda < (trans_a ? M : K) || ldb < (trans_b ? K : N) || ldc < N) return DTF_ERR_BAD_ARG;
-  const long big_tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
-  if (big_tiles >= 192)
-    return launch<128, 128>(A, B, C, bias, M, N, K, lda, ldb, ldc, trans_a, trans_b, act, 1, K,
-                            nullptr, stream);
-  int kchunk = K;
-  int splits = partial ? dtf_gemm_f32_splits(M, N, K, &kchunk) : 1;
-  if (splits == 1) kchunk = ((K + BK - 1) / BK) * BK;
+  if (tile != 64 && tile != 128) tile = dtf_gemm_f32_tile(M, N, K);
+  int kchunk = ((K + BK - 1) / BK) * BK;
+  if (!partial || splits <= 1) {
+    splits = 1;
+  } else {
+    kchunk = ((K + splits - 1) / splits + BK - 1) / BK * BK;
+    splits = (K + kchunk - 1) / kchunk;          // never more than the caller allotted
+  }
+  if (tile == 128)
+    return launch<128, 128>(A, B, C, bias, M, N, K, lda, ldb, ldc, trans_a, trans_b, act, splits,
+                            kchunk, partial, stream);
   return launch<64, 64>(A, B, C, bias, M, N, K, lda, ldb, ldc, trans_a, trans_b, act, splits,
                         kchunk, partial, stream);
 }

@@ -58,7 +58,7 @@ def _declare(L: ctypes.CDLL) -> None:
     c = ctypes
     P, I, LG, F, U = c.c_void_p, c.c_int, c.c_long, c.c_float, c.c_uint
     sigs = {
-        "dtf_gemm_f32": [P, P, P, P, I, I, I, LG, LG, LG, I, I, I, P, P],
+        "dtf_gemm_f32": [P, P, P, P, I, I, I, LG, LG, LG, I, I, I, P, I, I, P],
         "dtf_gemm_f32_splits": [I, I, I, P],
         "dtf_gemm_bf16_nt": [P, P, P, I, I, I, LG, LG, LG, F, F, I, I, P],
         "dtf_gemm_bf16_generic": [P, P, P, I, I, I, LG, LG, LG, LG, LG, F, F, I, P],
@@ -142,7 +142,8 @@ def _aligned(t: torch.Tensor) -> torch.Tensor:
 # ---------------------------------------------------------------------------------------
 def gemm_f32(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool = False,
              bias: Optional[torch.Tensor] = None, activation: int = ACT_NONE,
-             out: Optional[torch.Tensor] = None) -> torch.Tensor:
+             out: Optional[torch.Tensor] = None, splits: Optional[int] = None,
+             tile: int = 0) -> torch.Tensor:
     """``act(op(a) @ op(b) + bias)`` on the fp32 MFMA kernel. ``a`` is [M,K] ([K,M] when
     ``trans_a``), ``b`` is [K,N] ([N,K] when ``trans_b``)."""
     a = _req(a, torch.float32, "gemm_f32 a")
@@ -168,13 +169,16 @@ def gemm_f32(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: b
         return out.zero_()
     L = lib()
     partial = None
-    splits = L.dtf_gemm_f32_splits(m, n, k, None)
+    if splits is None:
+        splits = L.dtf_gemm_f32_splits(m, n, k, None)
+    splits = max(1, min(int(splits), 64))
     if splits > 1:
         # split-K workspace: one plane per split (caching allocator; graph-capturable)
         partial = torch.empty(splits * m * n, dtype=torch.float32, device=a.device)
     _check(L.dtf_gemm_f32(a.data_ptr(), b.data_ptr(), out.data_ptr(), _ptr(bias), m, n, k,
                           a.stride(0), b.stride(0), out.stride(0), int(trans_a), int(trans_b),
-                          int(activation), _ptr(partial), _stream()), "gemm_f32")
+                          int(activation), _ptr(partial), splits, int(tile), _stream()),
+           "gemm_f32")
     return out
 
 

@@ -62,6 +62,8 @@ def build_hip(force: bool = False, jobs: int = 8) -> str:
     headers = glob.glob(os.path.join(CSRC, "kernels", "*.h"))
     flags = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-fvisibility=hidden",
              "-Wall", "-Wno-unused-function", "-I" + os.path.join(CSRC, "kernels")]
+    if os.environ.get("DTF_GEMM_EXPERIMENTS"):      # timing-ablation variants of the GEMM kernels
+        flags.append("-DDTF_GEMM_EXPERIMENTS")
     objs, todo = [], []
     for src in sources:
         obj = os.path.join(OBJDIR, os.path.basename(src) + ".o")

@@ -381,6 +381,190 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
     }
 }
 
+// ---- four-wave kernel: one wave per SIMD, 128x128 outputs per wave ------------------------------
+// (variant 3; NOT the default. Measured at 16384^3 on MI355X: 1245 TF against 1456-1513 TF for
+// the 8-wave ping-pong kernel above; with the K-loop's LDS-DMA removed 1785 vs 1811 TF, with every
+// load an L2 hit 1491 vs 1556 TF. With one wave per SIMD nothing covers a wave's barrier and
+// DMA-latency stalls, and two 64 KiB K-tile buffers allow only one K-tile of prefetch distance.
+// Kept as a correct, tested alternative schedule.)
+// Same 256x256x64 block tile and LDS image as above, but 256 threads = 4 waves as 2(M) x 2(N),
+// each owning a 128x128 quarter (8x8 MFMA tiles, all 256 accumulator registers). A wave then
+// reads (128 + 128) rows of fragments per k-step instead of the (128 + 64) x 2 of two 128x64
+// waves: a third less LDS read traffic per flop.
+//  * Two K-tile buffers of 64 KiB. A K-tile is two k-steps (chunks 0-3 / 4-7 of each 128-byte
+//    row); fragments are double-buffered in registers one k-step ahead: while the 64 MFMAs of
+//    (t, 0) run the wave reads the fragments of (t, 1), while those of (t, 1) run it reads
+//    (t+1, 0) and issues the 16 LDS-DMA instructions of K-tile t+2 into the buffer of tile t.
+//  * One barrier per K-tile, between the two k-steps: behind it every wave has finished reading
+//    buffer t (so it may be refilled) and every wave's DMA of tile t+1 has landed (so it may be
+//    read). The DMA stream therefore runs one K-tile ahead.
+//  * A k-step is 64 slots of [one MFMA + at most one memory instruction]: a wave issues in
+//    order, so whatever sits between two MFMAs must fit in the 16-cycle shadow of the first or
+//    the matrix pipe idles. The MFMAs are inline asm with the accumulator tied to an AGPR quad:
+//    with all 256 AGPRs holding accumulators the register allocator otherwise parks some in
+//    VGPRs and shuttles them through v_accvgpr moves around every MFMA. The hardware interlocks
+//    back-to-back MFMAs on one accumulator; operand registers come from ds_reads the compiler
+//    still tracks.
+constexpr int W4_THREADS = 256;
+
+// DBG (timing experiments, -DDTF_GEMM_EXPERIMENTS only; results are wrong when set):
+// 1 = issue no LDS-DMA in the K-loop, 2 = always stage K-tile 0 (every load an L2 hit)
+template <bool OUT_F32, int DBG = 0>
+__global__ __launch_bounds__(W4_THREADS) void gemm_bf16_nt_w4_kernel(
+    const char* __restrict__ A, const char* __restrict__ Bt, void* __restrict__ C, int M, int N,
+    int K, long lda, long ldb, long ldc, int tiles_m, int tiles_n, float alpha, float beta) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+
+  const int ntiles = tiles_m * tiles_n;
+  const int id = dtf_xcd_remap(blockIdx.x, ntiles);
+  constexpr int GROUP = 8;
+  const int per_group = GROUP * tiles_n;
+  const int grp = id / per_group;
+  const int first_m = grp * GROUP;
+  const int gsize = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
+  const int tm = first_m + (id % per_group) % gsize;
+  const int tn = (id % per_group) / gsize;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int nkt = K / BK;
+
+  f32x4 acc[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // DMA sources: this wave fills pieces 8*wave .. 8*wave+7 (8 rows of 128 B each) of the A tile
+  // and of the Bt tile; lane i lands at row i>>3, position i&7 of its piece and fetches chunk
+  // (i&7) ^ swizzle(row) of that row (see chunk_off)
+  const char* src_a[8];
+  const char* src_b[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int trow = (wave * 8 + j) * 8 + (lane >> 3);
+    const int kc = (lane & 7) ^ ((trow >> 1) & 7);
+    int ra = m0 + trow, rb = n0 + trow;
+    ra = ra < M - 1 ? ra : M - 1;
+    rb = rb < N - 1 ? rb : N - 1;
+    src_a[j] = A + ((long)ra * lda) * 2 + kc * 16;
+    src_b[j] = Bt + ((long)rb * ldb) * 2 + kc * 16;
+  }
+
+  const int frow = lane & 15, fq = lane >> 4;
+  const int lane_off0 = chunk_off(frow, fq), lane_off1 = chunk_off(frow, 4 + fq);
+  const int a_base = wr * 16384;                    // wave's 8 row blocks of 2 KiB in the A tile
+  const int b_base = TILE_BYTES + wc * 16384;       // ... in the Bt tile
+
+  i32x4 fa[2][8], fb[2][8];
+// one k-step. CUR / NXT: fragment register sets. RD: byte address of (buffer, chunk half) the
+// NXT fragments come from. DMA: issue K-tile KT_DMA into buffer offset WR_BUF during the step.
+#define DTF_W4_STEP(CUR, NXT, RD_BUF, RD_LANE_OFF, DMA, KT_DMA, WR_BUF)                          \
+  {                                                                                              \
+    const char* rda_ = smem + (RD_BUF) + a_base + (RD_LANE_OFF);                                 \
+    const char* rdb_ = smem + (RD_BUF) + b_base + (RD_LANE_OFF);                                 \
+    const long koff_ = DBG == 2 ? 0 : (long)((KT_DMA) < nkt ? (KT_DMA) : nkt - 1) * 128;         \
+    char* wr_ = smem + (WR_BUF) + wave * 8192;                                                   \
+    _Pragma("unroll") for (int n_ = 0; n_ < 64; ++n_) {                                          \
+      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"                                      \
+                   : "+a"(acc[n_ >> 3][n_ & 7])                                                  \
+                   : "v"(fb[CUR][n_ & 7]), "v"(fa[CUR][n_ >> 3]));                               \
+      if (n_ < 16) {                                                                             \
+        if (n_ & 1)                                                                              \
+          fb[NXT][n_ >> 1] = *reinterpret_cast<const i32x4*>(rdb_ + (n_ >> 1) * 2048);           \
+        else                                                                                     \
+          fa[NXT][n_ >> 1] = *reinterpret_cast<const i32x4*>(rda_ + (n_ >> 1) * 2048);           \
+      } else if ((DMA) && DBG != 1 && n_ < 48 && ((n_ - 16) & 1) == 0) {                         \
+        const int d_ = (n_ - 16) >> 1, j_ = d_ >> 1;                                             \
+        if (d_ & 1)                                                                              \
+          __builtin_amdgcn_global_load_lds((global_void*)(src_b[j_] + koff_),                    \
+                                           (lds_void*)(wr_ + TILE_BYTES + j_ * 1024), 16, 0, 0); \
+        else                                                                                     \
+          __builtin_amdgcn_global_load_lds((global_void*)(src_a[j_] + koff_),                    \
+                                           (lds_void*)(wr_ + j_ * 1024), 16, 0, 0);              \
+      }                                                                                          \
+      __builtin_amdgcn_sched_barrier(0);                                                         \
+    }                                                                                            \
+  }
+
+  // prologue: K-tiles 0 and 1 in flight, tile 0 landed and visible, fragments of (0, 0) requested
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const long koff = (long)(t < nkt ? t : nkt - 1) * 128;
+    char* wr = smem + t * BUF_BYTES + wave * 8192;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      __builtin_amdgcn_global_load_lds((global_void*)(src_a[j] + koff),
+                                       (lds_void*)(wr + j * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((global_void*)(src_b[j] + koff),
+                                       (lds_void*)(wr + TILE_BYTES + j * 1024), 16, 0, 0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    fa[0][i] = *reinterpret_cast<const i32x4*>(smem + a_base + lane_off0 + i * 2048);
+    fb[0][i] = *reinterpret_cast<const i32x4*>(smem + b_base + lane_off0 + i * 2048);
+  }
+
+  for (int t = 0; t < nkt; ++t) {
+    const int cur_buf = (t & 1) * BUF_BYTES, nxt_buf = BUF_BYTES - cur_buf;
+    // (t, 0): fragments of (t, 1) from this tile's buffer
+    DTF_W4_STEP(0, 1, cur_buf, lane_off1, false, 0, 0)
+    // own reads of buffer t done (lgkmcnt 0), own DMA of tile t+1 landed (vmcnt 0); as the
+    // builtin (imm 0x0070 = vmcnt 0, expcnt 7, lgkmcnt 0) so the compiler's wait-count
+    // bookkeeping sees it and adds no second wait in front of the MFMAs
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // (t, 1): fragments of (t+1, 0) from the other buffer; K-tile t+2 into this tile's buffer
+    DTF_W4_STEP(1, 0, nxt_buf, lane_off0, true, t + 2, cur_buf)
+  }
+#undef DTF_W4_STEP
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // nothing may outlive the workgroup
+  // the last MFMAs were issued from inline asm: cover their result latency before the
+  // epilogue reads the accumulators
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int row = m0 + wr * 128 + i * 16 + frow;
+    if (row >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int col = n0 + wc * 128 + j * 16 + 4 * fq;
+      if (col >= N) continue;
+      f32x4 v = acc[i][j] * alpha;
+      if (OUT_F32) {
+        float* dst = reinterpret_cast<float*>(C) + (long)row * ldc + col;
+        if (col + 3 < N) {
+          if (beta != 0.f) v += *reinterpret_cast<const f32x4*>(dst) * beta;
+          *reinterpret_cast<f32x4*>(dst) = v;
+        } else {
+          for (int r = 0; r < 4 && col + r < N; ++r)
+            dst[r] = beta != 0.f ? v[r] + beta * dst[r] : v[r];
+        }
+      } else {
+        unsigned short* dst = reinterpret_cast<unsigned short*>(C) + (long)row * ldc + col;
+        if (beta != 0.f) {
+          for (int r = 0; r < 4 && col + r < N; ++r) v[r] += beta * dtf_bf16_to_f32(dst[r]);
+        }
+        if (col + 3 < N) {
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (short)dtf_f32_to_bf16(v[r]);
+          *reinterpret_cast<bf16x4*>(dst) = o;
+        } else {
+          for (int r = 0; r < 4 && col + r < N; ++r) dst[r] = dtf_f32_to_bf16(v[r]);
+        }
+      }
+    }
+  }
+}
+
 // ---- generic, fully predicated bf16 GEMM (any shape, NN / NT / TN / TT via strides) -------------
 // C[m,n] = alpha * sum_k A(m,k) * B(k,n), A(m,k) = A[m*a_rs + k*a_cs], B(k,n) = B[k*b_rs + n*b_cs]
 constexpr int GB = 64, GK = 32;
@@ -518,7 +702,8 @@ __global__ __launch_bounds__(256) void gemm_fp8_generic_kernel(
 // kernel: K % 64 == 0, lda/ldb % 8 == 0, 16-byte aligned A/Bt, ldc % 4 == 0 and 16-byte
 // (fp32) / 8-byte (bf16) aligned C. Returns DTF_ERR_UNSUPPORTED otherwise (callers then use
 // dtf_gemm_bf16_generic).
-// variant & 15: 0 = default (ping-pong schedule), 1 = two-phase double-buffer, 2 = ping-pong;
+// variant & 15: 0 = default (ping-pong schedule), 1 = two-phase double-buffer, 2 = ping-pong,
+// 3 = four-wave kernel (128x128 per wave);
 // variant >> 4: timing-experiment bits of the ping-pong kernel (0 in production).
 template <typename KernelT>
 static void dtf_allow_lds(KernelT kernel, size_t lds) {
@@ -549,6 +734,43 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
     attr_set = true;
   }
   dim3 grid(tiles_m * tiles_n), block(NTHREADS);
+  if ((variant & 15) == 3) {       // four-wave kernel
+    static bool w4_attr = false;
+    const size_t w4_lds = 2 * BUF_BYTES;
+    if (!w4_attr) {
+      dtf_allow_lds(gemm_bf16_nt_w4_kernel<true>, w4_lds);
+      dtf_allow_lds(gemm_bf16_nt_w4_kernel<false>, w4_lds);
+#ifdef DTF_GEMM_EXPERIMENTS
+      dtf_allow_lds(gemm_bf16_nt_w4_kernel<false, 1>, w4_lds);
+      dtf_allow_lds(gemm_bf16_nt_w4_kernel<false, 2>, w4_lds);
+#endif
+      w4_attr = true;
+    }
+#ifdef DTF_GEMM_EXPERIMENTS
+    if ((variant >> 4) == 1 || (variant >> 4) == 2) {
+      if ((variant >> 4) == 1)
+        hipLaunchKernelGGL((gemm_bf16_nt_w4_kernel<false, 1>), grid, dim3(W4_THREADS), w4_lds,
+                           stream, (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc,
+                           tiles_m, tiles_n, alpha, beta);
+      else
+        hipLaunchKernelGGL((gemm_bf16_nt_w4_kernel<false, 2>), grid, dim3(W4_THREADS), w4_lds,
+                           stream, (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc,
+                           tiles_m, tiles_n, alpha, beta);
+      DTF_LAUNCH_CHECK();
+      return DTF_OK;
+    }
+#endif
+    if (out_f32)
+      hipLaunchKernelGGL(gemm_bf16_nt_w4_kernel<true>, grid, dim3(W4_THREADS), w4_lds, stream,
+                         (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tiles_m,
+                         tiles_n, alpha, beta);
+    else
+      hipLaunchKernelGGL(gemm_bf16_nt_w4_kernel<false>, grid, dim3(W4_THREADS), w4_lds, stream,
+                         (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tiles_m,
+                         tiles_n, alpha, beta);
+    DTF_LAUNCH_CHECK();
+    return DTF_OK;
+  }
   if ((variant & 15) == 1 && beta != 0.f) return DTF_ERR_UNSUPPORTED;
   if ((variant & 15) != 1) {
 #define DTF_PP_LAUNCH(F32, DBGV)                                                                  \

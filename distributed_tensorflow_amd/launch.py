@@ -80,6 +80,9 @@ def child_command(script: str, script_args: Sequence[str], cluster: Dict[str, Li
 def child_env(cluster: Dict[str, List[str]], job: str, index: int, protocol: str) -> Dict[str, str]:
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # every task of the job runs on this host: split the cores between them
+    ntasks = sum(len(v) for v in cluster.values())
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // max(1, ntasks))))
     if protocol == "rccl" and job == "worker":
         chief_port = cluster["worker"][0].rpartition(":")[2]
         env.update(RANK=str(index), LOCAL_RANK=str(index),

@@ -158,10 +158,29 @@ class Server:
     def device_name(self) -> str:
         return DeviceSpec(job=self._job_name, task=self._task_index).to_string()
 
+    def _share_cpu_threads(self) -> None:
+        """Tasks of one cluster that share a host share its cores: give this process
+        ``cores / co-located tasks`` intra-op threads unless the user already chose
+        (``OMP_NUM_THREADS``). Three tasks each spinning a full-machine thread pool on small
+        ops is 10-20x slower than the same job with the pools sized to fit (measured on the
+        1 ps + 2 workers MNIST job: 50 ms vs 2.6 ms per step on 8 cores)."""
+        if self.device.type != "cpu" or os.environ.get("OMP_NUM_THREADS"):
+            return
+        host = self._address.rpartition(":")[0]
+        local = {"localhost", "127.0.0.1", "::1", host}
+        same_host = 0
+        for job in self._cluster.jobs:
+            for idx in self._cluster.task_indices(job):
+                if self._cluster.task_address(job, idx).rpartition(":")[0] in local:
+                    same_host += 1
+        if same_host > 1:
+            torch.set_num_threads(max(1, (os.cpu_count() or 1) // same_host))
+
     # -- lifecycle -----------------------------------------------------------------------
     def start(self) -> None:
         if self._started:
             return
+        self._share_cpu_threads()
         from ..parallel import runtime as rt
         host, _, port = self._address.rpartition(":")
         if self._protocol == "local":

@@ -22,6 +22,12 @@ if args.dtype == "bf16":
     out = torch.empty(n, n, device="cuda", dtype=torch.bfloat16)
     for _ in range(args.iters):
         hip.gemm_bf16_nt(a, bt, torch.bfloat16, out=out, variant=args.variant)
+elif args.dtype == "fp8":
+    a = hip.philox_window(n, n, 1, 1, 0, 0, n, torch.float8_e4m3fn, "cuda", False, -1.0, 2.0)
+    bt = hip.philox_window(n, n, 1, 2, 0, 0, n, torch.float8_e4m3fn, "cuda", False, -1.0, 2.0)
+    out = torch.empty(n, n, device="cuda", dtype=torch.bfloat16)
+    for _ in range(args.iters):
+        hip.gemm_fp8_nt(a, bt, torch.bfloat16, out=out)
 else:
     a = torch.rand(n, n, device="cuda") * 2 - 1
     b = torch.rand(n, n, device="cuda") * 2 - 1

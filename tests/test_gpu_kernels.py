@@ -493,3 +493,67 @@ def test_gemm_bf16_large_non_nt_layouts_use_fast_kernel(hip, ta, tb):
     b_in = (b.t().contiguous() if tb else b).bfloat16().cuda()
     c = hip.gemm_bf16(a_in, b_in, ta, tb, torch.float32)
     assert torch.equal(c.cpu(), a @ b)
+
+
+# -- guard bands: kernels must not write outside their output ------------------------------------
+def _guarded(rows, cols, dtype, pad_rows=3, pad_cols=5):
+    """A [rows, cols] view in the middle of a sentinel-filled matrix (row pitch > cols)."""
+    sentinel = 12345.0 if dtype == torch.float32 else 77.0
+    width = (cols + 2 * pad_cols + 16) // 8 * 8          # row pitch keeps every row 16-byte aligned
+    big = torch.full((rows + 2 * pad_rows, width), sentinel, dtype=dtype, device="cuda")
+    # keep 16-byte alignment of the view's first element for the vector-store paths
+    esize = big.element_size()
+    start_col = pad_cols
+    while ((big.data_ptr() + ((pad_rows * big.stride(0)) + start_col) * esize) % 16) != 0:
+        start_col += 1
+    view = big[pad_rows:pad_rows + rows, start_col:start_col + cols]
+    return big, view, sentinel, (pad_rows, start_col)
+
+
+def _band_intact(big, view_shape, origin, sentinel):
+    r0, c0 = origin
+    rows, cols = view_shape
+    mask = torch.ones_like(big, dtype=torch.bool)
+    mask[r0:r0 + rows, c0:c0 + cols] = False
+    return bool((big[mask].float() == sentinel).all().item())
+
+
+@pytest.mark.parametrize("m,n,k", [(1000, 1000, 1000), (100, 100, 784), (257, 129, 1023), (33, 65, 17)])
+def test_gemm_f32_writes_only_its_output(hip, m, n, k):
+    a = torch.randint(-2, 3, (m, k)).float().cuda()
+    b = torch.randint(-2, 3, (k, n)).float().cuda()
+    # the fp32 launcher wants a contiguous out: guard rows before and after a dense block
+    big = torch.full((m + 6, n), 12345.0, device="cuda")
+    out = big[3:3 + m]
+    hip.gemm_f32(a, b, out=out)
+    assert torch.equal(out, a @ b)
+    assert bool((big[:3] == 12345.0).all()) and bool((big[3 + m:] == 12345.0).all())
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("m,n,k", [(300, 520, 128), (257, 255, 320), (512, 768, 256), (1, 1, 64)])
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
+def test_gemm_bf16_writes_only_its_output(hip, m, n, k, out_dtype, variant):
+    g = torch.Generator().manual_seed(m + n)
+    a = torch.randint(-2, 3, (m, k), generator=g).float()
+    bt = torch.randint(-2, 3, (n, k), generator=g).float()
+    n_pad = (n + 3) // 4 * 4                    # fast path wants ldc % 4 == 0; ragged n goes generic
+    big, view, sentinel, origin = _guarded(m, n, out_dtype, pad_cols=4 + (4 - n % 4) % 4)
+    if view.stride(0) % 4 or n_pad != n:
+        pytest.skip("layout not eligible for the fast kernel's strided store")
+    hip.gemm_bf16_nt(a.bfloat16().cuda(), bt.bfloat16().cuda(), out_dtype, out=view, variant=variant)
+    assert torch.equal(view.float().cpu(), (a @ bt.t()).to(out_dtype).float())
+    assert _band_intact(big, (m, n), origin, sentinel)
+
+
+@pytest.mark.parametrize("m,n,k", [(300, 520, 128), (512, 768, 256), (256, 256, 1408)])
+def test_gemm_fp8_writes_only_its_output(hip, m, n, k):
+    g = torch.Generator().manual_seed(k)
+    a = torch.randint(-2, 3, (m, k), generator=g).float()
+    bt = torch.randint(-2, 3, (n, k), generator=g).float()
+    big, view, sentinel, origin = _guarded(m, n, torch.float32, pad_cols=4)
+    if view.stride(0) % 4:
+        pytest.skip("row pitch not a multiple of 4")
+    hip.gemm_fp8_nt(a.to(FP8).cuda(), bt.to(FP8).cuda(), torch.float32, out=view)
+    assert torch.equal(view.cpu(), a @ bt.t())
+    assert _band_intact(big, (m, n), origin, sentinel)

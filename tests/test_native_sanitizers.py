@@ -1,0 +1,30 @@
+"""The C++ IO runtime under AddressSanitizer + UBSan (host code only; CPU): builds
+``csrc/io/host_io.cc`` together with its self-test and runs it."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "distributed_tensorflow_amd", "csrc")
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+def test_host_io_selftest_under_asan_ubsan(tmp_path):
+    exe = str(tmp_path / "host_io_selftest")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer",
+           "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-msse4.2",
+           os.path.join(CSRC, "io", "host_io.cc"),
+           os.path.join(CSRC, "tests", "host_io_selftest.cc"), "-o", exe]
+    build = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert build.returncode == 0, build.stdout
+    work = tmp_path / "work"
+    work.mkdir()
+    # the environment may preload libraries ahead of the sanitizer runtime; ASan is told not to
+    # insist on being first (its interceptors still cover this binary's own allocations)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0:verify_asan_link_order=0")
+    run = subprocess.run([exe, str(work)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                         text=True, env=env, timeout=120)
+    assert run.returncode == 0, run.stdout
+    assert "host_io selftest ok" in run.stdout

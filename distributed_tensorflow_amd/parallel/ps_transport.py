@@ -21,6 +21,7 @@ view of one ps task and plugs into the session like a local store.
 """
 from __future__ import annotations
 
+import ctypes
 import json
 import socket
 import struct
@@ -234,6 +235,125 @@ class PsService:
     @property
     def stopped(self) -> bool:
         return self._stop.is_set()
+
+
+class _NativeStoreView:
+    """Read access, for the hosting process, to the variables a ``NativePsService`` holds
+    (writes from this process go through the wire like anybody else's)."""
+
+    def __init__(self, service: "NativePsService"):
+        self._svc = service
+        self.device = torch.device("cpu")
+
+    @property
+    def update_count(self) -> int:
+        return int(self._svc._lib.dtf_ps_updates(self._svc._handle)) if self._svc._handle else 0
+
+    def names(self) -> List[str]:
+        svc = self._svc
+        need = svc._lib.dtf_ps_names(svc._handle, None, 0)
+        if need <= 0:
+            return []
+        buf = ctypes.create_string_buffer(need + 1)
+        svc._lib.dtf_ps_names(svc._handle, buf, need + 1)
+        return sorted(n for n in buf.value.decode().split("\n") if n)
+
+    def is_initialized(self, name: str) -> bool:
+        svc = self._svc
+        return svc._lib.dtf_ps_read(svc._handle, name.encode(), None, 0, None, 0) >= 0
+
+    def uninitialized(self, names: Iterable[str]) -> List[str]:
+        return [n for n in names if not self.is_initialized(n)]
+
+    def read(self, name: str) -> torch.Tensor:
+        svc = self._svc
+        meta = ctypes.create_string_buffer(256)
+        size = svc._lib.dtf_ps_read(svc._handle, name.encode(), None, 0, meta, 256)
+        if size < 0:
+            raise FailedPreconditionError("Attempting to use uninitialized value %s" % name)
+        dtype, _, dims = meta.value.decode().partition(":")
+        shape = [int(d) for d in dims.split(",") if d]
+        raw = ctypes.create_string_buffer(max(1, size))
+        svc._lib.dtf_ps_read(svc._handle, name.encode(), raw, size, None, 0)
+        arr = np.frombuffer(raw.raw[:size], dtype=np.dtype(_NP[dtype])).reshape(shape).copy()
+        return torch.from_numpy(arr)
+
+    def local_tensor(self, name: str) -> None:
+        return None
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        return {n: self.read(n) for n in self.names()}
+
+    def _client(self) -> "RemoteVariableStore":
+        if self._svc._loopback is None:
+            self._svc._loopback = RemoteVariableStore("127.0.0.1:%d" % self._svc.port)
+        return self._svc._loopback
+
+    def assign(self, name: str, value: torch.Tensor) -> torch.Tensor:
+        return self._client().assign(name, value)
+
+
+class NativePsService:
+    """The ps task served by the C++ runtime (``csrc/runtime/ps_server.cc``): same wire protocol
+    and the same Python-side interface as ``PsService``, with the connection threads, the
+    variable table and the SGD application outside the interpreter."""
+
+    def __init__(self, host: str, port: int, expected_workers: int = 0):
+        from ..utils import native
+        lib = native.load()
+        if lib is None or not hasattr(lib, "dtf_ps_start"):
+            raise RuntimeError("native host library with the ps server is not built")
+        self._lib = lib
+        self._host, self._req_port = host, port
+        self.expected_workers = expected_workers
+        self._handle = lib.dtf_ps_start((host or "127.0.0.1").encode(), int(port),
+                                        int(expected_workers))
+        if not self._handle:
+            raise OSError(lib.dtf_ps_last_error().decode())
+        self.port = lib.dtf_ps_port(self._handle)
+        self._loopback: Optional["RemoteVariableStore"] = None
+        self._stopped_flag = False
+        self.store = _NativeStoreView(self)
+
+    def start(self) -> None:
+        pass                       # serving since construction
+
+    @property
+    def requests_served(self) -> int:
+        return int(self._lib.dtf_ps_requests(self._handle)) if self._handle else 0
+
+    def wait(self, timeout: Optional[float] = None) -> bool:
+        if not self._handle:
+            return True
+        ms = -1 if timeout is None else int(timeout * 1000)
+        return bool(self._lib.dtf_ps_wait(self._handle, ms))
+
+    @property
+    def stopped(self) -> bool:
+        return self._stopped_flag or not self._handle or \
+            bool(self._lib.dtf_ps_stopped(self._handle))
+
+    def stop(self) -> None:
+        if self._loopback is not None:
+            self._loopback.close()
+            self._loopback = None
+        handle, self._handle = self._handle, None
+        self._stopped_flag = True
+        if handle:
+            self._lib.dtf_ps_stop(handle)
+
+
+def make_ps_service(host: str, port: int, expected_workers: int = 0):
+    """The C++ ps task when the host library is built (``DTF_PS_NATIVE=0`` forces the Python
+    one), else the Python implementation."""
+    import os
+    if os.environ.get("DTF_PS_NATIVE", "1") != "0":
+        try:
+            return NativePsService(host, port, expected_workers)
+        except RuntimeError:
+            pass
+    svc = PsService(host, port, expected_workers=expected_workers)
+    return svc
 
 
 # ---------------------------------------------------------------------------------------

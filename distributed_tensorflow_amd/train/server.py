@@ -187,11 +187,11 @@ class Server:
             self.runtime = rt.LocalRuntime(self.device)
         elif self._protocol == "grpc":
             if self._job_name == "ps":
-                from ..parallel.ps_transport import PsService
+                from ..parallel.ps_transport import make_ps_service
                 workers = self._cluster.num_tasks("worker") \
                     if "worker" in self._cluster.jobs else 0
-                self._ps_service = PsService(host or "127.0.0.1", int(port),
-                                             expected_workers=workers)
+                self._ps_service = make_ps_service(host or "127.0.0.1", int(port),
+                                                   expected_workers=workers)
                 self._ps_service.start()
                 self.runtime = rt.LocalRuntime(torch.device("cpu"))
                 self.runtime.local_store = self._ps_service.store

@@ -58,6 +58,28 @@ def load() -> Optional[ctypes.CDLL]:
     lib.dtf_table_close.restype = None
     lib.dtf_table_close.argtypes = [c.c_void_p]
     lib.dtf_last_error.restype = c.c_char_p
+    # parameter-server task
+    if hasattr(lib, "dtf_ps_start"):
+        lib.dtf_ps_start.restype = c.c_void_p
+        lib.dtf_ps_start.argtypes = [c.c_char_p, c.c_int, c.c_int]
+        lib.dtf_ps_last_error.restype = c.c_char_p
+        lib.dtf_ps_port.restype = c.c_int
+        lib.dtf_ps_port.argtypes = [c.c_void_p]
+        lib.dtf_ps_stopped.restype = c.c_int
+        lib.dtf_ps_stopped.argtypes = [c.c_void_p]
+        lib.dtf_ps_requests.restype = c.c_long
+        lib.dtf_ps_requests.argtypes = [c.c_void_p]
+        lib.dtf_ps_updates.restype = c.c_long
+        lib.dtf_ps_updates.argtypes = [c.c_void_p]
+        lib.dtf_ps_wait.restype = c.c_int
+        lib.dtf_ps_wait.argtypes = [c.c_void_p, c.c_long]
+        lib.dtf_ps_stop.restype = None
+        lib.dtf_ps_stop.argtypes = [c.c_void_p]
+        lib.dtf_ps_read.restype = c.c_long
+        lib.dtf_ps_read.argtypes = [c.c_void_p, c.c_char_p, c.c_void_p, c.c_long, c.c_char_p,
+                                    c.c_long]
+        lib.dtf_ps_names.restype = c.c_long
+        lib.dtf_ps_names.argtypes = [c.c_void_p, c.c_char_p, c.c_long]
     _LIB = lib
     return _LIB
 

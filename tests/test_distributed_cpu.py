@@ -130,9 +130,18 @@ def test_sharded_matmul_is_world_size_invariant():
 
 
 # -- parameter-server transport -----------------------------------------------------------------
-@pytest.fixture
-def ps_service():
-    svc = PsService("127.0.0.1", 0)
+@pytest.fixture(params=["python", "native"])
+def ps_service(request):
+    """Both implementations of the ps task speak the same protocol: the Python one and the C++
+    one (``csrc/runtime/ps_server.cc``)."""
+    if request.param == "native":
+        from distributed_tensorflow_amd.parallel.ps_transport import NativePsService
+        try:
+            svc = NativePsService("127.0.0.1", 0)
+        except RuntimeError:
+            pytest.skip("native host library not built")
+    else:
+        svc = PsService("127.0.0.1", 0)
     svc.start()
     yield svc
     svc.stop()
@@ -169,10 +178,44 @@ def test_ps_transport_pull_apply_semantics(ps_service):
     b.close()
 
 
-def test_ps_client_unavailable_and_done_protocol():
+def test_ps_native_service_error_paths_and_dtypes(ps_service):
+    addr = "127.0.0.1:%d" % ps_service.port
+    c = RemoteVariableStore(addr)
+    c.assign("i", torch.tensor([1, 2, 3], dtype=torch.int64))
+    c.assign("d", torch.tensor([[0.5, 1.5]], dtype=torch.float64))
+    c.begin_step(["i", "d"])
+    c.assign_add("i", torch.tensor([10, 10, 10], dtype=torch.int64))
+    c.apply_sgd("d", 2.0, torch.tensor([[1.0, 1.0]], dtype=torch.float64))
+    c.end_step()
+    c.begin_step(["i", "d"])
+    assert c.read("i").tolist() == [11, 12, 13] and c.read("i").dtype == torch.int64
+    assert c.read("d").tolist() == [[-1.5, -0.5]]
+    # re-assignment with a new shape replaces the variable
+    c.assign("i", torch.zeros(2, 2, dtype=torch.float32))
+    c.begin_step(["i"])
+    assert c.read("i").shape == (2, 2) and c.read("i").dtype == torch.float32
+    # a gradient of the wrong size is refused and the variable left untouched
+    from distributed_tensorflow_amd.parallel.ps_transport import OP_APPLY
+    bad = np.ones(3, np.float32)
+    with pytest.raises((RuntimeError, ValueError)):
+        c.client.call(OP_APPLY, {"sgd": [["i", 1.0]], "add": [],
+                                 "specs": [{"dtype": "float32", "shape": [3]}]}, [bad])
+    c.begin_step(["i"])
+    assert torch.equal(c.read("i"), torch.zeros(2, 2))
+    assert torch.equal(ps_service.store.read("d"), torch.tensor([[-1.5, -0.5]], dtype=torch.float64))
+    assert sorted(ps_service.store.names()) == ["d", "i"]
+    c.close()
+
+
+@pytest.mark.parametrize("impl", ["python", "native"])
+def test_ps_client_unavailable_and_done_protocol(impl):
     with pytest.raises(UnavailableError):
         RemoteVariableStore("127.0.0.1:%d" % _free_port(), connect_timeout_s=0.3).names()
-    svc = PsService("127.0.0.1", 0, expected_workers=2)
+    if impl == "native":
+        from distributed_tensorflow_amd.parallel.ps_transport import NativePsService
+        svc = NativePsService("127.0.0.1", 0, expected_workers=2)
+    else:
+        svc = PsService("127.0.0.1", 0, expected_workers=2)
     svc.start()
     addr = "127.0.0.1:%d" % svc.port
     w0, w1 = RemoteVariableStore(addr), RemoteVariableStore(addr)

@@ -131,3 +131,17 @@ def test_linear_regression_reduce_scatter_converges():
     assert rc == 0, out
     errs = [float(e) for e in re.findall(r"Weight-Error: (\d+\.\d+)", out)]
     assert len(errs) == 2 and errs[0] == errs[1] and errs[0] < 0.01
+
+
+def test_mnist_example_two_ps_tasks_round_robin(tmp_path):
+    """Variables are placed round-robin over two ps tasks (`global_step`, W2, b2 on task 0; W1,
+    b1 on task 1): every step pulls from and applies to both, and both leave `join()` when the
+    workers are done."""
+    rc, out = _run_launcher(["--num_workers", "2", "--num_ps", "2", "--timeout", "200",
+                             os.path.join(EX, "tf_distributed.py"), "--", "--max_steps", "120",
+                             "--device", "cpu", "--logs_path", str(tmp_path / "logs"),
+                             "--data_dir", str(tmp_path / "nodata")])
+    assert rc == 0, out
+    assert out.count("] done") == 2
+    costs = [float(c) for c in re.findall(r"Cost: (\d+\.\d{4}),", out)]
+    assert costs and all(c == c and c < 50 for c in costs)          # finite, sane

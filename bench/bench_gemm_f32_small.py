@@ -17,7 +17,21 @@ for m, n, k, ta, tb in shapes:
     a = torch.randn((k, m) if ta else (m, k), device="cuda")
     b = torch.randn((n, k) if tb else (k, n), device="cuda")
     out = torch.empty(m, n, device="cuda")
-    for tile, splits in ((0, None), (64, 1), (64, 4), (128, 1), (128, 2), (128, 4), (128, 8)):
+    # vendor reference (rocBLAS/hipBLASLt through torch.matmul), same process, same graph replay
+    torch.backends.cuda.matmul.allow_tf32 = False
+    ra = a.t() if ta else a
+    rb = b.t() if tb else b
+    g = torch.cuda.CUDAGraph()
+    torch.matmul(ra, rb, out=out)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g):
+        for _ in range(20):
+            torch.matmul(ra, rb, out=out)
+    ms = timeit(g.replay, 20) / 20
+    print(json.dumps({"m": m, "n": n, "k": k, "ta": ta, "tb": tb, "impl": "torch.matmul",
+                      "us": round(ms * 1e3, 2), "tflops": round(2.0 * m * n * k / ms / 1e9, 2)}),
+          flush=True)
+    for tile, splits in ((0, None), (64, 1), (64, 4), (128, 1)):
         g = torch.cuda.CUDAGraph()
         hip.gemm_f32(a, b, ta, tb, out=out, splits=splits, tile=tile)
         torch.cuda.synchronize()

@@ -12,10 +12,13 @@
 // -- lane l takes A[m = l&31][k = l>>5], B[k = l>>5][n = l&31] -- is 32 consecutive words per
 // half-wave: conflict-free ds_read_b32. An operand that is K-contiguous in memory is
 // transposed on its way into LDS (row stride BT+2 keeps those scattered writes
-// conflict-free); one that is M/N-contiguous is copied with 16-byte stores. Global loads for
-// tile k+1 are issued before the MFMAs of tile k and written to the other LDS buffer after
-// them: one barrier per K-tile. Shapes need no alignment: edge tiles are predicated
-// (1000 = 7*128 + 104, K = 784 / 100 / 10 all occur in the reference).
+// conflict-free); one that is M/N-contiguous is copied with 16-byte stores. Global loads run
+// DEPTH K-tiles ahead of the MFMAs through a ring of register sets (a K-tile is only 8 or 32
+// MFMAs of 64 cycles per wave, far less than a global-memory round trip, and a workgroup is
+// often alone on its CU): iteration k refills the set tile k just left with tile k+DEPTH,
+// runs the MFMAs of tile k, then moves tile k+1 -- loaded DEPTH-1 iterations ago -- into the
+// other LDS buffer: one barrier per K-tile. Shapes need no alignment: edge tiles are
+// predicated (1000 = 7*128 + 104, K = 784 / 100 / 10 all occur in the reference).
 //
 // Split-K: the exact-fp32 MFMA retires 32x32x2 per 64 cycles per wave, so a product with few
 // output tiles and a long K (the MLP's x*W1: 100x100 outputs, K = 784 -- four 64x64 tiles)
@@ -26,6 +29,8 @@
 // needs a device-scope release/acquire pair per workgroup; with one L2 per XCD that fence is a
 // cache write-back and measured 64 us on the 100x100x784 product against 23 us unsplit.)
 #include "common.h"
+
+#include <type_traits>
 
 namespace {
 
@@ -74,6 +79,38 @@ struct Loader {
         }
       }
       regs[i] = v;
+    }
+  }
+
+  // Branch-free fetch for 16-byte-aligned operands (ld % 4 == 0, aligned base, K % 4 == 0 when
+  // KCONTIG, T % 4 == 0 otherwise): every lane loads one aligned f32x4 from a CLAMPED address --
+  // rows / k-rows past the edge re-read the last valid one -- and elements with k >= k_end are
+  // zeroed by selects. Out-of-range rows only feed outputs the epilogue drops. With no branch
+  // around the loads the compiler can count them (s_waitcnt vmcnt(N)), which is what lets
+  // loads stay in flight across several K-tiles.
+  __device__ static void fetch_fast(f32x4 (&regs)[PER_THREAD], const float* __restrict__ X,
+                                    long ld, int t0, int k0, int T, int k_end, int tid) {
+#pragma unroll
+    for (int i = 0; i < PER_THREAD; ++i) {
+      const int idx = tid + i * NTHREADS;
+      if (KCONTIG) {
+        const int t = idx >> 2, k4 = idx & 3;
+        int gt = t0 + t;
+        gt = gt < T - 1 ? gt : T - 1;
+        const int gk = k0 + 4 * k4;                      // multiple of 4; k_end is too
+        const int ck = gk < k_end - 4 ? gk : k_end - 4;
+        f32x4 v = *reinterpret_cast<const f32x4*>(X + (long)gt * ld + ck);
+        regs[i] = gk < k_end ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      } else {
+        constexpr int V = BT / 4;
+        const int k = idx / V, t4 = idx % V;
+        int gt = t0 + 4 * t4;
+        gt = gt < T - 4 ? gt : T - 4;
+        const int gk = k0 + k;
+        const int ck = gk < k_end - 1 ? gk : k_end - 1;
+        f32x4 v = *reinterpret_cast<const f32x4*>(X + (long)ck * ld + gt);
+        regs[i] = gk < k_end ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
     }
   }
 
@@ -126,43 +163,79 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  f32x4 ra[LA::PER_THREAD], rb[LB::PER_THREAD];
   const int nkt = (k_end - k_begin + BK - 1) / BK;
-  LA::fetch(ra, A, lda, m0, k_begin, M, k_end, a_vec != 0, tid);
-  LB::fetch(rb, B, ldb, n0, k_begin, N, k_end, b_vec != 0, tid);
-  LA::stash(ra, As, tid);
-  LB::stash(rb, Bs, tid);
-  __syncthreads();
-
   const int lrow = lane & 31, lk = lane >> 5;
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int cur = kt & 1;
-    const bool more = kt + 1 < nkt;
-    if (more) {
-      LA::fetch(ra, A, lda, m0, k_begin + (kt + 1) * BK, M, k_end, a_vec != 0, tid);
-      LB::fetch(rb, B, ldb, n0, k_begin + (kt + 1) * BK, N, k_end, b_vec != 0, tid);
-    }
-    const float* as = As + cur * A_BUF + wr * WM + lrow;
-    const float* bs = Bs + cur * B_BUF + wc * WN + lrow;
+  // aligned operands take the branch-free loads (block-uniform choice, made once)
+  const bool fast = a_vec != 0 && b_vec != 0 && k_end - k_begin >= 4 &&
+                    (A_KC ? (K & 3) == 0 : ((M & 3) == 0 && M >= 4)) &&
+                    (B_KC ? (K & 3) == 0 : ((N & 3) == 0 && N >= 4));
+
+  // The K loop, instantiated twice (FAST: branch-free loads; otherwise fully predicated ones).
+  auto k_loop = [&](auto fast_tag) {
+    constexpr bool FAST = decltype(fast_tag)::value;
+    constexpr int DEPTH = (BM == 128) ? 3 : 4;        // register sets = K-tiles in flight
+    f32x4 ra[DEPTH][LA::PER_THREAD], rb[DEPTH][LB::PER_THREAD];
+    auto fetch_tile = [&](f32x4 (&qa)[LA::PER_THREAD], f32x4 (&qb)[LB::PER_THREAD], int kt) {
+      const int k0 = k_begin + kt * BK;
+      if (FAST) {
+        LA::fetch_fast(qa, A, lda, m0, k0, M, k_end, tid);
+        LB::fetch_fast(qb, B, ldb, n0, k0, N, k_end, tid);
+      } else {
+        LA::fetch(qa, A, lda, m0, k0, M, k_end, a_vec != 0, tid);
+        LB::fetch(qb, B, ldb, n0, k0, N, k_end, b_vec != 0, tid);
+      }
+    };
 #pragma unroll
-    for (int kk = 0; kk < BK / 2; ++kk) {
-      float a[TM], b[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = as[(2 * kk + lk) * LA::LD + 32 * i];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = bs[(2 * kk + lk) * LB::LD + 32 * j];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-    if (more) {
-      LA::stash(ra, As + (cur ^ 1) * A_BUF, tid);
-      LB::stash(rb, Bs + (cur ^ 1) * B_BUF, tid);
-    }
+    for (int u = 0; u < DEPTH; ++u) fetch_tile(ra[u], rb[u], u);   // tiles past the end: zeros
+    LA::stash(ra[0], As, tid);
+    LB::stash(rb[0], Bs, tid);
     __syncthreads();
-  }
+
+    for (int kt0 = 0; kt0 < nkt; kt0 += DEPTH) {
+#pragma unroll
+      for (int u = 0; u < DEPTH; ++u) {
+        const int kt = kt0 + u;
+        if (kt >= nkt) break;
+        const int cur = kt & 1;
+        // set u held tile kt, already in LDS: refill it with tile kt + DEPTH
+        fetch_tile(ra[u], rb[u], kt + DEPTH);
+        const float* as = As + cur * A_BUF + wr * WM + lrow;
+        const float* bs = Bs + cur * B_BUF + wc * WN + lrow;
+        // fragments are double-buffered in registers one k-pair ahead, so an LDS round trip
+        // hides under the previous group of MFMAs instead of following it
+        float a[2][TM], b[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[0][i] = as[lk * LA::LD + 32 * i];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[0][j] = bs[lk * LB::LD + 32 * j];
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+          const int c = kk & 1, nx = c ^ 1;
+          if (kk + 1 < BK / 2) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[nx][i] = as[(2 * kk + 2 + lk) * LA::LD + 32 * i];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[nx][j] = bs[(2 * kk + 2 + lk) * LB::LD + 32 * j];
+          }
+          if (kk == BK / 4 && kt + 1 < nkt) {
+            // tile kt+1 (loaded DEPTH-1 tiles ago) goes into the other LDS buffer in the
+            // middle of this tile's MFMAs, not after them: the barrier below then waits on
+            // nothing but the last MFMA group
+            LA::stash(ra[(u + 1) % DEPTH], As + (cur ^ 1) * A_BUF, tid);
+            LB::stash(rb[(u + 1) % DEPTH], Bs + (cur ^ 1) * B_BUF, tid);
+          }
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][i], b[c][j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+      }
+    }
+  };
+  if (fast) k_loop(std::true_type{});
+  else k_loop(std::false_type{});
 
   // C/D fragment: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   if (splits > 1) {

@@ -150,8 +150,17 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(
   const int lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int split = blockIdx.x / ntiles;
+  // XCD-aware remap (each XCD's L2 sees a contiguous chunk of the walk) + grouped walk: the
+  // ~32-64 tiles resident on one XCD form a block GROUP tile-rows deep, so they share A and B
+  // panels instead of streaming a whole tile-row of B each
   const int tile = dtf_xcd_remap(blockIdx.x % ntiles, ntiles);
-  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+  constexpr int GROUP = 8;
+  const int tiles_m = ntiles / tiles_n;
+  const int per_group = GROUP * tiles_n;
+  const int first_m = (tile / per_group) * GROUP;
+  const int gsize = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
+  const int m0 = (first_m + (tile % per_group) % gsize) * BM;
+  const int n0 = ((tile % per_group) / gsize) * BN;
   const int k_begin = split * kchunk;                 // kchunk is a multiple of BK
   const int k_end = (k_begin + kchunk < K) ? k_begin + kchunk : K;
 

@@ -48,12 +48,20 @@ class ConfigProto:
     ``hip_graphs``     -- capture steady-state steps into HIP graphs on GPU (default on).
     ``device``         -- torch device string; default: ``cuda:<LOCAL_RANK>`` when a GPU is
                           visible, else ``cpu``.
+    ``strategy`` / ``grad_aggregation`` -- collective runtime options (see ``parallel.runtime``).
+    ``capture_collectives`` -- under a collective runtime, capture the step INCLUDING its RCCL
+                          calls into the HIP graph (RCCL collectives enqueued during stream
+                          capture become graph nodes). Off by default: a step is then eager
+                          kernel launches around eager collectives.
     ``allow_soft_placement`` / ``log_device_placement`` -- accepted for compatibility.
     """
 
     def __init__(self, graph_fusion: bool = True, hip_graphs: bool = True,
                  device: Optional[str] = None, allow_soft_placement: bool = True,
-                 log_device_placement: bool = False, strategy: Optional[str] = None):
+                 log_device_placement: bool = False, strategy: Optional[str] = None,
+                 grad_aggregation: Optional[str] = None, capture_collectives: bool = False):
+        self.grad_aggregation = grad_aggregation
+        self.capture_collectives = capture_collectives
         self.graph_fusion = graph_fusion
         self.hip_graphs = hip_graphs
         self.device = device
@@ -398,7 +406,9 @@ class Session:
             if s.node.type in ("Assign", "RandomStandardNormal", "RandomUniform",
                                "TruncatedNormal", "IsVariableInitialized"):
                 plan.capturable = False
-        if self._runtime is not None and not self._runtime.capturable:
+        if self._runtime is not None and not self._runtime.capturable and not (
+                self.config.capture_collectives and
+                getattr(self._runtime, "capturable_with_collectives", False)):
             plan.capturable = False
         return plan
 

@@ -40,6 +40,8 @@ def define_flags():
     tf.app.flags.DEFINE_integer("max_steps", 300, "local steps")
     tf.app.flags.DEFINE_boolean("shutdown_ps", False, "report completion to the ps tasks")
     tf.app.flags.DEFINE_string("device", "", "torch device of this task (default: auto)")
+    tf.app.flags.DEFINE_boolean("capture_collectives", False, "rccl: record the step's RCCL calls "
+                                "into the HIP graph together with its kernels")
     return tf.app.flags.FLAGS
 
 
@@ -53,7 +55,8 @@ def main(argv=None):
         FLAGS.job_name, FLAGS.task_index = tf.train.task_from_env()
     else:
         cluster = tf.train.ClusterSpec({"worker": ["localhost:2223"]})
-    config = tf.ConfigProto(device=FLAGS.device or None, strategy=FLAGS.strategy)
+    config = tf.ConfigProto(device=FLAGS.device or None, strategy=FLAGS.strategy,
+                            capture_collectives=FLAGS.capture_collectives)
     server = tf.train.Server(cluster, job_name=FLAGS.job_name, task_index=FLAGS.task_index,
                              protocol=FLAGS.protocol, config=config)
     if FLAGS.job_name == "ps":

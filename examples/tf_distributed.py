@@ -63,6 +63,8 @@ def define_flags(default_job=DEFAULT_JOB, default_epochs=DEFAULT_EPOCHS):
     tf.app.flags.DEFINE_string("checkpoint_dir", "", "Supervisor logdir (enables checkpoints)")
     tf.app.flags.DEFINE_boolean("shutdown_ps", False, "report completion so the ps exits once all workers are done")
     tf.app.flags.DEFINE_string("device", "", "torch device of this task (default: auto)")
+    tf.app.flags.DEFINE_boolean("capture_collectives", False, "rccl: record the step's RCCL calls "
+                                "into the HIP graph together with its kernels")
     tf.app.flags.DEFINE_boolean("device_data", True, "keep the data set resident in GPU memory "
                                 "(GPU tasks only) so feeds are device-to-device copies")
     return tf.app.flags.FLAGS
@@ -86,7 +88,8 @@ def main(argv=None, default_num_workers=DEFAULT_NUM_WORKERS):
     cluster = build_cluster(FLAGS, default_num_workers)
     if "WORLD_SIZE" in os.environ and FLAGS.protocol == "rccl" and not FLAGS.worker_hosts:
         FLAGS.job_name, FLAGS.task_index = tf.train.task_from_env()
-    config = tf.ConfigProto(device=FLAGS.device or None, strategy=FLAGS.strategy)
+    config = tf.ConfigProto(device=FLAGS.device or None, strategy=FLAGS.strategy,
+                            capture_collectives=FLAGS.capture_collectives)
 
     # start a server for a specific task
     server = tf.train.Server(cluster, job_name=FLAGS.job_name, task_index=FLAGS.task_index,

@@ -1,0 +1,102 @@
+"""RCCL code paths on the GPU box (one GPU: world size 1 under the real ``nccl`` backend):
+every collective of ``TorchDistComm``, and the two synchronous runtimes training the MNIST MLP
+through ``Server(protocol="rccl")`` with results identical to a plain local session."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nccl_comm():
+    assert torch.cuda.is_available()
+    from distributed_tensorflow_amd.parallel.comm import TorchDistComm
+    from distributed_tensorflow_amd.train.server import _free_port
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    comm = TorchDistComm(rank=0, world_size=1, device=torch.device("cuda", 0), backend="nccl",
+                         master_addr="127.0.0.1", master_port=_free_port())
+    yield comm
+    comm.close()
+
+
+def test_rccl_collectives_world_one(nccl_comm):
+    c = nccl_comm
+    assert c.rank == 0 and c.world_size == 1 and c.backend == "nccl"
+    t = torch.arange(8, dtype=torch.float32, device="cuda")
+    c.all_reduce(t, "sum")
+    c.all_reduce(t, "avg")
+    assert torch.equal(t.cpu(), torch.arange(8, dtype=torch.float32))
+    out = torch.empty(8, device="cuda")
+    c.reduce_scatter(out, t, "sum")
+    assert torch.equal(out, t)
+    g = torch.empty(8, device="cuda")
+    work = c.all_gather(g, t, async_op=True)
+    work.wait()
+    assert torch.equal(g, t)
+    b = torch.full((4,), 3.0, device="cuda").bfloat16()
+    c.broadcast(b, src=0)
+    f8 = torch.ones(16, device="cuda").to(torch.float8_e4m3fn)
+    c.broadcast(f8, src=0)                       # 1-byte floats travel as uint8
+    assert c.broadcast_object({"k": 1}) == {"k": 1}
+    c.barrier()
+    sub = c.split(0)
+    assert sub.world_size == 1
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("capture", [False, True])
+@pytest.mark.parametrize("strategy", ["allreduce_sync", "reduce_scatter_sync"])
+def test_collective_runtime_trains_like_local_session(nccl_comm, strategy, capture):
+    import distributed_tensorflow_amd as tf
+    from distributed_tensorflow_amd.models import mnist_mlp
+    from distributed_tensorflow_amd.train.server import _free_port
+    rng = np.random.RandomState(2)
+    batches = [(rng.rand(100, 784).astype(np.float32),
+                np.eye(10, dtype=np.float32)[rng.randint(0, 10, 100)]) for _ in range(5)]
+
+    def run(distributed):
+        g = tf.Graph()
+        with g.as_default():
+            cfg = tf.ConfigProto(device="cuda:0", strategy=strategy, capture_collectives=capture)
+            target, server = "", None
+            if distributed:
+                cluster = tf.train.ClusterSpec({"worker": ["127.0.0.1:%d" % _free_port()]})
+                server = tf.train.Server(cluster, job_name="worker", task_index=0,
+                                         protocol="rccl", config=cfg, comm=nccl_comm)
+                target = server.target
+                scope = tf.device(tf.train.replica_device_setter(cluster=cluster))
+            else:
+                scope = tf.device(None)
+            with scope:
+                model = mnist_mlp.build_model(learning_rate=0.01, seed=1)
+            losses = []
+            if distributed:
+                sv = tf.train.Supervisor(is_chief=True, global_step=model.global_step,
+                                         init_op=model.init_op)
+                sess = sv.prepare_or_wait_for_session(target, config=cfg)
+            else:
+                sess = tf.Session(config=cfg)
+                sess.run(model.init_op)
+            for bx, by in batches:
+                _, l, st = sess.run([model.train_op, model.loss, model.global_step],
+                                    {model.x: bx, model.y_: by})
+                losses.append(float(l))
+            w2 = sess.run(model.w2)
+            stats = dict(sess.stats)
+            sess.close()
+            if distributed:
+                sv.stop()
+                assert server.runtime.strategy == strategy
+                assert server.runtime.comm is nccl_comm
+                # with capture_collectives the RCCL calls are nodes of the replayed HIP graph
+                assert (stats["graph_replays"] >= 3) == capture, stats
+            return losses, w2, float(st)
+
+    ref = run(False)
+    got = run(True)
+    assert got[2] == ref[2] == 5.0
+    assert np.allclose(got[0], ref[0], rtol=1e-5)
+    assert np.allclose(got[1], ref[1], rtol=1e-5, atol=1e-6)

@@ -209,6 +209,7 @@ class Server:
                 self.runtime = rt.LocalRuntime(torch.device("cpu"))
             else:
                 comm = self._comm
+                self._owns_comm = comm is None
                 if comm is None:
                     from ..parallel.comm import SingleComm, TorchDistComm
                     world = self._cluster.num_tasks(self._job_name)
@@ -254,6 +255,15 @@ class Server:
             self._ps_service.stop()
         if self.runtime is not None:
             self.runtime.shutdown()
+        if getattr(self, "_owns_comm", False) and self._comm is not None:
+            # the process group this server created: tear it down here, not at interpreter
+            # exit (a backend's worker threads must not outlive their group)
+            try:
+                self._comm.barrier()
+            except Exception:  # noqa: BLE001 -- peers may already be gone
+                pass
+            self._comm.close()
+            self._comm = None
         with _REGISTRY_LOCK:
             if _REGISTRY.get(self._target) is self:
                 del _REGISTRY[self._target]

@@ -1,0 +1,68 @@
+"""The example scripts end to end on the GPU box: one worker per GPU through the launcher
+(``--protocol rccl``; world size 1 on a one-GPU box), the whole user-facing flow -- flags,
+ClusterSpec from the launcher environment, Server, replica_device_setter, Supervisor, HIP-graph
+steps, device-resident data, event files."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+from distributed_tensorflow_amd.summary import read_events
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EX = os.path.join(ROOT, "examples")
+
+
+def _launch(args, timeout=240):
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    proc = subprocess.run([sys.executable, "-m", "distributed_tensorflow_amd.launch"] + args,
+                          cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                          text=True, timeout=timeout)
+    return proc.returncode, proc.stdout
+
+
+@pytest.mark.parametrize("strategy", ["allreduce_sync", "reduce_scatter_sync"])
+def test_mnist_example_on_gpu(strategy, tmp_path):
+    logs = str(tmp_path / "logs")
+    rc, out = _launch(["--num_workers", "1", "--protocol", "rccl", "--strategy", strategy,
+                       "--timeout", "200", os.path.join(EX, "tf_distributed.py"), "--",
+                       "--max_steps", "600", "--logs_path", logs,
+                       "--data_dir", str(tmp_path / "nodata")])
+    assert rc == 0, out
+    assert "[worker:0] done" in out
+    m = re.findall(r"Cost: (\d+\.\d{4}),\s+AvgTime:\s*(\d+\.\d\d)ms", out)
+    assert len(m) >= 5
+    costs = [float(c) for c, _ in m]
+    assert costs[-1] < costs[0]                                   # it learns
+    assert min(float(t) for _, t in m) < 1.0                      # sub-millisecond steps
+    acc = float(re.search(r"Test-Accuracy: (\d+\.\d\d)", out).group(1))
+    assert 0.0 <= acc <= 1.0
+    events = []
+    for fname in os.listdir(logs):
+        events += list(read_events(os.path.join(logs, fname)))
+    steps = [e["step"] for e in events if e.get("summary")]
+    assert len(steps) == 600 and steps[-1] == 600                 # one summary per step
+
+
+def test_matmul_example_on_gpu(tmp_path):
+    rc, out = _launch(["--num_workers", "1", "--protocol", "rccl", "--timeout", "200",
+                       os.path.join(EX, "tf_distributed_1000Matrix.py"), "--",
+                       "--max_steps", "301", "--logs_path", str(tmp_path / "logs")])
+    assert rc == 0, out
+    gflops = [float(g) for g in re.findall(r"GFLOPS: (\d+\.\d)", out)]
+    assert gflops and max(gflops) > 5000.0                        # >5 TFLOP/s through sess.run
+    assert "[worker:0] done" in out
+
+
+def test_linear_regression_example_on_gpu():
+    rc, out = _launch(["--num_workers", "1", "--protocol", "rccl", "--strategy",
+                       "reduce_scatter_sync", "--timeout", "200",
+                       os.path.join(EX, "linear_regression.py"), "--", "--max_steps", "300",
+                       "--features", "1024"])
+    assert rc == 0, out
+    err = float(re.search(r"Weight-Error: (\d+\.\d+)", out).group(1))
+    assert err < 0.05

@@ -141,10 +141,15 @@ class PsRuntime(LocalRuntime):
 class CollectiveRuntime(LocalRuntime):
     """Synchronous data parallelism over a communicator (RCCL on GPUs, gloo on CPUs)."""
 
-    capturable = False      # collectives are issued eagerly between kernel launches ...
-    # ... unless the session asks for them inside the captured step: every buffer a collective
-    # touches here (flat arena, gradient bucket, shards) keeps its address from step to step
+    # collectives are issued eagerly between kernel launches unless the session asks for them
+    # inside the captured step (every buffer a collective touches here -- flat arena, gradient
+    # bucket, shards -- keeps its address from step to step); a world of one has no
+    # collectives to issue and is captured like a local session
     capturable_with_collectives = True
+
+    @property
+    def capturable(self) -> bool:
+        return self.comm.world_size == 1
 
     def __init__(self, comm: Communicator, device: torch.device,
                  strategy: str = "allreduce_sync", grad_aggregation: str = "sum"):

@@ -91,8 +91,9 @@ def test_collective_runtime_trains_like_local_session(nccl_comm, strategy, captu
                 sv.stop()
                 assert server.runtime.strategy == strategy
                 assert server.runtime.comm is nccl_comm
-                # with capture_collectives the RCCL calls are nodes of the replayed HIP graph
-                assert (stats["graph_replays"] >= 3) == capture, stats
+                # a world of one is captured like a local session; with capture_collectives the
+                # RCCL calls themselves are nodes of the replayed HIP graph
+                assert stats["graph_replays"] >= 3, stats
             return losses, w2, float(st)
 
     ref = run(False)

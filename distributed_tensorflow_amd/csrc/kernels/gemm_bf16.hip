@@ -6,7 +6,8 @@
 // bf16 matrix variable that is used as a matmul right-hand side.
 //
 // Fast path (dtf_gemm_bf16_nt, tile 256x256x64, 512 threads = 8 waves as 2(M) x 4(N)):
-//  * global -> LDS by LDS-DMA (global_load_lds_dwordx4): no VGPR staging, two LDS buffers
+//  * global -> LDS by LDS-DMA (16 bytes per lane, global_load_lds_dwordx4 or its buffer form
+//    with SGPR base + one offset VGPR in the ping-pong kernel): no VGPR staging, two LDS buffers
 //    (2 x 64 KiB), the loads of K-tile t+1 are in flight while the MFMAs of tile t run; one
 //    barrier per K-tile.
 //  * LDS image: row-major tile rows of 128 B (64 k), with the eight 16-byte chunks of row r
@@ -181,30 +182,54 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_nt_kernel(
 //    retired it, and a slot is restaged at least two phases after its last read.
 // ESIZE = bytes per element (2: bf16, 1: fp8); a K-tile is always 128 bytes of k per row, and
 // lda / ldb are in elements.
+// The DMA is a buffer load: its address is (block tile's base, an SGPR resource) + (K-tile's byte
+// offset, an SGPR) + (32-bit per-lane offset in one VGPR). The per-lane part (row inside the block tile, clamped at the matrix edge,
+// times the leading dimension, plus the swizzled 16-byte chunk) is loop-invariant and computed
+// once per kind and piece, so staging a half-tile costs no vector ALU work and the instruction
+// carries one address VGPR instead of a 64-bit pair.
 template <int ESIZE>
-__device__ __forceinline__ void stage_half(const char* __restrict__ A,
-                                           const char* __restrict__ Bt, long lda,
-                                           long ldb, int m0, int n0, int M, int N, int h, int nkt,
-                                           int kind, int buf, char* smem, int wave, int lane) {
+__device__ __forceinline__ void stage_offsets(unsigned (&voff)[4][2], long lda, long ldb, int m0,
+                                              int n0, int M, int N, int wave, int lane) {
+#pragma unroll
+  for (int kind = 0; kind < 4; ++kind) {
+    const bool is_a = (kind == 0 || kind == 3);
+    const int half = (kind >= 2) ? 1 : 0;
+    const unsigned ld = (unsigned)((is_a ? lda : ldb) * ESIZE);
+    const int base_row = is_a ? m0 : n0;
+    const int max_row = (is_a ? M : N) - 1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int piece = wave * 2 + j;               // 16 pieces of 8 rows per half-tile
+      const int trow = piece * 8 + (lane >> 3);     // row inside the half-tile (128 = 0 mod 16)
+      int row = base_row + half * 128 + trow;
+      row = row < max_row ? row : max_row;
+      const int kc = (lane & 7) ^ ((trow >> 1) & 7);
+      voff[kind][j] = (unsigned)(row - base_row) * ld + (unsigned)(kc * 16);
+    }
+  }
+}
+
+// a_tile / b_tile: unbounded raw buffer resources whose base is the block tile's first row
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const char* base) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0xffffffff, 0x00020000);
+}
+
+__device__ __forceinline__ void stage_half(__amdgpu_buffer_rsrc_t a_tile,
+                                           __amdgpu_buffer_rsrc_t b_tile,
+                                           const unsigned (&voff)[4][2], int h, int nkt, int kind,
+                                           int buf, char* smem, int wave) {
   int t = h >> 2;
   t = t < nkt ? t : nkt - 1;        // past the end: restage a dead slot with valid memory
-  const long k0 = (long)t * 128;    // bytes
   const bool is_a = (kind == 0 || kind == 3);
   const int half = (kind >= 2) ? 1 : 0;
-  const char* X = is_a ? A : Bt;
-  const long ld = (is_a ? lda : ldb) * ESIZE;
-  const int base_row = (is_a ? m0 : n0) + half * 128;
-  const int max_row = (is_a ? M : N) - 1;
+  const int k0 = t * 128;           // 128 bytes of k per K-tile
   char* dst = smem + buf * BUF_BYTES + (is_a ? 0 : TILE_BYTES) + half * (TILE_BYTES / 2);
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int piece = wave * 2 + j;               // 16 pieces of 8 rows per half-tile
-    const int trow = piece * 8 + (lane >> 3);     // row inside the half-tile (128 = 0 mod 16)
-    int row = base_row + trow;
-    row = row < max_row ? row : max_row;
-    const int kc = (lane & 7) ^ ((trow >> 1) & 7);
-    const char* src = X + (long)row * ld + k0 + kc * 16;
-    __builtin_amdgcn_global_load_lds((global_void*)src, (lds_void*)(dst + piece * 1024), 16, 0, 0);
+    const int piece = wave * 2 + j;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(is_a ? a_tile : b_tile,
+                                             (lds_void*)(dst + piece * 1024), 16, voff[kind][j],
+                                             k0, 0, 0);
   }
 }
 
@@ -217,7 +242,12 @@ __device__ __forceinline__ void stage_half(const char* __restrict__ A,
 //   instruction's k-assignment requires of a full-K reduction. That MFMA takes twice the
 //   cycles of the bf16 one at 4x the k, so a K-tile costs the same matrix-pipe time and the
 //   same bytes as in bf16 while doing twice the flops.
-template <bool OUT_F32, int DBG, bool FP8>
+// MERGE = true (the default schedule; measured 1511-1515 TF against 1499 TF at 16384^3 bf16):
+//   two quadrants (32 MFMAs) per phase instead of one -- half as many barrier crossings per
+//   K-tile. A phase then reads (B0, A0, B1) or (A1) and stages two half-tiles;
+//   the half-tile stream still runs six ahead (1.5 K-tiles), with vmcnt(6) = three half-tiles
+//   in flight across each barrier.
+template <bool OUT_F32, int DBG, bool FP8, bool MERGE = false>
 __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
     const char* __restrict__ A, const char* __restrict__ Bt,
     void* __restrict__ C, int M, int N, int K, long lda, long ldb, long ldc, int tiles_m,
@@ -263,12 +293,17 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
   const int a_wave = (wr * 4) * 2048;                  // wave's first 16-row block in an A half
   const int b_wave = TILE_BYTES + (wc * 2) * 2048;     // ... in a Bt half
 
+  unsigned voff[4][2];
+  stage_offsets<ESIZE>(voff, lda, ldb, m0, n0, M, N, wave, lane);
+  const __amdgpu_buffer_rsrc_t a_tile = tile_rsrc(A + (long)m0 * lda * ESIZE);
+  const __amdgpu_buffer_rsrc_t b_tile = tile_rsrc(Bt + (long)n0 * ldb * ESIZE);
+
   // prologue: half-tiles 0..5 in flight, 0 and 1 landed and visible
 #pragma unroll
   for (int h = 0; h < 6; ++h)
-    stage_half<ESIZE>(A, Bt, lda, ldb, m0, n0, M, N, h, nkt, h & 3, (h >> 2) & 1, smem, wave,
-                      lane);
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    stage_half(a_tile, b_tile, voff, h, nkt, h & 3, (h >> 2) & 1, smem, wave);
+  if constexpr (MERGE) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // half-tiles 0-2 landed
+  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                   // half-tiles 0-1 landed
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();          // waves 4-7 run one barrier behind
 
@@ -302,8 +337,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
   {                                                                                              \
     READS;                                                                                       \
     if (!(dbg & 1))                                                                              \
-      stage_half<ESIZE>(A, Bt, lda, ldb, m0, n0, M, N, (dbg & 2) ? 0 : g0 + (P) + 6, nkt,        \
-                        ((P) + 2) & 3, (((P) + 6) >> 2) & 1, smem, wave, lane);                  \
+      stage_half(a_tile, b_tile, voff, (dbg & 2) ? 0 : g0 + (P) + 6, nkt, ((P) + 2) & 3,         \
+                 (((P) + 6) >> 2) & 1, smem, wave);                                              \
     if (!(dbg & 4)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                             \
     __builtin_amdgcn_sched_barrier(0);                                                           \
     __builtin_amdgcn_s_barrier();                                                                \
@@ -316,7 +351,43 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
     __builtin_amdgcn_sched_barrier(0);                                                           \
   }
 
+// merged phase P (0..3) of an iteration that starts at global (single-quadrant) phase g0:
+// stages half-tiles g0 + 2P + 6 and g0 + 2P + 7
+#define DTF_PHASE2(P, READS, MH, NH0, NH1)                                                       \
+  {                                                                                              \
+    READS;                                                                                       \
+    if (!(dbg & 1)) {                                                                            \
+      stage_half(a_tile, b_tile, voff, (dbg & 2) ? 0 : g0 + 2 * (P) + 6, nkt,                    \
+                 (2 * (P) + 2) & 3, ((2 * (P) + 6) >> 2) & 1, smem, wave);                       \
+      stage_half(a_tile, b_tile, voff, (dbg & 2) ? 0 : g0 + 2 * (P) + 7, nkt,                    \
+                 (2 * (P) + 3) & 3, ((2 * (P) + 7) >> 2) & 1, smem, wave);                       \
+    }                                                                                            \
+    if (!(dbg & 4)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                             \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    __builtin_amdgcn_s_barrier();                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    __builtin_amdgcn_s_setprio(1);                                                               \
+    DTF_MFMA_QUAD(MH, NH0)                                                                       \
+    DTF_MFMA_QUAD(MH, NH1)                                                                       \
+    __builtin_amdgcn_s_setprio(0);                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    __builtin_amdgcn_s_barrier();                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+  }
+
   int g0 = 0;
+  if constexpr (MERGE) {
+    for (int it = 0; it < nkt / 2; ++it, g0 += 8) {
+      DTF_PHASE2(0, DTF_READ_B(0, 0) DTF_READ_A(0, 0) DTF_READ_B(1, 0), 0, 0, 1)
+      DTF_PHASE2(1, DTF_READ_A(1, 0), 1, 1, 0)
+      DTF_PHASE2(2, DTF_READ_B(0, 1) DTF_READ_A(0, 1) DTF_READ_B(1, 1), 0, 0, 1)
+      DTF_PHASE2(3, DTF_READ_A(1, 1), 1, 1, 0)
+    }
+    if (nkt & 1) {
+      DTF_PHASE2(0, DTF_READ_B(0, 0) DTF_READ_A(0, 0) DTF_READ_B(1, 0), 0, 0, 1)
+      DTF_PHASE2(1, DTF_READ_A(1, 0), 1, 1, 0)
+    }
+  } else {
   for (int it = 0; it < nkt / 2; ++it, g0 += 8) {
     DTF_PHASE(0, DTF_READ_B(0, 0) DTF_READ_A(0, 0), 0, 0)
     DTF_PHASE(1, DTF_READ_B(1, 0), 0, 1)
@@ -333,6 +404,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
     DTF_PHASE(2, DTF_READ_A(1, 0), 1, 1)
     DTF_PHASE(3, , 1, 0)
   }
+  }
+#undef DTF_PHASE2
 #undef DTF_PHASE
 #undef DTF_MFMA_QUAD
 #undef DTF_READ_A
@@ -702,9 +775,11 @@ __global__ __launch_bounds__(256) void gemm_fp8_generic_kernel(
 // kernel: K % 64 == 0, lda/ldb % 8 == 0, 16-byte aligned A/Bt, ldc % 4 == 0 and 16-byte
 // (fp32) / 8-byte (bf16) aligned C. Returns DTF_ERR_UNSUPPORTED otherwise (callers then use
 // dtf_gemm_bf16_generic).
-// variant & 15: 0 = default (ping-pong schedule), 1 = two-phase double-buffer, 2 = ping-pong,
-// 3 = four-wave kernel (128x128 per wave);
-// variant >> 4: timing-experiment bits of the ping-pong kernel (0 in production).
+// variant & 15: 0 = default (= 4), 1 = two-phase double-buffer, 2 = ping-pong with one quadrant
+// per phase, 3 = four-wave kernel (128x128 per wave), 4 = ping-pong with two quadrants per phase;
+// variant >> 4: timing-experiment bits of the one-quadrant ping-pong kernel (0 in production).
+// The staging DMA addresses a block tile with 32-bit offsets: 256 rows of lda / ldb bytes must
+// stay below 4 GiB (DTF_ERR_UNSUPPORTED otherwise).
 template <typename KernelT>
 static void dtf_allow_lds(KernelT kernel, size_t lds) {
   hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -718,6 +793,7 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
   if (K % BK || lda % 8 || ldb % 8 || ldc % 4 || ((uintptr_t)A & 15) || ((uintptr_t)Bt & 15) ||
       ((uintptr_t)C & (out_f32 ? 15 : 7)))
     return DTF_ERR_UNSUPPORTED;
+  if (lda * 2 * BM >= (1L << 32) || ldb * 2 * BN >= (1L << 32)) return DTF_ERR_UNSUPPORTED;
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const size_t lds = 2 * BUF_BYTES;   // 128 KiB
   static bool attr_set = false;
@@ -771,6 +847,24 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
     DTF_LAUNCH_CHECK();
     return DTF_OK;
   }
+  if ((variant & 15) == 4 || variant == 0) {       // ping-pong with two-quadrant phases
+    static bool m_attr = false;
+    if (!m_attr) {
+      dtf_allow_lds(gemm_nt_pp_kernel<true, 0, false, true>, lds);
+      dtf_allow_lds(gemm_nt_pp_kernel<false, 0, false, true>, lds);
+      m_attr = true;
+    }
+    if (out_f32)
+      hipLaunchKernelGGL((gemm_nt_pp_kernel<true, 0, false, true>), grid, block, lds, stream,
+                         (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tiles_m,
+                         tiles_n, alpha, beta);
+    else
+      hipLaunchKernelGGL((gemm_nt_pp_kernel<false, 0, false, true>), grid, block, lds, stream,
+                         (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tiles_m,
+                         tiles_n, alpha, beta);
+    DTF_LAUNCH_CHECK();
+    return DTF_OK;
+  }
   if ((variant & 15) == 1 && beta != 0.f) return DTF_ERR_UNSUPPORTED;
   if ((variant & 15) != 1) {
 #define DTF_PP_LAUNCH(F32, DBGV)                                                                  \
@@ -814,21 +908,22 @@ DTF_API int dtf_gemm_fp8_nt(const void* A, const void* Bt, void* C, int M, int N
   if (K % 128 || lda % 16 || ldb % 16 || ldc % 4 || ((uintptr_t)A & 15) || ((uintptr_t)Bt & 15) ||
       ((uintptr_t)C & (out_f32 ? 15 : 7)))
     return DTF_ERR_UNSUPPORTED;
+  if (lda * BM >= (1L << 32) || ldb * BN >= (1L << 32)) return DTF_ERR_UNSUPPORTED;
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const size_t lds = 2 * BUF_BYTES;
   static bool attr_set = false;
   if (!attr_set) {
-    dtf_allow_lds(gemm_nt_pp_kernel<true, 0, true>, lds);
-    dtf_allow_lds(gemm_nt_pp_kernel<false, 0, true>, lds);
+    dtf_allow_lds(gemm_nt_pp_kernel<true, 0, true, true>, lds);
+    dtf_allow_lds(gemm_nt_pp_kernel<false, 0, true, true>, lds);
     attr_set = true;
   }
   dim3 grid(tiles_m * tiles_n), block(NTHREADS);
   if (out_f32)
-    hipLaunchKernelGGL((gemm_nt_pp_kernel<true, 0, true>), grid, block, lds, stream,
+    hipLaunchKernelGGL((gemm_nt_pp_kernel<true, 0, true, true>), grid, block, lds, stream,
                        (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tiles_m,
                        tiles_n, alpha, beta);
   else
-    hipLaunchKernelGGL((gemm_nt_pp_kernel<false, 0, true>), grid, block, lds, stream,
+    hipLaunchKernelGGL((gemm_nt_pp_kernel<false, 0, true, true>), grid, block, lds, stream,
                        (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tiles_m,
                        tiles_n, alpha, beta);
   DTF_LAUNCH_CHECK();

@@ -2,7 +2,7 @@
 """Headline benchmark: sharded GEMM TFLOP/s (whole job) and step latency on N MI355X.
 
 Workload: ``C = A @ B`` with A, B 16384 x 16384 bf16 (synthetic: counter-based Philox
-U(-1,1) generated in place on each rank), fp32 accumulation on the hand-written MFMA kernel,
+N(0,1) -- the reference's ``tf.random_normal`` operands -- generated in place on each rank), fp32 accumulation on the hand-written MFMA kernel,
 result bf16 materialised in full on every rank. One *step* = one complete product including
 its collectives -- the analogue of one ``sess.run(C)`` of the reference's matmul script
 (``tf_distributed_1000Matrix.py:48,74``), at the 16384^3 bf16 size of the sharded-GEMM
@@ -62,6 +62,9 @@ def main() -> None:
     ap.add_argument("--dtype", default="bf16", choices=sorted(DTYPES))
     ap.add_argument("--strategy", default="auto")
     ap.add_argument("--panels", type=int, default=None)
+    ap.add_argument("--distribution", default="normal", choices=("normal", "uniform"),
+                    help="operand values: N(0,1) as the reference's tf.random_normal "
+                         "(tf_distributed_1000Matrix.py:43-44), or U(-1,1)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -81,7 +84,8 @@ def main() -> None:
 
     def make(strategy: str) -> ShardedMatmul:
         eng = ShardedMatmul(args.m, args.n, args.k, comm, dtype=dtype, strategy=strategy,
-                            panels=args.panels, seed=1, device=device)
+                            panels=args.panels, seed=1, device=device,
+                            distribution=args.distribution)
         eng.init_operands()
         return eng
 
@@ -141,7 +145,8 @@ def main() -> None:
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": args.dtype,
-            "data": "synthetic (Philox U(-1,1) operands generated on device, random init)",
+            "data": "synthetic (Philox %s operands generated on device, random init)"
+                    % ("N(0,1)" if args.distribution == "normal" else "U(-1,1)"),
             "config": {"model": "gemm_%dx%dx%d_%s" % (args.m, args.n, args.k, args.dtype),
                        "global_batch": args.m, "seq_len": args.k,
                        "m": args.m, "n": args.n, "k": args.k,

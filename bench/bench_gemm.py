@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from distributed_tensorflow_amd.ops import hip  # noqa: E402
 
 
-def timeit(fn, iters: int, warmup: int = 3) -> float:
+def timeit(fn, iters: int, warmup: int = 10) -> float:
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()

@@ -31,6 +31,7 @@
 //
 // Generic path (dtf_gemm_bf16_generic): 64x64 tile, register-staged, fully predicated; any
 // shape/stride, NN/NT/TN; used for ragged problems and as an in-library cross-check.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -233,6 +234,43 @@ __device__ __forceinline__ void stage_half(__amdgpu_buffer_rsrc_t a_tile,
   }
 }
 
+// Workgroup id -> output tile of the ping-pong kernel.
+// Workgroups go to the 8 XCDs round-robin (id % 8) and, inside an XCD, start in id order on its
+// 32 CUs; an XCD's 32 resident tiles form an 8(M) x 4(N) block that shares 8 A panels and 4 Bt
+// panels through its L2 (12 panel loads per 32 tile loads) in both walks below.
+//  * Chunk walk: a contiguous chunk of the tile grid per XCD, walked 8 tile-rows deep. With 64 or
+//    more tile rows every XCD then streams a private strip of A (8 strips of 8 x 256 rows x K
+//    at once -- 512 MiB at K = 16384 bf16, more than the memory-side cache holds).
+//  * Super-tile walk (grids of >= 64 tile rows whose sides divide by 16): the 256 tiles in flight
+//    on the chip form ONE 16 x 16 super-tile, XCDs arranged 2(M) x 4(N), so that XCDs share A
+//    and Bt panels through the memory-side cache; super-tiles are walked in a snake along N so
+//    that consecutive ones reuse the same A strip. Measured against the chunk walk: 16384^3
+//    bf16 1533-1539 vs 1509-1513 TF, 16384 x 16384 x 2048 1288 vs 1226 TF, 16384^3 fp8 3050 vs
+//    2931 TF; no gain (or 1-2 % loss) on grids with fewer tile rows, which keep the chunk walk.
+__device__ __forceinline__ void pp_tile_of_block(int bid, int tiles_m, int tiles_n, int& tm,
+                                                 int& tn, bool chunk_walk_only) {
+  if (!chunk_walk_only && tiles_m >= 64 && tiles_m % 16 == 0 && tiles_n % 16 == 0) {
+    constexpr int xm = 2, xn = 4;
+    const int xcd = bid & 7, local = bid >> 3;
+    const int sup = local >> 5, within = local & 31;
+    const int sup_n = tiles_n / (xn * 4);
+    const int sm = sup / sup_n;
+    int sn = sup - sm * sup_n;
+    if (sm & 1) sn = sup_n - 1 - sn;
+    tm = (sm * xm + xcd / xn) * 8 + (within & 7);
+    tn = (sn * xn + xcd % xn) * 4 + (within >> 3);
+    return;
+  }
+  const int id = dtf_xcd_remap(bid, tiles_m * tiles_n);
+  constexpr int GROUP = 8;
+  const int per_group = GROUP * tiles_n;
+  const int grp = id / per_group;
+  const int first_m = grp * GROUP;
+  const int gsize = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
+  tm = first_m + (id % per_group) % gsize;
+  tn = (id % per_group) / gsize;
+}
+
 // FP8 = false: bf16 operands, K-tile 64, two v_mfma_f32_16x16x32_bf16 per output tile and K-tile.
 // FP8 = true : OCP e4m3 operands, K-tile 128 (the same 128 bytes per row, so the LDS image, the
 //   DMA stream and the fragment reads are byte-for-byte those of the bf16 kernel); the two
@@ -255,22 +293,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
   constexpr int ESIZE = FP8 ? 1 : 2;
   // DBG (timing experiments only, built with -DDTF_GEMM_EXPERIMENTS; results are wrong when
   // set): bit 0 = issue no LDS-DMA in the K-loop, bit 1 = always stage K-tile 0 (every load an
-  // L2 hit), bit 2 = skip the counted wait
+  // L2 hit), bit 2 = skip the counted wait, bit 3 = per-phase cycle sums, bit 4 = chunk walk
   constexpr int dbg = DBG;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
 
-  const int ntiles = tiles_m * tiles_n;
-  const int id = dtf_xcd_remap(blockIdx.x, ntiles);
-  constexpr int GROUP = 8;
-  const int per_group = GROUP * tiles_n;
-  const int grp = id / per_group;
-  const int first_m = grp * GROUP;
-  const int gsize = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
-  const int tm = first_m + (id % per_group) % gsize;
-  const int tn = (id % per_group) / gsize;
+  int tm, tn;
+  pp_tile_of_block(blockIdx.x, tiles_m, tiles_n, tm, tn, (DBG & 16) != 0);
   const int m0 = tm * BM, n0 = tn * BN;
   const int nkt = K / (128 / ESIZE);
 
@@ -293,6 +324,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
   const int a_wave = (wr * 4) * 2048;                  // wave's first 16-row block in an A half
   const int b_wave = TILE_BYTES + (wc * 2) * 2048;     // ... in a Bt half
 
+  // timing experiment (dbg & 8): per-wave, per-phase cycle sums of the five segments of a phase
+  // [issue reads + DMA | counted wait | barrier | MFMAs | barrier] and the phase count
+  unsigned seg[4][6] = {};
   unsigned voff[4][2];
   stage_offsets<ESIZE>(voff, lda, ldb, m0, n0, M, N, wave, lane);
   const __amdgpu_buffer_rsrc_t a_tile = tile_rsrc(A + (long)m0 * lda * ESIZE);
@@ -355,6 +389,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
 // stages half-tiles g0 + 2P + 6 and g0 + 2P + 7
 #define DTF_PHASE2(P, READS, MH, NH0, NH1)                                                       \
   {                                                                                              \
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0;                     \
+    if constexpr ((dbg & 8) != 0) ts0 = __builtin_amdgcn_s_memtime();                            \
     READS;                                                                                       \
     if (!(dbg & 1)) {                                                                            \
       stage_half(a_tile, b_tile, voff, (dbg & 2) ? 0 : g0 + 2 * (P) + 6, nkt,                    \
@@ -362,17 +398,30 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
       stage_half(a_tile, b_tile, voff, (dbg & 2) ? 0 : g0 + 2 * (P) + 7, nkt,                    \
                  (2 * (P) + 3) & 3, ((2 * (P) + 7) >> 2) & 1, smem, wave);                       \
     }                                                                                            \
+    if constexpr ((dbg & 8) != 0) ts1 = __builtin_amdgcn_s_memtime();                            \
     if (!(dbg & 4)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                             \
+    if constexpr ((dbg & 8) != 0) ts2 = __builtin_amdgcn_s_memtime();                            \
     __builtin_amdgcn_sched_barrier(0);                                                           \
     __builtin_amdgcn_s_barrier();                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                           \
+    if constexpr ((dbg & 8) != 0) ts3 = __builtin_amdgcn_s_memtime();                            \
     __builtin_amdgcn_s_setprio(1);                                                               \
     DTF_MFMA_QUAD(MH, NH0)                                                                       \
     DTF_MFMA_QUAD(MH, NH1)                                                                       \
     __builtin_amdgcn_s_setprio(0);                                                               \
     __builtin_amdgcn_sched_barrier(0);                                                           \
+    if constexpr ((dbg & 8) != 0) ts4 = __builtin_amdgcn_s_memtime();                            \
     __builtin_amdgcn_s_barrier();                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                           \
+    if constexpr ((dbg & 8) != 0) {                                                              \
+      ts5 = __builtin_amdgcn_s_memtime();                                                        \
+      seg[P][0] += (unsigned)(ts1 - ts0);                                                        \
+      seg[P][1] += (unsigned)(ts2 - ts1);                                                        \
+      seg[P][2] += (unsigned)(ts3 - ts2);                                                        \
+      seg[P][3] += (unsigned)(ts4 - ts3);                                                        \
+      seg[P][4] += (unsigned)(ts5 - ts4);                                                        \
+      seg[P][5] += 1u;                                                                           \
+    }                                                                                            \
   }
 
   int g0 = 0;
@@ -412,7 +461,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
 #undef DTF_READ_B
   if (wr == 0) __builtin_amdgcn_s_barrier();          // every wave has passed the same count
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // no LDS-DMA may outlive the workgroup
-
   // epilogue: lane holds C[row = frow][col = 4*fq + r] of each 16x16 tile
 #pragma unroll
   for (int mh = 0; mh < 2; ++mh)
@@ -452,6 +500,18 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
           }
         }
     }
+  if constexpr ((dbg & 8) != 0) {   // overwrite the head of the tile's rows 0-7 with the sums
+    __syncthreads();
+    if (lane == 0 && m0 + 8 <= M && n0 + 64 <= N) {
+      unsigned* dst = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(C) +
+                                                  ((long)(m0 + wave) * ldc + n0) *
+                                                      (OUT_F32 ? 4 : 2));
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 6; ++q) dst[p * 6 + q] = seg[p][q];
+    }
+  }
 }
 
 // ---- four-wave kernel: one wave per SIMD, 128x128 outputs per wave ------------------------------
@@ -847,6 +907,38 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
     DTF_LAUNCH_CHECK();
     return DTF_OK;
   }
+#ifdef DTF_GEMM_EXPERIMENTS
+  if ((variant & 15) == 4 && (variant >> 4) != 0) {   // timing experiments on the default schedule
+    static bool e_attr = false;
+    if (!e_attr) {
+      dtf_allow_lds(gemm_nt_pp_kernel<false, 8, false, true>, lds + 1024);
+      dtf_allow_lds(gemm_nt_pp_kernel<false, 10, false, true>, lds + 1024);
+      dtf_allow_lds(gemm_nt_pp_kernel<false, 9, false, true>, lds + 1024);
+      dtf_allow_lds(gemm_nt_pp_kernel<false, 16, false, true>, lds);
+      e_attr = true;
+    }
+    const int dbg = variant >> 4;
+    if (dbg == 8)
+      hipLaunchKernelGGL((gemm_nt_pp_kernel<false, 8, false, true>), grid, block, lds + 1024,
+                         stream, (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc,
+                         tiles_m, tiles_n, alpha, beta);
+    else if (dbg == 10)
+      hipLaunchKernelGGL((gemm_nt_pp_kernel<false, 10, false, true>), grid, block, lds + 1024,
+                         stream, (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc,
+                         tiles_m, tiles_n, alpha, beta);
+    else if (dbg == 9)
+      hipLaunchKernelGGL((gemm_nt_pp_kernel<false, 9, false, true>), grid, block, lds + 1024,
+                         stream, (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc,
+                         tiles_m, tiles_n, alpha, beta);
+    else if (dbg == 16)
+      hipLaunchKernelGGL((gemm_nt_pp_kernel<false, 16, false, true>), grid, block, lds, stream,
+                         (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tiles_m,
+                         tiles_n, alpha, beta);
+    else return DTF_ERR_UNSUPPORTED;
+    DTF_LAUNCH_CHECK();
+    return DTF_OK;
+  }
+#endif
   if ((variant & 15) == 4 || variant == 0) {       // ping-pong with two-quadrant phases
     static bool m_attr = false;
     if (!m_attr) {
@@ -918,6 +1010,17 @@ DTF_API int dtf_gemm_fp8_nt(const void* A, const void* Bt, void* C, int M, int N
     attr_set = true;
   }
   dim3 grid(tiles_m * tiles_n), block(NTHREADS);
+#ifdef DTF_GEMM_EXPERIMENTS
+  if (getenv("DTF_PP_CHUNK_WALK") && !out_f32) {
+    static bool e_attr = false;
+    if (!e_attr) { dtf_allow_lds(gemm_nt_pp_kernel<false, 16, true, true>, lds); e_attr = true; }
+    hipLaunchKernelGGL((gemm_nt_pp_kernel<false, 16, true, true>), grid, block, lds, stream,
+                       (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tiles_m,
+                       tiles_n, alpha, beta);
+    DTF_LAUNCH_CHECK();
+    return DTF_OK;
+  }
+#endif
   if (out_f32)
     hipLaunchKernelGGL((gemm_nt_pp_kernel<true, 0, true, true>), grid, block, lds, stream,
                        (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tiles_m,

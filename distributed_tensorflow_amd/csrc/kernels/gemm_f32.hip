@@ -16,8 +16,8 @@
 // DEPTH K-tiles ahead of the MFMAs through a ring of register sets (a K-tile is only 8 or 32
 // MFMAs of 64 cycles per wave, far less than a global-memory round trip, and a workgroup is
 // often alone on its CU): iteration k refills the set tile k just left with tile k+DEPTH,
-// runs the MFMAs of tile k, then moves tile k+1 -- loaded DEPTH-1 iterations ago -- into the
-// other LDS buffer: one barrier per K-tile. Shapes need no alignment: edge tiles are
+// runs the MFMAs of tile k and meanwhile moves tile k+1 -- loaded DEPTH-1 iterations ago -- into
+// the other LDS buffer: one barrier per K-tile, placed inside the MFMA stream. Shapes need no alignment: edge tiles are
 // predicated (1000 = 7*128 + 104, K = 784 / 100 / 10 all occur in the reference).
 //
 // Split-K: the exact-fp32 MFMA retires 32x32x2 per 64 cycles per wave, so a product with few
@@ -30,6 +30,7 @@
 // cache write-back and measured 64 us on the 100x100x784 product against 23 us unsplit.)
 #include "common.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -114,6 +115,53 @@ struct Loader {
     }
   }
 
+  // Interior K-tiles (k0 + BK <= k_end) of aligned operands need neither the k clamp nor the
+  // zero select, and what is left of the address -- the lane's row (clamped at the edge) times
+  // the leading dimension plus its 16-byte column -- does not change from tile to tile. The
+  // lane part is computed once as a 32-bit byte offset and the tile part is a wave-uniform base
+  // advanced on the scalar unit, so an interior fetch is a buffer load with no vector ALU work
+  // (recomputing row * ld in 64 bits per tile cost more issue time than the tile's MFMAs leave).
+  // Needs BT * ld * 4 (KCONTIG) or BK * ld * 4 bytes below 4 GiB.
+  __device__ static void lane_offsets(unsigned (&voff)[PER_THREAD], long ld, int t0, int T,
+                                      int tid) {
+#pragma unroll
+    for (int i = 0; i < PER_THREAD; ++i) {
+      const int idx = tid + i * NTHREADS;
+      if (KCONTIG) {
+        const int t = idx >> 2, k4 = idx & 3;
+        int gt = t0 + t;
+        gt = gt < T - 1 ? gt : T - 1;
+        voff[i] = (unsigned)(gt - t0) * (unsigned)(ld * 4) + 16u * k4;
+      } else {
+        constexpr int V = BT / 4;
+        const int k = idx / V, t4 = idx % V;
+        const int tb = t0 < T - 4 ? t0 : T - 4;
+        int gt = t0 + 4 * t4;
+        gt = gt < T - 4 ? gt : T - 4;
+        voff[i] = (unsigned)k * (unsigned)(ld * 4) + 4u * (gt - tb);
+      }
+    }
+  }
+
+  // wave-uniform address of element (row t0, k = k0) -- KCONTIG -- or (k-row k0, column
+  // min(t0, T - 4)) of the tile
+  __device__ static const float* tile_base(const float* __restrict__ X, long ld, int t0, int T,
+                                           int k0) {
+    if (KCONTIG) return X + (long)t0 * ld + k0;
+    return X + (long)k0 * ld + (t0 < T - 4 ? t0 : T - 4);
+  }
+
+  __device__ static void fetch_interior(f32x4 (&regs)[PER_THREAD], const float* base,
+                                        const unsigned (&voff)[PER_THREAD]) {
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0xffffffff, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < PER_THREAD; ++i) {
+      const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[i], 0, 0);
+      regs[i] = __builtin_bit_cast(f32x4, v);
+    }
+  }
+
   __device__ static void stash(const f32x4 (&regs)[PER_THREAD], float* __restrict__ Xs, int tid) {
 #pragma unroll
     for (int i = 0; i < PER_THREAD; ++i) {
@@ -131,7 +179,9 @@ struct Loader {
   }
 };
 
-template <int BM, int BN, bool A_KC, bool B_KC>
+// ABL (timing experiments, -DDTF_GEMM_EXPERIMENTS only; results are wrong when set): bit 0 = no
+// global loads in the K loop, bit 1 = no LDS stash, bit 2 = no barrier, bit 3 = no fragment reads
+template <int BM, int BN, bool A_KC, bool B_KC, int ABL = 0>
 __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
     const float* __restrict__ bias, int M, int N, int K, long lda, long ldb, long ldc,
@@ -172,10 +222,19 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // A wave with a single 32x32 output tile would issue every MFMA on the accumulator the one
+  // before it is still writing; two accumulators (even / odd k-pairs, summed before the epilogue)
+  // keep consecutive MFMAs independent.
+  f32x16 acc_odd[1];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc_odd[0][r] = 0.f;
+
   const int nkt = (k_end - k_begin + BK - 1) / BK;
   const int lrow = lane & 31, lk = lane >> 5;
   // aligned operands take the branch-free loads (block-uniform choice, made once)
   const bool fast = a_vec != 0 && b_vec != 0 && k_end - k_begin >= 4 &&
+                    lda * 4 * (A_KC ? BM : BK) < (1L << 32) &&
+                    ldb * 4 * (B_KC ? BN : BK) < (1L << 32) &&
                     (A_KC ? (K & 3) == 0 : ((M & 3) == 0 && M >= 4)) &&
                     (B_KC ? (K & 3) == 0 : ((N & 3) == 0 && N >= 4));
 
@@ -184,6 +243,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(
     constexpr bool FAST = decltype(fast_tag)::value;
     constexpr int DEPTH = (BM == 128) ? 3 : 4;        // register sets = K-tiles in flight
     f32x4 ra[DEPTH][LA::PER_THREAD], rb[DEPTH][LB::PER_THREAD];
+    unsigned voff_a[LA::PER_THREAD], voff_b[LB::PER_THREAD];
+    if (FAST) {
+      LA::lane_offsets(voff_a, lda, m0, M, tid);
+      LB::lane_offsets(voff_b, ldb, n0, N, tid);
+    }
+    // any tile: clamped addresses, zeros beyond k_end (K tail, prefetches past the end)
     auto fetch_tile = [&](f32x4 (&qa)[LA::PER_THREAD], f32x4 (&qb)[LB::PER_THREAD], int kt) {
       const int k0 = k_begin + kt * BK;
       if (FAST) {
@@ -194,58 +259,106 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(
         LB::fetch(qb, B, ldb, n0, k0, N, k_end, b_vec != 0, tid);
       }
     };
+    // a tile that lies wholly inside [k_begin, k_end) of aligned operands
+    auto fetch_interior_tile = [&](f32x4 (&qa)[LA::PER_THREAD], f32x4 (&qb)[LB::PER_THREAD],
+                                   int kt) {
+      const int k0 = k_begin + kt * BK;
+      LA::fetch_interior(qa, LA::tile_base(A, lda, m0, M, k0), voff_a);
+      LB::fetch_interior(qb, LB::tile_base(B, ldb, n0, N, k0), voff_b);
+    };
 #pragma unroll
     for (int u = 0; u < DEPTH; ++u) fetch_tile(ra[u], rb[u], u);   // tiles past the end: zeros
     LA::stash(ra[0], As, tid);
     LB::stash(rb[0], Bs, tid);
     __syncthreads();
 
-    for (int kt0 = 0; kt0 < nkt; kt0 += DEPTH) {
+    // MFMA fragments run through a register ring PD k-pairs ahead of the MFMAs and straight
+    // across K-tile boundaries. With one 32x32 tile per wave (64x64 block tile) a k-pair is a
+    // single 64-cycle MFMA, less than an LDS round trip with four waves reading: PD = 3. The
+    // barrier of a K-tile sits PD k-pairs before its end -- the last point before the ring reads
+    // the next tile's buffer -- so the waves meet in mid-stream with MFMAs still queued, not at
+    // an empty pipe followed by a cold fragment read.
+    constexpr int KP = BK / 2;                        // k-pairs per K-tile
+    constexpr int PD = (BM == 128) ? 1 : 3;
+    constexpr int RING = PD + 1;                      // divides KP: slots line up across tiles
+    static_assert(KP % RING == 0, "fragment ring must divide the K-tile");
+    float a[RING][TM], b[RING][TN];
+    auto read_frag = [&](int slot, const float* as, const float* bs, int kp) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[slot][i] = as[(2 * kp + lk) * LA::LD + 32 * i];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[slot][j] = bs[(2 * kp + lk) * LB::LD + 32 * j];
+    };
+#pragma unroll
+    for (int p = 0; p < PD; ++p) read_frag(p, As + wr * WM + lrow, Bs + wc * WN + lrow, p);
+
+    // DEPTH consecutive K-tiles (ring slots 0..DEPTH-1). INTERIOR: every tile of the group, and
+    // the tile each one prefetches, lies wholly inside the K range -- the loads are then buffer
+    // loads with loop-invariant lane offsets. The two kinds of fetch live in separate loops: a
+    // join of paths that issue different loads makes the compiler drain vmcnt to zero before
+    // the next LDS stash, which empties the prefetch ring once per group.
+    auto group = [&](auto interior_tag, int kt0) {
+      constexpr bool INTERIOR = decltype(interior_tag)::value;
 #pragma unroll
       for (int u = 0; u < DEPTH; ++u) {
         const int kt = kt0 + u;
-        if (kt >= nkt) break;
+        if (!INTERIOR && kt >= nkt) break;
         const int cur = kt & 1;
         // set u held tile kt, already in LDS: refill it with tile kt + DEPTH
-        fetch_tile(ra[u], rb[u], kt + DEPTH);
+        if (!(ABL & 1)) {
+          if (INTERIOR) fetch_interior_tile(ra[u], rb[u], kt + DEPTH);
+          else fetch_tile(ra[u], rb[u], kt + DEPTH);
+        }
         const float* as = As + cur * A_BUF + wr * WM + lrow;
         const float* bs = Bs + cur * B_BUF + wc * WN + lrow;
-        // fragments are double-buffered in registers one k-pair ahead, so an LDS round trip
-        // hides under the previous group of MFMAs instead of following it
-        float a[2][TM], b[2][TN];
+        const float* asn = As + (cur ^ 1) * A_BUF + wr * WM + lrow;
+        const float* bsn = Bs + (cur ^ 1) * B_BUF + wc * WN + lrow;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a[0][i] = as[lk * LA::LD + 32 * i];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) b[0][j] = bs[lk * LB::LD + 32 * j];
-#pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
-          const int c = kk & 1, nx = c ^ 1;
-          if (kk + 1 < BK / 2) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[nx][i] = as[(2 * kk + 2 + lk) * LA::LD + 32 * i];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[nx][j] = bs[(2 * kk + 2 + lk) * LB::LD + 32 * j];
-          }
-          if (kk == BK / 4 && kt + 1 < nkt) {
-            // tile kt+1 (loaded DEPTH-1 tiles ago) goes into the other LDS buffer in the
-            // middle of this tile's MFMAs, not after them: the barrier below then waits on
-            // nothing but the last MFMA group
+        for (int kk = 0; kk < KP; ++kk) {
+          if (kk == (KP - PD) / 2 && !(ABL & 2)) {
+            // tile kt+1 (loaded DEPTH-1 tiles ago; zeros past the end) goes into the other LDS
+            // buffer, whose last readers finished before the previous tile's barrier. Neither
+            // this nor the ring's reads below are skipped on the last tile: a branch around LDS
+            // operations would force the compiler to drain lgkmcnt to zero at the join instead
+            // of counting, and every MFMA would then wait for the newest fragment read.
             LA::stash(ra[(u + 1) % DEPTH], As + (cur ^ 1) * A_BUF, tid);
             LB::stash(rb[(u + 1) % DEPTH], Bs + (cur ^ 1) * B_BUF, tid);
+          }
+          if (kk == KP - PD && !(ABL & 4)) __syncthreads();
+          {
+            const int pf = kk + PD;
+            if (ABL & 8) {}
+            else if (pf < KP) read_frag(pf % RING, as, bs, pf);
+            else read_frag(pf % RING, asn, bsn, pf - KP);
           }
 #pragma unroll
           for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][i], b[c][j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < TN; ++j) {
+              if (TM * TN == 1 && (kk & 1))
+                acc_odd[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk % RING][i], b[kk % RING][j],
+                                                                  acc_odd[0], 0, 0, 0);
+              else
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk % RING][i], b[kk % RING][j],
+                                                                 acc[i][j], 0, 0, 0);
+            }
         }
-        __syncthreads();
       }
+    };
+    int kt0 = 0;
+    if constexpr (FAST) {
+      const int n_full = (k_end - k_begin) / BK;
+      for (; kt0 + 2 * DEPTH <= n_full; kt0 += DEPTH) group(std::true_type{}, kt0);
     }
+    for (; kt0 < nkt; kt0 += DEPTH) group(std::false_type{}, kt0);
   };
   if (fast) k_loop(std::true_type{});
   else k_loop(std::false_type{});
 
+  if (TM * TN == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][0][r] += acc_odd[0][r];
+  }
   // C/D fragment: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   if (splits > 1) {
     const long plane = (long)M * N;
@@ -321,6 +434,21 @@ int launch(const float* A, const float* B, float* C, const float* bias, int M, i
   hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, AKC, BKC>), grid, block, 0, stream, A, B, C,    \
                      bias, M, N, K, lda, ldb, ldc, a_vec, b_vec, act, tiles_n, ntiles, splits,  \
                      kchunk, partial)
+#ifdef DTF_GEMM_EXPERIMENTS
+  if (const char* e = getenv("DTF_F32_ABL")) {
+    const int abl = atoi(e);
+#define DTF_ABL_CASE(V)                                                                       \
+  if (abl == V) {                                                                             \
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, false, V>), grid, block, 0, stream, A,  \
+                       B, C, bias, M, N, K, lda, ldb, ldc, a_vec, b_vec, act, tiles_n,        \
+                       ntiles, splits, kchunk, partial);                                      \
+    return DTF_OK;                                                                            \
+  }
+    DTF_ABL_CASE(1) DTF_ABL_CASE(2) DTF_ABL_CASE(4) DTF_ABL_CASE(8) DTF_ABL_CASE(6)
+    DTF_ABL_CASE(7) DTF_ABL_CASE(15) DTF_ABL_CASE(14)
+#undef DTF_ABL_CASE
+  }
+#endif
   if (!trans_a && !trans_b) DTF_GEMM_CASE(true, false);
   else if (!trans_a && trans_b) DTF_GEMM_CASE(true, true);
   else if (trans_a && !trans_b) DTF_GEMM_CASE(false, false);
@@ -339,17 +467,16 @@ int launch(const float* A, const float* B, float* C, const float* bias, int M, i
 }  // namespace
 
 // Block tile for an M x N x K product, from measurements on MI355X: the 128x128 tile (2x2 MFMA
-// tiles per wave, half the LDS reads per flop) wins from ~4096^2 outputs on (122 TF at 4096^3);
-// below that the 64x64 tile keeps more workgroups per CU in flight and is faster (2048^3: 98 vs
-// 85 TF; 1536^3 with split-K 4: 87 vs 47 TF).
+// tiles per wave, half the LDS reads per flop) wins from 4096^2 outputs on (4096^3: 136 vs 131
+// TF, 8192^3: 140 vs 139 TF); below that the 64x64 tile keeps more workgroups per CU in flight
+// and is faster (3072^3: 120 vs 96 TF, 2048^3: 128 vs 113 TF).
 DTF_API int dtf_gemm_f32_tile(int M, int N, int K) {
   const long big_tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
-  return big_tiles >= 512 ? 128 : 64;
+  return big_tiles >= 1024 ? 128 : 64;
 }
 
-// Split-K plan: number of K splits (1 = none). A 64x64-tile grid of up to ~1000 workgroups gains
-// from up to 4 splits (four resident workgroups per CU hide each other's load latency: 1000^3
-// 41 -> 33 us); tiny grids (the MLP's 100x100 outputs with K = 784) take as many splits as give
+// Split-K plan: number of K splits (1 = none). A 64x64-tile grid of up to ~1000 workgroups that
+// leaves CUs idle in its last round gains from up to 4 splits; tiny grids (the MLP's 100x100 outputs with K = 784) take as many splits as give
 // every CU a workgroup, each split keeping at least four K-tiles.
 DTF_API int dtf_gemm_f32_splits(int M, int N, int K, int* kchunk_out) {
   int splits = 1, kchunk = K;
@@ -360,8 +487,14 @@ DTF_API int dtf_gemm_f32_splits(int M, int N, int K, int* kchunk_out) {
       want = (int)(256 / tiles);
       if (want > 32) want = 32;
     } else if (tiles < 1024) {
-      want = (int)((1024 + tiles - 1) / tiles);
-      if (want > 4) want = 4;
+      // a grid that fills whole rounds of the 256 CUs (1000^3: 256 tiles) runs unsplit at the
+      // vendor library's speed (23.5 us); a ragged one (1536^3: 576 tiles = 2.25 rounds) gains
+      // from finer work items
+      const long rounds = (tiles + 255) / 256;
+      if (tiles * 10 < rounds * 256 * 9) {
+        want = (int)((1024 + tiles - 1) / tiles);
+        if (want > 4) want = 4;
+      }
     }
     if (want > 1) {
       int chunk = ((K + want - 1) / want + 15) / 16 * 16;

@@ -64,6 +64,13 @@ def build_hip(force: bool = False, jobs: int = 8) -> str:
              "-Wall", "-Wno-unused-function", "-I" + os.path.join(CSRC, "kernels")]
     if os.environ.get("DTF_GEMM_EXPERIMENTS"):      # timing-ablation variants of the GEMM kernels
         flags.append("-DDTF_GEMM_EXPERIMENTS")
+    # a change of flags (e.g. DTF_GEMM_EXPERIMENTS toggled) rebuilds everything
+    stamp = os.path.join(OBJDIR, "hip_flags.txt")
+    flag_text = " ".join(flags)
+    if not os.path.exists(stamp) or open(stamp).read() != flag_text:
+        force = True
+        with open(stamp, "w") as fh:
+            fh.write(flag_text)
     objs, todo = [], []
     for src in sources:
         obj = os.path.join(OBJDIR, os.path.basename(src) + ".o")

@@ -401,9 +401,19 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   if ((N & 3) == 0) {
     const long n4 = plane >> 2;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-      f32x4 v = reinterpret_cast<const f32x4*>(partial)[i];
-      for (int sp = 1; sp < splits; ++sp)
-        v += reinterpret_cast<const f32x4*>(partial + sp * plane)[i];
+      // planes are summed in split order, eight independent loads at a time
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      for (int sp0 = 0; sp0 < splits; sp0 += 8) {
+        f32x4 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int sp = sp0 + u < splits ? sp0 + u : splits - 1;
+          t[u] = reinterpret_cast<const f32x4*>(partial + sp * plane)[i];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (sp0 + u < splits) v += t[u];
+      }
       const long e = i << 2;
       const int row = (int)(e / N), col = (int)(e % N);
 #pragma unroll

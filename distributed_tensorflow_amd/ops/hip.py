@@ -87,7 +87,8 @@ def _declare(L: ctypes.CDLL) -> None:
         "dtf_softmax_xent_grad_f32": [P, P, P, P, P, LG, LG, P],
         "dtf_xent_grad_narrow_f32": [P, P, P, P, P, LG, LG, P],
         "dtf_mlp_head_supported": [LG, LG, LG],
-        "dtf_mlp_head_train": [P, P, P, P, P, P, P, P, P, P, P, P, LG, LG, LG, I, P],
+        "dtf_mlp_head_train": [P, P, P, P, P, P, P, P, P, P, P, P, P, LG, LG, LG, I, P],
+        "dtf_mlp_head_workspace": [LG, LG, LG],
         "dtf_argmax_accuracy_f32": [P, P, P, LG, LG, P],
         "dtf_softmax_rows_f32": [P, P, P, LG, LG, P],
         "dtf_softmax_xent_workspace": [LG],
@@ -579,7 +580,7 @@ def mlp_head_supported(b: int, h: int, c: int) -> bool:
 
 def mlp_head_train(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, labels: torch.Tensor,
                    dloss: torch.Tensor, sigmoid_input: bool, want_accuracy: bool):
-    """One-launch forward + backward of a small softmax head (B <= 128, H <= 128, C <= 16).
+    """Fused forward + backward of a small softmax head (B <= 128, H <= 128, C <= 16).
     Returns ``(loss, y, dw, db, da_or_dz_prev, db_prev_or_None, accuracy_or_None)``."""
     a = _req(a, torch.float32, "mlp_head a")
     w = _req(w, torch.float32, "mlp_head w")
@@ -594,7 +595,8 @@ def mlp_head_train(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, labels:
     b, h = a.shape
     c = w.shape[1]
     dev = a.device
-    buf = torch.empty(2 + b * c + h * c + c + b * h + h, dtype=torch.float32, device=dev)
+    ws_n = int(lib().dtf_mlp_head_workspace(b, h, c))
+    buf = torch.empty(2 + b * c + h * c + c + b * h + h + ws_n, dtype=torch.float32, device=dev)
     off = 0
 
     def take(n, shape):
@@ -606,11 +608,12 @@ def mlp_head_train(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, labels:
     loss, acc = take(1, ()), take(1, ())
     y, dw, db = take(b * c, (b, c)), take(h * c, (h, c)), take(c, (c,))
     da, dbp = take(b * h, (b, h)), take(h, (h,))
+    ws = take(ws_n, (ws_n,))
     _check(lib().dtf_mlp_head_train(a.data_ptr(), w.data_ptr(), bias.data_ptr(),
                                     labels.data_ptr(), dloss.data_ptr(), loss.data_ptr(),
                                     y.data_ptr(), dw.data_ptr(), db.data_ptr(), da.data_ptr(),
                                     dbp.data_ptr() if sigmoid_input else None,
-                                    acc.data_ptr() if want_accuracy else None,
+                                    acc.data_ptr() if want_accuracy else None, ws.data_ptr(),
                                     b, h, c, int(sigmoid_input), _stream()), "mlp_head_train")
     return loss, y, dw, db, da, (dbp if sigmoid_input else None), (acc if want_accuracy else None)
 

@@ -14,7 +14,8 @@ configuration. Total work is fixed as N grows (strong scaling).
 
 Rank 0 prints ONE JSON line. ``--strategy auto`` (default) times the full-result strategies
 (row-sharded A + all-gather of C; K-sharded operands + all-reduce of partial sums) during
-warm-up and runs the faster one; the choice is reported in ``config.parallelism``.
+warm-up -- plus the all-gather over peer-mapped memory when that is available and bit-identical
+-- and runs the fastest; the choice is reported in ``config.parallelism``.
 """
 from __future__ import annotations
 
@@ -33,10 +34,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from distributed_tensorflow_amd.parallel.comm import SingleComm, TorchDistComm  # noqa: E402
+from distributed_tensorflow_amd.parallel.peer_mem import PeerMemError  # noqa: E402
 from distributed_tensorflow_amd.parallel.sharded_matmul import ShardedMatmul  # noqa: E402
 
 DTYPES = {"bf16": torch.bfloat16, "fp32": torch.float32, "fp8": torch.float8_e4m3fn}
 FULL_RESULT_STRATEGIES = ("m_shard_allgather", "k_shard_allreduce")
+DIRECT_STRATEGIES = ("m_shard_allgather_direct",)     # peer-memory collectives (one node)
 
 
 def timed_steps(engine: ShardedMatmul, comm, steps: int) -> float:
@@ -67,6 +70,9 @@ def main() -> None:
                          "(tf_distributed_1000Matrix.py:43-44), or U(-1,1)")
     args = ap.parse_args()
 
+    if os.environ.get("DTF_BENCH_DEBUG"):        # dump every thread's stack if a run stalls
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["DTF_BENCH_DEBUG"]), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -74,7 +80,10 @@ def main() -> None:
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     use_dist = world > 1 or os.environ.get("DTF_FORCE_DIST") == "1"   # world-1 RCCL smoke
-    comm = TorchDistComm(device=device) if use_dist else SingleComm(device)
+    # DTF_COMM_BACKEND=gloo: control plane for rehearsing several ranks on ONE GPU (RCCL refuses
+    # two ranks per device); the driver's runs use the default, RCCL
+    comm = TorchDistComm(device=device, backend=os.environ.get("DTF_COMM_BACKEND") or None) \
+        if use_dist else SingleComm(device)
     rank = comm.rank
     if world != args.gpus and rank == 0:
         print("note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world),
@@ -102,12 +111,36 @@ def main() -> None:
         for _ in range(args.warmup):
             engine.step()
     else:
-        # measured choice, inside the (untimed) warm-up: run each candidate, keep the faster
+        # measured choice, inside the (untimed) warm-up: run each candidate, keep the fastest.
+        # The peer-memory variant is only eligible if its buffers could be mapped on every rank
+        # and its result is bit-identical to the RCCL variant's (same kernel, same panels).
         best = None
         probe = max(2, args.warmup)
-        for cand in FULL_RESULT_STRATEGIES:
-            eng = make(cand)
+        baseline_rows = None
+        sample = torch.arange(0, args.m, max(1, args.m // 64), device=device)
+        for cand in FULL_RESULT_STRATEGIES + DIRECT_STRATEGIES:
+            try:
+                eng = make(cand)
+            except PeerMemError as e:                    # raised on every rank or on none
+                if rank == 0:
+                    print("note: %s unavailable (%s)" % (cand, str(e)[:200]), file=sys.stderr)
+                continue
             eng.step()                                   # first-touch / communicator setup
+            torch.cuda.synchronize()
+            if cand == "m_shard_allgather":
+                baseline_rows = eng.result_dense().index_select(0, sample).clone()
+            if cand in DIRECT_STRATEGIES:
+                same = baseline_rows is not None and torch.equal(
+                    eng.result_dense().index_select(0, sample), baseline_rows)
+                ok = torch.tensor([1.0 if same else 0.0], device=device)
+                comm.all_reduce(ok, "min")
+                if ok.item() < 1.0:
+                    if rank == 0:
+                        print("note: %s result differs from the RCCL variant; not used" % cand,
+                              file=sys.stderr)
+                    del eng
+                    torch.cuda.empty_cache()
+                    continue
             secs = timed_steps(eng, comm, probe)
             t = torch.tensor([secs], device=device)
             comm.all_reduce(t, "max")
@@ -131,6 +164,8 @@ def main() -> None:
                "m_shard": "m_shard%d" % world,
                "m_shard_allgather": "m_shard%d+allgather" % world,
                "k_shard_allreduce": "k_shard%d+allreduce" % world,
+               "m_shard_allgather_direct": "m_shard%d+allgather(peer memory)" % world,
+               "k_shard_allreduce_direct": "k_shard%d+allreduce(peer memory)" % world,
                "k_shard_reduce_scatter": "k_shard%d+reduce_scatter" % world,
                "summa_2d": "summa2d_%d" % world}[strategy]
         print(json.dumps({
@@ -152,7 +187,8 @@ def main() -> None:
                        "m": args.m, "n": args.n, "k": args.k,
                        "parallelism": par, "panels": engine.panels,
                        "result": "full C on every rank" if strategy in
-                       ("replicated", "m_shard_allgather", "k_shard_allreduce")
+                       ("replicated", "m_shard_allgather", "k_shard_allreduce",
+                        "m_shard_allgather_direct", "k_shard_allreduce_direct")
                        else "C left sharded"},
         }), flush=True)
     comm.close()

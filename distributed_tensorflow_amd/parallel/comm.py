@@ -141,7 +141,8 @@ class TorchDistComm(Communicator):
             kwargs = {}
             if self.device.type == "cuda":
                 torch.cuda.set_device(self.device)
-                kwargs["device_id"] = self.device
+                if self.backend == "nccl":
+                    kwargs["device_id"] = self.device
             dist.init_process_group(self.backend, init_method="tcp://%s:%d" % (addr, port),
                                     rank=rank, world_size=world_size,
                                     timeout=datetime.timedelta(seconds=timeout_s), **kwargs)
@@ -173,13 +174,29 @@ class TorchDistComm(Communicator):
         backend build knows the fp8 dtypes)."""
         return t.view(torch.uint8) if t.element_size() == 1 and t.is_floating_point() else t
 
+    def _staged(self, tensor: torch.Tensor) -> bool:
+        """gloo with GPU tensors (several ranks rehearsed on one GPU): collectives go through
+        host copies, synchronously -- gloo's own device path stalls with several asynchronous
+        collectives in flight from processes that share a device."""
+        return self.backend == "gloo" and tensor.is_cuda
+
     def broadcast(self, tensor, src=0, async_op=False):
         src = self._global(src)
         tensor = self._bytes_view(tensor)
+        if self._staged(tensor):
+            host = tensor.cpu()
+            self._wrap(lambda: self._dist.broadcast(host, src=src, group=self._group), False)
+            tensor.copy_(host)
+            return _Done() if async_op else None
         return self._wrap(lambda: self._dist.broadcast(tensor, src=src, group=self._group,
                                                        async_op=async_op), async_op)
 
     def all_reduce(self, tensor, op="sum", async_op=False):
+        if self._staged(tensor):
+            host = tensor.float().cpu() if tensor.dtype == torch.bfloat16 else tensor.cpu()
+            self.all_reduce(host, op)
+            tensor.copy_(host)
+            return _Done() if async_op else None
         if op == "avg" and self.backend == "gloo":
             work = self._wrap(lambda: self._dist.all_reduce(tensor, op=self._op("sum"),
                                                             group=self._group), False)
@@ -190,6 +207,12 @@ class TorchDistComm(Communicator):
                           async_op)
 
     def reduce_scatter(self, output, input, op="sum", async_op=False):
+        if self._staged(input):
+            host = input.float().cpu() if input.dtype == torch.bfloat16 else input.cpu()
+            self.all_reduce(host, op)
+            n = output.numel()
+            output.copy_(host.reshape(-1)[self.rank * n:(self.rank + 1) * n].reshape(output.shape))
+            return _Done() if async_op else None
         if self.backend == "gloo":          # gloo has no reduce_scatter: all_reduce + slice
             tmp = input.clone()
             self._wrap(lambda: self._dist.all_reduce(tmp, op=self._op(op), group=self._group),
@@ -201,6 +224,13 @@ class TorchDistComm(Communicator):
             output, input, op=self._op(op), group=self._group, async_op=async_op), async_op)
 
     def all_gather(self, output, input, async_op=False):
+        if self._staged(input):
+            host_in = self._bytes_view(input).cpu().reshape(-1)
+            host_out = torch.empty((self.world_size,) + tuple(host_in.shape), dtype=host_in.dtype)
+            self._wrap(lambda: self._dist.all_gather(list(host_out.unbind(0)), host_in,
+                                                     group=self._group), False)
+            self._bytes_view(output).reshape(self.world_size, -1).copy_(host_out)
+            return _Done() if async_op else None
         if self.backend == "gloo":
             chunks = list(output.reshape(self.world_size, -1).unbind(0))
             return self._wrap(lambda: self._dist.all_gather(
@@ -210,7 +240,7 @@ class TorchDistComm(Communicator):
 
     def barrier(self):
         try:
-            if self.device.type == "cuda":
+            if self.device.type == "cuda" and self.backend == "nccl":
                 self._dist.barrier(group=self._group, device_ids=[self.device.index or 0])
             else:
                 self._dist.barrier(group=self._group)

@@ -17,6 +17,10 @@ strategy                   A / B shard per rank   communication     result
 ``summa_2d``               2-D block / 2-D block  row/col broadcast 2-D block of C
 =========================  =====================  ================  ==========================
 
+``m_shard_allgather_direct`` and ``k_shard_allreduce_direct`` are the same data layouts with the
+collective done over peer-mapped memory (``parallel/peer_mem.py``): every rank pushes its rows
+to all peers at once instead of passing them round a ring. GPU only, one node only.
+
 ``summa_2d`` runs on a P x Q process grid (the most square factorisation of the world size:
 8 ranks -> 2 x 4). K is cut into L = lcm(P, Q) panels; A's block (i, j) holds the L/Q panels of
 grid column j, Bt's block the L/P panels of grid row i, each stored contiguously. Step l
@@ -55,7 +59,8 @@ from ..ops import philox
 from .comm import Communicator, SingleComm
 
 STRATEGIES = ("replicated", "m_shard", "m_shard_allgather", "k_shard_allreduce",
-              "k_shard_reduce_scatter", "summa_2d")
+              "k_shard_reduce_scatter", "summa_2d", "m_shard_allgather_direct",
+              "k_shard_allreduce_direct")
 
 
 def _split(total: int, parts: int, index: int) -> Tuple[int, int]:
@@ -101,7 +106,8 @@ class ShardedMatmul:
             self.pr, self.pc = divmod(self.rank, self.grid_cols)
             self.row_comm = self.comm.split(self.pr, self.pc)     # ranks of my grid row
             self.col_comm = self.comm.split(self.pc, self.pr)     # ranks of my grid column
-        if strategy in ("m_shard", "m_shard_allgather", "k_shard_reduce_scatter") \
+        if strategy in ("m_shard", "m_shard_allgather", "k_shard_reduce_scatter",
+                        "m_shard_allgather_direct", "k_shard_allreduce_direct") \
                 and self.m % w:
             raise ValueError("M=%d must be divisible by the world size %d" % (self.m, w))
         if strategy.startswith("k_shard") and self.k % w:
@@ -173,7 +179,15 @@ class ShardedMatmul:
         m, n, w = self.m, self.n, self.world
         s = self.strategy
         dev, dt = self.device, self.out_dtype
-        if s in ("replicated", "m_shard_allgather", "k_shard_allreduce"):
+        if s in ("m_shard_allgather_direct", "k_shard_allreduce_direct"):
+            from .peer_mem import SymmetricBuffer
+            self._sym_c = SymmetricBuffer(self.comm, (m, n), dt, dev)
+            self.c = self._sym_c.local
+            if s == "k_shard_allreduce_direct":
+                self._sym_partial = SymmetricBuffer(self.comm, (m, n), self.reduce_dtype, dev)
+                self._stage = torch.empty((max(1, w - 1), m // w, n), dtype=self.reduce_dtype,
+                                          device=dev)
+        elif s in ("replicated", "m_shard_allgather", "k_shard_allreduce"):
             self.c = torch.empty((m, n), dtype=dt, device=dev)
         elif s in ("m_shard", "k_shard_reduce_scatter"):
             self.c = torch.empty((m // w, n), dtype=dt, device=dev)
@@ -230,7 +244,48 @@ class ShardedMatmul:
             return self._step_k_allreduce()
         if s == "k_shard_reduce_scatter":
             return self._step_k_reduce_scatter()
+        if s == "m_shard_allgather_direct":
+            return self._step_m_allgather_direct()
+        if s == "k_shard_allreduce_direct":
+            return self._step_k_allreduce_direct()
         return self._step_summa()
+
+    def _step_m_allgather_direct(self) -> torch.Tensor:
+        """Row panels of the local block are computed straight into this rank's rows of the
+        symmetric result buffer; the push of panel p to all peers (one copy per peer, each on
+        its own stream and link) is queued behind panel p's product and runs while panel p+1
+        is computed. One host synchronisation + barrier per step completes the exchange."""
+        w, p = self.world, self.panels
+        ml = self.m // w
+        rows = ml // p
+        base = self.rank * ml
+        for i in range(p):
+            r0 = base + i * rows
+            self._gemm(self.a[i * rows:(i + 1) * rows], self.bt, self.c[r0:r0 + rows])
+            self._sym_c.push_rows(r0, rows)
+        self._sym_c.finish()
+        return self.c
+
+    def _step_k_allreduce_direct(self) -> torch.Tensor:
+        """Two-shot all-reduce over peer memory: every rank pulls its M/world rows of all
+        ranks' partial products (N-1 concurrent copies), sums them in rank order, and pushes
+        the finished rows to all peers."""
+        from .peer_mem import reduce_scatter_rows
+        w, r = self.world, self.rank
+        per = self.m // w
+        part = self._sym_partial
+        self._gemm(self.a, self.bt, part.local)
+        part.quiesce()
+        mine = self.c[r * per:(r + 1) * per]
+        if self.reduce_dtype == self.out_dtype:
+            reduce_scatter_rows(part, mine, r * per, per, self._stage)
+        else:
+            tmp = torch.empty((per, self.n), dtype=self.reduce_dtype, device=self.device)
+            reduce_scatter_rows(part, tmp, r * per, per, self._stage)
+            mine.copy_(tmp)
+        self._sym_c.push_rows(r * per, per)
+        self._sym_c.finish()
+        return self.c
 
     def _step_m_allgather(self) -> torch.Tensor:
         """Row panels of the local block: GEMM panel p, then all-gather it while panel p+1 is
@@ -326,7 +381,8 @@ class ShardedMatmul:
     def rows_of_result(self) -> np.ndarray:
         """Global row index of every row of ``result_dense()``."""
         s, w, r, p = self.strategy, self.world, self.rank, self.panels
-        if s in ("replicated", "m_shard_allgather", "k_shard_allreduce"):
+        if s in ("replicated", "m_shard_allgather", "k_shard_allreduce",
+                 "m_shard_allgather_direct", "k_shard_allreduce_direct"):
             return np.arange(self.m)
         if s == "m_shard":
             return np.arange(self.m // w) + r * (self.m // w)

@@ -1,0 +1,74 @@
+"""Rank body for the peer-memory collective tests: N processes that all use GPU 0.
+
+RCCL refuses two ranks on one device, so the control plane here is gloo; the data plane -- HIP
+IPC mapped buffers, peer copies, the reduce kernel -- is the code that runs between GPUs of a
+node. Each rank writes ``<out_dir>/rank<r>.json``."""
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from distributed_tensorflow_amd.parallel.comm import SingleComm, TorchDistComm  # noqa: E402
+from distributed_tensorflow_amd.parallel.peer_mem import (SymmetricBuffer, all_gather_rows,  # noqa: E402
+                                                          all_reduce_rows)
+from distributed_tensorflow_amd.parallel.sharded_matmul import ShardedMatmul  # noqa: E402
+
+
+def main() -> int:
+    out_dir = sys.argv[1]
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    comm = TorchDistComm(device=dev, backend="gloo")
+    rank, world = comm.rank, comm.world_size
+    res = {"rank": rank, "world": world}
+
+    # all-gather: rank r owns rows [4r, 4r+4)
+    buf = SymmetricBuffer(comm, (4 * world, 256), torch.float32, dev)
+    buf.local.zero_()
+    buf.quiesce()                                  # nobody pushes into a buffer being zeroed
+    buf.local[4 * rank:4 * rank + 4] = float(rank + 1)
+    for _ in range(3):                             # repeated use of the same buffer
+        all_gather_rows(buf, 4)
+    want = torch.arange(1, world + 1, dtype=torch.float32, device=dev).repeat_interleave(4)
+    res["all_gather_ok"] = bool((buf.local == want[:, None]).all().item())
+
+    # two-shot all-reduce of bf16 partials
+    part = SymmetricBuffer(comm, (8 * world, 128), torch.bfloat16, dev)
+    total = SymmetricBuffer(comm, (8 * world, 128), torch.bfloat16, dev)
+    rows = torch.arange(8 * world, device=dev, dtype=torch.float32)[:, None]
+    part.local.copy_(((rank + 1) * (rows + 1)).expand(-1, 128))
+    all_reduce_rows(part, total)
+    s = world * (world + 1) / 2
+    want = (s * (rows + 1)).expand(-1, 128).to(torch.bfloat16)
+    res["all_reduce_ok"] = bool((total.local == want).all().item())
+
+    # sharded GEMM over peer memory against the single-process product
+    m, n, k = 1024, 512, 256
+    ref = ShardedMatmul(m, n, k, SingleComm(dev), dtype=torch.bfloat16, strategy="replicated",
+                        seed=5, device=dev)
+    ref.init_operands()
+    want = ref.step().float()
+    errs = {}
+    for strategy, panels in (("m_shard_allgather_direct", 2), ("k_shard_allreduce_direct", None)):
+        eng = ShardedMatmul(m, n, k, comm, dtype=torch.bfloat16, strategy=strategy, seed=5,
+                            device=dev, panels=panels)
+        eng.init_operands()
+        for _ in range(2):
+            got = eng.step()
+        torch.cuda.synchronize()
+        errs[strategy] = (got.float() - want).abs().max().item()
+    res["gemm_errs"] = errs
+    res["ref_scale"] = want.abs().max().item()
+    with open(os.path.join(out_dir, "rank%d.json" % rank), "w") as fh:
+        json.dump(res, fh)
+    comm.barrier()
+    comm.close()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -84,7 +84,7 @@ def test_loopback_fault_injection_detects_dead_and_slow_ranks():
     assert torch.equal(t, torch.ones(3)) and single.split(0).world_size == 1
 
 
-@pytest.mark.parametrize("strategy", STRATEGIES)
+@pytest.mark.parametrize("strategy", [s for s in STRATEGIES if not s.endswith("_direct")])
 @pytest.mark.parametrize("world", [1, 2, 4, 8])
 def test_sharded_matmul_strategies_match_reference(strategy, world):
     def fn(c):
@@ -435,3 +435,13 @@ def test_local_server_and_server_validation():
         tf.Session("grpc://nowhere:1")
     sd = tf.train.Server(c, job_name="worker", task_index=1, start=False).server_def
     assert sd.job_name == "worker" and sd.task_index == 1 and sd.SerializeToString()
+
+
+def test_peer_memory_strategies_need_a_gpu():
+    """The peer-memory strategies map GPU allocations between processes: on a CPU device they
+    refuse with a clear error instead of falling back silently."""
+    from distributed_tensorflow_amd.parallel.peer_mem import PeerMemError
+    eng = ShardedMatmul(64, 64, 64, SingleComm(torch.device("cpu")), dtype=torch.float32,
+                        strategy="m_shard_allgather_direct", device=torch.device("cpu"))
+    with pytest.raises(PeerMemError):
+        eng.init_operands()

@@ -359,7 +359,7 @@ def test_sharded_matmul_fp8_single_gpu(hip):
                                           (64, 64, 4096, False, True), (100, 100, 784, True, False),
                                           (130, 70, 300, True, True), (1000, 1000, 1000, False, False)])
 def test_gemm_f32_split_k(hip, m, n, k, ta, tb):
-    """Few output tiles + long K take the split-K path (ticketed last-workgroup reduction):
+    """Few output tiles + long K take the split-K path (partial planes + reduce kernel):
     exact on integer data, bit-identical across repeated launches, bias + activation applied
     once, after the reduction."""
     g = torch.Generator().manual_seed(k)
@@ -557,3 +557,19 @@ def test_gemm_fp8_writes_only_its_output(hip, m, n, k):
     hip.gemm_fp8_nt(a.to(FP8).cuda(), bt.to(FP8).cuda(), torch.float32, out=view)
     assert torch.equal(view.cpu(), a @ bt.t())
     assert _band_intact(big, (m, n), origin, sentinel)
+
+
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("m,n,k,splits,tile", [(300, 200, 2048, 2, 64), (300, 200, 2048, 1, 64),
+                                               (520, 388, 1000, 1, 128), (260, 132, 1536, 3, 128)])
+def test_gemm_f32_interior_tiles_exact(hip, m, n, k, splits, tile, ta, tb):
+    """Long K ranges run the buffer-load loop for interior K-tiles (inside each split, too) and
+    the clamped loop for the tail: integer data must come out exact in every layout, with M and
+    N edges that are multiples of 4 but not of the block tile."""
+    g = torch.Generator().manual_seed(m + k + splits)
+    a = torch.randint(-3, 4, (m, k), generator=g).float().cuda()
+    b = torch.randint(-3, 4, (k, n), generator=g).float().cuda()
+    a_in = a.t().contiguous() if ta else a
+    b_in = b.t().contiguous() if tb else b
+    out = hip.gemm_f32(a_in, b_in, ta, tb, splits=splits, tile=tile)
+    assert torch.equal(out, a @ b)

@@ -62,6 +62,7 @@ def main() -> int:
     job, idx = tf.train.task_from_env()
     server = tf.train.Server(cluster, job_name=job, task_index=idx, protocol="rccl",
                              config=tf.ConfigProto(device="cpu", strategy=strategy), comm=comm)
+    bucket_bytes = int(os.environ.get("DTF_BUCKET_BYTES", "0")) or None
     with tf.device(tf.train.replica_device_setter(cluster=cluster)):
         step = tf.train.get_or_create_global_step()
         x = tf.placeholder(tf.float32, [None, 4])
@@ -75,7 +76,8 @@ def main() -> int:
                              recovery_wait_secs=0.1)
     g = torch.Generator().manual_seed(100 + rank)          # every rank its own data
     true_w = torch.tensor([[1.0], [-2.0], [0.5], [3.0]])
-    with sv.prepare_or_wait_for_session(server.target) as sess:
+    run_config = tf.ConfigProto(device="cpu", strategy=strategy, grad_bucket_bytes=bucket_bytes)
+    with sv.prepare_or_wait_for_session(server.target, config=run_config) as sess:
         first = last = None
         for _ in range(60):
             bx = torch.randn(16, 4, generator=g)
@@ -86,6 +88,7 @@ def main() -> int:
         out["loss_first"], out["loss_last"] = float(first), float(last)
         out["w"] = [float(v) for v in sess.run(w).reshape(-1)]
         out["step"] = float(sess.run(step))
+        out["buckets_issued"] = getattr(server.runtime, "buckets_issued", 0)
     sv.stop()
     server.stop()
     with open(os.path.join(os.environ["DTF_RESULT_DIR"], "rank%d.json" % rank), "w") as fh:

@@ -232,11 +232,11 @@ def _cluster(num_workers=2):
 
 
 def _worker_job(cluster, task, steps, results, protocol="grpc", comm=None, strategy=None,
-                lr=0.05, logdir=None, start_delay=0.0):
+                lr=0.05, logdir=None, start_delay=0.0, bucket_bytes=None):
     time.sleep(start_delay)
     g = tf.Graph()
     with g.as_default():
-        config = tf.ConfigProto(device="cpu", strategy=strategy)
+        config = tf.ConfigProto(device="cpu", strategy=strategy, grad_bucket_bytes=bucket_bytes)
         server = tf.train.Server(cluster, job_name="worker", task_index=task, protocol=protocol,
                                  config=config, comm=comm)
         with tf.device(tf.train.replica_device_setter(
@@ -260,9 +260,10 @@ def _worker_job(cluster, task, steps, results, protocol="grpc", comm=None, strat
                      (("w1", m.w1), ("b2", m.b2), ("step", m.global_step))}
             placement = (m.w1.device, m.x.device, m.train_op.device)
             types = {s.node.type for p in sess._plans.values() for s in p.steps}
+            buckets = max(p.grad_buckets for p in sess._plans.values())
         sv.stop()
         results[task] = dict(costs=costs, final=final, placement=placement, types=types,
-                             runtime=server.runtime)
+                             runtime=server.runtime, grad_buckets=buckets)
         server.stop()
 
 
@@ -311,6 +312,36 @@ def test_sync_collective_job_keeps_replicas_identical(strategy):
     assert results[0]["costs"] != results[1]["costs"]    # different data on each worker
     assert np.mean(results[0]["costs"][-5:]) < np.mean(results[0]["costs"][:5])
     assert results[0]["runtime"].bytes_reduced > 0
+
+
+def test_bucketed_gradient_allreduce_overlaps_backward_and_matches_single_bucket():
+    """With a small bucket size the head's gradients are all-reduced while the first layer's
+    weight gradient is still being computed; the trained weights are bit-identical to the
+    single-collective run."""
+    world, steps = 2, 12
+    finals = {}
+    for label, bucket_bytes in (("one", None), ("bucketed", 4096)):
+        cluster = tf.train.ClusterSpec({"worker": ["127.0.0.1:%d" % _free_port()
+                                                   for _ in range(world)]})
+        comms = LoopbackComm.create_world(world, timeout_s=30)
+        results = {}
+        threads = [threading.Thread(target=_worker_job, args=(cluster, t, steps, results),
+                                    kwargs=dict(protocol="rccl", comm=comms[t],
+                                                strategy="allreduce_sync",
+                                                bucket_bytes=bucket_bytes))
+                   for t in range(world)]
+        [t.start() for t in threads]
+        [t.join(120) for t in threads]
+        assert set(results) == {0, 1}
+        finals[label] = results
+    one, many = finals["one"], finals["bucketed"]
+    assert one[0]["grad_buckets"] == 0 and one[0]["runtime"].buckets_issued == 0
+    assert many[0]["grad_buckets"] == 2                  # {b2, W2, b1} then {W1}
+    assert many[0]["runtime"].buckets_issued == 2 * steps
+    for t in range(world):
+        assert np.array_equal(one[t]["final"]["w1"], many[t]["final"]["w1"])
+        assert np.array_equal(one[t]["final"]["b2"], many[t]["final"]["b2"])
+        assert one[t]["costs"] == many[t]["costs"]
 
 
 def test_sync_sum_of_gradients_equals_sequential_application():

@@ -94,11 +94,12 @@ def test_mnist_example_two_collective_ranks(strategy, tmp_path):
     assert len(acc) == 2 and acc[0] == acc[1]       # replicas stay identical
 
 
-@pytest.mark.parametrize("strategy", ["allreduce_sync", "reduce_scatter_sync"])
-def test_gloo_two_process_comm_matmul_and_training(strategy, tmp_path):
+@pytest.mark.parametrize("strategy,bucket_bytes", [("allreduce_sync", 0), ("allreduce_sync", 8),
+                                                   ("reduce_scatter_sync", 0)])
+def test_gloo_two_process_comm_matmul_and_training(strategy, bucket_bytes, tmp_path):
     from distributed_tensorflow_amd.train.server import _free_port
     env = dict(os.environ, PYTHONPATH=ROOT, DTF_STRATEGY=strategy, OMP_NUM_THREADS="2",
-               DTF_RESULT_DIR=str(tmp_path))
+               DTF_RESULT_DIR=str(tmp_path), DTF_BUCKET_BYTES=str(bucket_bytes))
     proc = subprocess.run(
         [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
          "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
@@ -120,6 +121,8 @@ def test_gloo_two_process_comm_matmul_and_training(strategy, tmp_path):
         assert max(r["matmul_err"].values()) < 1e-3
         assert r["loss_last"] < 0.05 * r["loss_first"]
         assert r["step"] == 60.0
+        # 8-byte buckets: {b} and {w} are all-reduced asynchronously during the backward pass
+        assert r["buckets_issued"] == (120 if bucket_bytes else 0)
     assert results[0]["w"] == results[1]["w"]        # bit-identical replicas
 
 

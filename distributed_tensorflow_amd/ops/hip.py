@@ -89,7 +89,8 @@ def _declare(L: ctypes.CDLL) -> None:
         "dtf_mlp_head_supported": [LG, LG, LG],
         "dtf_mlp_head_train": [P, P, P, P, P, P, P, P, P, P, P, P, P, LG, LG, LG, I, P],
         "dtf_mlp_head_workspace": [LG, LG, LG],
-        "dtf_argmax_accuracy_f32": [P, P, P, LG, LG, P],
+        "dtf_argmax_accuracy_f32": [P, P, P, P, LG, LG, P],
+        "dtf_argmax_accuracy_workspace": [LG],
         "dtf_softmax_rows_f32": [P, P, P, LG, LG, P],
         "dtf_softmax_xent_workspace": [LG],
         "dtf_softmax_xent_f32": [P, P, P, P, P, P, LG, LG, P],
@@ -623,9 +624,12 @@ def argmax_accuracy(y: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
     labels = _req(labels, torch.float32, "argmax_accuracy labels")
     if y.dim() != 2 or y.shape != labels.shape or y.shape[1] == 0:
         raise HipKernelError("argmax_accuracy: need matching rank-2 inputs")
-    out = torch.empty((), dtype=torch.float32, device=y.device)
+    ws_n = int(lib().dtf_argmax_accuracy_workspace(y.shape[0]))
+    buf = torch.empty(1 + ws_n, dtype=torch.float32, device=y.device)
+    out = buf[0].view(())
     _check(lib().dtf_argmax_accuracy_f32(y.data_ptr(), labels.data_ptr(), out.data_ptr(),
-                                         y.shape[0], y.shape[1], _stream()), "argmax_accuracy")
+                                         buf[1:].data_ptr(), y.shape[0], y.shape[1], _stream()),
+           "argmax_accuracy")
     return out
 
 

@@ -285,12 +285,17 @@ __device__ __forceinline__ void pp_tile_of_block(int bid, int tiles_m, int tiles
 //   K-tile. A phase then reads (B0, A0, B1) or (A1) and stages two half-tiles;
 //   the half-tile stream still runs six ahead (1.5 K-tiles), with vmcnt(6) = three half-tiles
 //   in flight across each barrier.
+// PERSIST = FP8 ? false : true: the fp8 instantiation already uses 254 VGPRs (its MFMA takes
+//   8-register operands) and spills with the few more the tile loop keeps live, so it runs one
+//   tile per workgroup; a spill inside the K loop would also add scratch loads to the vmcnt
+//   stream the counted waits rely on.
 template <bool OUT_F32, int DBG, bool FP8, bool MERGE = false>
 __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
     const char* __restrict__ A, const char* __restrict__ Bt,
     void* __restrict__ C, int M, int N, int K, long lda, long ldb, long ldc, int tiles_m,
     int tiles_n, float alpha, float beta) {
   constexpr int ESIZE = FP8 ? 1 : 2;
+  constexpr bool PERSIST = !FP8 && !(DBG & 32);     // DBG bit 5: one tile per workgroup
   // DBG (timing experiments only, built with -DDTF_GEMM_EXPERIMENTS; results are wrong when
   // set): bit 0 = issue no LDS-DMA in the K-loop, bit 1 = always stage K-tile 0 (every load an
   // L2 hit), bit 2 = skip the counted wait, bit 3 = per-phase cycle sums, bit 4 = chunk walk
@@ -300,20 +305,24 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
 
-  int tm, tn;
-  pp_tile_of_block(blockIdx.x, tiles_m, tiles_n, tm, tn, (DBG & 16) != 0);
-  const int m0 = tm * BM, n0 = tn * BN;
+  // Persistent over tiles: workgroup b computes tiles b, b + gridDim, b + 2 gridDim, ... (the
+  // launcher starts one workgroup per CU). When a tile's K loop ends, every LDS slot is dead,
+  // so the first six half-tiles of the NEXT tile are requested before the epilogue of this one:
+  // their memory latency hides behind the 128 KiB of result stores instead of opening each
+  // tile with an idle matrix pipe.
+  const int ntiles = tiles_m * tiles_n;
   const int nkt = K / (128 / ESIZE);
+  int tile = blockIdx.x;
+  int m0, n0;
+  {
+    int tm, tn;
+    pp_tile_of_block(tile, tiles_m, tiles_n, tm, tn, (DBG & 16) != 0);
+    m0 = tm * BM;
+    n0 = tn * BN;
+  }
+  const int first_m0 = m0, first_n0 = n0;
 
   f32x4 acc[2][2][4][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   i32x4 af[4][2];         // [m-tile][16-byte k-chunk] of the current A half
   i32x4 bf[2][2][2];      // [n-half][n-tile][k-chunk]: both Bt halves stay resident
 
@@ -329,17 +338,35 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
   unsigned seg[4][6] = {};
   unsigned voff[4][2];
   stage_offsets<ESIZE>(voff, lda, ldb, m0, n0, M, N, wave, lane);
-  const __amdgpu_buffer_rsrc_t a_tile = tile_rsrc(A + (long)m0 * lda * ESIZE);
-  const __amdgpu_buffer_rsrc_t b_tile = tile_rsrc(Bt + (long)n0 * ldb * ESIZE);
+  __amdgpu_buffer_rsrc_t a_tile = tile_rsrc(A + (long)m0 * lda * ESIZE);
+  __amdgpu_buffer_rsrc_t b_tile = tile_rsrc(Bt + (long)n0 * ldb * ESIZE);
 
-  // prologue: half-tiles 0..5 in flight, 0 and 1 landed and visible
+  // prologue of the first tile: half-tiles 0..5 in flight
 #pragma unroll
   for (int h = 0; h < 6; ++h)
     stage_half(a_tile, b_tile, voff, h, nkt, h & 3, (h >> 2) & 1, smem, wave);
-  if constexpr (MERGE) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // half-tiles 0-2 landed
-  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                   // half-tiles 0-1 landed
+  bool first = true;
+
+  for (;;) {
+  if (first) {
+    if constexpr (MERGE) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // half-tiles 0-2 landed
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                   // half-tiles 0-1 landed
+  } else {
+    // prologue requested before the previous epilogue: wait for it and for those stores
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  first = false;
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();          // waves 4-7 run one barrier behind
+
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #define DTF_READ_A(MH, BUFI)                                                                     \
   _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) \
@@ -460,19 +487,41 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
 #undef DTF_READ_A
 #undef DTF_READ_B
   if (wr == 0) __builtin_amdgcn_s_barrier();          // every wave has passed the same count
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // no LDS-DMA may outlive the workgroup
-  // epilogue: lane holds C[row = frow][col = 4*fq + r] of each 16x16 tile
+  // every wave has finished reading LDS: request the next tile's first half-tiles now
+  const int cm0 = m0, cn0 = n0;                        // this tile's origin, for the epilogue
+  tile += gridDim.x;
+  const bool more = PERSIST && tile < ntiles;
+  if (more) {
+    int tm, tn;
+    pp_tile_of_block(tile, tiles_m, tiles_n, tm, tn, (DBG & 16) != 0);
+    m0 = tm * BM;
+    n0 = tn * BN;
+    int o_lane = lane;                    // opaque copy: keeps the offset arithmetic out of the
+    asm volatile("" : "+v"(o_lane));      // K loop's live registers (see the epilogue)
+    stage_offsets<ESIZE>(voff, lda, ldb, m0, n0, M, N, wave, o_lane);
+    a_tile = tile_rsrc(A + (long)m0 * lda * ESIZE);
+    b_tile = tile_rsrc(Bt + (long)n0 * ldb * ESIZE);
+#pragma unroll
+    for (int h = 0; h < 6; ++h)
+      stage_half(a_tile, b_tile, voff, h, nkt, h & 3, (h >> 2) & 1, smem, wave);
+  }
+  // epilogue: lane holds C[row = frow][col = 4*fq + r] of each 16x16 tile. The lane's row and
+  // column pass through an opaque copy so that the address arithmetic stays HERE: hoisted out
+  // of the tile loop it would occupy ~20 VGPRs across the K loop (the fp8 instantiation then
+  // spills, and scratch reloads inside the K loop would also break its counted vmcnt waits).
+  int e_frow = frow, e_fq = fq;
+  asm volatile("" : "+v"(e_frow), "+v"(e_fq));
 #pragma unroll
   for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int row = m0 + mh * 128 + wr * 64 + i * 16 + frow;
+      const int row = cm0 + mh * 128 + wr * 64 + i * 16 + e_frow;
       if (row >= M) continue;
 #pragma unroll
       for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const int col = n0 + nh * 128 + wc * 32 + j * 16 + 4 * fq;
+          const int col = cn0 + nh * 128 + wc * 32 + j * 16 + 4 * e_fq;
           if (col >= N) continue;
           f32x4 v = acc[mh][nh][i][j] * alpha;
           if (OUT_F32) {
@@ -500,11 +549,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
           }
         }
     }
-  if constexpr ((dbg & 8) != 0) {   // overwrite the head of the tile's rows 0-7 with the sums
+  if (!more) break;
+  }   // tile loop
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // no LDS-DMA may outlive the workgroup
+  if constexpr ((dbg & 8) != 0) {   // overwrite the head of the first tile's rows 0-7 with the sums
     __syncthreads();
-    if (lane == 0 && m0 + 8 <= M && n0 + 64 <= N) {
+    if (lane == 0 && first_m0 + 8 <= M && first_n0 + 64 <= N) {
       unsigned* dst = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(C) +
-                                                  ((long)(m0 + wave) * ldc + n0) *
+                                                  ((long)(first_m0 + wave) * ldc + first_n0) *
                                                       (OUT_F32 ? 4 : 2));
 #pragma unroll
       for (int p = 0; p < 4; ++p)
@@ -840,6 +892,21 @@ __global__ __launch_bounds__(256) void gemm_fp8_generic_kernel(
 // variant >> 4: timing-experiment bits of the one-quadrant ping-pong kernel (0 in production).
 // The staging DMA addresses a block tile with 32-bit offsets: 256 rows of lda / ldb bytes must
 // stay below 4 GiB (DTF_ERR_UNSUPPORTED otherwise).
+// workgroups of the persistent ping-pong kernel: one per CU (128 KiB of LDS each), fewer when
+// there are fewer tiles
+static int dtf_pp_grid(int ntiles) {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        n <= 0)
+      n = 256;
+    cus = n;
+  }
+  return ntiles < cus ? ntiles : cus;
+}
+
 template <typename KernelT>
 static void dtf_allow_lds(KernelT kernel, size_t lds) {
   hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -870,6 +937,7 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
     attr_set = true;
   }
   dim3 grid(tiles_m * tiles_n), block(NTHREADS);
+  const dim3 pp_grid(dtf_pp_grid(tiles_m * tiles_n));
   if ((variant & 15) == 3) {       // four-wave kernel
     static bool w4_attr = false;
     const size_t w4_lds = 2 * BUF_BYTES;
@@ -915,23 +983,28 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
       dtf_allow_lds(gemm_nt_pp_kernel<false, 10, false, true>, lds + 1024);
       dtf_allow_lds(gemm_nt_pp_kernel<false, 9, false, true>, lds + 1024);
       dtf_allow_lds(gemm_nt_pp_kernel<false, 16, false, true>, lds);
+      dtf_allow_lds(gemm_nt_pp_kernel<false, 32, false, true>, lds);
       e_attr = true;
     }
     const int dbg = variant >> 4;
     if (dbg == 8)
-      hipLaunchKernelGGL((gemm_nt_pp_kernel<false, 8, false, true>), grid, block, lds + 1024,
+      hipLaunchKernelGGL((gemm_nt_pp_kernel<false, 8, false, true>), pp_grid, block, lds + 1024,
                          stream, (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc,
                          tiles_m, tiles_n, alpha, beta);
     else if (dbg == 10)
-      hipLaunchKernelGGL((gemm_nt_pp_kernel<false, 10, false, true>), grid, block, lds + 1024,
+      hipLaunchKernelGGL((gemm_nt_pp_kernel<false, 10, false, true>), pp_grid, block, lds + 1024,
                          stream, (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc,
                          tiles_m, tiles_n, alpha, beta);
     else if (dbg == 9)
-      hipLaunchKernelGGL((gemm_nt_pp_kernel<false, 9, false, true>), grid, block, lds + 1024,
+      hipLaunchKernelGGL((gemm_nt_pp_kernel<false, 9, false, true>), pp_grid, block, lds + 1024,
                          stream, (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc,
                          tiles_m, tiles_n, alpha, beta);
     else if (dbg == 16)
-      hipLaunchKernelGGL((gemm_nt_pp_kernel<false, 16, false, true>), grid, block, lds, stream,
+      hipLaunchKernelGGL((gemm_nt_pp_kernel<false, 16, false, true>), pp_grid, block, lds, stream,
+                         (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tiles_m,
+                         tiles_n, alpha, beta);
+    else if (dbg == 32)
+      hipLaunchKernelGGL((gemm_nt_pp_kernel<false, 32, false, true>), grid, block, lds, stream,
                          (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tiles_m,
                          tiles_n, alpha, beta);
     else return DTF_ERR_UNSUPPORTED;
@@ -947,11 +1020,11 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
       m_attr = true;
     }
     if (out_f32)
-      hipLaunchKernelGGL((gemm_nt_pp_kernel<true, 0, false, true>), grid, block, lds, stream,
+      hipLaunchKernelGGL((gemm_nt_pp_kernel<true, 0, false, true>), pp_grid, block, lds, stream,
                          (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tiles_m,
                          tiles_n, alpha, beta);
     else
-      hipLaunchKernelGGL((gemm_nt_pp_kernel<false, 0, false, true>), grid, block, lds, stream,
+      hipLaunchKernelGGL((gemm_nt_pp_kernel<false, 0, false, true>), pp_grid, block, lds, stream,
                          (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tiles_m,
                          tiles_n, alpha, beta);
     DTF_LAUNCH_CHECK();
@@ -960,7 +1033,7 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
   if ((variant & 15) == 1 && beta != 0.f) return DTF_ERR_UNSUPPORTED;
   if ((variant & 15) != 1) {
 #define DTF_PP_LAUNCH(F32, DBGV)                                                                  \
-  hipLaunchKernelGGL((gemm_nt_pp_kernel<F32, DBGV, false>), grid, block, lds, stream,             \
+  hipLaunchKernelGGL((gemm_nt_pp_kernel<F32, DBGV, false>), pp_grid, block, lds, stream,             \
                      (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tiles_m,         \
                      tiles_n, alpha, beta)
     const int dbg = variant >> 4;
@@ -1009,7 +1082,7 @@ DTF_API int dtf_gemm_fp8_nt(const void* A, const void* Bt, void* C, int M, int N
     dtf_allow_lds(gemm_nt_pp_kernel<false, 0, true, true>, lds);
     attr_set = true;
   }
-  dim3 grid(tiles_m * tiles_n), block(NTHREADS);
+  const dim3 grid(tiles_m * tiles_n), block(NTHREADS);     // one tile per workgroup (no tile loop)
 #ifdef DTF_GEMM_EXPERIMENTS
   if (getenv("DTF_PP_CHUNK_WALK") && !out_f32) {
     static bool e_attr = false;

@@ -16,7 +16,6 @@ protobufs; the first record carries ``file_version = "brain.Event:2"``.
 from __future__ import annotations
 
 import os
-import queue
 import socket
 import struct
 import threading
@@ -205,10 +204,15 @@ class _NativeEventsFile:
 
 
 class EventFileWriter:
-    """Asynchronous writer: ``add_event`` enqueues, a daemon thread frames and writes, and
-    the file is flushed every ``flush_secs``."""
+    """Asynchronous writer: ``add_event`` appends to a pending list, a daemon thread frames and
+    writes what has accumulated every few milliseconds, and the file is flushed every
+    ``flush_secs``. The thread sleeps on a timer rather than on the queue: waking it per event
+    costs the training loop a GIL hand-over per step (measured ~50 us per step against a 76 us
+    step). ``max_queue`` keeps its meaning as back-pressure: a producer that finds more than
+    ``max(max_queue, 4096)`` events pending writes them itself."""
 
     _serial = 0
+    _POLL_SECS = 0.02
 
     def __init__(self, logdir: str, max_queue: int = 10, flush_secs: float = 120.0,
                  filename_suffix: str = ""):
@@ -224,10 +228,13 @@ class EventFileWriter:
         lib = native.load()
         self._file = _NativeEventsFile(lib, self.path) if lib is not None \
             else _PyEventsFile(self.path)
-        self._queue: "queue.Queue" = queue.Queue(max_queue)
+        self._pending: List[bytes] = []
+        self._cap = max(int(max_queue), 4096)
         self._flush_secs = flush_secs
         self._closed = False
-        self._lock = threading.Lock()
+        self._lock = threading.Lock()          # guards _pending
+        self._file_lock = threading.Lock()     # guards the file; taken before _lock is released
+        self._stop = threading.Event()
         self._worker = threading.Thread(target=self._run, name="EventFileWriter", daemon=True)
         self._file.write(encode_event(time.time(), file_version="brain.Event:2"))
         self._file.flush()
@@ -236,36 +243,37 @@ class EventFileWriter:
     def get_logdir(self) -> str:
         return self._logdir
 
+    def _drain(self) -> None:
+        """Write everything pending, in order (callable from any thread)."""
+        with self._file_lock:
+            with self._lock:
+                items, self._pending = self._pending, []
+            for item in items:
+                self._file.write(item)
+
     def _run(self) -> None:
         next_flush = time.time() + self._flush_secs
-        while True:
-            try:
-                item = self._queue.get(timeout=max(0.0, min(1.0, next_flush - time.time())))
-            except queue.Empty:
-                item = None
-            if item is _STOP:
-                self._queue.task_done()
-                return
-            if item is not None:
-                try:
-                    with self._lock:
-                        self._file.write(item)
-                finally:
-                    self._queue.task_done()
+        while not self._stop.wait(self._POLL_SECS):
+            self._drain()
             if time.time() >= next_flush:
-                with self._lock:
+                with self._file_lock:
                     self._file.flush()
                 next_flush = time.time() + self._flush_secs
 
     def add_event(self, event: bytes) -> None:
-        if not self._closed:
-            self._queue.put(event)
+        if self._closed:
+            return
+        with self._lock:
+            self._pending.append(event)
+            backlog = len(self._pending)
+        if backlog >= self._cap:
+            self._drain()
 
     def flush(self) -> None:
         if self._closed:
             return
-        self._queue.join()
-        with self._lock:
+        self._drain()
+        with self._file_lock:
             self._file.flush()
 
     def close(self) -> None:
@@ -273,13 +281,11 @@ class EventFileWriter:
             return
         self.flush()
         self._closed = True
-        self._queue.put(_STOP)
+        self._stop.set()
         self._worker.join(timeout=5.0)
-        with self._lock:
+        with self._file_lock:
             self._file.close()
 
-
-_STOP = object()
 
 
 class FileWriter:

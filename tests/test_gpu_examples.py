@@ -66,3 +66,22 @@ def test_linear_regression_example_on_gpu():
     assert rc == 0, out
     err = float(re.search(r"Weight-Error: (\d+\.\d+)", out).group(1))
     assert err < 0.05
+
+
+def test_device_resident_batches_match_host_batches():
+    """``DataSet.to_device``: batches come from a per-epoch device-side shuffle (views of the
+    permuted set) and must equal the host path's batches, including the one that straddles an
+    epoch boundary."""
+    import numpy as np
+    import torch
+    from distributed_tensorflow_amd.data.mnist import DataSet, synthetic_mnist
+    images, labels = synthetic_mnist(230, seed=3)
+    onehot = np.eye(10, dtype=np.float32)[labels]
+    host = DataSet(images, onehot, seed=7)
+    dev = DataSet(images, onehot, seed=7).to_device("cuda")
+    for _ in range(12):                      # 230 = 2 * 100 + 30: boundaries fall inside batches
+        hx, hy = host.next_batch(100)
+        dx, dy = dev.next_batch(100)
+        assert isinstance(dx, torch.Tensor) and dx.is_cuda
+        assert np.array_equal(dx.cpu().numpy(), hx) and np.array_equal(dy.cpu().numpy(), hy)
+    assert host.epochs_completed == dev.epochs_completed == 5

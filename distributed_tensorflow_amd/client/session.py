@@ -659,8 +659,8 @@ class Session:
         cap.h2d_done = None
         for static, f in zip(cap.static_feeds, feeds):
             static.copy_(f)
-        # small fp32 results (loss, step, accuracy ...) are packed into one pinned buffer by
-        # copy nodes inside the graph, so a step needs a single stream synchronisation. The
+        # small fp32 results (loss, step, accuracy ...) are packed into one pinned buffer by a
+        # gather kernel inside the graph, so a step needs a single stream synchronisation. The
         # pinned buffer is allocated before capture starts (host allocation is not capturable).
         want = [sl for sl in plan.fetch_slots if sl is not None] + plan.host_input_slots
         host_buf = torch.empty(_PACK_WORDS, dtype=torch.float32, pin_memory=True)
@@ -683,9 +683,8 @@ class Session:
             if packed:
                 from ..ops import hip
                 off = sum(p[4].numel() for p in packed)
-                stage = torch.empty(off, dtype=torch.float32, device=self.device)
-                hip.pack_f32([p[4] for p in packed], stage)      # one gather launch
-                host_buf[:off].copy_(stage, non_blocking=True)   # one device->host copy
+                # one gather launch whose stores go straight into the pinned host buffer
+                hip.pack_f32([p[4] for p in packed], host_buf)
                 cap.host_buf = host_buf
                 cap.host_np = host_buf.numpy()
                 cap.host_words = off

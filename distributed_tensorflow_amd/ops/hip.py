@@ -719,14 +719,17 @@ def reduce_partials(parts: Sequence[torch.Tensor], scale: float = 1.0,
 
 
 def pack_f32(parts: Sequence[torch.Tensor], out: torch.Tensor) -> List[int]:
-    """Gather up to 16 small fp32 tensors into the head of ``out`` with one launch; returns
-    the offset of each part."""
+    """Gather up to 16 small fp32 tensors into the head of ``out`` (a GPU tensor or a pinned
+    host tensor) with one launch; returns the offset of each part."""
     if not 1 <= len(parts) <= 16:
         raise HipKernelError("pack_f32: 1..16 parts")
     parts = [_req(p, torch.float32, "pack_f32 part") for p in parts]
     total = sum(p.numel() for p in parts)
+    # ``out`` lives in GPU memory or in pinned host memory: pinned memory is mapped into the
+    # GPU's address space, so the kernel can store the packed words straight into the buffer the
+    # host reads after the stream synchronisation -- no separate device->host copy
     if out.dtype != torch.float32 or out.numel() < total or not out.is_contiguous() \
-            or out.device.type != "cuda":
+            or not (out.device.type == "cuda" or out.is_pinned()):
         raise HipKernelError("pack_f32: bad out tensor")
     src = (ctypes.c_void_p * len(parts))(*[p.data_ptr() for p in parts])
     sizes = (ctypes.c_int * len(parts))(*[p.numel() for p in parts])

@@ -12,6 +12,10 @@ configuration. Total work is fixed as N grows (strong scaling).
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+Steps are independent products, so the all-gather strategies run them pipelined: two result
+buffers alternate and the tail of step s's all-gather overlaps the first panel of step s+1;
+every step's result is complete before the timed region ends (``--no-pipeline`` turns it off).
+
 Rank 0 prints ONE JSON line. ``--strategy auto`` (default) times the full-result strategies
 (row-sharded A + all-gather of C; K-sharded operands + all-reduce of partial sums) during
 warm-up -- plus the all-gather over peer-mapped memory when that is available and bit-identical
@@ -49,6 +53,7 @@ def timed_steps(engine: ShardedMatmul, comm, steps: int) -> float:
     t0 = time.perf_counter()
     for _ in range(steps):
         engine.step()
+    engine.wait()                 # pipelined strategies: drain the collectives still in flight
     torch.cuda.synchronize()
     comm.barrier()
     return time.perf_counter() - t0
@@ -65,6 +70,10 @@ def main() -> None:
     ap.add_argument("--dtype", default="bf16", choices=sorted(DTYPES))
     ap.add_argument("--strategy", default="auto")
     ap.add_argument("--panels", type=int, default=None)
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="all-gather strategies: wait for a step's collectives before the next "
+                         "step starts (default: two result buffers alternate, so the tail of one "
+                         "step's all-gather overlaps the first panel of the next step)")
     ap.add_argument("--distribution", default="normal", choices=("normal", "uniform"),
                     help="operand values: N(0,1) as the reference's tf.random_normal "
                          "(tf_distributed_1000Matrix.py:43-44), or U(-1,1)")
@@ -94,7 +103,7 @@ def main() -> None:
     def make(strategy: str) -> ShardedMatmul:
         eng = ShardedMatmul(args.m, args.n, args.k, comm, dtype=dtype, strategy=strategy,
                             panels=args.panels, seed=1, device=device,
-                            distribution=args.distribution)
+                            distribution=args.distribution, pipelined=not args.no_pipeline)
         eng.init_operands()
         return eng
 
@@ -126,6 +135,7 @@ def main() -> None:
                     print("note: %s unavailable (%s)" % (cand, str(e)[:200]), file=sys.stderr)
                 continue
             eng.step()                                   # first-touch / communicator setup
+            eng.wait()
             torch.cuda.synchronize()
             if cand == "m_shard_allgather":
                 baseline_rows = eng.result_dense().index_select(0, sample).clone()
@@ -186,6 +196,7 @@ def main() -> None:
                        "global_batch": args.m, "seq_len": args.k,
                        "m": args.m, "n": args.n, "k": args.k,
                        "parallelism": par, "panels": engine.panels,
+                       "pipelined_steps": bool(engine.pipelined),
                        "result": "full C on every rank" if strategy in
                        ("replicated", "m_shard_allgather", "k_shard_allreduce",
                         "m_shard_allgather_direct", "k_shard_allreduce_direct")

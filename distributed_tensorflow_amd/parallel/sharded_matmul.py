@@ -21,6 +21,10 @@ strategy                   A / B shard per rank   communication     result
 collective done over peer-mapped memory (``parallel/peer_mem.py``): every rank pushes its rows
 to all peers at once instead of passing them round a ring. GPU only, one node only.
 
+``pipelined=True`` (all-gather strategies): repeated steps are independent products, so two
+result buffers alternate and a step returns without waiting for its own collectives -- the tail
+of step s's all-gather runs under the first panel of step s+1. ``wait()`` completes everything.
+
 ``summa_2d`` runs on a P x Q process grid (the most square factorisation of the world size:
 8 ranks -> 2 x 4). K is cut into L = lcm(P, Q) panels; A's block (i, j) holds the L/Q panels of
 grid column j, Bt's block the L/P panels of grid row i, each stored contiguously. Step l
@@ -76,7 +80,8 @@ class ShardedMatmul:
                  dtype: torch.dtype = torch.bfloat16, strategy: str = "m_shard_allgather",
                  panels: Optional[int] = None, seed: int = 1,
                  device: Optional[torch.device] = None,
-                 reduce_dtype: Optional[torch.dtype] = None, distribution: str = "uniform"):
+                 reduce_dtype: Optional[torch.dtype] = None, distribution: str = "uniform",
+                 pipelined: bool = False):
         if strategy not in STRATEGIES:
             raise ValueError("unknown strategy %r (choose from %s)" % (strategy, STRATEGIES))
         self.m, self.n, self.k = int(m), int(n), int(k)
@@ -89,6 +94,14 @@ class ShardedMatmul:
         self.strategy = strategy
         self.seed = seed
         self.distribution = distribution
+        # pipelined (all-gather strategies): two result buffers alternate and a step does not
+        # wait for its own collectives, so the tail of step s's all-gather overlaps the first
+        # panel of step s+1 (the steps are independent products). Results are only guaranteed
+        # complete after wait().
+        self.pipelined = bool(pipelined) and strategy in ("m_shard_allgather",
+                                                          "m_shard_allgather_direct")
+        self._steps_done = 0
+        self._set_works: List[list] = [[], []]
         self.reduce_dtype = reduce_dtype or self.out_dtype
         self.on_gpu = self.device.type == "cuda"
         if self.on_gpu:
@@ -183,6 +196,9 @@ class ShardedMatmul:
             from .peer_mem import SymmetricBuffer
             self._sym_c = SymmetricBuffer(self.comm, (m, n), dt, dev)
             self.c = self._sym_c.local
+            self._sym_sets = [self._sym_c]
+            if self.pipelined:
+                self._sym_sets.append(SymmetricBuffer(self.comm, (m, n), dt, dev))
             if s == "k_shard_allreduce_direct":
                 self._sym_partial = SymmetricBuffer(self.comm, (m, n), self.reduce_dtype, dev)
                 self._stage = torch.empty((max(1, w - 1), m // w, n), dtype=self.reduce_dtype,
@@ -204,6 +220,10 @@ class ShardedMatmul:
             self._partial = torch.empty((m, n), dtype=self.reduce_dtype, device=dev)
         if s == "m_shard_allgather":
             self._local = torch.empty((m // w, n), dtype=dt, device=dev)
+            self._ag_sets = [(self.c, self._local)]
+            if self.pipelined:
+                self._ag_sets.append((torch.empty((m, n), dtype=dt, device=dev),
+                                      torch.empty((m // w, n), dtype=dt, device=dev)))
 
     # -- local product -------------------------------------------------------------------
     def _gemm(self, a: torch.Tensor, bt: torch.Tensor, out: torch.Tensor,
@@ -259,11 +279,21 @@ class ShardedMatmul:
         ml = self.m // w
         rows = ml // p
         base = self.rank * ml
+        which = self._steps_done % len(self._sym_sets)
+        sym = self._sym_sets[which]
+        if self.pipelined and self._set_works[which]:
+            sym.finish()                       # the exchange that used this set two steps ago
+            self._set_works[which] = []
+        self.c = sym.local
         for i in range(p):
             r0 = base + i * rows
             self._gemm(self.a[i * rows:(i + 1) * rows], self.bt, self.c[r0:r0 + rows])
-            self._sym_c.push_rows(r0, rows)
-        self._sym_c.finish()
+            sym.push_rows(r0, rows)
+        if self.pipelined:
+            self._set_works[which] = [True]
+        else:
+            sym.finish()
+        self._steps_done += 1
         return self.c
 
     def _step_k_allreduce_direct(self) -> torch.Tensor:
@@ -294,14 +324,23 @@ class ShardedMatmul:
         w, p = self.world, self.panels
         ml = self.m // w
         rows = ml // p
+        which = self._steps_done % len(self._ag_sets)
+        self.c, local_buf = self._ag_sets[which]
+        for wk in self._set_works[which]:      # pipelined: collectives of two steps ago
+            wk.wait()
+        self._set_works[which] = []
         out = self.c.view(p, w, rows, self.n)
         works = []
         for i in range(p):
-            local = self._local[i * rows:(i + 1) * rows]
+            local = local_buf[i * rows:(i + 1) * rows]
             self._gemm(self.a[i * rows:(i + 1) * rows], self.bt, local)
             works.append(self.comm.all_gather(out[i], local, async_op=True))
-        for wk in works:
-            wk.wait()
+        if self.pipelined:
+            self._set_works[which] = works
+        else:
+            for wk in works:
+                wk.wait()
+        self._steps_done += 1
         return self.c
 
     def _step_k_allreduce(self) -> torch.Tensor:
@@ -366,6 +405,22 @@ class ShardedMatmul:
                 nxt = issue(l + 1)
             self._gemm(a_blk, b_blk, self.c, accumulate=(l > 0))
         return self.c
+
+    def wait(self) -> None:
+        """Complete every collective a pipelined step left in flight (no-op otherwise): after
+        it, ``c`` / ``result_dense()`` of the latest step are whole on every rank."""
+        if not self.pipelined:
+            return
+        if self.strategy == "m_shard_allgather_direct":
+            for which, sym in enumerate(self._sym_sets):
+                if self._set_works[which]:
+                    sym.finish()
+                    self._set_works[which] = []
+        else:
+            for which in range(len(self._set_works)):
+                for wk in self._set_works[which]:
+                    wk.wait()
+                self._set_works[which] = []
 
     # -- checking ------------------------------------------------------------------------
     def result_dense(self) -> torch.Tensor:

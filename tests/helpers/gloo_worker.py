@@ -55,6 +55,14 @@ def main() -> int:
             expect = want
         errs[strategy] = (got.float() - expect.float()).abs().max().item()
     out["matmul_err"] = errs
+    # pipelined all-gather: steps do not wait for their own collectives; wait() drains them
+    eng = ShardedMatmul(m, n, k, comm, dtype=torch.float32, strategy="m_shard_allgather",
+                        seed=3, device=dev, pipelined=True, panels=2)
+    eng.init_operands()
+    for _ in range(5):
+        got = eng.step()
+    eng.wait()
+    out["pipelined_err"] = (eng.result_dense().float() - want.float()).abs().max().item()
 
     # synchronous data-parallel training through the facade
     strategy = os.environ.get("DTF_STRATEGY", "allreduce_sync")

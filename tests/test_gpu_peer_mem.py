@@ -57,3 +57,4 @@ def test_peer_memory_collectives_same_device(world, tmp_path):
         # the all-gather variant runs the same kernel on the same panels: identical bits
         assert res["gemm_errs"]["m_shard_allgather_direct"] <= 0.02 * scale, res
         assert res["gemm_errs"]["k_shard_allreduce_direct"] <= 0.02 * scale, res
+        assert res["gemm_errs"]["pipelined_direct"] <= 0.02 * scale, res

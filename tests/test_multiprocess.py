@@ -119,6 +119,7 @@ def test_gloo_two_process_comm_matmul_and_training(strategy, bucket_bytes, tmp_p
         lo = 4 * r["rank"]
         assert r["reduce_scatter"] == [3.0 * (lo + i) for i in range(4)]
         assert max(r["matmul_err"].values()) < 1e-3
+        assert r["pipelined_err"] < 1e-3
         assert r["loss_last"] < 0.05 * r["loss_first"]
         assert r["step"] == 60.0
         # 8-byte buckets: {b} and {w} are all-reduced asynchronously during the backward pass

@@ -293,7 +293,10 @@ template <bool OUT_F32, int DBG, bool FP8, bool MERGE = false>
 __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
     const char* __restrict__ A, const char* __restrict__ Bt,
     void* __restrict__ C, int M, int N, int K, long lda, long ldb, long ldc, int tiles_m,
-    int tiles_n, float alpha, float beta) {
+    int tiles_n, float alpha, float beta, int ksplits, long plane) {
+  // ksplits > 1 (few output tiles, long K): work item (split, tile) multiplies K-range `split`
+  // of K / ksplits columns and writes its partial tile to C + split * plane (elements); a
+  // second kernel sums the planes in split order.
   constexpr int ESIZE = FP8 ? 1 : 2;
   constexpr bool PERSIST = !FP8 && !(DBG & 32);     // DBG bit 5: one tile per workgroup
   // DBG (timing experiments only, built with -DDTF_GEMM_EXPERIMENTS; results are wrong when
@@ -310,13 +313,16 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
   // so the first six half-tiles of the NEXT tile are requested before the epilogue of this one:
   // their memory latency hides behind the 128 KiB of result stores instead of opening each
   // tile with an idle matrix pipe.
-  const int ntiles = tiles_m * tiles_n;
-  const int nkt = K / (128 / ESIZE);
+  const int ntiles_xy = tiles_m * tiles_n;
+  const int ntiles = ntiles_xy * ksplits;
+  const int ksub = K / ksplits;                       // columns of K per split
+  const int nkt = ksub / (128 / ESIZE);
   int tile = blockIdx.x;
-  int m0, n0;
+  int m0, n0, split;
   {
     int tm, tn;
-    pp_tile_of_block(tile, tiles_m, tiles_n, tm, tn, (DBG & 16) != 0);
+    split = tile / ntiles_xy;
+    pp_tile_of_block(tile - split * ntiles_xy, tiles_m, tiles_n, tm, tn, (DBG & 16) != 0);
     m0 = tm * BM;
     n0 = tn * BN;
   }
@@ -338,8 +344,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
   unsigned seg[4][6] = {};
   unsigned voff[4][2];
   stage_offsets<ESIZE>(voff, lda, ldb, m0, n0, M, N, wave, lane);
-  __amdgpu_buffer_rsrc_t a_tile = tile_rsrc(A + (long)m0 * lda * ESIZE);
-  __amdgpu_buffer_rsrc_t b_tile = tile_rsrc(Bt + (long)n0 * ldb * ESIZE);
+  __amdgpu_buffer_rsrc_t a_tile = tile_rsrc(A + ((long)m0 * lda + (long)split * ksub) * ESIZE);
+  __amdgpu_buffer_rsrc_t b_tile = tile_rsrc(Bt + ((long)n0 * ldb + (long)split * ksub) * ESIZE);
 
   // prologue of the first tile: half-tiles 0..5 in flight
 #pragma unroll
@@ -489,18 +495,20 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
   if (wr == 0) __builtin_amdgcn_s_barrier();          // every wave has passed the same count
   // every wave has finished reading LDS: request the next tile's first half-tiles now
   const int cm0 = m0, cn0 = n0;                        // this tile's origin, for the epilogue
+  char* const c_plane = reinterpret_cast<char*>(C) + (long)split * plane * (OUT_F32 ? 4 : 2);
   tile += gridDim.x;
   const bool more = PERSIST && tile < ntiles;
   if (more) {
     int tm, tn;
-    pp_tile_of_block(tile, tiles_m, tiles_n, tm, tn, (DBG & 16) != 0);
+    split = tile / ntiles_xy;
+    pp_tile_of_block(tile - split * ntiles_xy, tiles_m, tiles_n, tm, tn, (DBG & 16) != 0);
     m0 = tm * BM;
     n0 = tn * BN;
     int o_lane = lane;                    // opaque copy: keeps the offset arithmetic out of the
     asm volatile("" : "+v"(o_lane));      // K loop's live registers (see the epilogue)
     stage_offsets<ESIZE>(voff, lda, ldb, m0, n0, M, N, wave, o_lane);
-    a_tile = tile_rsrc(A + (long)m0 * lda * ESIZE);
-    b_tile = tile_rsrc(Bt + (long)n0 * ldb * ESIZE);
+    a_tile = tile_rsrc(A + ((long)m0 * lda + (long)split * ksub) * ESIZE);
+    b_tile = tile_rsrc(Bt + ((long)n0 * ldb + (long)split * ksub) * ESIZE);
 #pragma unroll
     for (int h = 0; h < 6; ++h)
       stage_half(a_tile, b_tile, voff, h, nkt, h & 3, (h >> 2) & 1, smem, wave);
@@ -525,7 +533,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
           if (col >= N) continue;
           f32x4 v = acc[mh][nh][i][j] * alpha;
           if (OUT_F32) {
-            float* dst = reinterpret_cast<float*>(C) + (long)row * ldc + col;
+            float* dst = reinterpret_cast<float*>(c_plane) + (long)row * ldc + col;
             if (col + 3 < N) {
               if (beta != 0.f) v += *reinterpret_cast<const f32x4*>(dst) * beta;
               *reinterpret_cast<f32x4*>(dst) = v;
@@ -534,7 +542,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
                 dst[r] = beta != 0.f ? v[r] + beta * dst[r] : v[r];
             }
           } else {
-            unsigned short* dst = reinterpret_cast<unsigned short*>(C) + (long)row * ldc + col;
+            unsigned short* dst = reinterpret_cast<unsigned short*>(c_plane) + (long)row * ldc + col;
             if (beta != 0.f) {
               for (int r = 0; r < 4 && col + r < N; ++r) v[r] += beta * dtf_bf16_to_f32(dst[r]);
             }
@@ -990,23 +998,23 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
     if (dbg == 8)
       hipLaunchKernelGGL((gemm_nt_pp_kernel<false, 8, false, true>), pp_grid, block, lds + 1024,
                          stream, (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc,
-                         tiles_m, tiles_n, alpha, beta);
+                         tiles_m, tiles_n, alpha, beta, 1, 0L);
     else if (dbg == 10)
       hipLaunchKernelGGL((gemm_nt_pp_kernel<false, 10, false, true>), pp_grid, block, lds + 1024,
                          stream, (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc,
-                         tiles_m, tiles_n, alpha, beta);
+                         tiles_m, tiles_n, alpha, beta, 1, 0L);
     else if (dbg == 9)
       hipLaunchKernelGGL((gemm_nt_pp_kernel<false, 9, false, true>), pp_grid, block, lds + 1024,
                          stream, (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc,
-                         tiles_m, tiles_n, alpha, beta);
+                         tiles_m, tiles_n, alpha, beta, 1, 0L);
     else if (dbg == 16)
       hipLaunchKernelGGL((gemm_nt_pp_kernel<false, 16, false, true>), pp_grid, block, lds, stream,
                          (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tiles_m,
-                         tiles_n, alpha, beta);
+                         tiles_n, alpha, beta, 1, 0L);
     else if (dbg == 32)
       hipLaunchKernelGGL((gemm_nt_pp_kernel<false, 32, false, true>), grid, block, lds, stream,
                          (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tiles_m,
-                         tiles_n, alpha, beta);
+                         tiles_n, alpha, beta, 1, 0L);
     else return DTF_ERR_UNSUPPORTED;
     DTF_LAUNCH_CHECK();
     return DTF_OK;
@@ -1022,11 +1030,11 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
     if (out_f32)
       hipLaunchKernelGGL((gemm_nt_pp_kernel<true, 0, false, true>), pp_grid, block, lds, stream,
                          (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tiles_m,
-                         tiles_n, alpha, beta);
+                         tiles_n, alpha, beta, 1, 0L);
     else
       hipLaunchKernelGGL((gemm_nt_pp_kernel<false, 0, false, true>), pp_grid, block, lds, stream,
                          (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tiles_m,
-                         tiles_n, alpha, beta);
+                         tiles_n, alpha, beta, 1, 0L);
     DTF_LAUNCH_CHECK();
     return DTF_OK;
   }
@@ -1035,7 +1043,7 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
 #define DTF_PP_LAUNCH(F32, DBGV)                                                                  \
   hipLaunchKernelGGL((gemm_nt_pp_kernel<F32, DBGV, false>), pp_grid, block, lds, stream,             \
                      (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tiles_m,         \
-                     tiles_n, alpha, beta)
+                     tiles_n, alpha, beta, 1, 0L)
     const int dbg = variant >> 4;
     if (dbg == 0) {
       if (out_f32) DTF_PP_LAUNCH(true, 0); else DTF_PP_LAUNCH(false, 0);
@@ -1058,6 +1066,105 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
     hipLaunchKernelGGL(gemm_bf16_nt_kernel<false>, grid, block, lds, stream,
                        (const unsigned short*)A, (const unsigned short*)Bt, C, M, N, K, lda, ldb,
                        ldc, tiles_m, tiles_n, alpha);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
+// ---- split-K for small tile grids -----------------------------------------------------------
+namespace {
+
+// C[r, c] = alpha * sum_s partial[s][r][c] (+ beta * C[r, c]); planes are M x N fp32, summed in
+// split order; four columns per thread (N % 4 == 0)
+template <bool OUT_F32>
+__global__ __launch_bounds__(256) void planes_reduce_kernel(const float* __restrict__ partial,
+                                                            int planes, long plane, void* C,
+                                                            long ldc, int M, int N, float alpha,
+                                                            float beta) {
+  const long n4 = plane >> 2;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < planes; s0 += 8) {
+      f32x4 t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int sp = s0 + u < planes ? s0 + u : planes - 1;
+        t[u] = reinterpret_cast<const f32x4*>(partial + sp * plane)[i];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (s0 + u < planes) v += t[u];
+    }
+    v *= alpha;
+    const long e = i << 2;
+    const int row = (int)(e / N), col = (int)(e % N);
+    if (OUT_F32) {
+      float* dst = reinterpret_cast<float*>(C) + (long)row * ldc + col;
+      if (beta != 0.f) v += *reinterpret_cast<const f32x4*>(dst) * beta;
+      *reinterpret_cast<f32x4*>(dst) = v;
+    } else {
+      unsigned short* dst = reinterpret_cast<unsigned short*>(C) + (long)row * ldc + col;
+      bf16x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float x = beta != 0.f ? v[r] + beta * dtf_bf16_to_f32(dst[r]) : v[r];
+        o[r] = (short)dtf_f32_to_bf16(x);
+      }
+      *reinterpret_cast<bf16x4*>(dst) = o;
+    }
+  }
+}
+
+}  // namespace
+
+// Number of K splits the fast bf16 kernel should use for an M x N x K product (1 = none): a
+// grid of 256x256 tiles that leaves most CUs without a workgroup is cut along K until there
+// is about one work item per CU, each split keeping at least 512 columns of K. Only for grids
+// of at most 32 tiles: the planes are fp32, and from 64 tiles on (2048^2 outputs) reading them
+// back costs what the extra CUs gain (measured: 2048^3 44.6 us split four ways, 44.2 us unsplit).
+DTF_API int dtf_gemm_bf16_splits(int M, int N, int K) {
+  const long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  if (tiles > 32 || K < 1024) return 1;
+  int splits = 1;
+  while (splits < 8 && tiles * splits * 2 <= 256 && K % (splits * 2 * BK) == 0 &&
+         K / (splits * 2) >= 512)
+    splits *= 2;
+  return splits;
+}
+
+// Split-K form of dtf_gemm_bf16_nt: `workspace` holds ksplits * M * N floats. Same operand
+// contract; additionally N % 4 == 0 and K % (ksplits * 64) == 0.
+DTF_API int dtf_gemm_bf16_nt_splitk(const void* A, const void* Bt, void* C, float* workspace,
+                                    int M, int N, int K, long lda, long ldb, long ldc,
+                                    float alpha, float beta, int out_f32, int ksplits,
+                                    hipStream_t stream) {
+  if (!A || !Bt || !C || !workspace || M <= 0 || N <= 0 || K <= 0 || ksplits < 2 || ksplits > 64)
+    return DTF_ERR_BAD_ARG;
+  if (lda < K || ldb < K || ldc < N) return DTF_ERR_BAD_ARG;
+  if (K % (ksplits * BK) || N % 4 || lda % 8 || ldb % 8 || ldc % 4 || ((uintptr_t)A & 15) ||
+      ((uintptr_t)Bt & 15) || ((uintptr_t)C & (out_f32 ? 15 : 7)) ||
+      ((uintptr_t)workspace & 15))
+    return DTF_ERR_UNSUPPORTED;
+  if (lda * 2 * BM >= (1L << 32) || ldb * 2 * BN >= (1L << 32)) return DTF_ERR_UNSUPPORTED;
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  const size_t lds = 2 * BUF_BYTES;
+  static bool attr_set = false;
+  if (!attr_set) {
+    dtf_allow_lds(gemm_nt_pp_kernel<true, 0, false, true>, lds);
+    attr_set = true;
+  }
+  const long plane = (long)M * N;
+  const dim3 grid(dtf_pp_grid(tiles_m * tiles_n * ksplits)), block(NTHREADS);
+  hipLaunchKernelGGL((gemm_nt_pp_kernel<true, 0, false, true>), grid, block, lds, stream,
+                     (const char*)A, (const char*)Bt, (void*)workspace, M, N, K, lda, ldb,
+                     (long)N, tiles_m, tiles_n, 1.0f, 0.0f, ksplits, plane);
+  const long work = plane / 4;
+  const int blocks = (int)((work + 255) / 256 > 2048 ? 2048 : (work + 255) / 256);
+  if (out_f32)
+    hipLaunchKernelGGL(planes_reduce_kernel<true>, dim3(blocks), dim3(256), 0, stream, workspace,
+                       ksplits, plane, C, ldc, M, N, alpha, beta);
+  else
+    hipLaunchKernelGGL(planes_reduce_kernel<false>, dim3(blocks), dim3(256), 0, stream,
+                       workspace, ksplits, plane, C, ldc, M, N, alpha, beta);
   DTF_LAUNCH_CHECK();
   return DTF_OK;
 }
@@ -1089,7 +1196,7 @@ DTF_API int dtf_gemm_fp8_nt(const void* A, const void* Bt, void* C, int M, int N
     if (!e_attr) { dtf_allow_lds(gemm_nt_pp_kernel<false, 16, true, true>, lds); e_attr = true; }
     hipLaunchKernelGGL((gemm_nt_pp_kernel<false, 16, true, true>), grid, block, lds, stream,
                        (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tiles_m,
-                       tiles_n, alpha, beta);
+                       tiles_n, alpha, beta, 1, 0L);
     DTF_LAUNCH_CHECK();
     return DTF_OK;
   }
@@ -1097,11 +1204,11 @@ DTF_API int dtf_gemm_fp8_nt(const void* A, const void* Bt, void* C, int M, int N
   if (out_f32)
     hipLaunchKernelGGL((gemm_nt_pp_kernel<true, 0, true, true>), grid, block, lds, stream,
                        (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tiles_m,
-                       tiles_n, alpha, beta);
+                       tiles_n, alpha, beta, 1, 0L);
   else
     hipLaunchKernelGGL((gemm_nt_pp_kernel<false, 0, true, true>), grid, block, lds, stream,
                        (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tiles_m,
-                       tiles_n, alpha, beta);
+                       tiles_n, alpha, beta, 1, 0L);
   DTF_LAUNCH_CHECK();
   return DTF_OK;
 }

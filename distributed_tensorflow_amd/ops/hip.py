@@ -61,6 +61,8 @@ def _declare(L: ctypes.CDLL) -> None:
         "dtf_gemm_f32": [P, P, P, P, I, I, I, LG, LG, LG, I, I, I, P, I, I, P],
         "dtf_gemm_f32_splits": [I, I, I, P],
         "dtf_gemm_bf16_nt": [P, P, P, I, I, I, LG, LG, LG, F, F, I, I, P],
+        "dtf_gemm_bf16_splits": [I, I, I],
+        "dtf_gemm_bf16_nt_splitk": [P, P, P, P, I, I, I, LG, LG, LG, F, F, I, I, P],
         "dtf_gemm_bf16_generic": [P, P, P, I, I, I, LG, LG, LG, LG, LG, F, F, I, P],
         "dtf_gemm_fp8_nt": [P, P, P, I, I, I, LG, LG, LG, F, F, I, P],
         "dtf_gemm_fp8_generic": [P, P, P, I, I, I, LG, LG, LG, LG, LG, F, F, I, P],
@@ -186,10 +188,12 @@ def gemm_f32(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: b
 
 def gemm_bf16_nt(a: torch.Tensor, bt: torch.Tensor, out_dtype: torch.dtype = torch.bfloat16,
                  alpha: float = 1.0, out: Optional[torch.Tensor] = None,
-                 variant: int = 0, beta: float = 0.0) -> torch.Tensor:
+                 variant: int = 0, beta: float = 0.0,
+                 splits: Optional[int] = None) -> torch.Tensor:
     """``alpha * a @ bt.T (+ beta * out)`` with a [M,K], bt [N,K] bf16 (both K-contiguous); fp32
     accumulate; result bf16 or fp32. Uses the 256x256x64 LDS-DMA kernel when the shape
-    qualifies and the predicated generic kernel otherwise."""
+    qualifies and the predicated generic kernel otherwise. ``splits``: K splits for grids with
+    few output tiles (default: the library's plan; 1 = never split)."""
     a = _req(a, torch.bfloat16, "gemm_bf16_nt a")
     bt = _req(bt, torch.bfloat16, "gemm_bf16_nt bt")
     if a.dim() != 2 or bt.dim() != 2 or a.shape[1] != bt.shape[1]:
@@ -210,6 +214,18 @@ def gemm_bf16_nt(a: torch.Tensor, bt: torch.Tensor, out_dtype: torch.dtype = tor
     if k == 0:
         return out.mul_(beta) if beta != 0.0 else out.zero_()
     out_f32 = int(out_dtype == torch.float32)
+    if splits is None:
+        splits = lib().dtf_gemm_bf16_splits(m, n, k) if variant == 0 else 1
+    if splits > 1:
+        ws = torch.empty(splits * m * n, dtype=torch.float32, device=a.device)
+        code = lib().dtf_gemm_bf16_nt_splitk(a.data_ptr(), bt.data_ptr(), out.data_ptr(),
+                                             ws.data_ptr(), m, n, k, a.stride(0), bt.stride(0),
+                                             out.stride(0), float(alpha), float(beta), out_f32,
+                                             int(splits), _stream())
+        if code == 0:
+            return out
+        if code != -2:
+            _check(code, "gemm_bf16_nt (split-K)")
     code = lib().dtf_gemm_bf16_nt(a.data_ptr(), bt.data_ptr(), out.data_ptr(), m, n, k,
                                   a.stride(0), bt.stride(0), out.stride(0), float(alpha),
                                   float(beta), out_f32, int(variant), _stream())

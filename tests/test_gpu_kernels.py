@@ -573,3 +573,29 @@ def test_gemm_f32_interior_tiles_exact(hip, m, n, k, splits, tile, ta, tb):
     b_in = b.t().contiguous() if tb else b
     out = hip.gemm_f32(a_in, b_in, ta, tb, splits=splits, tile=tile)
     assert torch.equal(out, a @ b)
+
+
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("m,n,k,splits", [(512, 768, 4096, None), (300, 260, 2048, 4),
+                                          (1024, 2048, 2048, None), (256, 256, 1024, 2)])
+def test_gemm_bf16_split_k(hip, m, n, k, splits, out_dtype):
+    """Few output tiles + long K: the ping-pong kernel runs (split, tile) work items into fp32
+    planes and a second kernel sums them in split order. Small-integer data makes every
+    partial sum exact, so the result must equal the unsplit product bit for bit; alpha and
+    beta are applied once, in the reduction."""
+    g = torch.Generator().manual_seed(m + n + k)
+    a = torch.randint(-2, 3, (m, k), generator=g).float()
+    bt = torch.randint(-2, 3, (n, k), generator=g).float()
+    ad, bd = a.bfloat16().cuda(), bt.bfloat16().cuda()
+    if splits is None:
+        assert hip.lib().dtf_gemm_bf16_splits(m, n, k) > 1
+    ref = a @ bt.t()
+    out = hip.gemm_bf16_nt(ad, bd, out_dtype, splits=splits)
+    assert torch.equal(out.float().cpu(), ref.to(out_dtype).float())
+    unsplit = hip.gemm_bf16_nt(ad, bd, out_dtype, splits=1)
+    assert torch.equal(out, unsplit)
+    base = torch.randint(-4, 5, (m, n), generator=g).float().to(out_dtype).cuda()
+    acc = base.clone()
+    hip.gemm_bf16_nt(ad, bd, out_dtype, alpha=0.5, out=acc, beta=2.0, splits=splits)
+    want = (0.5 * ref + 2.0 * base.float().cpu()).to(out_dtype).float()
+    assert torch.equal(acc.float().cpu(), want)

@@ -891,15 +891,158 @@ __global__ __launch_bounds__(256) void gemm_fp8_generic_kernel(
 
 }  // namespace
 
+// ---- 128x128 tile kernel for grids that leave CUs idle at 256x256 -----------------------------
+// 256 threads = 4 waves as 2(M) x 2(N), 64x64 outputs per wave, K-tile 64, the same LDS image
+// and MFMA as above. Two 32 KiB K-tile buffers per workgroup, so two workgroups share a CU and
+// cover each other's barrier and DMA waits. A product of 2048^2 outputs is 64 tiles of 256^2
+// (a quarter of the chip) but 256 tiles of 128^2.
+namespace {
+
+constexpr int T128 = 128;
+constexpr int T128_THREADS = 256;
+constexpr int T128_TILE_BYTES = T128 * BK * 2;     // 16 KiB per operand tile
+constexpr int T128_BUF_BYTES = 2 * T128_TILE_BYTES;
+
+template <bool OUT_F32>
+__global__ __launch_bounds__(T128_THREADS) void gemm_bf16_nt_t128_kernel(
+    const char* __restrict__ A, const char* __restrict__ Bt, void* __restrict__ C, int M, int N,
+    int K, long lda, long ldb, long ldc, int tiles_m, int tiles_n, float alpha, float beta) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (A tile | B tile)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+
+  const int ntiles = tiles_m * tiles_n;
+  const int id = dtf_xcd_remap(blockIdx.x, ntiles);
+  constexpr int GROUP = 8;
+  const int per_group = GROUP * tiles_n;
+  const int g = id / per_group;
+  const int first_m = g * GROUP;
+  const int gsize = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
+  const int tm = first_m + (id % per_group) % gsize;
+  const int tn = (id % per_group) / gsize;
+  const int m0 = tm * T128, n0 = tn * T128;
+
+  // staging: 16 pieces of 8 rows per operand tile, four per wave; the lane offsets are
+  // loop-invariant, the K-tile offset is the buffer load's scalar offset
+  unsigned voff_a[4], voff_b[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int piece = wave * 4 + j;
+    const int trow = piece * 8 + (lane >> 3);
+    const int kc = (lane & 7) ^ ((trow >> 1) & 7);
+    int ra = m0 + trow, rb = n0 + trow;
+    ra = ra < M - 1 ? ra : M - 1;
+    rb = rb < N - 1 ? rb : N - 1;
+    voff_a[j] = (unsigned)(ra - m0) * (unsigned)(lda * 2) + 16u * kc;
+    voff_b[j] = (unsigned)(rb - n0) * (unsigned)(ldb * 2) + 16u * kc;
+  }
+  const __amdgpu_buffer_rsrc_t a_rsrc = tile_rsrc(A + (long)m0 * lda * 2);
+  const __amdgpu_buffer_rsrc_t b_rsrc = tile_rsrc(Bt + (long)n0 * ldb * 2);
+  auto stage = [&](int kt, char* buf) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int piece = wave * 4 + j;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_void*)(buf + piece * 1024), 16,
+                                               voff_a[j], kt * 128, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          b_rsrc, (lds_void*)(buf + T128_TILE_BYTES + piece * 1024), 16, voff_b[j], kt * 128, 0,
+          0);
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nkt = K / BK;
+  stage(0, smem);
+  const int frow = lane & 15, fq = lane >> 4;
+  for (int kt = 0; kt < nkt; ++kt) {
+    // tile kt has landed for every wave, and every wave is done reading the other buffer
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    char* cur = smem + (kt & 1) * T128_BUF_BYTES;
+    if (kt + 1 < nkt) stage(kt + 1, smem + ((kt + 1) & 1) * T128_BUF_BYTES);
+    const char* as = cur;
+    const char* bs = cur + T128_TILE_BYTES;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      bf16x8 af[4], bf[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        bf[j] = *reinterpret_cast<const bf16x8*>(
+            bs + chunk_off(wc * 64 + j * 16 + frow, 4 * s2 + fq));
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        af[i] = *reinterpret_cast<const bf16x8*>(
+            as + chunk_off(wr * 64 + i * 16 + frow, 4 * s2 + fq));
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // swapped-operand accumulator: lane holds C[m = frow][n = 4*fq + r], r = 0..3
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = m0 + wr * 64 + i * 16 + frow;
+    if (row >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = n0 + wc * 64 + j * 16 + 4 * fq;
+      if (col >= N) continue;
+      f32x4 v = acc[i][j] * alpha;
+      if (OUT_F32) {
+        float* dst = reinterpret_cast<float*>(C) + (long)row * ldc + col;
+        if (col + 3 < N) {
+          if (beta != 0.f) v += *reinterpret_cast<const f32x4*>(dst) * beta;
+          *reinterpret_cast<f32x4*>(dst) = v;
+        } else {
+          for (int r = 0; r < 4 && col + r < N; ++r)
+            dst[r] = beta != 0.f ? v[r] + beta * dst[r] : v[r];
+        }
+      } else {
+        unsigned short* dst = reinterpret_cast<unsigned short*>(C) + (long)row * ldc + col;
+        if (beta != 0.f)
+          for (int r = 0; r < 4 && col + r < N; ++r) v[r] += beta * dtf_bf16_to_f32(dst[r]);
+        if (col + 3 < N) {
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (short)dtf_f32_to_bf16(v[r]);
+          *reinterpret_cast<bf16x4*>(dst) = o;
+        } else {
+          for (int r = 0; r < 4 && col + r < N; ++r) dst[r] = dtf_f32_to_bf16(v[r]);
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
 // C[M,N] (bf16, or fp32 when out_f32) = alpha * A[M,K] * Bt[N,K]^T. Requirements of the fast
 // kernel: K % 64 == 0, lda/ldb % 8 == 0, 16-byte aligned A/Bt, ldc % 4 == 0 and 16-byte
 // (fp32) / 8-byte (bf16) aligned C. Returns DTF_ERR_UNSUPPORTED otherwise (callers then use
 // dtf_gemm_bf16_generic).
-// variant & 15: 0 = default (= 4), 1 = two-phase double-buffer, 2 = ping-pong with one quadrant
-// per phase, 3 = four-wave kernel (128x128 per wave), 4 = ping-pong with two quadrants per phase;
+// variant & 15: 0 = default (4, or 5 for mid-size tile grids), 1 = two-phase double-buffer,
+// 2 = ping-pong with one quadrant per phase, 3 = four-wave kernel (128x128 per wave),
+// 4 = ping-pong with two quadrants per phase, 5 = 128x128 tiles with two workgroups per CU;
 // variant >> 4: timing-experiment bits of the one-quadrant ping-pong kernel (0 in production).
 // The staging DMA addresses a block tile with 32-bit offsets: 256 rows of lda / ldb bytes must
 // stay below 4 GiB (DTF_ERR_UNSUPPORTED otherwise).
+// default kernel choice: grids of more than 32 and fewer than this many 256x256 tiles run on
+// 128x128 tiles. Measured (128x128 against 256x256 tiles): 2048^3 (64 tiles) 617 vs 395 TF,
+// 2048x4096x4096 (128 tiles) 1020 vs 853 TF; 3072^3 (144 tiles) 707 vs 870 TF, 4096^3 (256
+// tiles) 1035 vs 1388 TF.
+#ifndef DTF_T128_BELOW_TILES
+#define DTF_T128_BELOW_TILES 129
+#endif
+
 // workgroups of the persistent ping-pong kernel: one per CU (128 KiB of LDS each), fewer when
 // there are fewer tiles
 static int dtf_pp_grid(int ntiles) {
@@ -1020,6 +1163,29 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
     return DTF_OK;
   }
 #endif
+  // 128x128 tiles (variant 5, or by default when 256x256 tiles would leave CUs idle)
+  if ((variant & 15) == 5 ||
+      (variant == 0 && tiles_m * tiles_n > 32 && tiles_m * tiles_n < DTF_T128_BELOW_TILES)) {
+    static bool t_attr = false;
+    const size_t t_lds = 2 * T128_BUF_BYTES;
+    if (!t_attr) {
+      dtf_allow_lds(gemm_bf16_nt_t128_kernel<true>, t_lds);
+      dtf_allow_lds(gemm_bf16_nt_t128_kernel<false>, t_lds);
+      t_attr = true;
+    }
+    const int tm128 = (M + T128 - 1) / T128, tn128 = (N + T128 - 1) / T128;
+    const dim3 t_grid(tm128 * tn128), t_block(T128_THREADS);
+    if (out_f32)
+      hipLaunchKernelGGL(gemm_bf16_nt_t128_kernel<true>, t_grid, t_block, t_lds, stream,
+                         (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tm128,
+                         tn128, alpha, beta);
+    else
+      hipLaunchKernelGGL(gemm_bf16_nt_t128_kernel<false>, t_grid, t_block, t_lds, stream,
+                         (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tm128,
+                         tn128, alpha, beta);
+    DTF_LAUNCH_CHECK();
+    return DTF_OK;
+  }
   if ((variant & 15) == 4 || variant == 0) {       // ping-pong with two-quadrant phases
     static bool m_attr = false;
     if (!m_attr) {

@@ -29,6 +29,16 @@
 //  * M and N edges are handled by clamping source rows (out-of-range rows are computed and
 //    dropped at the store); K must be a multiple of 64.
 //
+// Kernels in this file, all sharing that LDS image and MFMA layout:
+//  * gemm_nt_pp_kernel -- the default for large grids (bf16 and, instantiated with the
+//    block-scaled MFMA, fp8): quadrant-phased ping-pong of two wave groups, persistent over
+//    tiles, optional split-K work items for grids of at most 32 tiles (described below);
+//  * gemm_bf16_nt_t128_kernel -- 128x128 tiles, two workgroups per CU, for grids of 33-128
+//    large tiles;
+//  * gemm_bf16_nt_kernel (variant 1) -- the plain double-buffered schedule described above;
+//  * gemm_bf16_nt_w4_kernel (variant 3) -- one wave per SIMD with 128x128 outputs per wave, kept
+//    with its measured ablations.
+//
 // Generic path (dtf_gemm_bf16_generic): 64x64 tile, register-staged, fully predicated; any
 // shape/stride, NN/NT/TN; used for ragged problems and as an in-library cross-check.
 #include <cstdlib>

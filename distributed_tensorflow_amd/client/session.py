@@ -200,6 +200,7 @@ class _CapturedStep:
         self.host_words = 0
         self.layout: List[Tuple[int, int, tuple, int]] = []   # (slot, offset, shape, numel)
         self.slot_values: List[Any] = []
+        self.generation = 0                               # variable-store generation at capture
 
 
 _default_session = threading.local()
@@ -614,6 +615,9 @@ class Session:
     def _run_captured(self, plan: ExecutionPlan, feeds: List[Any]):
         sig = tuple((tuple(f.shape), str(f.dtype)) for f in feeds)
         cap = plan.graphs.get(sig)
+        generation = self._local_store.generation
+        if cap is not None and cap.generation != generation:
+            cap = None                  # a variable moved to new storage since the capture
         if cap is None:
             dev_feeds = [f if isinstance(f, torch.Tensor) else
                          torch.from_numpy(np.ascontiguousarray(f).reshape(f.shape)).to(self.device)
@@ -692,6 +696,7 @@ class Session:
                               for sl, o, shape, _dt, v in packed]
         cap.graph = graph
         cap.slot_values = vals
+        cap.generation = self._local_store.generation
         return cap
 
     # -- conveniences ----------------------------------------------------------------------

@@ -31,6 +31,9 @@ class LocalVariableStore:
         self._values: Dict[str, torch.Tensor] = {}
         self._lock = threading.Lock()
         self.update_count = 0     # number of apply_sgd calls served (async-PS accounting)
+        # bumped whenever a variable gets NEW storage (first value, reshaped value, adopted
+        # arena view, clear): HIP-graph captures hold raw addresses and are dropped on a change
+        self.generation = 0
 
     # -- reads ---------------------------------------------------------------------------
     def is_initialized(self, name: str) -> bool:
@@ -62,12 +65,14 @@ class LocalVariableStore:
                 cur.copy_(value)             # keep the address stable (captured graphs, views)
             else:
                 self._values[name] = value.to(self.device, copy=True).contiguous()
+                self.generation += 1         # new storage: captured steps point at the old one
             return self._values[name]
 
     def adopt(self, name: str, storage: torch.Tensor) -> None:
         """Install ``storage`` (e.g. a view into a flat parameter arena) as the variable."""
         with self._lock:
             self._values[name] = storage
+            self.generation += 1
 
     def assign_add(self, name: str, delta: torch.Tensor) -> torch.Tensor:
         var = self.read(name)
@@ -86,6 +91,7 @@ class LocalVariableStore:
     def clear(self) -> None:
         with self._lock:
             self._values.clear()
+            self.generation += 1
 
     def state_dict(self) -> Dict[str, torch.Tensor]:
         return dict(self._values)

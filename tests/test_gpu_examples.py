@@ -85,3 +85,33 @@ def test_device_resident_batches_match_host_batches():
         assert isinstance(dx, torch.Tensor) and dx.is_cuda
         assert np.array_equal(dx.cpu().numpy(), hx) and np.array_equal(dy.cpu().numpy(), hy)
     assert host.epochs_completed == dev.epochs_completed == 5
+
+
+def test_captured_step_follows_variables_to_new_storage():
+    """A HIP-graph capture holds raw addresses: when a variable is given new storage (here by
+    adopting a fresh tensor, as a collective runtime does after re-initialisation) the next
+    run must re-capture instead of updating the abandoned tensor."""
+    import numpy as np
+    import torch
+    import distributed_tensorflow_amd as tf
+    g = tf.Graph()
+    with g.as_default():
+        x = tf.placeholder(tf.float32, [None, 4])
+        w = tf.Variable(tf.zeros([4, 1]), name="w")
+        loss = tf.reduce_mean(tf.square(tf.matmul(x, w) - 1.0))
+        train = tf.train.GradientDescentOptimizer(0.1).minimize(loss)
+        init = tf.global_variables_initializer()
+        with tf.Session(config=tf.ConfigProto(device="cuda")) as sess:
+            sess.run(init)
+            feed = {x: np.ones((8, 4), np.float32)}
+            for _ in range(4):
+                sess.run(train, feed)
+            assert sess.stats["graph_replays"] >= 1
+            captures = sess.stats["captures"]
+            fresh = torch.zeros(4, 1, device="cuda")
+            sess.variable_store.adopt(w.op.name, fresh)
+            for _ in range(3):
+                sess.run(train, feed)
+            assert sess.stats["captures"] == captures + 1
+            assert float(fresh.abs().sum()) > 0.0            # the adopted tensor is the one trained
+            assert np.array_equal(sess.run(w), fresh.cpu().numpy())

@@ -1,5 +1,6 @@
-"""The C++ IO runtime under AddressSanitizer + UBSan (host code only; CPU): builds
-``csrc/io/host_io.cc`` together with its self-test and runs it."""
+"""The C++ runtime under sanitizers (host code only; CPU): ``csrc/io/host_io.cc`` with its
+self-test under AddressSanitizer + UBSan, and the multi-threaded parameter-server task
+``csrc/runtime/ps_server.cc`` with concurrent socket clients under ThreadSanitizer."""
 import os
 import shutil
 import subprocess
@@ -28,3 +29,21 @@ def test_host_io_selftest_under_asan_ubsan(tmp_path):
                          text=True, env=env, timeout=120)
     assert run.returncode == 0, run.stdout
     assert "host_io selftest ok" in run.stdout
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+def test_ps_server_selftest_under_tsan(tmp_path):
+    exe = str(tmp_path / "ps_server_selftest")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=thread",
+           "-pthread", os.path.join(CSRC, "runtime", "ps_server.cc"),
+           os.path.join(CSRC, "tests", "ps_server_selftest.cc"), "-o", exe]
+    build = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if build.returncode != 0 and "tsan" in build.stdout.lower():
+        pytest.skip("toolchain has no ThreadSanitizer runtime")
+    assert build.returncode == 0, build.stdout
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1:exitcode=66")
+    run = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                         env=env, timeout=120)
+    assert "ThreadSanitizer" not in run.stdout, run.stdout
+    assert run.returncode == 0, run.stdout
+    assert "ps_server selftest ok" in run.stdout

@@ -19,7 +19,10 @@ every step's result is complete before the timed region ends (``--no-pipeline`` 
 Rank 0 prints ONE JSON line. ``--strategy auto`` (default) times the full-result strategies
 (row-sharded A + all-gather of C; K-sharded operands + all-reduce of partial sums) during
 warm-up -- plus the all-gather over peer-mapped memory when that is available and bit-identical
--- and runs the fastest; the choice is reported in ``config.parallelism``.
+-- and runs the fastest; the choice is reported in ``config.parallelism``. If the fastest
+all-gather variant is transfer-bound, variants in which every rank recomputes the first rows of
+its peers' blocks instead of receiving them are timed too (``config.recompute_rows``); the
+TFLOP/s always count 2*M*N*K per step, never the recomputed rows.
 """
 from __future__ import annotations
 
@@ -39,7 +42,8 @@ if ROOT not in sys.path:
 
 from distributed_tensorflow_amd.parallel.comm import SingleComm, TorchDistComm  # noqa: E402
 from distributed_tensorflow_amd.parallel.peer_mem import PeerMemError  # noqa: E402
-from distributed_tensorflow_amd.parallel.sharded_matmul import ShardedMatmul  # noqa: E402
+from distributed_tensorflow_amd.parallel.sharded_matmul import (  # noqa: E402
+    ShardedMatmul, balanced_recompute_rows)
 
 DTYPES = {"bf16": torch.bfloat16, "fp32": torch.float32, "fp8": torch.float8_e4m3fn}
 FULL_RESULT_STRATEGIES = ("m_shard_allgather", "k_shard_allreduce")
@@ -74,6 +78,12 @@ def main() -> None:
                     help="all-gather strategies: wait for a step's collectives before the next "
                          "step starts (default: two result buffers alternate, so the tail of one "
                          "step's all-gather overlaps the first panel of the next step)")
+    ap.add_argument("--no-recompute", action="store_true",
+                    help="all-gather strategies: never trade recomputed rows of the peers' blocks "
+                         "for transfer (default: tried when the step is transfer-bound)")
+    ap.add_argument("--recompute-rows", type=int, default=None,
+                    help="time this many recomputed rows per peer block instead of the values "
+                         "around the measured balance point")
     ap.add_argument("--distribution", default="normal", choices=("normal", "uniform"),
                     help="operand values: N(0,1) as the reference's tf.random_normal "
                          "(tf_distributed_1000Matrix.py:43-44), or U(-1,1)")
@@ -100,10 +110,11 @@ def main() -> None:
 
     dtype = DTYPES[args.dtype]
 
-    def make(strategy: str) -> ShardedMatmul:
+    def make(strategy: str, recompute_rows: int = 0) -> ShardedMatmul:
         eng = ShardedMatmul(args.m, args.n, args.k, comm, dtype=dtype, strategy=strategy,
                             panels=args.panels, seed=1, device=device,
-                            distribution=args.distribution, pipelined=not args.no_pipeline)
+                            distribution=args.distribution, pipelined=not args.no_pipeline,
+                            recompute_rows=recompute_rows)
         eng.init_operands()
         return eng
 
@@ -127,30 +138,32 @@ def main() -> None:
         probe = max(2, args.warmup)
         baseline_rows = None
         sample = torch.arange(0, args.m, max(1, args.m // 64), device=device)
-        for cand in FULL_RESULT_STRATEGIES + DIRECT_STRATEGIES:
+        def consider(cand: str, recompute_rows: int = 0) -> None:
+            nonlocal best, baseline_rows
+            label = cand + ("+recompute%d" % recompute_rows if recompute_rows else "")
             try:
-                eng = make(cand)
+                eng = make(cand, recompute_rows)
             except PeerMemError as e:                    # raised on every rank or on none
                 if rank == 0:
-                    print("note: %s unavailable (%s)" % (cand, str(e)[:200]), file=sys.stderr)
-                continue
+                    print("note: %s unavailable (%s)" % (label, str(e)[:200]), file=sys.stderr)
+                return
             eng.step()                                   # first-touch / communicator setup
             eng.wait()
             torch.cuda.synchronize()
-            if cand == "m_shard_allgather":
+            if cand == "m_shard_allgather" and not recompute_rows:
                 baseline_rows = eng.result_dense().index_select(0, sample).clone()
-            if cand in DIRECT_STRATEGIES:
+            if cand in DIRECT_STRATEGIES or recompute_rows:
                 same = baseline_rows is not None and torch.equal(
                     eng.result_dense().index_select(0, sample), baseline_rows)
                 ok = torch.tensor([1.0 if same else 0.0], device=device)
                 comm.all_reduce(ok, "min")
                 if ok.item() < 1.0:
                     if rank == 0:
-                        print("note: %s result differs from the RCCL variant; not used" % cand,
+                        print("note: %s result differs from the RCCL variant; not used" % label,
                               file=sys.stderr)
                     del eng
                     torch.cuda.empty_cache()
-                    continue
+                    return
             secs = timed_steps(eng, comm, probe)
             t = torch.tensor([secs], device=device)
             comm.all_reduce(t, "max")
@@ -159,6 +172,25 @@ def main() -> None:
             else:
                 del eng
                 torch.cuda.empty_cache()
+
+        for cand in FULL_RESULT_STRATEGIES + DIRECT_STRATEGIES:
+            consider(cand)
+        # Full C on every rank puts M*N/world result elements on every link per step, however
+        # the all-gather is organised. When the fastest all-gather variant is transfer-bound,
+        # let every rank recompute the first x rows of its peers' blocks instead of receiving
+        # them: x from the measured product time and step time (agreed across ranks), the two
+        # multiples of 128 rows around the balance point are timed like any other candidate.
+        if best[1].startswith("m_shard_allgather") and not args.no_recompute:
+            t_step, base_cand, base_eng = best
+            tc = torch.tensor([base_eng.time_local_product()], device=device)
+            comm.all_reduce(tc, "max")
+            xs = [args.recompute_rows] if args.recompute_rows else balanced_recompute_rows(
+                args.m // world, world, tc.item(), t_step / probe)
+            if rank == 0:
+                print("note: %s: product %.3f ms, step %.3f ms -> recompute_rows candidates %s"
+                      % (base_cand, tc.item() * 1e3, t_step / probe * 1e3, xs), file=sys.stderr)
+            for x in xs:
+                consider(base_cand, x)
         _, strategy, engine = best
 
     elapsed = timed_steps(engine, comm, args.steps)
@@ -178,6 +210,8 @@ def main() -> None:
                "k_shard_allreduce_direct": "k_shard%d+allreduce(peer memory)" % world,
                "k_shard_reduce_scatter": "k_shard%d+reduce_scatter" % world,
                "summa_2d": "summa2d_%d" % world}[strategy]
+        if engine.recompute_rows:
+            par += "+recompute%d" % engine.recompute_rows
         print(json.dumps({
             "metric": "sharded_gemm_tflops",
             "value": round(tflops, 2),
@@ -197,6 +231,7 @@ def main() -> None:
                        "m": args.m, "n": args.n, "k": args.k,
                        "parallelism": par, "panels": engine.panels,
                        "pipelined_steps": bool(engine.pipelined),
+                       "recompute_rows": engine.recompute_rows,
                        "result": "full C on every rank" if strategy in
                        ("replicated", "m_shard_allgather", "k_shard_allreduce",
                         "m_shard_allgather_direct", "k_shard_allreduce_direct")

@@ -21,6 +21,17 @@ strategy                   A / B shard per rank   communication     result
 collective done over peer-mapped memory (``parallel/peer_mem.py``): every rank pushes its rows
 to all peers at once instead of passing them round a ring. GPU only, one node only.
 
+``recompute_rows=x`` (all-gather strategies): a rank also computes the first ``x`` rows of every
+*peer's* row block instead of receiving them, so only ``M/world - x`` rows per block travel.
+With full C wanted on every rank each xGMI link has to carry ``M*N/world`` result elements per
+step however the collective is organised (one link per peer pair), which for 16384^3 bf16 takes
+longer than a rank's share of the product at every world size; recomputing a slice of the
+neighbours' rows moves the balance point: ``(M/world + (world-1)x)`` rows of compute against
+``M/world - x`` rows per link. ``balanced_recompute_rows`` solves for ``x`` from a measured
+compute rate and step time. The heads of all blocks are one contiguous [world*x, N] region of
+the result buffer (one GEMM launch), followed by the transferred bodies; ``result_dense()``
+returns plain row order.
+
 ``pipelined=True`` (all-gather strategies): repeated steps are independent products, so two
 result buffers alternate and a step returns without waiting for its own collectives -- the tail
 of step s's all-gather runs under the first panel of step s+1. ``wait()`` completes everything.
@@ -75,13 +86,37 @@ def _split(total: int, parts: int, index: int) -> Tuple[int, int]:
     return start, base + (1 if index < extra else 0)
 
 
+def balanced_recompute_rows(block_rows: int, world: int, compute_secs_per_block: float,
+                            step_secs: float, granule: Optional[int] = None) -> List[int]:
+    """Candidate ``recompute_rows`` values around the balance point of compute and transfer.
+
+    ``compute_secs_per_block``: time of a rank's own M/world-row product; ``step_secs``: measured
+    time of a whole all-gather step without recomputation. When the step takes longer than the
+    product, the excess is transfer time that scales with the rows sent, ``step * (b - x) / b``,
+    while the product grows to ``compute * (b + (world-1) x) / b``; the two meet at
+    ``x = b (step - compute) / ((world-1) compute + step)``. Returns the multiples of
+    ``granule`` just below and above that point (empty when the step is already compute-bound).
+    The granule defaults to one 256-row output tile, half of one from 8 ranks on (where the
+    balance point of a 16384-row product lies below 256 rows).
+    """
+    b, w = int(block_rows), int(world)
+    if granule is None:
+        granule = 128 if w >= 8 else 256
+    if w < 2 or compute_secs_per_block <= 0 or step_secs <= 1.03 * compute_secs_per_block:
+        return []
+    x = b * (step_secs - compute_secs_per_block) / ((w - 1) * compute_secs_per_block + step_secs)
+    lo = int(x // granule) * granule
+    cands = [c for c in (lo, lo + granule) if 0 < c <= b // 2]
+    return sorted(set(cands))
+
+
 class ShardedMatmul:
     def __init__(self, m: int, n: int, k: int, comm: Optional[Communicator] = None,
                  dtype: torch.dtype = torch.bfloat16, strategy: str = "m_shard_allgather",
                  panels: Optional[int] = None, seed: int = 1,
                  device: Optional[torch.device] = None,
                  reduce_dtype: Optional[torch.dtype] = None, distribution: str = "uniform",
-                 pipelined: bool = False):
+                 pipelined: bool = False, recompute_rows: int = 0):
         if strategy not in STRATEGIES:
             raise ValueError("unknown strategy %r (choose from %s)" % (strategy, STRATEGIES))
         self.m, self.n, self.k = int(m), int(n), int(k)
@@ -126,6 +161,15 @@ class ShardedMatmul:
         if strategy.startswith("k_shard") and self.k % w:
             raise ValueError("K=%d must be divisible by the world size %d" % (self.k, w))
         rows_local = self.m // w if strategy.startswith("m_shard") else self.m
+        self.recompute_rows = int(recompute_rows)
+        if self.recompute_rows:
+            if strategy not in ("m_shard_allgather", "m_shard_allgather_direct") or w == 1:
+                raise ValueError("recompute_rows applies to the all-gather strategies on more "
+                                 "than one rank")
+            if not 0 < self.recompute_rows < rows_local:
+                raise ValueError("recompute_rows=%d must lie inside the %d-row block"
+                                 % (self.recompute_rows, rows_local))
+            rows_local -= self.recompute_rows          # rows per block that still travel
         if panels is None:
             # a panel's product must still fill the chip: at least one 256x256 output tile per
             # CU (256 of them), otherwise the pipelining costs more MFMA time than the overlap
@@ -137,9 +181,19 @@ class ShardedMatmul:
                 min_rows = 256 * max(1, (256 + col_tiles - 1) // col_tiles)
                 panels = max(1, min(8, rows_local // min_rows))
         self.panels = max(1, int(panels))
-        while rows_local % self.panels or (strategy == "k_shard_reduce_scatter"
-                                           and (self.m // self.panels) % w):
-            self.panels -= 1
+        if strategy in ("m_shard_allgather", "m_shard_allgather_direct") \
+                and rows_local % 256 == 0 and rows_local // 256 >= self.panels:
+            # panels of whole 256-row output tiles (a ragged last tile row costs a full tile's
+            # time), as even as the tile count allows; the same split on every rank
+            units = rows_local // 256
+            self._panel_rows = [256 * (units // self.panels + (1 if i < units % self.panels else 0))
+                                for i in range(self.panels)]
+        else:
+            while rows_local % self.panels or (strategy == "k_shard_reduce_scatter"
+                                               and (self.m // self.panels) % w):
+                self.panels -= 1
+            self._panel_rows = [rows_local // self.panels] * self.panels
+        self._panel_start = [sum(self._panel_rows[:i]) for i in range(self.panels)]
         self.a: Optional[torch.Tensor] = None
         self.bt: Optional[torch.Tensor] = None
         self.c: Optional[torch.Tensor] = None
@@ -169,6 +223,13 @@ class ShardedMatmul:
             ml = m // w
             self.a = self._window("a", ml, k, r * ml, 0, k)
             self.bt = self._window("b", n, k, 0, 0, k)
+            x = self.recompute_rows
+            if x:
+                # the first x rows of EVERY block, in rank order, as one contiguous operand
+                self.a_heads = torch.empty((w * x, k), dtype=self.dtype, device=self.device)
+                for q in range(w):
+                    self.a_heads[q * x:(q + 1) * x].copy_(
+                        self.a[:x] if q == r else self._window("a", x, k, q * ml, 0, k))
         elif s.startswith("k_shard"):
             kl = k // w
             self.a = self._window("a", m, kl, 0, r * kl, k)
@@ -194,6 +255,7 @@ class ShardedMatmul:
         dev, dt = self.device, self.out_dtype
         if s in ("m_shard_allgather_direct", "k_shard_allreduce_direct"):
             from .peer_mem import SymmetricBuffer
+            # (with recompute_rows the m rows are [world*x heads][world x (m/world - x) bodies])
             self._sym_c = SymmetricBuffer(self.comm, (m, n), dt, dev)
             self.c = self._sym_c.local
             self._sym_sets = [self._sym_c]
@@ -219,11 +281,12 @@ class ShardedMatmul:
                                              and self.reduce_dtype != dt):
             self._partial = torch.empty((m, n), dtype=self.reduce_dtype, device=dev)
         if s == "m_shard_allgather":
-            self._local = torch.empty((m // w, n), dtype=dt, device=dev)
+            body = m // w - self.recompute_rows
+            self._local = torch.empty((body, n), dtype=dt, device=dev)
             self._ag_sets = [(self.c, self._local)]
             if self.pipelined:
                 self._ag_sets.append((torch.empty((m, n), dtype=dt, device=dev),
-                                      torch.empty((m // w, n), dtype=dt, device=dev)))
+                                      torch.empty((body, n), dtype=dt, device=dev)))
 
     # -- local product -------------------------------------------------------------------
     def _gemm(self, a: torch.Tensor, bt: torch.Tensor, out: torch.Tensor,
@@ -275,20 +338,22 @@ class ShardedMatmul:
         symmetric result buffer; the push of panel p to all peers (one copy per peer, each on
         its own stream and link) is queued behind panel p's product and runs while panel p+1
         is computed. One host synchronisation + barrier per step completes the exchange."""
-        w, p = self.world, self.panels
-        ml = self.m // w
-        rows = ml // p
-        base = self.rank * ml
+        w, x = self.world, self.recompute_rows
+        body = self.m // w - x                 # rows of a block that travel
+        base = w * x + self.rank * body        # (x = 0: plain row order)
         which = self._steps_done % len(self._sym_sets)
         sym = self._sym_sets[which]
         if self.pipelined and self._set_works[which]:
             sym.finish()                       # the exchange that used this set two steps ago
             self._set_works[which] = []
         self.c = sym.local
-        for i in range(p):
-            r0 = base + i * rows
-            self._gemm(self.a[i * rows:(i + 1) * rows], self.bt, self.c[r0:r0 + rows])
+        for start, rows in zip(self._panel_start, self._panel_rows):
+            r0 = base + start
+            self._gemm(self.a[x + start:x + start + rows], self.bt, self.c[r0:r0 + rows])
             sym.push_rows(r0, rows)
+        if x:
+            # heads of all blocks, computed here while the links carry the bodies
+            self._gemm(self.a_heads, self.bt, self.c[:w * x])
         if self.pipelined:
             self._set_works[which] = [True]
         else:
@@ -319,22 +384,23 @@ class ShardedMatmul:
 
     def _step_m_allgather(self) -> torch.Tensor:
         """Row panels of the local block: GEMM panel p, then all-gather it while panel p+1 is
-        computed. ``c`` is stored panel-major ([panel][rank][rows][N]); ``result_dense`` undoes
-        the permutation."""
-        w, p = self.world, self.panels
-        ml = self.m // w
-        rows = ml // p
+        computed. ``c`` is stored panel-major ([panel][rank][rows][N], behind the recomputed
+        heads if any); ``result_dense`` undoes the permutation."""
+        w, x = self.world, self.recompute_rows
         which = self._steps_done % len(self._ag_sets)
         self.c, local_buf = self._ag_sets[which]
         for wk in self._set_works[which]:      # pipelined: collectives of two steps ago
             wk.wait()
         self._set_works[which] = []
-        out = self.c.view(p, w, rows, self.n)
         works = []
-        for i in range(p):
-            local = local_buf[i * rows:(i + 1) * rows]
-            self._gemm(self.a[i * rows:(i + 1) * rows], self.bt, local)
-            works.append(self.comm.all_gather(out[i], local, async_op=True))
+        for start, rows in zip(self._panel_start, self._panel_rows):
+            local = local_buf[start:start + rows]
+            self._gemm(self.a[x + start:x + start + rows], self.bt, local)
+            works.append(self.comm.all_gather(self._gathered_panel(start, rows), local,
+                                              async_op=True))
+        if x:
+            # heads of all blocks, computed here while the links carry the bodies
+            self._gemm(self.a_heads, self.bt, self.c[:w * x])
         if self.pipelined:
             self._set_works[which] = works
         else:
@@ -342,6 +408,13 @@ class ShardedMatmul:
                 wk.wait()
         self._steps_done += 1
         return self.c
+
+    def _gathered_panel(self, start: int, rows: int) -> torch.Tensor:
+        """[world, rows, N] view of ``c`` that the all-gather of the panel starting at local
+        body row ``start`` fills."""
+        w = self.world
+        off = w * self.recompute_rows + w * start
+        return self.c[off:off + w * rows].view(w, rows, self.n)
 
     def _step_k_allreduce(self) -> torch.Tensor:
         p = self.panels
@@ -406,6 +479,20 @@ class ShardedMatmul:
             self._gemm(a_blk, b_blk, self.c, accumulate=(l > 0))
         return self.c
 
+    def time_local_product(self, iters: int = 3) -> float:
+        """Seconds for this rank's own row-block product alone (no communication), GPU only:
+        the compute side of the balance ``balanced_recompute_rows`` solves."""
+        rows = self.a.shape[0]
+        scratch = torch.empty((rows, self.n), dtype=self.out_dtype, device=self.device)
+        self._gemm(self.a, self.bt, scratch)
+        start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()
+        for _ in range(iters):
+            self._gemm(self.a, self.bt, scratch)
+        stop.record()
+        stop.synchronize()
+        return start.elapsed_time(stop) * 1e-3 / iters
+
     def wait(self) -> None:
         """Complete every collective a pipelined step left in flight (no-op otherwise): after
         it, ``c`` / ``result_dense()`` of the latest step are whole on every rank."""
@@ -425,10 +512,18 @@ class ShardedMatmul:
     # -- checking ------------------------------------------------------------------------
     def result_dense(self) -> torch.Tensor:
         """This rank's result in plain row-major order (undoes the panel-major layouts)."""
-        s, w, p = self.strategy, self.world, self.panels
-        if s == "m_shard_allgather" and p > 1:
-            rows = self.m // w // p
-            return self.c.view(p, w, rows, self.n).permute(1, 0, 2, 3).reshape(self.m, self.n)
+        s, w, p, x = self.strategy, self.world, self.panels, self.recompute_rows
+        if s == "m_shard_allgather" and (p > 1 or x):
+            bodies = torch.cat([self._gathered_panel(start, rows) for start, rows
+                                in zip(self._panel_start, self._panel_rows)], dim=1)
+        elif x:
+            bodies = self.c[w * x:].view(w, self.m // w - x, self.n)
+        else:
+            bodies = None
+        if bodies is not None:
+            if x:
+                bodies = torch.cat([self.c[:w * x].view(w, x, self.n), bodies], dim=1)
+            return bodies.reshape(self.m, self.n)
         if s == "k_shard_reduce_scatter":
             return self.c   # [panel][rows/w][N]; rows_of_result() gives the global row ids
         return self.c

@@ -69,6 +69,17 @@ def main() -> int:
     eng.wait()
     torch.cuda.synchronize()
     errs["pipelined_direct"] = (eng.result_dense().float() - want).abs().max().item()
+    # recomputed heads: only rows x.. of every block travel; every rank computes the heads itself
+    for name, strategy in (("recompute_direct", "m_shard_allgather_direct"),
+                           ("recompute_rccl_layout", "m_shard_allgather")):
+        eng = ShardedMatmul(m, n, k, comm, dtype=torch.bfloat16, strategy=strategy, seed=5,
+                            device=dev, panels=1, pipelined=True, recompute_rows=128)
+        eng.init_operands()
+        for _ in range(3):
+            eng.step()
+        eng.wait()
+        torch.cuda.synchronize()
+        errs[name] = (eng.result_dense().float() - want).abs().max().item()
     res["gemm_errs"] = errs
     res["ref_scale"] = want.abs().max().item()
     with open(os.path.join(out_dir, "rank%d.json" % rank), "w") as fh:

@@ -99,6 +99,66 @@ def test_sharded_matmul_strategies_match_reference(strategy, world):
     assert max(run_ranks(world, fn)) < 1e-5
 
 
+@pytest.mark.parametrize("world,x,panels,pipelined", [(2, 8, 2, False), (4, 4, 3, True),
+                                                       (8, 2, 1, True), (4, 12, None, False)])
+def test_sharded_matmul_allgather_with_recomputed_heads(world, x, panels, pipelined):
+    """recompute_rows: every rank computes the first x rows of all blocks itself, only the rest
+    of each block is gathered; the result (in plain row order) is unchanged."""
+    def fn(c):
+        sm = ShardedMatmul(128, 48, 32, c, dtype=torch.float32, strategy="m_shard_allgather",
+                           panels=panels, pipelined=pipelined, recompute_rows=x)
+        errs = []
+        for _ in range(3):                       # pipelined: both buffer sets get used
+            sm.step()
+        sm.wait()
+        got = sm.result_dense().double()
+        assert got.shape == (128, 48)
+        ref = sm.reference(sm.rows_of_result(), sm.cols_of_result())
+        errs.append((got - ref).abs().max().item())
+        assert sm._local.shape[0] == 128 // world - x      # only the bodies travel
+        return max(errs)
+
+    assert max(run_ranks(world, fn)) < 1e-5
+
+
+def test_sharded_matmul_allgather_uneven_whole_tile_panels():
+    """Bodies of 5 x 256 rows in 2 panels: 768 + 512 rows, the same split on every rank."""
+    def fn(c):
+        sm = ShardedMatmul(2 * 1536, 16, 8, c, dtype=torch.float32, strategy="m_shard_allgather",
+                           panels=2, recompute_rows=256, pipelined=True)
+        assert sm._panel_rows == [768, 512] and sm._panel_start == [0, 768]
+        sm.step()
+        sm.step()
+        sm.wait()
+        got = sm.result_dense().double()
+        rows = sm.rows_of_result()[::97]
+        ref = sm.reference(rows, sm.cols_of_result())
+        return (got[::97] - ref).abs().max().item()
+
+    assert max(run_ranks(2, fn)) < 1e-5
+
+
+def test_recompute_rows_validation_and_balance_point():
+    from distributed_tensorflow_amd.parallel.sharded_matmul import balanced_recompute_rows
+    comm = LoopbackComm.create_world(4)[0]
+    with pytest.raises(ValueError):
+        ShardedMatmul(64, 32, 32, comm, strategy="k_shard_allreduce", recompute_rows=4)
+    with pytest.raises(ValueError):
+        ShardedMatmul(64, 32, 32, comm, strategy="m_shard_allgather", recompute_rows=16)
+    with pytest.raises(ValueError):
+        ShardedMatmul(64, 32, 32, strategy="m_shard_allgather", recompute_rows=4)   # world 1
+    # compute-bound step: nothing to gain
+    assert balanced_recompute_rows(2048, 8, 1.0e-3, 1.0e-3) == []
+    # 8 ranks, product 0.73 ms, step 1.34 ms: x = 2048 * 0.61 / (7 * 0.73 + 1.34) = 193.7
+    assert balanced_recompute_rows(2048, 8, 0.73e-3, 1.34e-3) == [128, 256]
+    # 2 ranks, product 2.9 ms, step 5.4 ms: x = 8192 * 2.5 / 8.3 = 2467
+    assert balanced_recompute_rows(8192, 2, 2.9e-3, 5.4e-3) == [2304, 2560]
+    # at the balance point both sides take the same time
+    b, w, tc, t0 = 4096, 4, 1.45e-3, 2.7e-3
+    x = b * (t0 - tc) / ((w - 1) * tc + t0)
+    assert abs(tc * (b + (w - 1) * x) / b - t0 * (b - x) / b) < 1e-9
+
+
 @pytest.mark.parametrize("strategy", ["m_shard_allgather", "summa_2d"])
 def test_sharded_matmul_fp8_operands(strategy):
     """fp8 e4m3 operands (bf16 / fp32 results): the CPU path multiplies the dequantised values,

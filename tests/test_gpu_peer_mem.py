@@ -58,3 +58,6 @@ def test_peer_memory_collectives_same_device(world, tmp_path):
         assert res["gemm_errs"]["m_shard_allgather_direct"] <= 0.02 * scale, res
         assert res["gemm_errs"]["k_shard_allreduce_direct"] <= 0.02 * scale, res
         assert res["gemm_errs"]["pipelined_direct"] <= 0.02 * scale, res
+        # recomputed heads come from the same kernel with the same K order: identical bits
+        assert res["gemm_errs"]["recompute_direct"] == 0.0, res
+        assert res["gemm_errs"]["recompute_rccl_layout"] == 0.0, res

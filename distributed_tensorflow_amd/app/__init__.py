@@ -17,7 +17,7 @@ def run(main: Optional[Callable[[List[str]], Optional[int]]] = None,
         argv: Optional[List[str]] = None) -> None:
     """Parse registered flags out of ``argv`` then call ``main(remaining_argv)``."""
     args = list(sys.argv if argv is None else argv)
-    rest = FLAGS._parse(args[1:])
+    rest = FLAGS._parse(args[1:], handle_help=True)
     if main is None:
         main = getattr(sys.modules.get("__main__"), "main", None)
         if main is None:

@@ -4,7 +4,8 @@ The reference selects a process's role with two flags declared at import time an
 lazily (``tf_distributed.py:14-18``): the first attribute access on ``FLAGS`` parses
 ``sys.argv``. Both ``--flag=value`` and ``--flag value`` are accepted, unknown arguments are
 left for the program (``app.run`` forwards them to ``main``), and booleans also accept the
-``--noflag`` spelling.
+``--noflag`` spelling. ``--help`` / ``-h`` / ``--helpfull`` on the command line print the flags
+declared so far and exit when the flags are first read -- before a ps task would start serving.
 """
 from __future__ import annotations
 
@@ -50,7 +51,10 @@ class _FlagValues:
             self.__dict__["_parsed"] = False
 
     # -- parsing -------------------------------------------------------------------------
-    def _parse(self, argv: Optional[List[str]] = None) -> List[str]:
+    def _parse(self, argv: Optional[List[str]] = None,
+               handle_help: Optional[bool] = None) -> List[str]:
+        if handle_help is None:
+            handle_help = argv is None          # the process's own command line
         args = list(sys.argv[1:] if argv is None else argv)
         defs: Dict[str, _FlagDef] = self._defs
         values: Dict[str, Any] = {}
@@ -66,6 +70,10 @@ class _FlagValues:
                 rest.append(arg)
                 continue
             body = arg.lstrip("-")
+            if handle_help and body in ("help", "h", "helpfull", "helpshort") \
+                    and body not in defs:
+                print("flags of %s:\n%s" % (sys.argv[0], self.get_help()))
+                sys.exit(0)
             name, has_eq, text = body.partition("=")
             name = name.replace("-", "_") if name.replace("-", "_") in defs else name
             if name in defs:

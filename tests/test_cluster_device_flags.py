@@ -1,5 +1,6 @@
 """T0: ClusterSpec, device strings, replica_device_setter, flags."""
 import json
+import sys
 
 import pytest
 from hypothesis import given, settings
@@ -179,3 +180,21 @@ def test_flags_lazy_parse_and_app_run(monkeypatch):
     with pytest.raises(SystemExit):
         tf.app.run(main=main, argv=["p", "--ps_hosts=a:1,b:2"])
     assert flags.FLAGS.ps_hosts == "a:1,b:2"
+
+
+def test_flags_help_prints_and_exits(monkeypatch, capsys):
+    """--help on the process's command line lists the declared flags and exits when the flags
+    are first read (so an example started with --help never reaches ``server.join()``)."""
+    from distributed_tensorflow_amd.app import flags as F
+    F.FLAGS._reset()
+    try:
+        F.DEFINE_string("job_name", "ps", "Either 'ps' or 'worker'")
+        monkeypatch.setattr(sys, "argv", ["prog", "--help"])
+        with pytest.raises(SystemExit) as e:
+            F.FLAGS.job_name
+        assert e.value.code == 0
+        assert "--job_name: Either 'ps' or 'worker' (default: 'ps')" in capsys.readouterr().out
+        # an explicit argv (a library caller's list) is not the command line: left alone
+        assert F.FLAGS._parse(["--help", "x"]) == ["--help", "x"]
+    finally:
+        F.FLAGS._reset()

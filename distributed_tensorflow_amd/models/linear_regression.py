@@ -60,15 +60,43 @@ def ground_truth(features: int, outputs: int, seed: int = 7) -> Tuple[np.ndarray
 
 
 class SyntheticRegressionData:
-    """Per-worker batch stream: worker ``task`` draws from its own counter range."""
+    """Per-worker batch stream: worker ``task`` draws from its own counter range.
+
+    ``to_device(device)`` moves the generator into GPU memory: a batch is then one window of a
+    counter-based Philox stream generated in place (rows advance by ``batch_size`` per call),
+    the targets one small fp32 product -- no host random numbers, no host-to-device copy (on the
+    host, drawing 256 x 1024 normals costs ~2.5 ms per step, 25 times the training step)."""
 
     def __init__(self, features: int, outputs: int, task: int = 0, noise: float = 0.01,
                  seed: int = 7):
         self.features, self.outputs, self.noise = features, outputs, noise
         self.w, self.b = ground_truth(features, outputs, seed)
         self._rng = np.random.RandomState(seed * 1000 + task)
+        self._seed, self._task = seed, task
+        self._device = None
+        self._row = 0
 
-    def next_batch(self, batch_size: int) -> Tuple[np.ndarray, np.ndarray]:
+    def to_device(self, device) -> "SyntheticRegressionData":
+        import torch
+        device = torch.device(device)
+        if device.type == "cuda":
+            self._device = device
+            self._w_dev = torch.from_numpy(np.ascontiguousarray(self.w, dtype=np.float32)).to(device)
+            self._b_dev = torch.from_numpy(np.ascontiguousarray(self.b, dtype=np.float32)).to(device)
+        return self
+
+    def next_batch(self, batch_size: int):
+        if self._device is not None:
+            from ..ops import hip
+            seed = self._seed * 1000 + self._task
+            x = hip.philox_window(batch_size, self.features, seed, 1, self._row, 0,
+                                  self.features, device=self._device)
+            y = hip.gemm_f32(x, self._w_dev, bias=self._b_dev)
+            if self.noise:
+                y.add_(hip.philox_window(batch_size, self.outputs, seed, 2, self._row, 0,
+                                         self.outputs, device=self._device), alpha=self.noise)
+            self._row += batch_size
+            return x, y
         x = self._rng.standard_normal((batch_size, self.features)).astype(np.float32)
         y = x @ self.w + self.b
         if self.noise:

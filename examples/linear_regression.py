@@ -40,6 +40,7 @@ def define_flags():
     tf.app.flags.DEFINE_integer("max_steps", 300, "local steps")
     tf.app.flags.DEFINE_boolean("shutdown_ps", False, "report completion to the ps tasks")
     tf.app.flags.DEFINE_string("device", "", "torch device of this task (default: auto)")
+    tf.app.flags.DEFINE_boolean("device_data", True, "GPU tasks: generate the batches in GPU memory")
     tf.app.flags.DEFINE_boolean("capture_collectives", False, "rccl: record the step's RCCL calls "
                                 "into the HIP graph together with its kernels")
     return tf.app.flags.FLAGS
@@ -69,6 +70,8 @@ def main(argv=None):
             worker_device="/job:worker/task:%d" % FLAGS.task_index, cluster=cluster)):
         model = lr_model.build_model(FLAGS.features, FLAGS.outputs, step_size)
     data = lr_model.SyntheticRegressionData(FLAGS.features, FLAGS.outputs, FLAGS.task_index)
+    if FLAGS.device_data:
+        data.to_device(server.device)       # GPU tasks: batches are generated in HBM
     sv = tf.train.Supervisor(is_chief=(FLAGS.task_index == 0), global_step=model.global_step,
                              init_op=model.init_op, recovery_wait_secs=1.0)
     begin = time.time()

@@ -115,3 +115,27 @@ def test_captured_step_follows_variables_to_new_storage():
             assert sess.stats["captures"] == captures + 1
             assert float(fresh.abs().sum()) > 0.0            # the adopted tensor is the one trained
             assert np.array_equal(sess.run(w), fresh.cpu().numpy())
+
+
+@pytest.mark.gpu
+def test_regression_batches_generated_on_device():
+    """Device-resident batch stream: counter-based (two generators agree, consecutive batches
+    differ), targets = x @ W* + b* + noise computed by the fp32 kernel."""
+    import numpy as np
+    import torch
+    from distributed_tensorflow_amd.models.linear_regression import SyntheticRegressionData
+    dev = torch.device("cuda")
+    a = SyntheticRegressionData(64, 3, task=1).to_device(dev)
+    b = SyntheticRegressionData(64, 3, task=1).to_device(dev)
+    other = SyntheticRegressionData(64, 3, task=2).to_device(dev)
+    x1, y1 = a.next_batch(128)
+    x2, y2 = a.next_batch(128)
+    bx1, by1 = b.next_batch(128)
+    ox1, _ = other.next_batch(128)
+    assert x1.is_cuda and y1.is_cuda and x1.shape == (128, 64) and y1.shape == (128, 3)
+    assert torch.equal(x1, bx1) and torch.equal(y1, by1)
+    assert not torch.equal(x1, x2) and not torch.equal(x1, ox1)
+    want = x1.double().cpu().numpy() @ a.w.astype(np.float64) + a.b
+    resid = y1.double().cpu().numpy() - want
+    assert np.abs(resid).max() < 6 * a.noise and 0.5 * a.noise < resid.std() < 1.5 * a.noise
+    assert abs(float(x1.mean())) < 0.05 and abs(float(x1.std()) - 1.0) < 0.05

@@ -7,7 +7,8 @@ The reference prints, every ``frequency`` = 100 local steps or at the last batch
 
 but always divides the elapsed time by ``frequency``, so the 50-step window at the end of
 each 550-batch epoch (550 = 5*100 + 50) reports half its true per-step time. The reporter
-below keeps the format and divides by the number of steps actually in the window.
+below keeps the format and divides by the number of steps actually in the window. With a
+``sink`` (``utils.metrics.JsonLinesSink``) every report is also appended as a JSON line.
 """
 from __future__ import annotations
 
@@ -17,11 +18,12 @@ from typing import Callable, List, Optional
 
 class StepTimeReporter:
     def __init__(self, frequency: int = 100, printer: Callable[[str], None] = print,
-                 clock: Callable[[], float] = time.time, rank_prefix: str = ""):
+                 clock: Callable[[], float] = time.time, rank_prefix: str = "", sink=None):
         self.frequency = frequency
         self._print = printer
         self._clock = clock
         self._prefix = rank_prefix
+        self._sink = sink
         self._count = 0
         self._window_start = clock()
         self.history: List[float] = []      # ms per step of every reported window
@@ -47,5 +49,9 @@ class StepTimeReporter:
         self._print("%sStep: %d,  Epoch: %2d,  Batch: %3d of %3d,  Cost: %.4f,  AvgTime: %3.2fms"
                     % (self._prefix, int(global_step) + 1, epoch + 1, batch_index + 1,
                        batch_count, cost, avg_ms))
+        if self._sink is not None:
+            self._sink.write("step_window", global_step=int(global_step) + 1, epoch=epoch + 1,
+                             batch=batch_index + 1, batch_count=batch_count, cost=float(cost),
+                             steps_in_window=self._count, avg_ms_per_step=avg_ms)
         self._count = 0
         return avg_ms

@@ -60,6 +60,7 @@ def define_flags(default_job=DEFAULT_JOB, default_epochs=DEFAULT_EPOCHS):
     tf.app.flags.DEFINE_integer("max_steps", 0, "stop after this many local steps (0 = off)")
     tf.app.flags.DEFINE_string("data_dir", "MNIST_data", "directory with the MNIST IDX files")
     tf.app.flags.DEFINE_string("logs_path", logs_path, "event-file directory")
+    tf.app.flags.DEFINE_string("metrics_path", "", "also append every report as a JSON line here")
     tf.app.flags.DEFINE_string("checkpoint_dir", "", "Supervisor logdir (enables checkpoints)")
     tf.app.flags.DEFINE_boolean("shutdown_ps", False, "report completion so the ps exits once all workers are done")
     tf.app.flags.DEFINE_string("device", "", "torch device of this task (default: auto)")
@@ -123,7 +124,12 @@ def main(argv=None, default_num_workers=DEFAULT_NUM_WORKERS):
     local_step = 0
     with sv.prepare_or_wait_for_session(server.target, config=config) as sess:
         writer = tf.summary.FileWriter(FLAGS.logs_path, graph=tf.get_default_graph())
-        reporter = StepTimeReporter(frequency)
+        sink = None
+        if FLAGS.metrics_path:
+            from distributed_tensorflow_amd.utils.metrics import JsonLinesSink
+            sink = JsonLinesSink(FLAGS.metrics_path, common={"job": FLAGS.job_name,
+                                                             "task": FLAGS.task_index})
+        reporter = StepTimeReporter(frequency, sink=sink)
         cost = float("nan")
         done = False
         # perform training cycles
@@ -143,13 +149,19 @@ def main(argv=None, default_num_workers=DEFAULT_NUM_WORKERS):
                 if FLAGS.max_steps and local_step >= FLAGS.max_steps:
                     done = True
                     break
-            print("Test-Accuracy: %2.2f" % sess.run(
-                model.accuracy, feed_dict={model.x: test_images, model.y_: test_labels}))
+            test_accuracy = sess.run(
+                model.accuracy, feed_dict={model.x: test_images, model.y_: test_labels})
+            print("Test-Accuracy: %2.2f" % test_accuracy)
             print("Total Time: %3.2fs" % float(time.time() - begin_time))
             print("Final Cost: %.4f" % cost)
+            if sink is not None:
+                sink.write("epoch", epoch=epoch + 1, test_accuracy=float(test_accuracy),
+                           total_secs=float(time.time() - begin_time), final_cost=float(cost))
             if done:
                 break
         writer.close()
+        if sink is not None:
+            sink.close()
         if FLAGS.shutdown_ps and hasattr(server.runtime, "report_done"):
             server.runtime.report_done()      # the ps exits join() once every worker has
     sv.stop()

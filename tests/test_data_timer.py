@@ -72,3 +72,35 @@ def test_step_time_reporter_windows(capsys):
     assert len(lines) == 3
     assert lines[0].startswith("Step: 4,") and "Epoch:  1," in lines[0] and "Batch:   4 of  10," in lines[0]
     assert "Cost: 1.5000," in lines[0] and lines[0].rstrip().endswith("AvgTime: 2.00ms")
+
+
+def test_step_reports_mirrored_into_jsonl_sink(tmp_path):
+    """Every printed report is also one JSON line (flushed as written); common fields are
+    merged in, numpy scalars become plain numbers, a closed sink refuses writes."""
+    import numpy as np
+    import pytest
+    from distributed_tensorflow_amd.utils.metrics import JsonLinesSink, read_jsonl
+    from distributed_tensorflow_amd.utils.step_timer import StepTimeReporter
+    path = str(tmp_path / "sub" / "metrics.jsonl")
+    ticks = iter(range(1000))
+    lines = []
+    with JsonLinesSink(path, common={"job": "worker", "task": 1}, clock=lambda: 42.0) as sink:
+        rep = StepTimeReporter(100, printer=lines.append, clock=lambda: next(ticks) * 0.1,
+                               sink=sink)
+        rep.start_epoch()
+        for i in range(550):
+            rep.step(i, 0, i, 550, np.float32(2.5))
+        sink.write("epoch", epoch=1, test_accuracy=np.float32(0.5), values=np.arange(3))
+        got = list(read_jsonl(path))            # readable before close: line buffered
+        assert len(got) == 7
+    with pytest.raises(ValueError):
+        sink.write("late")
+    windows = [r for r in got if r["kind"] == "step_window"]
+    assert len(windows) == len(lines) == 6
+    assert [w["steps_in_window"] for w in windows] == [100] * 5 + [50]
+    assert windows[-1]["batch"] == 550 and windows[0]["global_step"] == 100
+    assert all(w["job"] == "worker" and w["task"] == 1 and w["wall_time"] == 42.0
+               for w in windows)
+    assert windows[0]["cost"] == 2.5
+    assert got[-1] == {"kind": "epoch", "wall_time": 42.0, "job": "worker", "task": 1,
+                       "epoch": 1, "test_accuracy": 0.5, "values": [0, 1, 2]}

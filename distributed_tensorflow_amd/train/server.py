@@ -235,19 +235,55 @@ class Server:
         (reference ``tf_distributed.py:31``)."""
         if not self._started:
             self.start()
-        if self._ps_service is not None:
+        restore = self._stop_on_signals()
+        try:
+            if self._ps_service is not None:
+                if timeout is None:
+                    while not self._ps_service.wait(0.5):
+                        if self._stopped.is_set():
+                            break
+                else:
+                    self._ps_service.wait(timeout)
+                if self._ps_service.stopped or self._stopped.is_set():
+                    import time
+                    time.sleep(0.1)               # let the reply to the last request drain
+                    self._ps_service.stop()       # join the service threads before returning
+                return
             if timeout is None:
-                while not self._ps_service.wait(0.5):
-                    if self._stopped.is_set():
-                        break
+                while not self._stopped.wait(0.5):    # short waits: signal handlers get to run
+                    pass
             else:
-                self._ps_service.wait(timeout)
-            if self._ps_service.stopped:
-                import time
-                time.sleep(0.1)               # let the reply to the last request drain
-                self._ps_service.stop()       # join the service threads before returning
-            return
-        self._stopped.wait(timeout)
+                self._stopped.wait(timeout)
+        finally:
+            restore()
+
+    def _stop_on_signals(self):
+        """While a task is parked in ``join()``, SIGTERM / SIGINT end the wait instead of
+        killing the process mid-request: the service threads are joined and ``join`` returns
+        (the reference's ps has no shutdown path at all and has to be killed,
+        ``tf_distributed.py:31``). Only possible from the main thread; returns the undo."""
+        import signal
+        import threading
+        if threading.current_thread() is not threading.main_thread():
+            return lambda: None
+        previous = {}
+
+        def handler(signum, frame):
+            self._stopped.set()
+
+        for sig in (signal.SIGTERM, signal.SIGINT):
+            try:
+                previous[sig] = signal.signal(sig, handler)
+            except (ValueError, OSError):
+                pass
+
+        def restore():
+            for sig, old in previous.items():
+                try:
+                    signal.signal(sig, old)
+                except (ValueError, OSError):
+                    pass
+        return restore
 
     def stop(self) -> None:
         self._stopped.set()

@@ -149,3 +149,39 @@ def test_mnist_example_two_ps_tasks_round_robin(tmp_path):
     assert out.count("] done") == 2
     costs = [float(c) for c in re.findall(r"Cost: (\d+\.\d{4}),", out)]
     assert costs and all(c == c and c < 50 for c in costs)          # finite, sane
+
+
+def test_ps_task_leaves_join_cleanly_on_sigterm(tmp_path):
+    """A ps task parked in ``server.join()`` (the reference's can only be killed,
+    ``tf_distributed.py:31``) ends the wait on SIGTERM, joins its service threads and runs the
+    code after ``join()``: exit status 0, not death by signal."""
+    import signal
+    import socket
+    import time
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        ps_port = sk.getsockname()[1]
+    script = tmp_path / "ps_task.py"
+    script.write_text(
+        "import sys\n"
+        "import distributed_tensorflow_amd as tf\n"
+        "cluster = tf.train.ClusterSpec({'ps': ['127.0.0.1:%d'], 'worker': ['127.0.0.1:1']})\n"
+        "server = tf.train.Server(cluster, job_name='ps', task_index=0)\n"
+        "print('serving', flush=True)\n"
+        "server.join()\n"
+        "print('left join', flush=True)\n"
+        "server.stop()\n"
+        "sys.exit(0)\n" % ps_port)
+    proc = subprocess.Popen([sys.executable, "-u", str(script)], cwd=ROOT,
+                            env=dict(os.environ, PYTHONPATH=ROOT), stdout=subprocess.PIPE,
+                            stderr=subprocess.STDOUT, text=True)
+    try:
+        assert proc.stdout.readline().strip() == "serving"
+        time.sleep(0.3)
+        proc.send_signal(signal.SIGTERM)
+        out, _ = proc.communicate(timeout=30)
+    finally:
+        if proc.poll() is None:
+            proc.kill()
+    assert proc.returncode == 0, out
+    assert "left join" in out

@@ -24,8 +24,11 @@
 //    A operand, A fragment as its B operand): the accumulator then holds, per lane, four
 //    consecutive n of one row m, so the epilogue issues 8-byte (bf16) / 16-byte (fp32) row
 //    stores instead of 2-byte column scatters.
-//  * workgroup id -> tile: XCD-aware remap (contiguous chunk of the tile grid per XCD L2) and
-//    a grouped walk (8 tile-rows deep) so the ~32 tiles resident on an XCD share A/B panels.
+//  * workgroup id -> tile: XCD-aware. Large square-ish grids use the super-tile walk of
+//    pp_tile_of_block (the eight XCDs as a 2 x 4 arrangement of 8 x 4-tile blocks that advance
+//    together in a snake, so concurrently resident tiles share A/B panels inside an XCD's L2
+//    and across XCDs through the memory-side cache); other grids a contiguous chunk of the
+//    tile grid per XCD, walked 8 tile-rows deep.
 //  * M and N edges are handled by clamping source rows (out-of-range rows are computed and
 //    dropped at the store); K must be a multiple of 64.
 //

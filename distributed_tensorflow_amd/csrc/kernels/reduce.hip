@@ -70,13 +70,33 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
   return t;   // valid on thread 0
 }
 
-// stage 1: partial[b] = sum of this block's grid-stride slice
+// stage 1: partial[b] = sum of this block's grid-stride slice. 16-byte loads, four of them in
+// flight per thread into independent accumulators (a single scalar-load chain per thread ran
+// the 64 MiB mean of a 4096^2 product at 130 GB/s); the fold order is fixed by the launch
+// shape, so the result is deterministic.
 __global__ __launch_bounds__(BLOCK) void reduce_all_stage1(const float* __restrict__ x,
                                                            float* __restrict__ partial, long n) {
   __shared__ float sh[BLOCK / 64];
+  const long tid = blockIdx.x * (long)BLOCK + threadIdx.x;
+  const long nthreads = (long)gridDim.x * BLOCK;
   float acc = 0.f;
-  for (long i = blockIdx.x * (long)BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * BLOCK)
-    acc += x[i];
+  const long head = (4 - (((uintptr_t)x >> 2) & 3)) & 3;      // elements before 16-byte alignment
+  const long lead = head < n ? head : n;
+  if (tid < lead) acc += x[tid];
+  const f32x4* xv = reinterpret_cast<const f32x4*>(x + lead);
+  const long nv = (n - lead) >> 2;
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+  long i = tid;
+  for (; i + 3 * nthreads < nv; i += 4 * nthreads) {
+    const f32x4 v0 = xv[i], v1 = xv[i + nthreads], v2 = xv[i + 2 * nthreads],
+                v3 = xv[i + 3 * nthreads];
+    a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+  }
+  for (; i < nv; i += nthreads) a0 += xv[i];
+  a0 += a1; a2 += a3; a0 += a2;
+  acc += (a0[0] + a0[1]) + (a0[2] + a0[3]);
+  const long tail0 = lead + (nv << 2);
+  if (tail0 + tid < n) acc += x[tail0 + tid];                 // at most 3 elements
   const float t = block_sum(acc, sh);
   if (threadIdx.x == 0) partial[blockIdx.x] = t;
 }

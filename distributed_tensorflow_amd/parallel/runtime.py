@@ -148,6 +148,7 @@ class CollectiveRuntime(LocalRuntime):
     # bucket, shards -- keeps its address from step to step); a world of one has no
     # collectives to issue and is captured like a local session
     capturable_with_collectives = True
+    ARENA_ALIGN = 64            # fp32 elements: variables start on 256-byte boundaries
 
     @property
     def capturable(self) -> bool:
@@ -186,17 +187,24 @@ class CollectiveRuntime(LocalRuntime):
         f32 = [(n, shape) for n, shape, dt in present if dt == "torch.float32"]
         other = [(n, shape, dt) for n, shape, dt in present if dt != "torch.float32"]
         w = self.comm.world_size
-        total = sum(int(torch.Size(s).numel()) for _, s in f32)
+        # every variable starts on a 256-byte boundary of the arena: the GEMM kernels take their
+        # 16-byte vector / buffer-load paths only for aligned operands (a scalar such as
+        # global_step in front of a matrix would otherwise push it onto the element-wise path:
+        # 1.65 ms instead of 1.06 ms for the 4096^3 fp32 product)
+        align = self.ARENA_ALIGN
+        offsets, total = [], 0
+        for _, shape in f32:
+            offsets.append(total)
+            numel = int(torch.Size(shape).numel())
+            total += ((numel + align - 1) // align) * align
         padded = ((total + w - 1) // w) * w if total else 0
         flat = torch.zeros(padded, dtype=torch.float32, device=self.device)
-        off = 0
         self._layout = []
-        for n, shape in f32:
+        for (n, shape), off in zip(f32, offsets):
             numel = int(torch.Size(shape).numel())
             if self.is_chief:
                 flat[off:off + numel].copy_(store.read(n).reshape(-1))
             self._layout.append((n, off, numel, shape))
-            off += numel
         if padded:
             self.comm.broadcast(flat, src=0)
         for n, o, numel, shape in self._layout:

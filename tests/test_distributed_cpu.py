@@ -372,6 +372,14 @@ def test_sync_collective_job_keeps_replicas_identical(strategy):
     assert results[0]["costs"] != results[1]["costs"]    # different data on each worker
     assert np.mean(results[0]["costs"][-5:]) < np.mean(results[0]["costs"][:5])
     assert results[0]["runtime"].bytes_reduced > 0
+    # the flat arena keeps every variable on a 256-byte boundary (the scalar global_step must not
+    # push the matrices off the GEMM kernels' 16-byte paths) and its length divides by the world
+    rt = results[0]["runtime"]
+    assert {n for n, _, _, _ in rt._layout} >= {"global_step", "weights/Variable"}
+    assert all(off % 64 == 0 for _, off, _, _ in rt._layout)
+    spans = sorted((off, off + numel) for _, off, numel, _ in rt._layout)
+    assert all(a_end <= b_start for (_, a_end), (b_start, _) in zip(spans, spans[1:]))
+    assert rt._flat_params.numel() % world == 0 and rt._flat_params.numel() >= spans[-1][1]
 
 
 def test_bucketed_gradient_allreduce_overlaps_backward_and_matches_single_bucket():

@@ -182,6 +182,13 @@ def test_reductions(hip):
     assert abs(hip.reduce_all(big).item() - big.double().sum().item()) < 0.05
     r1, r2 = hip.reduce_all(big), hip.reduce_all(big)
     assert torch.equal(r1, r2)                      # fixed-order fold: bitwise reproducible
+    # every length / alignment class of the vectorised first stage, exact on small integers
+    ints = torch.randint(-8, 9, (70001,), generator=g).float().cuda()
+    for off in range(4):
+        for n in (1, 2, 3, 4, 5, 7, 255, 1024, 4099, 70001 - off):
+            v = ints[off:off + n]
+            assert hip.reduce_all(v).item() == v.double().sum().item(), (off, n)
+    assert hip.reduce_all(ints[:1000], 0.5).item() == 0.5 * ints[:1000].sum().item()
     wide = torch.randn(64, 1000, generator=g).cuda()
     assert torch.allclose(hip.reduce_rows(wide, hip.ROW_SUM), wide.sum(1), atol=1e-4)
     assert torch.equal(hip.argmax_rows(wide), wide.argmax(1))

@@ -89,6 +89,12 @@ def main() -> None:
                          "(tf_distributed_1000Matrix.py:43-44), or U(-1,1)")
     args = ap.parse_args()
 
+    # stdout carries exactly one line, the result: everything else that writes to descriptor 1
+    # while the job runs (RCCL prints a version banner there from C) is sent to stderr
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     if os.environ.get("DTF_BENCH_DEBUG"):        # dump every thread's stack if a run stalls
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ["DTF_BENCH_DEBUG"]), exit=True)
@@ -212,7 +218,7 @@ def main() -> None:
                "summa_2d": "summa2d_%d" % world}[strategy]
         if engine.recompute_rows:
             par += "+recompute%d" % engine.recompute_rows
-        print(json.dumps({
+        line = json.dumps({
             "metric": "sharded_gemm_tflops",
             "value": round(tflops, 2),
             "unit": "TFLOP/s",
@@ -236,7 +242,9 @@ def main() -> None:
                        ("replicated", "m_shard_allgather", "k_shard_allreduce",
                         "m_shard_allgather_direct", "k_shard_allreduce_direct")
                        else "C left sharded"},
-        }), flush=True)
+        })
+        sys.stdout.flush()
+        os.write(result_fd, (line + "\n").encode())
     comm.close()
 
 

@@ -101,3 +101,33 @@ def test_collective_runtime_trains_like_local_session(nccl_comm, strategy, captu
     assert got[2] == ref[2] == 5.0
     assert np.allclose(got[0], ref[0], rtol=1e-5)
     assert np.allclose(got[1], ref[1], rtol=1e-5, atol=1e-6)
+
+
+def test_bench_contract_one_json_line_on_stdout():
+    """bench.py under the real RCCL backend (world 1): stdout is exactly one JSON line with the
+    contract's keys -- RCCL's version banner and every note go to stderr."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, DTF_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    proc = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3",
+                           "--warmup", "1", "--m", "2048", "--n", "2048", "--k", "2048"],
+                          env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                          timeout=200)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    lines = proc.stdout.strip().splitlines()
+    assert len(lines) == 1, proc.stdout
+    rec = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert key in rec, key
+    assert rec["n_gpus"] == 1 and rec["steps"] == 3 and rec["warmup"] == 1
+    assert rec["dtype"] == "bf16" and rec["higher_is_better"] is True
+    assert rec["config"]["model"] == "gemm_2048x2048x2048_bf16"
+    assert abs(rec["value"] - 2.0 * 2048 ** 3 / (rec["ms_per_step"] * 1e-3) / 1e12) < 0.02 * rec["value"]

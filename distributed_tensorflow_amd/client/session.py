@@ -499,6 +499,11 @@ class Session:
         pinned memory (one asynchronous H2D copy straight into the graph's input buffer)."""
         if isinstance(value, torch.Tensor):
             if value.device.type == "cuda" or t.dtype.numpy is None:
+                if (value.device == self.device and value.dtype == t.dtype.torch
+                        and value.is_contiguous() and t.shape is not None
+                        and len(t.shape) == value.dim()
+                        and all(d is None or d == s for d, s in zip(t.shape, value.shape))):
+                    return value            # the common case: a batch view of a resident data set
                 return self._to_device(t, value)
             value = value.detach().numpy()
         if t.dtype.numpy is None:
@@ -613,7 +618,7 @@ class Session:
 
     # -- HIP-graph path --------------------------------------------------------------------
     def _run_captured(self, plan: ExecutionPlan, feeds: List[Any]):
-        sig = tuple((tuple(f.shape), str(f.dtype)) for f in feeds)
+        sig = tuple((tuple(f.shape), f.dtype) for f in feeds)
         cap = plan.graphs.get(sig)
         generation = self._local_store.generation
         if cap is not None and cap.generation != generation:

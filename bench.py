@@ -81,6 +81,9 @@ def main() -> None:
     ap.add_argument("--no-recompute", action="store_true",
                     help="all-gather strategies: never trade recomputed rows of the peers' blocks "
                          "for transfer (default: tried when the step is transfer-bound)")
+    ap.add_argument("--peer-transport", default="copy", choices=("copy", "kernel"),
+                    help="peer-memory all-gather: one runtime copy per peer on the copy engines "
+                         "(default) or one kernel that stores the rows into all peers itself")
     ap.add_argument("--recompute-rows", type=int, default=None,
                     help="time this many recomputed rows per peer block instead of the values "
                          "around the measured balance point")
@@ -120,7 +123,7 @@ def main() -> None:
         eng = ShardedMatmul(args.m, args.n, args.k, comm, dtype=dtype, strategy=strategy,
                             panels=args.panels, seed=1, device=device,
                             distribution=args.distribution, pipelined=not args.no_pipeline,
-                            recompute_rows=recompute_rows)
+                            recompute_rows=recompute_rows, peer_transport=args.peer_transport)
         eng.init_operands()
         return eng
 
@@ -238,6 +241,8 @@ def main() -> None:
                        "parallelism": par, "panels": engine.panels,
                        "pipelined_steps": bool(engine.pipelined),
                        "recompute_rows": engine.recompute_rows,
+                       "peer_transport": engine.peer_transport
+                       if strategy.endswith("_direct") else None,
                        "result": "full C on every rank" if strategy in
                        ("replicated", "m_shard_allgather", "k_shard_allreduce",
                         "m_shard_allgather_direct", "k_shard_allreduce_direct")

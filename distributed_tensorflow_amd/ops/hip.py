@@ -82,6 +82,7 @@ def _declare(L: ctypes.CDLL) -> None:
         "dtf_row_scale_f32": [P, P, P, LG, LG, P],
         "dtf_reduce_rows_f32": [I, P, P, LG, LG, P],
         "dtf_argmax_rows_f32": [P, P, LG, LG, P],
+        "dtf_peer_push": [P, P, I, LG, I, P],
         "dtf_reduce_all_workspace": [LG],
         "dtf_reduce_all_f32": [P, P, LG, F, P, P],
         "dtf_reduce_cols_f32": [P, P, LG, LG, P],
@@ -755,6 +756,28 @@ def pack_f32(parts: Sequence[torch.Tensor], out: torch.Tensor) -> List[int]:
         offsets.append(off)
         off += p.numel()
     return offsets
+
+
+def peer_push(src: torch.Tensor, dsts: Sequence[torch.Tensor], blocks_per_peer: int = 8) -> None:
+    """Copy the contiguous GPU tensor ``src`` into each of ``dsts`` (1..8 contiguous tensors of
+    the same dtype and size, typically peer-mapped buffers of other GPUs) with one kernel on the
+    current stream; ``blocks_per_peer`` workgroups serve each destination."""
+    dsts = list(dsts)
+    if not 1 <= len(dsts) <= 8:
+        raise HipKernelError("peer_push: 1..8 destinations")
+    if not (isinstance(src, torch.Tensor) and src.device.type == "cuda" and src.is_contiguous()):
+        raise HipKernelError("peer_push: src must be a contiguous GPU tensor")
+    nbytes = src.numel() * src.element_size()
+    for d in dsts:
+        if not (isinstance(d, torch.Tensor) and d.device.type == "cuda" and d.is_contiguous()
+                and d.dtype == src.dtype and d.numel() == src.numel()):
+            raise HipKernelError("peer_push: destinations must be contiguous GPU tensors of the "
+                                 "source's dtype and size")
+    if src.data_ptr() % 16 or any(d.data_ptr() % 16 for d in dsts):
+        raise HipKernelError("peer_push: buffers must be 16-byte aligned")
+    ptrs = (ctypes.c_void_p * len(dsts))(*[d.data_ptr() for d in dsts])
+    _check(lib().dtf_peer_push(src.data_ptr(), ptrs, len(dsts), nbytes, int(blocks_per_peer),
+                               _stream()), "peer_push")
 
 
 def philox_window(rows: int, cols: int, seed: int, op_seed: int, row0: int, col0: int,

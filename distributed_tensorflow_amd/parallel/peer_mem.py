@@ -10,7 +10,9 @@ time. The collectives here are *direct*: every rank talks to all of its peers at
   torch's CUDA-tensor sharing; one process per GPU, all GPUs visible to every process). The
   handles travel over the job's ordinary communicator (RCCL or gloo) once, at allocation.
 * ``all_gather_rows`` (push): a rank copies its block of rows into the same rows of every peer's
-  buffer, one copy per peer on that peer's own stream -- N-1 concurrent transfers on N-1 links.
+  buffer, one copy per peer on that peer's own stream -- N-1 concurrent transfers on N-1 links
+  (or, with ``transport="kernel"``, one ``peer_push`` kernel whose workgroups store the rows
+  into all peers themselves).
 * ``reduce_scatter_rows`` (pull): a rank fetches its block of rows from every peer's buffer --
   again N-1 concurrent copies -- and sums the N blocks with the ``reduce_partials`` kernel in rank
   order (deterministic).
@@ -41,7 +43,12 @@ class SymmetricBuffer:
     local``). Collective constructor: every rank of ``comm`` must call it with the same shape."""
 
     def __init__(self, comm: Communicator, shape: Sequence[int], dtype: torch.dtype,
-                 device: torch.device):
+                 device: torch.device, transport: str = "copy", blocks_per_peer: int = 8):
+        if transport not in ("copy", "kernel"):
+            raise ValueError("transport must be 'copy' or 'kernel'")
+        self.transport = transport
+        self.blocks_per_peer = int(blocks_per_peer)
+        self._push_stream: Optional[torch.cuda.Stream] = None
         self.comm = comm
         self.rank, self.world = comm.rank, comm.world_size
         self.device = torch.device(device)
@@ -79,6 +86,8 @@ class SymmetricBuffer:
         # one copy stream per peer so the N-1 transfers of a push run concurrently
         self._streams = [None if r == self.rank else torch.cuda.Stream(device=self.device)
                          for r in range(self.world)]
+        if transport == "kernel":
+            self._push_stream = torch.cuda.Stream(device=self.device)
         # prove the copy path before anything depends on it: every rank writes its rank number
         # into byte `rank` of every peer's buffer (the buffer holds no data yet)
         nbytes = self.local.numel() * self.local.element_size()
@@ -108,13 +117,25 @@ class SymmetricBuffer:
     def push_rows(self, row0: int, rows: int, ready: Optional[torch.cuda.Event] = None) -> None:
         """Queue the copy of ``local[row0:row0+rows]`` into the same rows of every peer. The
         copies start once ``ready`` (default: everything queued so far on the current stream)
-        has happened; :meth:`finish` completes them."""
+        has happened; :meth:`finish` completes them.
+
+        ``transport = "copy"`` (default): one runtime copy per peer, each on its own stream (the
+        copy engines move the data). ``transport = "kernel"``: one ``peer_push`` kernel on a side
+        stream stores the rows into all peers itself."""
         if self.world == 1:
             return
         if ready is None:
             ready = torch.cuda.Event()
             ready.record()
         src = self.local[row0:row0 + rows]
+        if self.transport == "kernel":
+            from ..ops import hip
+            st = self._push_stream
+            st.wait_event(ready)
+            with torch.cuda.stream(st):
+                hip.peer_push(src, [self.views[r][row0:row0 + rows] for r in range(self.world)
+                                    if r != self.rank], self.blocks_per_peer)
+            return
         for r in range(self.world):
             if r == self.rank:
                 continue
@@ -131,6 +152,8 @@ class SymmetricBuffer:
         for st in self._streams:
             if st is not None:
                 st.synchronize()
+        if self._push_stream is not None:
+            self._push_stream.synchronize()
         self.comm.barrier()
 
     def quiesce(self) -> None:

@@ -116,7 +116,8 @@ class ShardedMatmul:
                  panels: Optional[int] = None, seed: int = 1,
                  device: Optional[torch.device] = None,
                  reduce_dtype: Optional[torch.dtype] = None, distribution: str = "uniform",
-                 pipelined: bool = False, recompute_rows: int = 0):
+                 pipelined: bool = False, recompute_rows: int = 0,
+                 peer_transport: str = "copy"):
         if strategy not in STRATEGIES:
             raise ValueError("unknown strategy %r (choose from %s)" % (strategy, STRATEGIES))
         self.m, self.n, self.k = int(m), int(n), int(k)
@@ -161,6 +162,7 @@ class ShardedMatmul:
         if strategy.startswith("k_shard") and self.k % w:
             raise ValueError("K=%d must be divisible by the world size %d" % (self.k, w))
         rows_local = self.m // w if strategy.startswith("m_shard") else self.m
+        self.peer_transport = peer_transport      # *_direct strategies: "copy" | "kernel"
         self.recompute_rows = int(recompute_rows)
         if self.recompute_rows:
             if strategy not in ("m_shard_allgather", "m_shard_allgather_direct") or w == 1:
@@ -256,11 +258,12 @@ class ShardedMatmul:
         if s in ("m_shard_allgather_direct", "k_shard_allreduce_direct"):
             from .peer_mem import SymmetricBuffer
             # (with recompute_rows the m rows are [world*x heads][world x (m/world - x) bodies])
-            self._sym_c = SymmetricBuffer(self.comm, (m, n), dt, dev)
+            self._sym_c = SymmetricBuffer(self.comm, (m, n), dt, dev, self.peer_transport)
             self.c = self._sym_c.local
             self._sym_sets = [self._sym_c]
             if self.pipelined:
-                self._sym_sets.append(SymmetricBuffer(self.comm, (m, n), dt, dev))
+                self._sym_sets.append(SymmetricBuffer(self.comm, (m, n), dt, dev,
+                                                      self.peer_transport))
             if s == "k_shard_allreduce_direct":
                 self._sym_partial = SymmetricBuffer(self.comm, (m, n), self.reduce_dtype, dev)
                 self._stage = torch.empty((max(1, w - 1), m // w, n), dtype=self.reduce_dtype,

@@ -80,6 +80,16 @@ def main() -> int:
         eng.wait()
         torch.cuda.synchronize()
         errs[name] = (eng.result_dense().float() - want).abs().max().item()
+    # the kernel transport: one peer_push launch stores the rows into every peer
+    eng = ShardedMatmul(m, n, k, comm, dtype=torch.bfloat16, strategy="m_shard_allgather_direct",
+                        seed=5, device=dev, panels=2, pipelined=True, recompute_rows=128,
+                        peer_transport="kernel")
+    eng.init_operands()
+    for _ in range(3):
+        eng.step()
+    eng.wait()
+    torch.cuda.synchronize()
+    errs["kernel_transport"] = (eng.result_dense().float() - want).abs().max().item()
     res["gemm_errs"] = errs
     res["ref_scale"] = want.abs().max().item()
     with open(os.path.join(out_dir, "rank%d.json" % rank), "w") as fh:

@@ -606,3 +606,23 @@ def test_gemm_bf16_split_k(hip, m, n, k, splits, out_dtype):
     hip.gemm_bf16_nt(ad, bd, out_dtype, alpha=0.5, out=acc, beta=2.0, splits=splits)
     want = (0.5 * ref + 2.0 * base.float().cpu()).to(out_dtype).float()
     assert torch.equal(acc.float().cpu(), want)
+
+
+def test_peer_push_kernel(hip):
+    """One launch copies a block into several destinations (here buffers of the same GPU):
+    sizes around the vector / grid-stride boundaries, odd byte tails (bf16), guard bands."""
+    g = torch.Generator().manual_seed(21)
+    for n, dtype in ((4, torch.float32), (1000, torch.float32), (8 * 256 * 4 * 4 + 12, torch.float32),
+                     (2048 * 1024, torch.bfloat16), (4099, torch.bfloat16)):
+        src = torch.randn(n, generator=g).to(dtype).cuda()
+        backing = [torch.full((n + 16,), -3.0, dtype=dtype, device="cuda") for _ in range(7)]
+        dsts = [b[8:8 + n] for b in backing]
+        hip.peer_push(src, dsts, blocks_per_peer=8)
+        torch.cuda.synchronize()
+        for b, d in zip(backing, dsts):
+            assert torch.equal(d, src)
+            assert (b[:8] == -3.0).all() and (b[-8:] == -3.0).all()
+    with pytest.raises(hip.HipKernelError):
+        hip.peer_push(src, [src[1:]])
+    with pytest.raises(hip.HipKernelError):
+        hip.peer_push(src[1:], [torch.empty_like(src[1:])])       # 2-byte offset: misaligned

@@ -61,3 +61,4 @@ def test_peer_memory_collectives_same_device(world, tmp_path):
         # recomputed heads come from the same kernel with the same K order: identical bits
         assert res["gemm_errs"]["recompute_direct"] == 0.0, res
         assert res["gemm_errs"]["recompute_rccl_layout"] == 0.0, res
+        assert res["gemm_errs"]["kernel_transport"] == 0.0, res

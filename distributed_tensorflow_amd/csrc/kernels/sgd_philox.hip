@@ -205,6 +205,46 @@ __global__ __launch_bounds__(BLOCK) void pack_f32_kernel(PackArgs args, float* _
   }
 }
 
+// ---- feeds of a captured step, gathered through a pointer table ---------------------------------
+// A captured step reads its inputs from fixed buffers. When the inputs already live in GPU memory
+// (batch views of a device-resident data set) their addresses change every step; instead of one
+// runtime copy per input in front of the graph launch, the graph's first node is this kernel: it
+// reads the CURRENT source addresses from a small table in pinned host memory, which the host
+// rewrites with plain stores before each launch, and copies the inputs into the fixed buffers.
+constexpr int MAX_FEEDS = 8;
+struct FeedDst {
+  char* dst[MAX_FEEDS];
+  long bytes[MAX_FEEDS];
+  long first_block[MAX_FEEDS + 1];   // feed i owns workgroups [first_block[i], first_block[i+1])
+  int count;
+};
+constexpr int FEED_BYTES_PER_BLOCK = BLOCK * 16 * 4;
+
+__global__ __launch_bounds__(BLOCK) void gather_feeds_kernel(
+    const unsigned long long* __restrict__ table, FeedDst args) {
+  int seg = 0;
+  while (seg + 1 < args.count && (long)blockIdx.x >= args.first_block[seg + 1]) ++seg;
+  const char* src = reinterpret_cast<const char*>(
+      __builtin_nontemporal_load(table + seg));          // host memory: never from a stale line
+  char* dst = args.dst[seg];
+  const long n = args.bytes[seg];
+  const long base = ((long)blockIdx.x - args.first_block[seg]) * FEED_BYTES_PER_BLOCK;
+  if ((((uintptr_t)src) & 15) == 0) {                     // dst buffers are allocator-aligned
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long o = base + ((long)u * BLOCK + threadIdx.x) * 16;
+      if (o + 16 <= n) {
+        *reinterpret_cast<f32x4*>(dst + o) = *reinterpret_cast<const f32x4*>(src + o);
+      } else {
+        for (long b = o; b < n && b < o + 16; ++b) dst[b] = src[b];
+      }
+    }
+  } else {
+    const long end = base + FEED_BYTES_PER_BLOCK < n ? base + FEED_BYTES_PER_BLOCK : n;
+    for (long b = base + threadIdx.x; b < end; b += BLOCK) dst[b] = src[b];
+  }
+}
+
 int grid_for(long n, int per_thread) {
   long blocks = (n + (long)BLOCK * per_thread - 1) / ((long)BLOCK * per_thread);
   return (int)(blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks);
@@ -238,6 +278,30 @@ DTF_API int dtf_multi_sgd_f32(int count, float* const* w, const float* const* g,
     args.t[0] = SgdTensor{args.counter[0], args.counter[0], 0, 0.f};
   dim3 grid(grid_for(max_n, 4), count > 0 ? count : 1), block(BLOCK);
   hipLaunchKernelGGL(multi_sgd_kernel, grid, block, 0, stream, args);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
+// dst[i][0..bytes[i]) = (*table[i])[0..bytes[i]) for count <= 8 inputs: `table` holds the source
+// ADDRESSES (64-bit, in pinned host memory or device memory) and is read when the kernel runs,
+// not when it is launched or captured.
+DTF_API int dtf_gather_feeds(const void* table, int count, void* const* dst, const long* bytes,
+                             hipStream_t stream) {
+  if (!table || count < 1 || count > MAX_FEEDS) return DTF_ERR_BAD_ARG;
+  FeedDst args = {};
+  long blocks = 0;
+  for (int i = 0; i < count; ++i) {
+    if (!dst[i] || bytes[i] <= 0 || ((uintptr_t)dst[i] & 15)) return DTF_ERR_BAD_ARG;
+    args.dst[i] = (char*)dst[i];
+    args.bytes[i] = bytes[i];
+    args.first_block[i] = blocks;
+    blocks += (bytes[i] + FEED_BYTES_PER_BLOCK - 1) / FEED_BYTES_PER_BLOCK;
+  }
+  args.first_block[count] = blocks;
+  args.count = count;
+  if (blocks > 0x7fffffffL) return DTF_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(gather_feeds_kernel, dim3((unsigned)blocks), dim3(BLOCK), 0, stream,
+                     (const unsigned long long*)table, args);
   DTF_LAUNCH_CHECK();
   return DTF_OK;
 }

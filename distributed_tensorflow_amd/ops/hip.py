@@ -103,6 +103,7 @@ def _declare(L: ctypes.CDLL) -> None:
         "dtf_philox_uniform": [P, LG, U, U, LG, F, F, I, P],
         "dtf_reduce_partials": [I, P, P, LG, F, I, P],
         "dtf_pack_f32": [I, P, P, P, P],
+        "dtf_gather_feeds": [P, I, P, P, P],
         "dtf_philox_fill_2d": [P, LG, LG, LG, U, U, LG, LG, LG, F, F, I, I, P],
     }
     for name, argtypes in sigs.items():
@@ -778,6 +779,29 @@ def peer_push(src: torch.Tensor, dsts: Sequence[torch.Tensor], blocks_per_peer: 
     ptrs = (ctypes.c_void_p * len(dsts))(*[d.data_ptr() for d in dsts])
     _check(lib().dtf_peer_push(src.data_ptr(), ptrs, len(dsts), nbytes, int(blocks_per_peer),
                                _stream()), "peer_push")
+
+
+def gather_feeds(table: torch.Tensor, dsts: Sequence[torch.Tensor]) -> None:
+    """Launch the kernel that copies ``len(dsts)`` (<= 8) inputs into the contiguous GPU tensors
+    ``dsts`` from the source ADDRESSES stored in ``table`` (int64, pinned host or GPU memory,
+    one per destination). The table is read when the kernel runs: a captured launch picks up
+    whatever addresses the host stored before the replay. Sources must hold at least as many
+    bytes as their destination and stay alive until the kernel has run."""
+    dsts = list(dsts)
+    if not 1 <= len(dsts) <= 8:
+        raise HipKernelError("gather_feeds: 1..8 destinations")
+    if table.dtype != torch.int64 or table.numel() < len(dsts) or not table.is_contiguous() \
+            or not (table.device.type == "cuda" or table.is_pinned()):
+        raise HipKernelError("gather_feeds: table must be int64 in pinned host or GPU memory")
+    for d in dsts:
+        if not (isinstance(d, torch.Tensor) and d.device.type == "cuda" and d.is_contiguous()
+                and d.numel() > 0 and d.data_ptr() % 16 == 0):
+            raise HipKernelError("gather_feeds: destinations must be non-empty contiguous "
+                                 "16-byte aligned GPU tensors")
+    n = len(dsts)
+    dst = (ctypes.c_void_p * n)(*[d.data_ptr() for d in dsts])
+    nbytes = (ctypes.c_long * n)(*[d.numel() * d.element_size() for d in dsts])
+    _check(lib().dtf_gather_feeds(table.data_ptr(), n, dst, nbytes, _stream()), "gather_feeds")
 
 
 def philox_window(rows: int, cols: int, seed: int, op_seed: int, row0: int, col0: int,

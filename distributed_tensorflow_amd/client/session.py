@@ -38,6 +38,7 @@ from . import fusion
 from .variable_store import FailedPreconditionError, LocalVariableStore
 
 _VAR_TYPES = ("VariableV2",)
+_TABLE_HOST_BYTES = 1 << 20      # host inputs up to this size are read by the gather kernel
 _PACK_WORDS = 256     # fp32 words of pinned staging per captured step for small fetches
 
 
@@ -624,8 +625,12 @@ class Session:
     def _run_captured(self, plan: ExecutionPlan, feeds: List[Any]):
         # every input already in GPU memory: the graph's first node gathers them itself from a
         # table of source addresses in pinned memory -- no runtime copy in front of the launch
+        # (small host inputs ride the same way: they are staged in pinned memory, whose address
+        # goes into the table, and the kernel reads them over PCIe -- no copy call either; large
+        # host inputs keep the DMA path)
         use_table = (0 < len(feeds) <= 8 and not os.environ.get("DTF_NO_FEED_TABLE")
-                     and all(isinstance(f, torch.Tensor) and f.numel() > 0 for f in feeds))
+                     and all((f.numel() > 0) if isinstance(f, torch.Tensor)
+                             else (0 < f.nbytes <= _TABLE_HOST_BYTES) for f in feeds))
         sig = tuple((tuple(f.shape), f.dtype) for f in feeds) + (use_table,)
         cap = plan.graphs.get(sig)
         generation = self._local_store.generation
@@ -643,7 +648,16 @@ class Session:
                 cap.table_read.synchronize()     # the previous replay has read its addresses
             table = cap.feed_table_np
             for i, f in enumerate(feeds):
-                table[i] = f.data_ptr()
+                if isinstance(f, torch.Tensor):
+                    table[i] = f.data_ptr()
+                    continue
+                pin = cap.pinned[i]
+                if pin is None:
+                    static = cap.static_feeds[i]
+                    pin = torch.empty(static.shape, dtype=static.dtype, pin_memory=True)
+                    pin = cap.pinned[i] = (pin, pin.numpy(), pin.data_ptr())
+                np.copyto(pin[1], f)
+                table[i] = pin[2]
             cap.live_feeds = feeds               # the sources stay alive until the step has run
             feeds = ()
         if cap.h2d_done is not None:

@@ -178,7 +178,20 @@ def test_captured_step_gathers_device_feeds_through_the_address_table():
             sess.run(bump.op, {x: bx})
             total += float(bx.sum())
         assert abs(float(sess.run(acc)) - total) <= 1e-3 * total
-        # host data for the same placeholders takes the staged path (its own capture)
-        got = sess.run(out, {x: pool_x[:10].cpu().numpy(), y: pool_y[:10].cpu().numpy()})
-        want = ref.run(out, {x: pool_x[:10].cpu().numpy(), y: pool_y[:10].cpu().numpy()})
-        assert abs(got - want) <= 1e-4 * abs(want)
+        # small host data rides the same table (staged in pinned memory the kernel reads), also
+        # mixed with a device tensor; changing values step to step must be seen
+        for i in range(4):
+            hx = (pool_x[i:i + 10] * (i + 1)).cpu().numpy()
+            hy = pool_y[:10].cpu().numpy()
+            got = sess.run(out, {x: hx, y: hy if i % 2 else pool_y[:10]})
+            want = ref.run(out, {x: hx, y: hy})
+            assert abs(got - want) <= 1e-4 * abs(want), i
+        # a large host input (> 1 MiB) keeps the DMA staging path (its own capture)
+        big_x = np.random.RandomState(0).rand(50000, 6).astype(np.float32)
+        big_y = np.random.RandomState(1).rand(50000, 3).astype(np.float32)
+        for _ in range(3):
+            got = sess.run(out, {x: big_x, y: big_y})
+        want = ref.run(out, {x: big_x, y: big_y})
+        assert abs(got - want) <= 1e-3 * abs(want)
+        kinds = {c.feed_table is not None for p in sess._plans.values() for c in p.graphs.values()}
+        assert kinds == {True, False}

@@ -39,6 +39,8 @@ from .variable_store import FailedPreconditionError, LocalVariableStore
 
 _VAR_TYPES = ("VariableV2",)
 _TABLE_HOST_BYTES = 1 << 20      # host inputs up to this size are read by the gather kernel
+_SPIN_SECS = 300e-6              # how long a step's completion word is polled before blocking
+_NO_SPIN_FETCH = bool(os.environ.get("DTF_NO_SPIN_FETCH"))
 _PACK_WORDS = 256     # fp32 words of pinned staging per captured step for small fetches
 
 
@@ -206,6 +208,11 @@ class _CapturedStep:
         self.feed_table_np = None
         self.live_feeds: Any = None
         self.table_read: Optional[torch.cuda.Event] = None
+        self.seq: Optional[torch.Tensor] = None           # pinned word: number of the replay
+        self.seq_np = None
+        self.seq_val = 0
+        self.signalled = False                            # the gather kernel echoes seq
+        self.skip_spin = 0                                # replays left that block without polling
 
 
 _default_session = threading.local()
@@ -678,6 +685,9 @@ class Session:
             if cap.h2d_done is None:
                 cap.h2d_done = torch.cuda.Event()
             cap.h2d_done.record()
+        if cap.signalled:
+            cap.seq_val = cap.seq_val % 1000000 + 1
+            cap.seq_np[0] = cap.seq_val
         cap.graph.replay()
         self.stats["graph_replays"] += 1
         if cap.feed_table is not None and cap.host_buf is None:
@@ -687,7 +697,24 @@ class Session:
             cap.table_read.record()
         out: Dict[int, Any] = {}
         if cap.host_buf is not None:
-            torch.cuda.current_stream(self.device).synchronize()
+            done = False
+            if cap.skip_spin > 0:
+                cap.skip_spin -= 1               # a long step: block right away for a while
+            elif cap.signalled and not _NO_SPIN_FETCH:
+                # the step's last kernel stores this replay's number behind the packed values:
+                # poll it in pinned memory for a bounded time (a short step finishes well
+                # inside it; the wake-up of a stream synchronisation costs several microseconds)
+                flag, want = cap.host_np, cap.seq_val
+                deadline = time.perf_counter() + _SPIN_SECS
+                while True:
+                    if flag[_PACK_WORDS - 1] == want:
+                        done = True
+                        break
+                    if time.perf_counter() > deadline:
+                        cap.skip_spin = 64
+                        break
+            if not done:
+                torch.cuda.current_stream(self.device).synchronize()
             snap = cap.host_np[:cap.host_words].copy()      # one copy out of the pinned buffer
             for slot_idx, off, shape, n in cap.layout:
                 out[slot_idx] = snap[off:off + n].reshape(shape) if shape else snap[off]
@@ -714,7 +741,8 @@ class Session:
         # gather kernel inside the graph, so a step needs a single stream synchronisation. The
         # pinned buffer is allocated before capture starts (host allocation is not capturable).
         want = [sl for sl in plan.fetch_slots if sl is not None] + plan.host_input_slots
-        host_buf = torch.empty(_PACK_WORDS, dtype=torch.float32, pin_memory=True)
+        host_buf = torch.zeros(_PACK_WORDS, dtype=torch.float32).pin_memory()
+        cap.seq = torch.zeros(1, dtype=torch.float32).pin_memory()
         torch.cuda.synchronize(self.device)
         graph = torch.cuda.CUDAGraph()
         vals: List[Any] = [None] * plan.num_slots
@@ -738,7 +766,11 @@ class Session:
                 from ..ops import hip
                 off = sum(p[4].numel() for p in packed)
                 # one gather launch whose stores go straight into the pinned host buffer
-                hip.pack_f32([p[4] for p in packed], host_buf)
+                # (the last word of the buffer is the completion word the host polls)
+                hip.pack_f32([p[4] for p in packed], host_buf,
+                             signal=(cap.seq, _PACK_WORDS - 1) if off < _PACK_WORDS else None)
+                cap.signalled = off < _PACK_WORDS
+                cap.seq_np = cap.seq.numpy()
                 cap.host_buf = host_buf
                 cap.host_np = host_buf.numpy()
                 cap.host_words = off

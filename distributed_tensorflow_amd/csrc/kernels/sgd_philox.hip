@@ -197,11 +197,25 @@ struct PackArgs {
   int count;
 };
 
-// one workgroup: wave-strided copy of up to 16 tiny tensors into one contiguous staging buffer
-__global__ __launch_bounds__(BLOCK) void pack_f32_kernel(PackArgs args, float* __restrict__ dst) {
+// one workgroup: wave-strided copy of up to 16 tiny tensors into one contiguous staging buffer.
+// With a signal pair the kernel finally copies the word at `seq_src` (the host's step number,
+// read when the kernel runs) to `seq_dst` behind a system-scope release: a host that polls
+// `seq_dst` in pinned memory sees the packed words complete as soon as it sees the number, without
+// going through a stream synchronisation (whose wake-up costs several microseconds).
+__global__ __launch_bounds__(BLOCK) void pack_f32_kernel(PackArgs args, float* __restrict__ dst,
+                                                         const float* __restrict__ seq_src,
+                                                         float* __restrict__ seq_dst) {
   for (int i = 0; i < args.count; ++i) {
     const int n = args.offset[i + 1] - args.offset[i];
     for (int j = threadIdx.x; j < n; j += BLOCK) dst[args.offset[i] + j] = args.src[i][j];
+  }
+  if (seq_dst != nullptr) {
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float seq = __builtin_nontemporal_load(seq_src);
+      __hip_atomic_store(seq_dst, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
@@ -365,9 +379,10 @@ DTF_API int dtf_reduce_partials(int count, const void* const* src, void* out, lo
 // dst = concat(src[0][0..n0), src[1][0..n1), ...) for count <= 16 small fp32 buffers: the values
 // a step returns to the host (loss, step counter, accuracy) gathered by one launch so that
 // one device->host copy delivers all of them.
-DTF_API int dtf_pack_f32(int count, const float* const* src, const int* sizes, float* dst,
-                         hipStream_t stream) {
-  if (count < 1 || count > MAX_PACK || !dst) return DTF_ERR_BAD_ARG;
+DTF_API int dtf_pack_f32_signal(int count, const float* const* src, const int* sizes, float* dst,
+                                const float* seq_src, float* seq_dst, hipStream_t stream) {
+  if (count < 1 || count > MAX_PACK || !dst || ((seq_src == nullptr) != (seq_dst == nullptr)))
+    return DTF_ERR_BAD_ARG;
   PackArgs args = {};
   int off = 0;
   for (int i = 0; i < count; ++i) {
@@ -378,9 +393,15 @@ DTF_API int dtf_pack_f32(int count, const float* const* src, const int* sizes, f
   }
   args.offset[count] = off;
   args.count = count;
-  hipLaunchKernelGGL(pack_f32_kernel, dim3(1), dim3(BLOCK), 0, stream, args, dst);
+  hipLaunchKernelGGL(pack_f32_kernel, dim3(1), dim3(BLOCK), 0, stream, args, dst, seq_src,
+                     seq_dst);
   DTF_LAUNCH_CHECK();
   return DTF_OK;
+}
+
+DTF_API int dtf_pack_f32(int count, const float* const* src, const int* sizes, float* dst,
+                         hipStream_t stream) {
+  return dtf_pack_f32_signal(count, src, sizes, dst, nullptr, nullptr, stream);
 }
 
 // out[i*ld_out + j] = a + b * g(stream element (row0+i)*global_cols + col0 + j), g = N(0,1) when

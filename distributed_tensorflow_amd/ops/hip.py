@@ -103,6 +103,7 @@ def _declare(L: ctypes.CDLL) -> None:
         "dtf_philox_uniform": [P, LG, U, U, LG, F, F, I, P],
         "dtf_reduce_partials": [I, P, P, LG, F, I, P],
         "dtf_pack_f32": [I, P, P, P, P],
+        "dtf_pack_f32_signal": [I, P, P, P, P, P, P],
         "dtf_gather_feeds": [P, I, P, P, P],
         "dtf_philox_fill_2d": [P, LG, LG, LG, U, U, LG, LG, LG, F, F, I, I, P],
     }
@@ -736,9 +737,13 @@ def reduce_partials(parts: Sequence[torch.Tensor], scale: float = 1.0,
     return out
 
 
-def pack_f32(parts: Sequence[torch.Tensor], out: torch.Tensor) -> List[int]:
+def pack_f32(parts: Sequence[torch.Tensor], out: torch.Tensor, signal=None) -> List[int]:
     """Gather up to 16 small fp32 tensors into the head of ``out`` (a GPU tensor or a pinned
-    host tensor) with one launch; returns the offset of each part."""
+    host tensor) with one launch; returns the offset of each part. ``signal = (seq, index)``:
+    after the gather the kernel copies the current value of the one-word pinned tensor ``seq``
+    into ``out[index]`` behind a system-scope release, so a host polling that word knows the
+    packed values are complete when it sees the number it stored in ``seq`` before the launch
+    (or before the replay of a graph that captured it)."""
     if not 1 <= len(parts) <= 16:
         raise HipKernelError("pack_f32: 1..16 parts")
     parts = [_req(p, torch.float32, "pack_f32 part") for p in parts]
@@ -751,7 +756,15 @@ def pack_f32(parts: Sequence[torch.Tensor], out: torch.Tensor) -> List[int]:
         raise HipKernelError("pack_f32: bad out tensor")
     src = (ctypes.c_void_p * len(parts))(*[p.data_ptr() for p in parts])
     sizes = (ctypes.c_int * len(parts))(*[p.numel() for p in parts])
-    _check(lib().dtf_pack_f32(len(parts), src, sizes, out.data_ptr(), _stream()), "pack_f32")
+    seq_src = seq_dst = None
+    if signal is not None:
+        seq, index = signal
+        if seq.dtype != torch.float32 or seq.numel() != 1 or not (seq.is_pinned() or seq.is_cuda) \
+                or not total <= index < out.numel():
+            raise HipKernelError("pack_f32: bad signal")
+        seq_src, seq_dst = seq.data_ptr(), out.data_ptr() + 4 * int(index)
+    _check(lib().dtf_pack_f32_signal(len(parts), src, sizes, out.data_ptr(), seq_src, seq_dst,
+                                     _stream()), "pack_f32")
     offsets, off = [], 0
     for p in parts:
         offsets.append(off)

@@ -195,3 +195,30 @@ def test_captured_step_gathers_device_feeds_through_the_address_table():
         assert abs(got - want) <= 1e-3 * abs(want)
         kinds = {c.feed_table is not None for p in sess._plans.values() for c in p.graphs.values()}
         assert kinds == {True, False}
+
+
+def test_captured_step_completion_polling_and_blocking_fallback(monkeypatch):
+    """A captured step's results are read after polling the completion word; with a zero polling
+    budget every step falls back to the stream synchronisation (and then skips polling for a
+    while) -- the values are the same either way."""
+    import numpy as np
+    import distributed_tensorflow_amd as tf
+    from distributed_tensorflow_amd.client import session as S
+    g = tf.Graph()
+    with g.as_default():
+        x = tf.placeholder(tf.float32, [None, 4], name="x")
+        v = tf.Variable(tf.zeros([]))
+        total = v.assign_add(tf.reduce_sum(x))
+        sess = tf.Session(config=tf.ConfigProto(device="cuda"))
+        sess.run(tf.global_variables_initializer())
+        batch = np.ones((5, 4), np.float32)
+        got = [float(sess.run(total, {x: batch * (i + 1)})) for i in range(6)]
+        assert got == [20.0, 60.0, 120.0, 200.0, 300.0, 420.0]
+        cap = next(iter(next(p for p in sess._plans.values() if p.graphs).graphs.values()))
+        assert cap.signalled and cap.seq_val >= 4 and cap.skip_spin == 0
+        monkeypatch.setattr(S, "_SPIN_SECS", -1.0)       # no polling budget
+        got = [float(sess.run(total, {x: batch})) for i in range(3)]
+        assert got == [440.0, 460.0, 480.0]
+        cap.skip_spin = 2                                  # as after a step that outlasted it
+        got = [float(sess.run(total, {x: batch})) for i in range(3)]
+        assert got == [500.0, 520.0, 540.0] and cap.skip_spin == 0

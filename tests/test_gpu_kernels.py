@@ -626,3 +626,25 @@ def test_peer_push_kernel(hip):
         hip.peer_push(src, [src[1:]])
     with pytest.raises(hip.HipKernelError):
         hip.peer_push(src[1:], [torch.empty_like(src[1:])])       # 2-byte offset: misaligned
+
+
+def test_pack_f32_completion_word(hip):
+    """The gather can echo a host-chosen number behind its packed values (system-scope release):
+    a host that polls the word in pinned memory needs no stream synchronisation."""
+    import time
+    a = torch.tensor([1.5, 2.5], device="cuda")
+    b = torch.tensor([7.0], device="cuda")
+    out = torch.zeros(64, dtype=torch.float32).pin_memory()
+    seq = torch.zeros(1, dtype=torch.float32).pin_memory()
+    view = out.numpy()
+    for number in (1.0, 2.0, 999999.0):
+        seq[0] = number
+        a.add_(1.0)
+        hip.pack_f32([a, b], out, signal=(seq, 63))
+        deadline = time.perf_counter() + 5.0
+        while view[63] != number and time.perf_counter() < deadline:
+            pass
+        assert view[63] == number                     # seen without synchronising the stream
+        assert view[:3].tolist() == [a[0].item(), a[1].item(), 7.0]
+    with pytest.raises(hip.HipKernelError):
+        hip.pack_f32([a, b], out, signal=(seq, 2))     # the word would overlap packed values

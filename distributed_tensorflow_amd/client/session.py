@@ -232,6 +232,8 @@ class Session:
         self._closed = False
         self._close_hooks: List[Any] = []
         self._plans: Dict[Tuple, ExecutionPlan] = {}
+        self._eager_buf = self._eager_seq = self._eager_np = None   # pinned staging of _fetch_small
+        self._eager_count = 0
         self._lock = threading.RLock()
         self.device = torch.device(self.config.device) if self.config.device \
             else default_device()
@@ -598,6 +600,8 @@ class Session:
                 self.stats["eager_runs"] += 1
                 slot_vals = {sl: vals[sl] for sl in plan.fetch_slots if sl is not None}
                 slot_vals.update((sl, vals[sl]) for sl in plan.host_input_slots)
+                if self.device.type == "cuda" and trace is None:
+                    self._fetch_small(slot_vals)
             plan.runs += 1
         finally:
             self._end_step(plan, token)
@@ -617,6 +621,36 @@ class Session:
                    (host_out[sl] if sl in host_out else self._to_host(slot_vals[sl]))
                    for sl in plan.fetch_slots]
         return self._unflatten(structure, results)
+
+    def _fetch_small(self, slot_vals: Dict[int, Any]) -> None:
+        """Eager steps: the small fp32 results among ``slot_vals`` (loss, step counter,
+        summaries) reach the host through ONE gather launch into pinned memory whose completion
+        word is polled, instead of one synchronising device-to-host copy per value; they are
+        replaced by numpy values in place."""
+        small = [(sl, v) for sl, v in slot_vals.items()
+                 if isinstance(v, torch.Tensor) and v.is_cuda and v.dtype == torch.float32
+                 and 0 < v.numel() <= 64 and v.is_contiguous()][:16]
+        if len(small) < 2 or sum(v.numel() for _, v in small) >= _PACK_WORDS:
+            return
+        from ..ops import hip
+        if self._eager_buf is None:
+            self._eager_buf = torch.zeros(_PACK_WORDS, dtype=torch.float32).pin_memory()
+            self._eager_seq = torch.zeros(1, dtype=torch.float32).pin_memory()
+            self._eager_np = (self._eager_buf.numpy(), self._eager_seq.numpy())
+        buf_np, seq_np = self._eager_np
+        self._eager_count = self._eager_count % 1000000 + 1
+        seq_np[0] = want = self._eager_count
+        offsets = hip.pack_f32([v for _, v in small], self._eager_buf,
+                               signal=(self._eager_seq, _PACK_WORDS - 1))
+        deadline = time.perf_counter() + (0.0 if _NO_SPIN_FETCH else _SPIN_SECS)
+        while buf_np[_PACK_WORDS - 1] != want:
+            if time.perf_counter() > deadline:
+                torch.cuda.current_stream(self.device).synchronize()
+                break
+        for (sl, v), off in zip(small, offsets):
+            n = v.numel()
+            slot_vals[sl] = buf_np[off:off + n].reshape(tuple(v.shape)).copy() if v.dim() \
+                else buf_np[off].copy()
 
     # -- step brackets for remote stores ---------------------------------------------------
     def _begin_step(self, plan: ExecutionPlan):

@@ -39,3 +39,19 @@ def test_hot_kernels_use_no_scratch(source, pattern, tmp_path):
             found += 1
             assert scratch == 0, "%s spills %d bytes of scratch" % (name, scratch)
     assert found > 0
+
+
+def test_every_declared_entry_point_is_exported_by_the_built_library():
+    """The ctypes signatures in ops/hip.py and the symbols of the in-tree libdtf_hip.so must
+    agree (a launcher lost from a .hip file otherwise shows up only on the GPU box)."""
+    import ctypes
+    import re
+    from distributed_tensorflow_amd.ops import hip
+    if not hip.library_present():
+        pytest.skip("native library not built")
+    lib = ctypes.CDLL(hip.LIB_PATH)
+    src = open(os.path.join(ROOT, "distributed_tensorflow_amd", "ops", "hip.py")).read()
+    names = sorted(set(re.findall(r'"(dtf_\w+)":', src)))
+    assert len(names) > 40
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing

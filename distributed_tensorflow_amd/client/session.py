@@ -41,6 +41,7 @@ _VAR_TYPES = ("VariableV2",)
 _TABLE_HOST_BYTES = 1 << 20      # host inputs up to this size are read by the gather kernel
 _SPIN_SECS = 300e-6              # how long a step's completion word is polled before blocking
 _NO_SPIN_FETCH = bool(os.environ.get("DTF_NO_SPIN_FETCH"))
+_NO_FETCH_AHEAD = bool(os.environ.get("DTF_NO_FETCH_AHEAD"))
 _PACK_WORDS = 256     # fp32 words of pinned staging per captured step for small fetches
 
 
@@ -622,6 +623,48 @@ class Session:
                    for sl in plan.fetch_slots]
         return self._unflatten(structure, results)
 
+    def _fetch_ahead_addends(self, sgd_node, parts: List[torch.Tensor],
+                             fetched: List[Any]) -> Optional[List[float]]:
+        """Addend per packed part when the gather may run ahead of the optimizer launch
+        ``sgd_node``: the increment for a part that IS one of the counters it bumps, 0 for parts
+        it does not touch; ``None`` when any fetched value (packed or not) overlaps a tensor the
+        launch writes, or a variable is not local."""
+        def local(var_op):
+            fast = getattr(self._store_for(var_op), "local_tensor", None)
+            return fast(var_op.name) if fast is not None else None
+
+        def span(t):
+            return t.data_ptr(), t.data_ptr() + t.numel() * t.element_size()
+
+        written, counters = [], {}
+        for var_op in sgd_node.attrs["var_ops"]:
+            t = local(var_op)
+            if t is None or not t.is_cuda:
+                return None
+            written.append(span(t))
+        for var_op, delta in sgd_node.attrs.get("counter_increments", []):
+            t = local(var_op)
+            if t is None or not t.is_cuda or t.numel() != 1 or t.dtype != torch.float32:
+                return None
+            counters[t.data_ptr()] = float(delta)
+            written.append(span(t))
+        packed_ids = {id(p) for p in parts}
+        for v in fetched:                        # values that bypass the gather must be untouched
+            if isinstance(v, torch.Tensor) and v.is_cuda and id(v) not in packed_ids:
+                lo, hi = span(v)
+                if any(lo < b and a < hi for a, b in written):
+                    return None
+        adds = []
+        for p in parts:
+            if p.numel() == 1 and p.data_ptr() in counters:
+                adds.append(counters[p.data_ptr()])
+                continue
+            lo, hi = span(p)
+            if any(lo < b and a < hi for a, b in written):
+                return None
+            adds.append(0.0)
+        return adds
+
     def _fetch_small(self, slot_vals: Dict[int, Any]) -> None:
         """Eager steps: the small fp32 results among ``slot_vals`` (loss, step counter,
         summaries) reach the host through ONE gather launch into pinned memory whose completion
@@ -786,7 +829,23 @@ class Session:
                 hip.gather_feeds(cap.feed_table, cap.static_feeds)
             for (_, sl), v in zip(plan.feed_slots, cap.static_feeds):
                 vals[sl] = v
-            self._run_steps(plan.steps, vals)
+            # A step that ends in the fused optimizer launch: nothing that is fetched depends on
+            # it except the step counters it bumps, and their new value is known beforehand
+            # (old + increment). The gather of the small results -- with that increment added --
+            # then runs BEFORE the optimizer launch: the host has its results while the GPU still
+            # applies the update, and prepares the next step in that time.
+            # (Variable reads scheduled behind the update return the live storage; they may run
+            # first as long as that is what they return.)
+            k = max((i for i, st in enumerate(plan.steps) if st.node.type == "MultiApplySGD"),
+                    default=-1)
+            held = None                              # (optimizer step, reads behind it)
+            if (k >= 0 and not _NO_FETCH_AHEAD
+                    and all(st.node.type == "VariableV2" for st in plan.steps[k + 1:])):
+                held = (plan.steps[k], plan.steps[k + 1:])
+                self._run_steps(plan.steps[:k], vals)
+                self._run_steps(held[1], vals)
+            else:
+                self._run_steps(plan.steps, vals)
             packed = []
             off = 0
             for sl in dict.fromkeys(want):
@@ -796,13 +855,34 @@ class Session:
                     packed.append((sl, off, v.shape, v.dtype, v))
                     off += v.numel()
             packed = packed[:16]
+            adds = None
+            if held is not None:
+                live_reads = True
+                for st in held[1]:
+                    fast = getattr(self._store_for(st.node), "local_tensor", None)
+                    live = fast(st.node.name) if fast is not None else None
+                    out_t = vals[st.out_slots[0]] if st.out_slots else None
+                    if live is None or not isinstance(out_t, torch.Tensor) \
+                            or out_t.data_ptr() != live.data_ptr():
+                        live_reads = False
+                if live_reads:
+                    adds = self._fetch_ahead_addends(held[0].node, [p[4] for p in packed],
+                                                     [vals[sl] for sl in dict.fromkeys(want)])
+                if adds is None:       # something fetched is touched by the update: usual order
+                    self._run_steps([held[0]], vals)
+                    self._run_steps(held[1], vals)
+                    packed = [(sl, o, shape, dt, vals[sl]) for sl, o, shape, dt, _ in packed]
             if packed:
                 from ..ops import hip
                 off = sum(p[4].numel() for p in packed)
                 # one gather launch whose stores go straight into the pinned host buffer
                 # (the last word of the buffer is the completion word the host polls)
                 hip.pack_f32([p[4] for p in packed], host_buf,
-                             signal=(cap.seq, _PACK_WORDS - 1) if off < _PACK_WORDS else None)
+                             signal=(cap.seq, _PACK_WORDS - 1) if off < _PACK_WORDS else None,
+                             adds=adds)
+            if adds is not None:
+                self._run_steps([held[0]], vals)
+            if packed:
                 cap.signalled = off < _PACK_WORDS
                 cap.seq_np = cap.seq.numpy()
                 cap.host_buf = host_buf

@@ -193,7 +193,8 @@ __global__ __launch_bounds__(BLOCK) void reduce_partials_bf16_kernel(PartialArgs
 constexpr int MAX_PACK = 16;
 struct PackArgs {
   const float* src[MAX_PACK];
-  int offset[MAX_PACK + 1];   // dst[offset[i] .. offset[i+1]) <- src[i]
+  int offset[MAX_PACK + 1];   // dst[offset[i] .. offset[i+1]) <- src[i] + add[i]
+  float add[MAX_PACK];        // (a step counter fetched ahead of the launch that bumps it)
   int count;
 };
 
@@ -207,7 +208,8 @@ __global__ __launch_bounds__(BLOCK) void pack_f32_kernel(PackArgs args, float* _
                                                          float* __restrict__ seq_dst) {
   for (int i = 0; i < args.count; ++i) {
     const int n = args.offset[i + 1] - args.offset[i];
-    for (int j = threadIdx.x; j < n; j += BLOCK) dst[args.offset[i] + j] = args.src[i][j];
+    const float add = args.add[i];
+    for (int j = threadIdx.x; j < n; j += BLOCK) dst[args.offset[i] + j] = args.src[i][j] + add;
   }
   if (seq_dst != nullptr) {
     __threadfence_system();
@@ -379,8 +381,9 @@ DTF_API int dtf_reduce_partials(int count, const void* const* src, void* out, lo
 // dst = concat(src[0][0..n0), src[1][0..n1), ...) for count <= 16 small fp32 buffers: the values
 // a step returns to the host (loss, step counter, accuracy) gathered by one launch so that
 // one device->host copy delivers all of them.
-DTF_API int dtf_pack_f32_signal(int count, const float* const* src, const int* sizes, float* dst,
-                                const float* seq_src, float* seq_dst, hipStream_t stream) {
+DTF_API int dtf_pack_f32_signal(int count, const float* const* src, const int* sizes,
+                                const float* adds, float* dst, const float* seq_src,
+                                float* seq_dst, hipStream_t stream) {
   if (count < 1 || count > MAX_PACK || !dst || ((seq_src == nullptr) != (seq_dst == nullptr)))
     return DTF_ERR_BAD_ARG;
   PackArgs args = {};
@@ -389,6 +392,7 @@ DTF_API int dtf_pack_f32_signal(int count, const float* const* src, const int* s
     if (!src[i] || sizes[i] < 0) return DTF_ERR_BAD_ARG;
     args.src[i] = src[i];
     args.offset[i] = off;
+    args.add[i] = adds ? adds[i] : 0.f;
     off += sizes[i];
   }
   args.offset[count] = off;
@@ -401,7 +405,7 @@ DTF_API int dtf_pack_f32_signal(int count, const float* const* src, const int* s
 
 DTF_API int dtf_pack_f32(int count, const float* const* src, const int* sizes, float* dst,
                          hipStream_t stream) {
-  return dtf_pack_f32_signal(count, src, sizes, dst, nullptr, nullptr, stream);
+  return dtf_pack_f32_signal(count, src, sizes, nullptr, dst, nullptr, nullptr, stream);
 }
 
 // out[i*ld_out + j] = a + b * g(stream element (row0+i)*global_cols + col0 + j), g = N(0,1) when

@@ -103,7 +103,7 @@ def _declare(L: ctypes.CDLL) -> None:
         "dtf_philox_uniform": [P, LG, U, U, LG, F, F, I, P],
         "dtf_reduce_partials": [I, P, P, LG, F, I, P],
         "dtf_pack_f32": [I, P, P, P, P],
-        "dtf_pack_f32_signal": [I, P, P, P, P, P, P],
+        "dtf_pack_f32_signal": [I, P, P, P, P, P, P, P],
         "dtf_gather_feeds": [P, I, P, P, P],
         "dtf_philox_fill_2d": [P, LG, LG, LG, U, U, LG, LG, LG, F, F, I, I, P],
     }
@@ -737,13 +737,15 @@ def reduce_partials(parts: Sequence[torch.Tensor], scale: float = 1.0,
     return out
 
 
-def pack_f32(parts: Sequence[torch.Tensor], out: torch.Tensor, signal=None) -> List[int]:
+def pack_f32(parts: Sequence[torch.Tensor], out: torch.Tensor, signal=None,
+             adds: Optional[Sequence[float]] = None) -> List[int]:
     """Gather up to 16 small fp32 tensors into the head of ``out`` (a GPU tensor or a pinned
     host tensor) with one launch; returns the offset of each part. ``signal = (seq, index)``:
     after the gather the kernel copies the current value of the one-word pinned tensor ``seq``
     into ``out[index]`` behind a system-scope release, so a host polling that word knows the
     packed values are complete when it sees the number it stored in ``seq`` before the launch
-    (or before the replay of a graph that captured it)."""
+    (or before the replay of a graph that captured it). ``adds[i]`` is added to every element
+    of part i (0 by default): a step counter can be fetched ahead of the launch that bumps it."""
     if not 1 <= len(parts) <= 16:
         raise HipKernelError("pack_f32: 1..16 parts")
     parts = [_req(p, torch.float32, "pack_f32 part") for p in parts]
@@ -763,8 +765,13 @@ def pack_f32(parts: Sequence[torch.Tensor], out: torch.Tensor, signal=None) -> L
                 or not total <= index < out.numel():
             raise HipKernelError("pack_f32: bad signal")
         seq_src, seq_dst = seq.data_ptr(), out.data_ptr() + 4 * int(index)
-    _check(lib().dtf_pack_f32_signal(len(parts), src, sizes, out.data_ptr(), seq_src, seq_dst,
-                                     _stream()), "pack_f32")
+    add_arr = None
+    if adds is not None:
+        if len(adds) != len(parts):
+            raise HipKernelError("pack_f32: one addend per part")
+        add_arr = (ctypes.c_float * len(parts))(*[float(a) for a in adds])
+    _check(lib().dtf_pack_f32_signal(len(parts), src, sizes, add_arr, out.data_ptr(), seq_src,
+                                     seq_dst, _stream()), "pack_f32")
     offsets, off = [], 0
     for p in parts:
         offsets.append(off)

@@ -222,3 +222,44 @@ def test_captured_step_completion_polling_and_blocking_fallback(monkeypatch):
         cap.skip_spin = 2                                  # as after a step that outlasted it
         got = [float(sess.run(total, {x: batch})) for i in range(3)]
         assert got == [500.0, 520.0, 540.0] and cap.skip_spin == 0
+
+
+def test_fetch_ahead_of_the_optimizer_launch_matches_eager_values():
+    """Captured training steps gather their small results before the optimizer launch (the step
+    counter with its increment added). Loss, summaries and global_step must equal those of an
+    eager session step for step; fetching a parameter the launch updates falls back to the usual
+    order and returns the post-update value."""
+    import numpy as np
+    import distributed_tensorflow_amd as tf
+    from distributed_tensorflow_amd.models import mnist_mlp
+    rng = np.random.RandomState(3)
+    batches = [(rng.rand(100, 784).astype(np.float32),
+                np.eye(10, dtype=np.float32)[rng.randint(0, 10, 100)]) for _ in range(6)]
+    results = {}
+    for label, graphs in (("graph", True), ("eager", False)):
+        g = tf.Graph()
+        with g.as_default():
+            m = mnist_mlp.build_model(learning_rate=0.01, seed=1)
+            sess = tf.Session(config=tf.ConfigProto(device="cuda", hip_graphs=graphs))
+            sess.run(m.init_op)
+            rows = []
+            for bx, by in batches:
+                _, loss, step = sess.run([m.train_op, m.loss, m.global_step],
+                                         {m.x: bx, m.y_: by})
+                rows.append((float(loss), float(step)))
+            for bx, by in batches[:3]:
+                _, loss, b2 = sess.run([m.train_op, m.loss, m.b2], {m.x: bx, m.y_: by})
+                rows.append((float(loss), b2.tolist()))
+            rows.append(sess.run(m.b2).tolist())
+            rows.append(float(sess.run(m.global_step)))
+            if graphs:
+                assert sess.stats["graph_replays"] >= 6
+            results[label] = rows
+    ga, ea = results["graph"], results["eager"]
+    assert [r[1] for r in ga[:6]] == [1.0, 2.0, 3.0, 4.0, 5.0, 6.0] == [r[1] for r in ea[:6]]
+    for a, b in zip(ga[:9], ea[:9]):
+        assert abs(a[0] - b[0]) <= 1e-5 * max(1.0, abs(b[0]))
+    for a, b in zip(ga[6:9], ea[6:9]):
+        assert np.allclose(a[1], b[1], atol=1e-6)            # post-update b2 in both
+    assert np.allclose(ga[9], ea[9], atol=1e-6) and ga[10] == ea[10] == 9.0
+    assert np.allclose(ga[8][1], ga[9], atol=0)              # the fetched b2 was the final one

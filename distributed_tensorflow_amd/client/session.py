@@ -42,6 +42,9 @@ _TABLE_HOST_BYTES = 1 << 20      # host inputs up to this size are read by the g
 _SPIN_SECS = 300e-6              # how long a step's completion word is polled before blocking
 _NO_SPIN_FETCH = bool(os.environ.get("DTF_NO_SPIN_FETCH"))
 _NO_FETCH_AHEAD = bool(os.environ.get("DTF_NO_FETCH_AHEAD"))
+# ops that write a variable in place (a gather must not move across them)
+_MUTATING_OPS = frozenset(("Assign", "AssignAdd", "AssignSub", "ApplyGradientDescent",
+                           "MultiApplySGD"))
 _PACK_WORDS = 256     # fp32 words of pinned staging per captured step for small fetches
 
 
@@ -841,9 +844,18 @@ class Session:
             held = None                              # (optimizer step, reads behind it)
             if (k >= 0 and not _NO_FETCH_AHEAD
                     and all(st.node.type == "VariableV2" for st in plan.steps[k + 1:])):
-                held = (plan.steps[k], plan.steps[k + 1:])
-                self._run_steps(plan.steps[:k], vals)
-                self._run_steps(held[1], vals)
+                # the gather can move further up: behind the last step that produces something
+                # fetched, provided nothing between there and the optimizer writes in place
+                reads = plan.steps[k + 1:]
+                from_reads = {sl for st in reads for sl in st.out_slots}
+                made_at = {sl: i for i, st in enumerate(plan.steps[:k]) for sl in st.out_slots}
+                j = 1 + max((made_at.get(sl, -1) for sl in want if sl not in from_reads),
+                            default=-1)
+                if any(st.node.type in _MUTATING_OPS for st in plan.steps[j:k]):
+                    j = k
+                held = (plan.steps[k], reads, plan.steps[j:k])
+                self._run_steps(plan.steps[:j], vals)
+                self._run_steps(reads, vals)
             else:
                 self._run_steps(plan.steps, vals)
             packed = []
@@ -869,6 +881,7 @@ class Session:
                     adds = self._fetch_ahead_addends(held[0].node, [p[4] for p in packed],
                                                      [vals[sl] for sl in dict.fromkeys(want)])
                 if adds is None:       # something fetched is touched by the update: usual order
+                    self._run_steps(held[2], vals)
                     self._run_steps([held[0]], vals)
                     self._run_steps(held[1], vals)
                     packed = [(sl, o, shape, dt, vals[sl]) for sl, o, shape, dt, _ in packed]
@@ -881,6 +894,7 @@ class Session:
                              signal=(cap.seq, _PACK_WORDS - 1) if off < _PACK_WORDS else None,
                              adds=adds)
             if adds is not None:
+                self._run_steps(held[2], vals)
                 self._run_steps([held[0]], vals)
             if packed:
                 cap.signalled = off < _PACK_WORDS

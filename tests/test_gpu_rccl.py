@@ -131,3 +131,60 @@ def test_bench_contract_one_json_line_on_stdout():
     assert rec["dtype"] == "bf16" and rec["higher_is_better"] is True
     assert rec["config"]["model"] == "gemm_2048x2048x2048_bf16"
     assert abs(rec["value"] - 2.0 * 2048 ** 3 / (rec["ms_per_step"] * 1e-3) / 1e12) < 0.02 * rec["value"]
+
+
+def test_two_synchronous_workers_on_one_gpu_keep_replicas_identical():
+    """Two worker sessions of a synchronous job in one process (loopback communicator, both on
+    GPU 0): the eager multi-rank step path -- gradient all-reduce, fused update, small results
+    fetched through the polled gather -- keeps the replicas bit-identical and learns."""
+    import threading
+    import distributed_tensorflow_amd as tf
+    from distributed_tensorflow_amd.data.mnist import synthetic_mnist
+    from distributed_tensorflow_amd.models import mnist_mlp
+    from distributed_tensorflow_amd.parallel.comm import LoopbackComm
+    world, steps = 2, 30
+    cluster = tf.train.ClusterSpec({"worker": ["127.0.0.1:%d" % (23450 + i) for i in range(world)]})
+    comms = LoopbackComm.create_world(world, timeout_s=60)
+    results, errors = {}, []
+
+    def job(task):
+        try:
+            g = tf.Graph()
+            with g.as_default():
+                config = tf.ConfigProto(device="cuda", strategy="allreduce_sync")
+                server = tf.train.Server(cluster, job_name="worker", task_index=task,
+                                         protocol="rccl", config=config, comm=comms[task])
+                with tf.device(tf.train.replica_device_setter(
+                        worker_device="/job:worker/task:%d" % task, cluster=cluster)):
+                    m = mnist_mlp.build_model(learning_rate=0.05, seed=1)
+                sv = tf.train.Supervisor(is_chief=(task == 0), global_step=m.global_step,
+                                         init_op=m.init_op, recovery_wait_secs=0.05,
+                                         summary_op=None)
+                images, labels = synthetic_mnist(600, seed=task)
+                onehot = np.eye(10, dtype=np.float32)[labels]
+                rng = np.random.RandomState(100 + task)
+                costs = []
+                with sv.prepare_or_wait_for_session(server.target, config=config) as sess:
+                    for _ in range(steps):
+                        idx = rng.randint(0, 600, 50)
+                        _, c, step = sess.run([m.train_op, m.loss, m.global_step],
+                                              {m.x: images[idx], m.y_: onehot[idx]})
+                        costs.append(float(c))
+                    results[task] = (costs, sess.run(m.w1), float(sess.run(m.global_step)),
+                                     dict(sess.stats))
+                sv.stop()
+                server.stop()
+        except Exception as e:  # noqa: BLE001
+            errors.append((task, repr(e)))
+            comms[task].kill()
+
+    threads = [threading.Thread(target=job, args=(t,)) for t in range(world)]
+    [t.start() for t in threads]
+    [t.join(180) for t in threads]
+    assert not errors, errors
+    assert set(results) == {0, 1}
+    (c0, w0, s0, st0), (c1, w1, s1, _) = results[0], results[1]
+    assert np.array_equal(w0, w1) and s0 == s1 == float(steps)
+    assert c0 != c1 and np.isfinite(c0).all()
+    assert np.mean(c0[-5:]) < np.mean(c0[:5])
+    assert st0["eager_runs"] >= steps            # multi-rank steps are not captured by default

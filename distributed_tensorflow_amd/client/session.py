@@ -238,6 +238,7 @@ class Session:
         self._plans: Dict[Tuple, ExecutionPlan] = {}
         self._eager_buf = self._eager_seq = self._eager_np = None   # pinned staging of _fetch_small
         self._eager_count = 0
+        self._fetch_lock = threading.Lock()
         self._lock = threading.RLock()
         self.device = torch.device(self.config.device) if self.config.device \
             else default_device()
@@ -679,6 +680,10 @@ class Session:
         if len(small) < 2 or sum(v.numel() for _, v in small) >= _PACK_WORDS:
             return
         from ..ops import hip
+        with self._fetch_lock:               # one staging buffer per session
+            self._fetch_small_locked(small, slot_vals, hip)
+
+    def _fetch_small_locked(self, small, slot_vals, hip) -> None:
         if self._eager_buf is None:
             self._eager_buf = torch.zeros(_PACK_WORDS, dtype=torch.float32).pin_memory()
             self._eager_seq = torch.zeros(1, dtype=torch.float32).pin_memory()

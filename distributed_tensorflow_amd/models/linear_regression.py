@@ -75,6 +75,7 @@ class SyntheticRegressionData:
         self._seed, self._task = seed, task
         self._device = None
         self._row = 0
+        self._chunk, self._chunk_pos, self._chunk_batch = None, 0, 0
 
     def to_device(self, device) -> "SyntheticRegressionData":
         import torch
@@ -87,16 +88,25 @@ class SyntheticRegressionData:
 
     def next_batch(self, batch_size: int):
         if self._device is not None:
-            from ..ops import hip
-            seed = self._seed * 1000 + self._task
-            x = hip.philox_window(batch_size, self.features, seed, 1, self._row, 0,
-                                  self.features, device=self._device)
-            y = hip.gemm_f32(x, self._w_dev, bias=self._b_dev)
-            if self.noise:
-                y.add_(hip.philox_window(batch_size, self.outputs, seed, 2, self._row, 0,
-                                         self.outputs, device=self._device), alpha=self.noise)
-            self._row += batch_size
-            return x, y
+            # generated 64 batches at a time (three launches per chunk instead of per step);
+            # a batch is a view of the chunk
+            if self._chunk is None or self._chunk_batch != batch_size \
+                    or self._chunk_pos + batch_size > self._chunk[0].shape[0]:
+                from ..ops import hip
+                rows = 64 * batch_size
+                seed = self._seed * 1000 + self._task
+                x = hip.philox_window(rows, self.features, seed, 1, self._row, 0,
+                                      self.features, device=self._device)
+                y = hip.gemm_f32(x, self._w_dev, bias=self._b_dev)
+                if self.noise:
+                    y.add_(hip.philox_window(rows, self.outputs, seed, 2, self._row, 0,
+                                             self.outputs, device=self._device),
+                           alpha=self.noise)
+                self._row += rows
+                self._chunk, self._chunk_pos, self._chunk_batch = (x, y), 0, batch_size
+            lo = self._chunk_pos
+            self._chunk_pos += batch_size
+            return self._chunk[0][lo:lo + batch_size], self._chunk[1][lo:lo + batch_size]
         x = self._rng.standard_normal((batch_size, self.features)).astype(np.float32)
         y = x @ self.w + self.b
         if self.noise:

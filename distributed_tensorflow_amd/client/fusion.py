@@ -201,12 +201,61 @@ def _match_head(dense, logits, dlogits_t, emit_bias, grad_map, alive, fed, rw, c
     return a_t, w_t, dw_t, da_t, sig
 
 
+def _plan_sharding(graph: Graph, ops: Sequence[Operation], fed: Set[Tensor],
+                   fetched: Set[Tensor], consumers, rw: Rewrite, shard_plan, stored_layouts) -> None:
+    """Cross-device edges of sharded products: the planned ``MatMul`` ops become
+    ``ShardedMatMul`` nodes (local block product + one collective), the initialisers of
+    variables stored as shards become ``ShardedVariableInit`` (the rank's own window of the
+    random stream), and any other reader of such a variable -- a fetch, an op outside the plan --
+    reads it through ``GatherShardedVariable`` (an all-gather of the blocks)."""
+    alive = set(ops)
+    sharded_ops = set()
+    if shard_plan:
+        for op in ops:
+            spec = shard_plan.matmuls.get(op)
+            if spec is not None and op.outputs[0] not in fed:
+                out = op.outputs[0]
+                node = FusedNode(graph, "ShardedMatMul", op.name + "/sharded", list(op.inputs),
+                                 [(out.dtype, out.shape)],
+                                 {"shard": spec, "world": shard_plan.world, "_raw_inputs": True},
+                                 control_inputs=op.control_inputs, device=op.device)
+                rw.tensor_map[out] = node.outputs[0]
+                sharded_ops.add(op)
+            lay = shard_plan.init_of.get(op)
+            if lay is not None and op.type == "Assign":
+                out = op.outputs[0]
+                node = FusedNode(graph, "ShardedVariableInit", op.name + "/sharded_init", [],
+                                 [(out.dtype, lay.local_shape())],
+                                 {"layout": lay, "var_op": op.inputs[0].op},
+                                 control_inputs=op.control_inputs, device=op.device)
+                rw.op_map[op] = node
+                rw.tensor_map[out] = node.outputs[0]
+    for op in ops:
+        lay = stored_layouts.get(op.name) if (stored_layouts and op.type == "VariableV2") else None
+        if lay is None:
+            continue
+        t = op.outputs[0]
+        outside = [c for c in consumers.get(t, []) if c in alive and c not in sharded_ops
+                   and c.type not in ("Assign", "AssignAdd", "AssignSub", "ApplyGradientDescent",
+                                      "IsVariableInitialized", "ReportUninitializedVariables")]
+        if outside or t in fetched:
+            node = FusedNode(graph, "GatherShardedVariable", op.name + "/gather", [t],
+                             [(t.dtype, t.shape)], {"layout": lay, "_raw_inputs": True},
+                             device=op.device)
+            rw.tensor_map[t] = node.outputs[0]
+
+
 def build_rewrite(graph: Graph, ops: Sequence[Operation], fed: Set[Tensor],
-                  fetched: Set[Tensor] = frozenset()) -> Rewrite:
+                  fetched: Set[Tensor] = frozenset(), shard_plan=None,
+                  stored_layouts=None, fuse: bool = True) -> Rewrite:
     """Find fusable patterns among ``ops`` (the pruned, topologically ordered subgraph)."""
     rw = Rewrite()
     alive = set(ops)
     consumers = _consumers(ops)
+    if shard_plan or stored_layouts:
+        _plan_sharding(graph, ops, fed, fetched, consumers, rw, shard_plan, stored_layouts or {})
+    if not fuse:
+        return rw
     grad_map = graph.grad_map
     dense_of: Dict[Tensor, FusedNode] = {}     # dense output tensor -> its FusedDense node
 
@@ -221,6 +270,8 @@ def build_rewrite(graph: Graph, ops: Sequence[Operation], fed: Set[Tensor],
         x, w, b, mm = hit
         if mm.outputs[0] in fed or not only_consumer(mm.outputs[0], op):
             continue
+        if shard_plan and mm in shard_plan.matmuls:
+            continue                   # the product runs sharded; bias and activation follow it
         z = op.outputs[0]
         act_name, act_op = "none", None
         users = [c for c in consumers.get(z, []) if c in alive]

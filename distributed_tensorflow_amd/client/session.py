@@ -34,6 +34,7 @@ from ..framework.device import DeviceSpec
 from ..framework.graph import Graph, Operation, Tensor, get_default_graph, value_inputs
 from ..framework.op_registry import get_opdef
 from ..ops import ref_kernels  # noqa: F401  (registers the reference kernels)
+from ..parallel import sharded_ops  # noqa: F401  (registers the sharded-product kernels)
 from . import fusion
 from .variable_store import FailedPreconditionError, LocalVariableStore
 
@@ -66,6 +67,14 @@ class ConfigProto:
                           backward pass (default: the runtime's 32 MiB; a model whose
                           gradients fit one bucket -- the reference MLP's 318 KB -- is reduced
                           in a single collective after the backward pass).
+    ``matmul_sharding`` -- under a collective runtime with several workers: how a
+                          ``tf.matmul`` of two variables is distributed -- ``"none"`` (every
+                          rank multiplies replicas, the reference's layout), ``"m"`` (row blocks
+                          of A, all-gather of C), ``"k"`` (inner-dimension blocks, all-reduce of
+                          the partial products) or ``"2d"`` (row blocks of A x column blocks of B
+                          on the rank grid). Default: ``DTF_MATMUL_SHARDING`` or ``"none"``.
+    ``shard_variables`` -- store a variable that only sharded products read as its local block
+                          (default on); off keeps replicas and multiplies views of them.
     ``allow_soft_placement`` / ``log_device_placement`` -- accepted for compatibility.
     """
 
@@ -73,7 +82,10 @@ class ConfigProto:
                  device: Optional[str] = None, allow_soft_placement: bool = True,
                  log_device_placement: bool = False, strategy: Optional[str] = None,
                  grad_aggregation: Optional[str] = None, capture_collectives: bool = False,
-                 grad_bucket_bytes: Optional[int] = None):
+                 grad_bucket_bytes: Optional[int] = None, matmul_sharding: Optional[str] = None,
+                 shard_variables: bool = True):
+        self.matmul_sharding = matmul_sharding
+        self.shard_variables = shard_variables
         self.grad_bucket_bytes = grad_bucket_bytes
         self.grad_aggregation = grad_aggregation
         self.capture_collectives = capture_collectives
@@ -118,6 +130,7 @@ class ExecContext:
         self.session = session
         self.device = session.device
         self.const_cache: Dict[Any, torch.Tensor] = {}
+        self.buffers: Dict[Any, torch.Tensor] = {}     # per-node scratch with stable addresses
         self._nd_seed = int.from_bytes(os.urandom(4), "little")
 
     def nondeterministic_seed(self) -> int:
@@ -240,6 +253,11 @@ class Session:
         self._eager_count = 0
         self._fetch_lock = threading.Lock()
         self._lock = threading.RLock()
+        # the device phase of run() is serialised per session: the Supervisor's service threads
+        # (checkpoint, summaries, step rate) call run() next to the training loop, and a step's
+        # collectives, gradient buckets and HIP-graph capture must not interleave with another's
+        self._run_lock = threading.RLock()
+        self._shard_cache: Tuple[int, Any] = (-1, None)
         self.device = torch.device(self.config.device) if self.config.device \
             else default_device()
         self._runtime = None
@@ -364,10 +382,11 @@ class Session:
                     state[node] = 1
                     stack.append((node, True))
                     deps = []
+                    raw = node.attrs.get("_raw_inputs")
                     for _i, t in value_inputs(node):
                         if t in fed_set:
                             continue
-                        rt = rw.resolve(t)
+                        rt = t if raw else rw.resolve(t)
                         if rt not in fed_set:
                             deps.append(rt.op)
                     deps.extend(rw.resolve_op(c) for c in node.control_inputs)
@@ -378,9 +397,12 @@ class Session:
 
         rw = fusion.Rewrite()
         order = prune(rw)
-        if self.config.graph_fusion:
+        shard_plan = self._shard_plan()
+        stored = getattr(self._runtime, "var_layouts", None)
+        if self.config.graph_fusion or shard_plan or stored:
             rw = fusion.build_rewrite(self.graph, sorted(order, key=lambda o: o.id), fed_set,
-                                      fetched_tensors)
+                                      fetched_tensors, shard_plan=shard_plan,
+                                      stored_layouts=stored, fuse=self.config.graph_fusion)
             if rw.tensor_map or rw.op_map:
                 order = prune(rw)
 
@@ -402,8 +424,9 @@ class Session:
             if kernel is None:
                 raise NotImplementedError("op type %r has no kernel" % node.type)
             ins = [-1] * len(node.inputs)          # -1: a variable reference, not a value
+            raw = node.attrs.get("_raw_inputs")
             for i, t in value_inputs(node):
-                rt = t if t in fed_set else rw.resolve(t)
+                rt = t if (t in fed_set or raw) else rw.resolve(t)
                 ins[i] = slot(rt)
             outs = [slot(o) for o in node.outputs]
             step = _Step(node, kernel, ins, outs, d.host_only)
@@ -434,7 +457,8 @@ class Session:
         # anything that talks to another process, or initialises storage, stays eager
         for s in plan.steps:
             if s.node.type in ("Assign", "RandomStandardNormal", "RandomUniform",
-                               "TruncatedNormal", "IsVariableInitialized"):
+                               "TruncatedNormal", "IsVariableInitialized",
+                               "ShardedVariableInit", "GatherShardedVariable"):
                 plan.capturable = False
         if self._runtime is not None and not self._runtime.capturable and not (
                 self.config.capture_collectives and
@@ -443,6 +467,29 @@ class Session:
         if not plan.capturable:
             self._plan_gradient_buckets(plan, {sl: t for t, sl in slot_of.items()})
         return plan
+
+    def _shard_plan(self):
+        """The graph-wide sharding plan of variable x variable products (``parallel/planner``),
+        recomputed when the graph has grown; ``None`` without a multi-rank collective runtime or
+        with ``matmul_sharding="none"``. The runtime is told about it so that the initial-state
+        exchange (``after_init``) lays the variables out accordingly."""
+        rt = self._runtime
+        comm = getattr(rt, "comm", None)
+        if rt is None or comm is None or comm.world_size < 2 \
+                or not hasattr(rt, "set_shard_plan"):
+            return None
+        mode = (self.config.matmul_sharding or getattr(rt, "matmul_sharding", None)
+                or os.environ.get("DTF_MATMUL_SHARDING") or "none")
+        if mode == "none":
+            return None
+        version = self.graph.version
+        if self._shard_cache[0] != version:
+            from ..parallel.planner import plan_matmul_sharding
+            plan = plan_matmul_sharding(self.graph, comm.world_size, mode,
+                                        self.config.shard_variables)
+            rt.set_shard_plan(plan)
+            self._shard_cache = (version, plan)
+        return self._shard_cache[1]
 
     def _plan_gradient_buckets(self, plan: ExecutionPlan, tensor_of: Dict[int, Tensor]) -> None:
         """Bucketed gradient all-reduce overlapped with the backward pass. The gradients the
@@ -563,7 +610,10 @@ class Session:
         if isinstance(value, torch.Tensor):
             if value.dtype in (torch.bfloat16, torch.float8_e4m3fn):
                 value = value.float()
+            on_host = value.device.type == "cpu"
             arr = value.detach().cpu().numpy()
+            if on_host:
+                arr = arr.copy()      # never hand out live storage (variables, result buffers)
             return arr[()] if arr.ndim == 0 else arr
         return value
 
@@ -589,8 +639,10 @@ class Session:
         self.stats["runs"] += 1
         trace = [] if (options is not None and options.trace_level) else None
 
-        token = self._begin_step(plan)
+        self._run_lock.acquire()
+        token = None
         try:
+            token = self._begin_step(plan)
             use_graph = (self.device.type == "cuda" and self.config.hip_graphs
                          and plan.capturable and trace is None and plan.runs >= 1)
             if use_graph:
@@ -609,7 +661,10 @@ class Session:
                     self._fetch_small(slot_vals)
             plan.runs += 1
         finally:
-            self._end_step(plan, token)
+            try:
+                self._end_step(plan, token)
+            finally:
+                self._run_lock.release()
 
         host_out: Dict[int, Any] = {}
         if plan.host_steps:
@@ -831,7 +886,9 @@ class Session:
         torch.cuda.synchronize(self.device)
         graph = torch.cuda.CUDAGraph()
         vals: List[Any] = [None] * plan.num_slots
-        with torch.cuda.graph(graph):
+        # (thread-local capture mode: a service thread's host allocation or copy during this
+        # capture must not invalidate it)
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             if cap.feed_table is not None:
                 from ..ops import hip
                 hip.gather_feeds(cap.feed_table, cap.static_feeds)

@@ -1,0 +1,321 @@
+// Small data-movement and bookkeeping kernels around the GEMMs: strided 2-D block copy (the
+// assembly of a sharded product's result blocks, variable shards), in-place variable updates
+// (AssignAdd / AssignSub), broadcast / reduction gradients, log-softmax gradient, sign, the
+// truncated-normal initialiser and the abs-max reduction fp8 quantisation scales come from.
+// All memory-bound; 16 B per lane where alignment allows.
+#include "common.h"
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr int MAX_BLOCKS = 2048;
+
+inline int grid_for(long n, int per_thread) {
+  long blocks = (n + (long)BLOCK * per_thread - 1) / ((long)BLOCK * per_thread);
+  if (blocks < 1) blocks = 1;
+  return (int)(blocks > MAX_BLOCKS ? MAX_BLOCKS : blocks);
+}
+
+// dst[r, 0:row_bytes) = src[r, 0:row_bytes) for r < rows; pitches in bytes. VEC = bytes per lane.
+template <typename V>
+__global__ __launch_bounds__(BLOCK) void copy_2d_kernel(const unsigned char* __restrict__ src,
+                                                        unsigned char* __restrict__ dst, long rows,
+                                                        long row_units, long src_pitch,
+                                                        long dst_pitch) {
+  const long n = rows * row_units;
+  for (long i = blockIdx.x * (long)BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * BLOCK) {
+    const long r = i / row_units, u = i - r * row_units;
+    *reinterpret_cast<V*>(dst + r * dst_pitch + u * (long)sizeof(V)) =
+        *reinterpret_cast<const V*>(src + r * src_pitch + u * (long)sizeof(V));
+  }
+}
+
+// var[i] += sign * delta[i % dn]
+__global__ __launch_bounds__(BLOCK) void assign_add_kernel(float* __restrict__ var,
+                                                           const float* __restrict__ delta, long n,
+                                                           long dn, float sign) {
+  for (long i = blockIdx.x * (long)BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * BLOCK)
+    var[i] += sign * delta[dn == n ? i : i % dn];
+}
+
+__global__ __launch_bounds__(BLOCK) void sign_kernel(const float* __restrict__ x,
+                                                     float* __restrict__ out, long n) {
+  for (long i = blockIdx.x * (long)BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * BLOCK) {
+    const float v = x[i];
+    out[i] = v > 0.f ? 1.f : (v < 0.f ? -1.f : v);      // keeps +-0 and NaN
+  }
+}
+
+// Gradient of a reduction / broadcast target: out[o, m, i] = g[o, i] * scale, where the output is
+// viewed as [outer, mid, inner] and g as [outer, inner] (mid = the reduced extent). Covers
+// reduce over all axes (outer = inner = 1), over axis 1 of a matrix (inner = 1), over axis 0
+// (outer = 1) and the bias-style broadcast of a vector over rows (outer = 1).
+__global__ __launch_bounds__(BLOCK) void broadcast_mid_kernel(const float* __restrict__ g,
+                                                              float* __restrict__ out, long outer,
+                                                              long mid, long inner, float scale) {
+  const long n = outer * mid * inner;
+  for (long i = blockIdx.x * (long)BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * BLOCK) {
+    const long in = i % inner, o = i / (inner * mid);
+    out[i] = g[o * inner + in] * scale;
+  }
+}
+
+// dx = dy - exp(y) * rowsum(dy), y = log-softmax output; one wave per row
+__global__ __launch_bounds__(BLOCK) void log_softmax_grad_kernel(const float* __restrict__ y,
+                                                                 const float* __restrict__ dy,
+                                                                 float* __restrict__ dx, long rows,
+                                                                 long cols) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (long r = blockIdx.x * (long)(BLOCK / 64) + wave; r < rows;
+       r += (long)gridDim.x * (BLOCK / 64)) {
+    const float* yr = y + r * cols;
+    const float* dr = dy + r * cols;
+    float s = 0.f;
+    for (long c = lane; c < cols; c += 64) s += dr[c];
+    s = dtf_wave_sum(s);
+    for (long c = lane; c < cols; c += 64) dx[r * cols + c] = dr[c] - expf(yr[c]) * s;
+  }
+}
+
+// ---- abs-max (fixed-order two-pass; the result is the same bits on every launch) --------------
+template <bool SRC_BF16>
+__global__ __launch_bounds__(BLOCK) void absmax_partial_kernel(const void* __restrict__ x_, long n,
+                                                               float* __restrict__ partial) {
+  __shared__ float red[BLOCK / 64];
+  float m = 0.f;
+  for (long i = blockIdx.x * (long)BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * BLOCK) {
+    const float v = SRC_BF16 ? dtf_bf16_to_f32(reinterpret_cast<const unsigned short*>(x_)[i])
+                             : reinterpret_cast<const float*>(x_)[i];
+    m = fmaxf(m, fabsf(v));
+  }
+  m = dtf_wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = red[0];
+    for (int i = 1; i < BLOCK / 64; ++i) t = fmaxf(t, red[i]);
+    partial[blockIdx.x] = t;
+  }
+}
+
+// out[0] = max(partials); out[1] = scale = target / max (1 when max == 0); out[2] = 1 / scale
+__global__ __launch_bounds__(64) void absmax_final_kernel(const float* __restrict__ partial, int n,
+                                                          float target, float* __restrict__ out) {
+  float m = 0.f;
+  for (int i = threadIdx.x; i < n; i += 64) m = fmaxf(m, partial[i]);
+  m = dtf_wave_max(m);
+  if (threadIdx.x == 0) {
+    const float scale = m > 0.f ? target / m : 1.f;
+    out[0] = m;
+    out[1] = scale;
+    out[2] = 1.f / scale;
+  }
+}
+
+// quantise with the scale read from device memory (no host round trip)
+template <bool SRC_BF16>
+__global__ __launch_bounds__(BLOCK) void cast_to_fp8_dev_scale_kernel(
+    const void* __restrict__ x_, unsigned char* __restrict__ out, long n,
+    const float* __restrict__ scale_ptr) {
+  const float scale = *scale_ptr;
+  const long n4 = n >> 2;
+  const long start = blockIdx.x * (long)BLOCK + threadIdx.x, step = (long)gridDim.x * BLOCK;
+  for (long i = start; i < n4; i += step) {
+    f32x4 v;
+    if (SRC_BF16) {
+      const bf16x4 h = reinterpret_cast<const bf16x4*>(x_)[i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = dtf_bf16_to_f32((unsigned short)h[j]);
+    } else {
+      v = reinterpret_cast<const f32x4*>(x_)[i];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = __builtin_amdgcn_fmed3f(v[j] * scale, -448.f, 448.f);
+    int packed = 0;
+    packed = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], packed, false);
+    packed = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], packed, true);
+    reinterpret_cast<int*>(out)[i] = packed;
+  }
+  for (long i = (n4 << 2) + start; i < n; i += step) {
+    const float f = SRC_BF16 ? dtf_bf16_to_f32(reinterpret_cast<const unsigned short*>(x_)[i])
+                             : reinterpret_cast<const float*>(x_)[i];
+    out[i] = dtf_f32_to_e4m3(__builtin_amdgcn_fmed3f(f * scale, -448.f, 448.f));
+  }
+}
+
+// ---- truncated normal: N(0,1) restricted to [-2, 2] by inverse-CDF of a Philox uniform --------
+__device__ __forceinline__ void philox_round(unsigned int (&c)[4], unsigned int k0,
+                                             unsigned int k1) {
+  const unsigned long long p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
+  const unsigned int hi0 = (unsigned int)(p0 >> 32), lo0 = (unsigned int)p0;
+  const unsigned int hi1 = (unsigned int)(p1 >> 32), lo1 = (unsigned int)p1;
+  c[0] = hi1 ^ c[1] ^ k0;
+  c[1] = lo1;
+  c[2] = hi0 ^ c[3] ^ k1;
+  c[3] = lo0;
+}
+
+__device__ __forceinline__ float philox_uniform_at(long e, unsigned int seed,
+                                                   unsigned int op_seed) {
+  const unsigned long long b = (unsigned long long)e >> 2;
+  unsigned int c[4] = {(unsigned int)b, (unsigned int)(b >> 32), 0u, 0u};
+  unsigned int k0 = seed, k1 = op_seed;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  const unsigned int bits = c[e & 3];
+  return (float)(bits >> 8) * 5.9604644775390625e-8f + 2.98023223876953125e-8f;   // (0, 1)
+}
+
+// Acklam-style rational approximation of the normal quantile, refined by one Newton step on
+// erfc (|error| < 1e-7 in fp32 over the [-2, 2] range used here)
+__device__ __forceinline__ float normal_quantile(float p) {
+  const float a[6] = {-3.969683028665376e+01f, 2.209460984245205e+02f, -2.759285104469687e+02f,
+                      1.383577518672690e+02f, -3.066479806614716e+01f, 2.506628277459239e+00f};
+  const float b[5] = {-5.447609879822406e+01f, 1.615858368580409e+02f, -1.556989798598866e+02f,
+                      6.680131188771972e+01f, -1.328068155288572e+01f};
+  const float q = p - 0.5f, r = q * q;
+  float x = (((((a[0] * r + a[1]) * r + a[2]) * r + a[3]) * r + a[4]) * r + a[5]) * q /
+            (((((b[0] * r + b[1]) * r + b[2]) * r + b[3]) * r + b[4]) * r + 1.0f);
+  // Newton: f(x) = Phi(x) - p, f'(x) = phi(x)
+  const float e = 0.5f * erfcf(-x * 0.70710678118654752f) - p;
+  const float u = e * 2.50662827463100050f * expf(0.5f * x * x);
+  x = x - u / (1.0f + 0.5f * x * u);
+  return x;
+}
+
+__global__ __launch_bounds__(BLOCK) void truncated_normal_kernel(float* __restrict__ out, long n,
+                                                                 unsigned int seed,
+                                                                 unsigned int op_seed, float mean,
+                                                                 float stddev) {
+  const float lo = 0.02275013194817921f;           // Phi(-2)
+  const float span = 1.0f - 2.0f * lo;
+  for (long i = blockIdx.x * (long)BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * BLOCK) {
+    const float u = philox_uniform_at(i, seed, op_seed);
+    float z = normal_quantile(lo + u * span);
+    z = fminf(fmaxf(z, -2.0f), 2.0f);
+    out[i] = mean + stddev * z;
+  }
+}
+
+bool aligned(const void* p, unsigned a) { return ((uintptr_t)p & (a - 1)) == 0; }
+
+}  // namespace
+
+// Copy a [rows, row_bytes] block between buffers with row pitches src_pitch / dst_pitch (bytes).
+DTF_API int dtf_copy_2d(const void* src, void* dst, long rows, long row_bytes, long src_pitch,
+                        long dst_pitch, hipStream_t stream) {
+  if (rows <= 0 || row_bytes <= 0) return DTF_OK;
+  if (!src || !dst || src_pitch < row_bytes || dst_pitch < row_bytes) return DTF_ERR_BAD_ARG;
+  const unsigned char* s = (const unsigned char*)src;
+  unsigned char* d = (unsigned char*)dst;
+  const long all = row_bytes | src_pitch | dst_pitch;
+  if (aligned(s, 16) && aligned(d, 16) && all % 16 == 0) {
+    const long units = row_bytes / 16;
+    hipLaunchKernelGGL(copy_2d_kernel<u32x4>, dim3(grid_for(rows * units, 1)), dim3(BLOCK), 0,
+                       stream, s, d, rows, units, src_pitch, dst_pitch);
+  } else if (aligned(s, 4) && aligned(d, 4) && all % 4 == 0) {
+    const long units = row_bytes / 4;
+    hipLaunchKernelGGL(copy_2d_kernel<unsigned int>, dim3(grid_for(rows * units, 1)), dim3(BLOCK),
+                       0, stream, s, d, rows, units, src_pitch, dst_pitch);
+  } else if (aligned(s, 2) && aligned(d, 2) && all % 2 == 0) {
+    const long units = row_bytes / 2;
+    hipLaunchKernelGGL(copy_2d_kernel<unsigned short>, dim3(grid_for(rows * units, 1)),
+                       dim3(BLOCK), 0, stream, s, d, rows, units, src_pitch, dst_pitch);
+  } else {
+    hipLaunchKernelGGL(copy_2d_kernel<unsigned char>, dim3(grid_for(rows * row_bytes, 1)),
+                       dim3(BLOCK), 0, stream, s, d, rows, row_bytes, src_pitch, dst_pitch);
+  }
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
+// var[i] += sign * delta[i % dn] in place (AssignAdd: sign = 1, AssignSub: sign = -1)
+DTF_API int dtf_assign_add_f32(float* var, const float* delta, long n, long dn, float sign,
+                               hipStream_t stream) {
+  if (n <= 0) return DTF_OK;
+  if (!var || !delta || dn <= 0 || dn > n || n % dn) return DTF_ERR_BAD_ARG;
+  hipLaunchKernelGGL(assign_add_kernel, dim3(grid_for(n, 1)), dim3(BLOCK), 0, stream, var, delta,
+                     n, dn, sign);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
+DTF_API int dtf_sign_f32(const float* x, float* out, long n, hipStream_t stream) {
+  if (n <= 0) return DTF_OK;
+  if (!x || !out) return DTF_ERR_BAD_ARG;
+  hipLaunchKernelGGL(sign_kernel, dim3(grid_for(n, 1)), dim3(BLOCK), 0, stream, x, out, n);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
+// out[outer, mid, inner] = g[outer, inner] * scale
+DTF_API int dtf_broadcast_mid_f32(const float* g, float* out, long outer, long mid, long inner,
+                                  float scale, hipStream_t stream) {
+  if (outer <= 0 || mid <= 0 || inner <= 0) return DTF_OK;
+  if (!g || !out) return DTF_ERR_BAD_ARG;
+  hipLaunchKernelGGL(broadcast_mid_kernel, dim3(grid_for(outer * mid * inner, 1)), dim3(BLOCK), 0,
+                     stream, g, out, outer, mid, inner, scale);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
+DTF_API int dtf_log_softmax_grad_f32(const float* y, const float* dy, float* dx, long rows,
+                                     long cols, hipStream_t stream) {
+  if (rows <= 0 || cols <= 0) return DTF_OK;
+  if (!y || !dy || !dx) return DTF_ERR_BAD_ARG;
+  long blocks = (rows + BLOCK / 64 - 1) / (BLOCK / 64);
+  if (blocks > MAX_BLOCKS) blocks = MAX_BLOCKS;
+  hipLaunchKernelGGL(log_softmax_grad_kernel, dim3((unsigned)blocks), dim3(BLOCK), 0, stream, y, dy,
+                     dx, rows, cols);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
+DTF_API long dtf_absmax_workspace(long n) { return grid_for(n, 8); }
+
+// out[0] = max|x|, out[1] = target / max|x| (1 if the tensor is all zero), out[2] = 1 / out[1];
+// src_kind 0 = fp32, 1 = bf16; workspace: dtf_absmax_workspace(n) floats
+DTF_API int dtf_absmax_scale(const void* x, int src_kind, long n, float target, float* workspace,
+                             float* out, hipStream_t stream) {
+  if (!out || !workspace || (n > 0 && !x) || src_kind < 0 || src_kind > 1) return DTF_ERR_BAD_ARG;
+  const int blocks = n > 0 ? grid_for(n, 8) : 1;
+  if (src_kind == 1)
+    hipLaunchKernelGGL(absmax_partial_kernel<true>, dim3(blocks), dim3(BLOCK), 0, stream, x,
+                       n > 0 ? n : 0, workspace);
+  else
+    hipLaunchKernelGGL(absmax_partial_kernel<false>, dim3(blocks), dim3(BLOCK), 0, stream, x,
+                       n > 0 ? n : 0, workspace);
+  hipLaunchKernelGGL(absmax_final_kernel, dim3(1), dim3(64), 0, stream, workspace, blocks, target,
+                     out);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
+DTF_API int dtf_cast_to_fp8_dev_scale(const void* x, int src_kind, void* out, long n,
+                                      const float* scale, hipStream_t stream) {
+  if (n <= 0) return DTF_OK;
+  if (!x || !out || !scale || !aligned(x, 16) || !aligned(out, 4) || src_kind < 0 || src_kind > 1)
+    return DTF_ERR_BAD_ARG;
+  if (src_kind == 1)
+    hipLaunchKernelGGL(cast_to_fp8_dev_scale_kernel<true>, dim3(grid_for(n, 4)), dim3(BLOCK), 0,
+                       stream, x, (unsigned char*)out, n, scale);
+  else
+    hipLaunchKernelGGL(cast_to_fp8_dev_scale_kernel<false>, dim3(grid_for(n, 4)), dim3(BLOCK), 0,
+                       stream, x, (unsigned char*)out, n, scale);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
+DTF_API int dtf_truncated_normal_f32(float* out, long n, unsigned int seed, unsigned int op_seed,
+                                     float mean, float stddev, hipStream_t stream) {
+  if (n <= 0) return DTF_OK;
+  if (!out) return DTF_ERR_BAD_ARG;
+  hipLaunchKernelGGL(truncated_normal_kernel, dim3(grid_for(n, 1)), dim3(BLOCK), 0, stream, out, n,
+                     seed, op_seed, mean, stddev);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}

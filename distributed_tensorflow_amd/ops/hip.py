@@ -106,11 +106,21 @@ def _declare(L: ctypes.CDLL) -> None:
         "dtf_pack_f32_signal": [I, P, P, P, P, P, P, P],
         "dtf_gather_feeds": [P, I, P, P, P],
         "dtf_philox_fill_2d": [P, LG, LG, LG, U, U, LG, LG, LG, F, F, I, I, P],
+        "dtf_copy_2d": [P, P, LG, LG, LG, LG, P],
+        "dtf_assign_add_f32": [P, P, LG, LG, F, P],
+        "dtf_sign_f32": [P, P, LG, P],
+        "dtf_broadcast_mid_f32": [P, P, LG, LG, LG, F, P],
+        "dtf_log_softmax_grad_f32": [P, P, P, LG, LG, P],
+        "dtf_absmax_scale": [P, I, LG, F, P, P, P],
+        "dtf_cast_to_fp8_dev_scale": [P, I, P, LG, P, P],
+        "dtf_truncated_normal_f32": [P, LG, U, U, F, F, P],
     }
     for name, argtypes in sigs.items():
         fn = getattr(L, name)
         fn.argtypes = argtypes
         fn.restype = c.c_int
+    L.dtf_absmax_workspace.argtypes = [LG]
+    L.dtf_absmax_workspace.restype = LG
 
 
 # ---------------------------------------------------------------------------------------
@@ -135,6 +145,19 @@ def _req(t: torch.Tensor, dtype: torch.dtype, what: str) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _req_rows(t: torch.Tensor, dtype: torch.dtype, what: str) -> torch.Tensor:
+    """Rank-2 GPU tensor whose rows are contiguous (any row pitch): a row or column block of a
+    larger matrix is passed to the kernel as it is, with its pitch as leading dimension."""
+    if not isinstance(t, torch.Tensor) or t.device.type != "cuda":
+        raise HipKernelError("%s: expected a GPU tensor" % what)
+    if t.dtype != dtype:
+        raise HipKernelError("%s: expected dtype %s, got %s" % (what, dtype, t.dtype))
+    if t.dim() == 2 and (t.stride(1) == 1 or t.shape[1] <= 1) \
+            and (t.stride(0) >= t.shape[1] or t.shape[0] <= 1):
+        return t
+    return t.contiguous()
+
+
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -153,10 +176,10 @@ def gemm_f32(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: b
              tile: int = 0) -> torch.Tensor:
     """``act(op(a) @ op(b) + bias)`` on the fp32 MFMA kernel. ``a`` is [M,K] ([K,M] when
     ``trans_a``), ``b`` is [K,N] ([N,K] when ``trans_b``)."""
-    a = _req(a, torch.float32, "gemm_f32 a")
-    b = _req(b, torch.float32, "gemm_f32 b")
-    if a.dim() != 2 or b.dim() != 2:
+    if getattr(a, "dim", lambda: 0)() != 2 or getattr(b, "dim", lambda: 0)() != 2:
         raise HipKernelError("gemm_f32: operands must be rank 2")
+    a = _req_rows(a, torch.float32, "gemm_f32 a")
+    b = _req_rows(b, torch.float32, "gemm_f32 b")
     m, k = (a.shape[1], a.shape[0]) if trans_a else a.shape
     k2, n = (b.shape[1], b.shape[0]) if trans_b else b.shape
     if k != k2:
@@ -168,13 +191,17 @@ def gemm_f32(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: b
             raise HipKernelError("gemm_f32: bias has %d elements, N=%d" % (bias.numel(), n))
     if out is None:
         out = torch.empty((m, n), dtype=torch.float32, device=a.device)
-    elif out.shape != (m, n) or out.dtype != torch.float32 or not out.is_contiguous():
+    elif out.shape != (m, n) or out.dtype != torch.float32 or out.device != a.device \
+            or not (out.stride(1) == 1 or n <= 1) or (m > 1 and out.stride(0) < n):
         raise HipKernelError("gemm_f32: bad out tensor")
     if m == 0 or n == 0:
         return out
     if k == 0:
         return out.zero_()
     L = lib()
+    lda = a.stride(0) if a.shape[0] > 1 else a.shape[1]
+    ldb = b.stride(0) if b.shape[0] > 1 else b.shape[1]
+    ldc = out.stride(0) if m > 1 else n
     partial = None
     if splits is None:
         splits = L.dtf_gemm_f32_splits(m, n, k, None)
@@ -183,7 +210,7 @@ def gemm_f32(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: b
         # split-K workspace: one plane per split (caching allocator; graph-capturable)
         partial = torch.empty(splits * m * n, dtype=torch.float32, device=a.device)
     _check(L.dtf_gemm_f32(a.data_ptr(), b.data_ptr(), out.data_ptr(), _ptr(bias), m, n, k,
-                          a.stride(0), b.stride(0), out.stride(0), int(trans_a), int(trans_b),
+                          lda, ldb, ldc, int(trans_a), int(trans_b),
                           int(activation), _ptr(partial), splits, int(tile), _stream()),
            "gemm_f32")
     return out
@@ -289,7 +316,8 @@ def quantize_fp8(x: torch.Tensor, scale: Optional[float] = None):
         raise HipKernelError("quantize_fp8: source must be fp32 or bf16")
     x = _aligned(_req(x, x.dtype, "quantize_fp8 x"))
     if scale is None:
-        amax = float(x.abs().amax().item()) if x.numel() else 0.0
+        # abs-max on the device (fixed-order kernel), one 12-byte read-back for the Python float
+        amax = float(absmax_scale(x)[0].item()) if x.numel() else 0.0
         scale = FP8_MAX / amax if amax > 0 else 1.0
     out = torch.empty(x.shape, dtype=FP8, device=x.device)
     _check(lib().dtf_cast_to_fp8(x.data_ptr(), int(x.dtype == torch.bfloat16), out.data_ptr(),
@@ -324,28 +352,35 @@ def transpose2d(x: torch.Tensor) -> torch.Tensor:
 
 
 def gemm_bf16(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool = False,
-              out_dtype: torch.dtype = torch.bfloat16, alpha: float = 1.0,
-              force_generic: bool = False) -> torch.Tensor:
+              out_dtype: Optional[torch.dtype] = None, alpha: float = 1.0,
+              force_generic: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """General bf16 matmul ``op(a) @ op(b)``. The NT case (``trans_b`` with K-contiguous
     operands) is the fast kernel's native layout; for the other layouts a large product
     re-lays the offending operand out with one tiled transpose pass (memory-bound: ~3 % of the
     GEMM at 16384^3) and runs the same kernel, a small one runs the generic strided kernel."""
     a = _req(a, torch.bfloat16, "gemm_bf16 a")
     b = _req(b, torch.bfloat16, "gemm_bf16 b")
+    if out_dtype is None:
+        out_dtype = out.dtype if out is not None else torch.bfloat16
+    if out is not None and (out.dtype != out_dtype or not out.is_contiguous()):
+        raise HipKernelError("gemm_bf16: bad out tensor")
     if not trans_a and trans_b and not force_generic:
-        return gemm_bf16_nt(a, b, out_dtype, alpha)
+        return gemm_bf16_nt(a, b, out_dtype, alpha, out=out)
     if not force_generic and a.dim() == 2 and b.dim() == 2:
         m_, k_ = (a.shape[1], a.shape[0]) if trans_a else a.shape
         n_ = b.shape[0] if trans_b else b.shape[1]
         if k_ % 64 == 0 and 2.0 * m_ * n_ * k_ >= 2.0 * 512 ** 3:
             a_kc = transpose2d(a) if trans_a else a          # [M, K]
             bt_kc = b if trans_b else transpose2d(b)         # [N, K]
-            return gemm_bf16_nt(a_kc, bt_kc, out_dtype, alpha)
+            return gemm_bf16_nt(a_kc, bt_kc, out_dtype, alpha, out=out)
     m, k = (a.shape[1], a.shape[0]) if trans_a else a.shape
     k2, n = (b.shape[1], b.shape[0]) if trans_b else b.shape
     if k != k2:
         raise HipKernelError("gemm_bf16: inner dimensions differ")
-    out = torch.empty((m, n), dtype=out_dtype, device=a.device)
+    if out is None:
+        out = torch.empty((m, n), dtype=out_dtype, device=a.device)
+    elif tuple(out.shape) != (m, n):
+        raise HipKernelError("gemm_bf16: bad out tensor")
     if m == 0 or n == 0:
         return out
     a_rs, a_cs = (1, a.stride(0)) if trans_a else (a.stride(0), 1)
@@ -430,11 +465,14 @@ def axpby(alpha: float, x: torch.Tensor, beta: float = 0.0, y: Optional[torch.Te
     return out
 
 
-def cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
-    if x.dtype == dtype:
+def cast(x: torch.Tensor, dtype: torch.dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    if x.dtype == dtype and out is None:
         return x
     x = x.contiguous()
-    out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    if out is None:
+        out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    elif out.shape != x.shape or out.dtype != dtype or not out.is_contiguous():
+        raise HipKernelError("cast: bad out tensor")
     n = x.numel()
     if x.dtype == torch.float32 and dtype == torch.bfloat16:
         _check(lib().dtf_cast_f32_to_bf16(_aligned(x).data_ptr(), out.data_ptr(), n, _stream()),
@@ -841,4 +879,117 @@ def philox_window(rows: int, cols: int, seed: int, op_seed: int, row0: int, col0
                                     seed & 0xFFFFFFFF, op_seed & 0xFFFFFFFF, row0, col0,
                                     global_cols, float(a), float(b), int(normal),
                                     kinds[dtype], _stream()), "philox_window")
+    return out
+
+
+# ---------------------------------------------------------------------------------------
+# data movement / bookkeeping (csrc/kernels/misc_ops.hip)
+# ---------------------------------------------------------------------------------------
+def copy_2d(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    """``dst[...] = src`` for two rank-2 GPU views of the same shape and dtype whose rows are
+    contiguous (any row pitch): one launch, no temporary."""
+    for t, what in ((src, "src"), (dst, "dst")):
+        if not (isinstance(t, torch.Tensor) and t.device.type == "cuda" and t.dim() == 2):
+            raise HipKernelError("copy_2d: %s must be a rank-2 GPU tensor" % what)
+        if t.shape[1] > 1 and t.stride(1) != 1:
+            raise HipKernelError("copy_2d: %s rows must be contiguous" % what)
+    if src.shape != dst.shape or src.dtype != dst.dtype:
+        raise HipKernelError("copy_2d: shape / dtype mismatch")
+    rows, cols = src.shape
+    es = src.element_size()
+    sp = (src.stride(0) if rows > 1 else cols) * es
+    dp = (dst.stride(0) if rows > 1 else cols) * es
+    _check(lib().dtf_copy_2d(src.data_ptr(), dst.data_ptr(), rows, cols * es, sp, dp, _stream()),
+           "copy_2d")
+    return dst
+
+
+def assign_add(var: torch.Tensor, delta: torch.Tensor, sign: float = 1.0) -> torch.Tensor:
+    """``var += sign * delta`` in place (delta the same shape, a trailing suffix or a scalar)."""
+    var_c = _req(var, torch.float32, "assign_add var")
+    if var_c is not var:
+        raise HipKernelError("assign_add: the variable must be contiguous")
+    delta = _req(delta, torch.float32, "assign_add delta")
+    dn = _bcast_numel(var.shape, delta, "assign_add delta") if delta.numel() != 1 else 1
+    _check(lib().dtf_assign_add_f32(var.data_ptr(), delta.data_ptr(), var.numel(), dn,
+                                    float(sign), _stream()), "assign_add")
+    return var
+
+
+def sign(x: torch.Tensor) -> torch.Tensor:
+    x = _req(x, torch.float32, "sign x")
+    out = torch.empty_like(x)
+    _check(lib().dtf_sign_f32(x.data_ptr(), out.data_ptr(), x.numel(), _stream()), "sign")
+    return out
+
+
+def broadcast_mid(g: torch.Tensor, outer: int, mid: int, inner: int, scale: float,
+                  shape: Sequence[int]) -> torch.Tensor:
+    """``out[o, m, i] = g[o, i] * scale`` reshaped to ``shape`` (gradient of a reduction over the
+    middle extent; bias-style broadcast when ``outer == 1``)."""
+    g = _req(g, torch.float32, "broadcast_mid g")
+    if g.numel() != outer * inner:
+        raise HipKernelError("broadcast_mid: g has %d elements, expected %d"
+                             % (g.numel(), outer * inner))
+    out = torch.empty(tuple(shape), dtype=torch.float32, device=g.device)
+    if out.numel() != outer * mid * inner:
+        raise HipKernelError("broadcast_mid: shape does not match the extents")
+    _check(lib().dtf_broadcast_mid_f32(g.data_ptr(), out.data_ptr(), outer, mid, inner,
+                                       float(scale), _stream()), "broadcast_mid")
+    return out
+
+
+def log_softmax_grad(y: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    y = _req(y, torch.float32, "log_softmax_grad y")
+    dy = _req(dy, torch.float32, "log_softmax_grad dy")
+    if y.shape != dy.shape or y.dim() < 1:
+        raise HipKernelError("log_softmax_grad: shapes differ")
+    y2, dy2 = _as_rows(y), _as_rows(dy)
+    dx = torch.empty_like(y2)
+    _check(lib().dtf_log_softmax_grad_f32(y2.data_ptr(), dy2.data_ptr(), dx.data_ptr(),
+                                          y2.shape[0], y2.shape[1], _stream()),
+           "log_softmax_grad")
+    return dx.view(y.shape)
+
+
+def absmax_scale(x: torch.Tensor, target: float = FP8_MAX) -> torch.Tensor:
+    """3-element GPU tensor ``[max|x|, target / max|x|, max|x| / target]`` (scale 1 for an
+    all-zero tensor), computed on the device in a fixed order: the quantisation scale never
+    visits the host."""
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        raise HipKernelError("absmax_scale: source must be fp32 or bf16")
+    x = _req(x, x.dtype, "absmax_scale x")
+    n = x.numel()
+    ws = torch.empty((max(1, int(lib().dtf_absmax_workspace(max(n, 1)))),), dtype=torch.float32,
+                     device=x.device)
+    out = torch.empty((3,), dtype=torch.float32, device=x.device)
+    _check(lib().dtf_absmax_scale(x.data_ptr(), int(x.dtype == torch.bfloat16), n, float(target),
+                                  ws.data_ptr(), out.data_ptr(), _stream()), "absmax_scale")
+    return out
+
+
+def quantize_fp8_device(x: torch.Tensor):
+    """Per-tensor fp8 quantisation with the scale found and applied on the device: returns
+    ``(q, stats)`` with ``stats = [max|x|, scale, 1/scale]`` in GPU memory. Two launches, no
+    synchronisation (``quantize_fp8`` returns the inverse scale as a Python float and therefore
+    reads it back)."""
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        raise HipKernelError("quantize_fp8: source must be fp32 or bf16")
+    x = _aligned(_req(x, x.dtype, "quantize_fp8 x"))
+    stats = absmax_scale(x)
+    out = torch.empty(x.shape, dtype=FP8, device=x.device)
+    _check(lib().dtf_cast_to_fp8_dev_scale(x.data_ptr(), int(x.dtype == torch.bfloat16),
+                                           out.data_ptr(), x.numel(), stats[1:].data_ptr(),
+                                           _stream()), "quantize_fp8")
+    return out, stats
+
+
+def truncated_normal(shape: Sequence[int], seed: int, op_seed: int, mean: float = 0.0,
+                     stddev: float = 1.0, device=None) -> torch.Tensor:
+    """N(mean, stddev) restricted to two standard deviations, element e drawn by inverse CDF from
+    uniform e of the Philox stream keyed by (seed, op_seed)."""
+    out = torch.empty(tuple(shape), dtype=torch.float32, device=device)
+    _check(lib().dtf_truncated_normal_f32(out.data_ptr(), out.numel(), seed & 0xFFFFFFFF,
+                                          op_seed & 0xFFFFFFFF, float(mean), float(stddev),
+                                          _stream()), "truncated_normal")
     return out

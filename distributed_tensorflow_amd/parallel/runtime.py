@@ -176,17 +176,69 @@ class CollectiveRuntime(LocalRuntime):
         self._flat_grads: Optional[torch.Tensor] = None
         self._layout: List[Any] = []       # (name, offset, numel, shape)
         self.bytes_reduced = 0
+        self.bytes_gathered = 0
+        self.sharded_steps = 0             # steps that took the reduce-scatter / owner-update path
+        self.shard_plan = None             # parallel.planner.ShardPlan of the session's graph
+        self.var_layouts: Dict[str, Any] = {}   # variables stored as blocks: name -> VarLayout
+        self.matmul_sharding: Optional[str] = None
 
-    # -- initial state: chief's values -> everyone (one broadcast of one flat buffer) ------
+    # -- sharded products (parallel/planner.py) ------------------------------------------
+    def set_shard_plan(self, plan) -> None:
+        """The session's graph-wide plan of sharded products; ``after_init`` lays the variables
+        it marks as stored-sharded out as blocks."""
+        self.shard_plan = plan
+
+    def has_sharded_storage(self) -> bool:
+        return bool(self.var_layouts)
+
+    def read_variable_full(self, name: str) -> torch.Tensor:
+        """The whole value of ``name``. For a variable stored as blocks this is an all-gather:
+        every rank must call it (the Saver does, through this method)."""
+        value = self.local_store.read(name)
+        lay = self.var_layouts.get(name)
+        if lay is None or tuple(value.shape) == tuple(lay.shape):
+            return value
+        from .sharded_ops import gather_blocks
+        return gather_blocks(self.comm, lay, value)
+
+    def assign_variable_full(self, name: str, value: torch.Tensor) -> torch.Tensor:
+        """Assign a whole value; a variable stored as blocks keeps this rank's block of it."""
+        lay = self.var_layouts.get(name)
+        if lay is not None and tuple(value.shape) == tuple(lay.shape):
+            value = lay.slice_of(value, self.comm.rank, self.comm.world_size).contiguous()
+        return self.local_store.assign(name, value.to(self.device))
+
+    # -- initial state: chief's values -> everyone -----------------------------------------
     def after_init(self, session, var_names: Sequence[str]) -> None:
+        """Collective: the chief's initial (or restored) values reach every rank.
+
+        * replicated fp32 variables: packed into ONE flat arena, one broadcast; afterwards the
+          variables are views of the arena (the flat buffer the gradient collectives run on);
+        * variables the shard plan stores as blocks: when the chief's value already is a block
+          (its initialiser generated only the local window of a seeded random stream) every
+          other rank generates its own window -- no transfer at all; otherwise (restored from a
+          checkpoint, or a constant initial value) the whole tensor is broadcast once and every
+          rank keeps its block;
+        * anything else (other dtypes): one broadcast each.
+        """
         store = self.local_store
-        names = [n for n in var_names]
+        plan = self.shard_plan
+        w, r = self.comm.world_size, self.comm.rank
+
+        def describe(n):
+            t = store.read(n)
+            lay = plan.stored(n) if plan else None
+            state = "replicated"
+            if lay is not None and w > 1:
+                state = "block" if (tuple(t.shape) == tuple(lay.local_shape())
+                                    and lay.init is not None) else "whole"
+            return (n, tuple(t.shape), str(t.dtype), state)
+
         present = self.comm.broadcast_object(
-            [(n, tuple(store.read(n).shape), str(store.read(n).dtype)) for n in names]
-            if self.is_chief else None, src=0)
-        f32 = [(n, shape) for n, shape, dt in present if dt == "torch.float32"]
-        other = [(n, shape, dt) for n, shape, dt in present if dt != "torch.float32"]
-        w = self.comm.world_size
+            [describe(n) for n in var_names] if self.is_chief else None, src=0)
+        plain = [(n, shape, dt) for n, shape, dt, state in present if state == "replicated"]
+        f32 = [(n, shape) for n, shape, dt in plain if dt == "torch.float32"]
+        other = [(n, shape, dt) for n, shape, dt in plain if dt != "torch.float32"]
         # every variable starts on a 256-byte boundary of the arena: the GEMM kernels take their
         # 16-byte vector / buffer-load paths only for aligned operands (a scalar such as
         # global_step in front of a matrix would otherwise push it onto the element-wise path:
@@ -214,6 +266,20 @@ class CollectiveRuntime(LocalRuntime):
                 torch.empty(shape, dtype=getattr(torch, dt.split(".")[-1]), device=self.device)
             self.comm.broadcast(t, src=0)
             store.assign(n, t)
+        for n, shape, dt, state in present:
+            if state == "replicated":
+                continue
+            lay = plan.stored(n)
+            if state == "block":
+                if not self.is_chief:
+                    from .sharded_ops import local_window
+                    store.assign(n, local_window(lay, r, w, self.device))
+            else:
+                whole = store.read(n) if self.is_chief else \
+                    torch.empty(shape, dtype=getattr(torch, dt.split(".")[-1]), device=self.device)
+                self.comm.broadcast(whole, src=0)
+                store.assign(n, lay.slice_of(whole, r, w).clone())
+            self.var_layouts[n] = lay
         self._flat_params = flat
         self._flat_grads = torch.zeros_like(flat)
         self.comm.barrier()

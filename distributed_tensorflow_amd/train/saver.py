@@ -246,7 +246,12 @@ class Saver:
             begin = getattr(store, "begin_step", None)
             if begin is not None:
                 begin([v.op.name for v in variables])       # one pull per ps task
-            values = {v.op.name: store.read(v.op.name) for v in variables}
+            # a variable stored as per-rank blocks (sharded products) is all-gathered: saving
+            # such a graph is a collective, every worker calls save()
+            whole = getattr(getattr(sess, "_runtime", None), "read_variable_full", None)
+            values = {v.op.name: (whole(v.op.name) if whole is not None
+                                  and store is getattr(sess._runtime, "local_store", None)
+                                  else store.read(v.op.name)) for v in variables}
             if self._sharded:
                 shards.append(values)
             else:
@@ -282,4 +287,8 @@ class Saver:
                 raise ValueError("shape mismatch for %s: checkpoint %s, variable %s"
                                  % (v.op.name, tuple(t.shape), v.shape))
             store = sess._store_for(v.op)
-            store.assign(v.op.name, t.to(getattr(store, "device", "cpu")))
+            assign_whole = getattr(getattr(sess, "_runtime", None), "assign_variable_full", None)
+            if assign_whole is not None and store is getattr(sess._runtime, "local_store", None):
+                assign_whole(v.op.name, t)       # keeps the local block of a sharded variable
+            else:
+                store.assign(v.op.name, t.to(getattr(store, "device", "cpu")))

@@ -172,6 +172,7 @@ class SessionManager:
     def _publish_initial_state(self, sess: Session) -> None:
         runtime = sess._runtime
         if runtime is not None:
+            sess._shard_plan()      # every rank knows the variable layouts before the exchange
             names = [v.op.name for v in self._graph.get_collection(GraphKeys.GLOBAL_VARIABLES)]
             runtime.after_init(sess, names)
 
@@ -293,7 +294,14 @@ class Supervisor:
         elif self._summary_writer_arg is not Supervisor.USE_DEFAULT:
             self._summary_writer = self._summary_writer_arg
         threads = []
-        if self._saver is not None and self._save_model_secs:
+        sharded = getattr(getattr(sess, "_runtime", None), "has_sharded_storage", None)
+        if sharded is not None and sharded() and self._save_model_secs:
+            # reading a variable that is stored as per-rank blocks is a collective: the chief's
+            # background thread cannot do it alone. Call Saver.save from every worker instead.
+            import warnings
+            warnings.warn("variables are stored sharded: the chief-only checkpoint service is "
+                          "off; call saver.save(...) on every worker")
+        elif self._saver is not None and self._save_model_secs:
             threads.append(_Looper(self._coord, self._save_model_secs, "sv-checkpoint",
                                    lambda: self._checkpoint(sess)))
             # final checkpoint: taken when the session closes (the reference's

@@ -11,8 +11,18 @@ meant to do -- and what this script does -- is run ``sess.run(C)`` once per step
 average step time in the same stdout format, plus the derived GFLOP/s.
 
 Roles and flags as in ``tf_distributed.py``. With ``--protocol=grpc`` (default) every step pulls
-A and B (8 MB) from the ps like the reference would; with ``--protocol=rccl`` the operands are
-replicated in HBM and a step is one fp32 MFMA GEMM launch (captured in a HIP graph).
+A and B (8 MB) from the ps like the reference would; with ``--protocol=rccl`` the operands live
+in HBM and a step is fp32 MFMA GEMM work plus at most one collective:
+
+* ``--shard=none``: A and B replicated, every worker computes all of C (the reference's layout);
+* ``--shard=m``: worker r stores rows [r*M/W, (r+1)*M/W) of A, multiplies them by B, and the
+  row blocks of C are all-gathered over RCCL -- the same graph, ``tf.matmul`` of two variables
+  under ``replica_device_setter``, planned as a sharded product (``parallel/planner.py``);
+* ``--shard=k``: inner-dimension blocks of A and B, all-reduce of the partial products;
+* ``--shard=2d``: row blocks of A x column blocks of B on the P x Q worker grid, all-gather.
+
+The variables are generated shard by shard from the seeded counter-based stream, so C does not
+depend on the number of workers (``--shard=m``: bit for bit).
 ``--matrix_size``, ``--steps_per_epoch`` and ``--training_epochs`` replace the reference's
 borrowed MNIST loop bounds (550 x 100).
 """
@@ -34,6 +44,10 @@ def define_flags():
     tf.app.flags.define_cluster_flags("ps")     # default role ps, like the reference (:13)
     tf.app.flags.DEFINE_string("protocol", "grpc", "grpc (async parameter server) | rccl")
     tf.app.flags.DEFINE_string("strategy", "allreduce_sync", "rccl strategy")
+    tf.app.flags.DEFINE_string("shard", "none", "rccl: how C = A @ B is distributed over the "
+                               "workers: none | m | k | 2d")
+    tf.app.flags.DEFINE_string("dump_result", "", "write the last C of this worker to this .npy "
+                               "file (tests compare worlds)")
     tf.app.flags.DEFINE_integer("matrix_size", 1000, "N of the NxN operands")
     tf.app.flags.DEFINE_integer("training_epochs", 100, "epochs (reference: 100)")
     tf.app.flags.DEFINE_integer("steps_per_epoch", 550, "steps per epoch (reference: 550)")
@@ -59,7 +73,8 @@ def main(argv=None):
         cluster = tf.train.ClusterSpec({"ps": ["localhost:2222"],
                                         "worker": ["localhost:%d" % (2223 + i) for i in range(7)]})
     config = tf.ConfigProto(device=FLAGS.device or None, strategy=FLAGS.strategy,
-                            capture_collectives=FLAGS.capture_collectives)
+                            capture_collectives=FLAGS.capture_collectives,
+                            matmul_sharding=FLAGS.shard)
     server = tf.train.Server(cluster, job_name=FLAGS.job_name, task_index=FLAGS.task_index,
                              protocol=FLAGS.protocol, config=config)
     if FLAGS.job_name == "ps":
@@ -96,6 +111,10 @@ def main(argv=None):
     with sv.prepare_or_wait_for_session(server.target, config=config) as sess:
         writer = tf.summary.FileWriter(FLAGS.logs_path, graph=tf.get_default_graph())
         reporter = StepTimeReporter(frequency)
+        for name, lay in sorted(getattr(server.runtime, "var_layouts", {}).items()):
+            print("Sharded variable %s: %s blocks of %s -> local %s" % (
+                name, "row" if lay.axis == 0 else "column", list(lay.shape),
+                list(sess.variable_store.read(name).shape)))
         done = False
         value = float("nan")
         for epoch in range(FLAGS.training_epochs):
@@ -115,6 +134,9 @@ def main(argv=None):
             print("Final Cost: %.4f" % value)
             if done:
                 break
+        if FLAGS.dump_result:
+            import numpy as np
+            np.save(FLAGS.dump_result.replace("{rank}", str(FLAGS.task_index)), sess.run(C))
         writer.close()
         if FLAGS.shutdown_ps and hasattr(server.runtime, "report_done"):
             server.runtime.report_done()      # the ps exits join() once every worker has

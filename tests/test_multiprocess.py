@@ -185,3 +185,44 @@ def test_ps_task_leaves_join_cleanly_on_sigterm(tmp_path):
             proc.kill()
     assert proc.returncode == 0, out
     assert "left join" in out
+
+
+def _run_matmul_example(workers, shard, tmp_path, tag, size=1000):
+    dump = str(tmp_path / ("c_%s" % tag))
+    args = ["--num_workers", str(workers), "--protocol", "rccl", "--timeout", "200",
+            os.path.join(EX, "tf_distributed_1000Matrix.py"), "--", "--max_steps", "101",
+            "--device", "cpu", "--shard", shard, "--matrix_size", str(size),
+            "--logs_path", str(tmp_path / ("logs_" + tag)),
+            "--dump_result", dump + "_{rank}.npy"]
+    rc, out = _run_launcher(args)
+    assert rc == 0, out
+    return out, dump
+
+
+@pytest.mark.parametrize("shard", ["m", "k", "2d"])
+def test_matmul_example_sharded_over_two_collective_ranks(shard, tmp_path):
+    """BASELINE configuration 2: the reference's graph -- ``tf.matmul`` of two variables under
+    ``replica_device_setter`` (``tf_distributed_1000Matrix.py:33-48``) -- run by 2 collective
+    ranks with the product sharded, against the same script on 1 rank. Row sharding must
+    reproduce the single-rank C bit for bit; the K split sums in another order."""
+    import numpy as np
+    out1, dump1 = _run_matmul_example(1, "none", tmp_path, "w1")
+    out2, dump2 = _run_matmul_example(2, shard, tmp_path, "w2" + shard)
+    assert out2.count("done") == 2
+    assert re.search(r"AvgTime:\s*\d+\.\d\dms", out2) and re.search(r"GFLOPS: \d+\.\d", out2)
+    # the operands really are stored as blocks (not replicas multiplied as views)
+    want = {"m": ["weights/Variable: row blocks of [1000, 1000] -> local [500, 1000]"],
+            "k": ["weights/Variable: column blocks of [1000, 1000] -> local [1000, 500]",
+                  "weights/Variable_1: row blocks of [1000, 1000] -> local [500, 1000]"],
+            "2d": ["weights/Variable_1: column blocks of [1000, 1000] -> local [1000, 500]"]}[shard]
+    for line in want:
+        assert out2.count("Sharded variable " + line) == 2, out2
+    assert "Sharded variable" not in out1
+    ref = np.load(dump1 + "_0.npy")
+    assert ref.shape == (1000, 1000)
+    for r in (0, 1):
+        c = np.load(dump2 + "_%d.npy" % r)
+        if shard == "k":
+            assert np.abs(c - ref).max() < 1e-3 * np.abs(ref).max()
+        else:
+            assert np.array_equal(c, ref)

@@ -39,6 +39,10 @@ from . import fusion
 from .variable_store import FailedPreconditionError, LocalVariableStore
 
 _VAR_TYPES = ("VariableV2",)
+# op types that need no kernel of their own on a GPU: views, variable reads, one-time constant
+# uploads and host bookkeeping. Everything else must have a hand-written kernel.
+_NO_KERNEL_NEEDED = frozenset(("Const", "Identity", "StopGradient", "Reshape", "ReshapeLike",
+                               "NoOp", "Placeholder", "VariableV2", "IsVariableInitialized"))
 _TABLE_HOST_BYTES = 1 << 20      # host inputs up to this size are read by the gather kernel
 _SPIN_SECS = 300e-6              # how long a step's completion word is polled before blocking
 _NO_SPIN_FETCH = bool(os.environ.get("DTF_NO_SPIN_FETCH"))
@@ -75,6 +79,11 @@ class ConfigProto:
                           on the rank grid). Default: ``DTF_MATMUL_SHARDING`` or ``"none"``.
     ``shard_variables`` -- store a variable that only sharded products read as its local block
                           (default on); off keeps replicas and multiplies views of them.
+    ``allow_torch_fallback`` -- GPU sessions only. Off (default): an op, element type or layout
+                          without a hand-written kernel raises when it is planned / first run.
+                          On (or ``DTF_ALLOW_TORCH_FALLBACK=1``): such a case runs the torch
+                          reference kernel and is counted in ``stats["torch_fallbacks"]`` and
+                          listed in ``Session.fallback_log``.
     ``allow_soft_placement`` / ``log_device_placement`` -- accepted for compatibility.
     """
 
@@ -83,7 +92,9 @@ class ConfigProto:
                  log_device_placement: bool = False, strategy: Optional[str] = None,
                  grad_aggregation: Optional[str] = None, capture_collectives: bool = False,
                  grad_bucket_bytes: Optional[int] = None, matmul_sharding: Optional[str] = None,
-                 shard_variables: bool = True):
+                 shard_variables: bool = True, allow_torch_fallback: Optional[bool] = None):
+        self.allow_torch_fallback = bool(os.environ.get("DTF_ALLOW_TORCH_FALLBACK")) \
+            if allow_torch_fallback is None else bool(allow_torch_fallback)
         self.matmul_sharding = matmul_sharding
         self.shard_variables = shard_variables
         self.grad_bucket_bytes = grad_bucket_bytes
@@ -132,6 +143,19 @@ class ExecContext:
         self.const_cache: Dict[Any, torch.Tensor] = {}
         self.buffers: Dict[Any, torch.Tensor] = {}     # per-node scratch with stable addresses
         self._nd_seed = int.from_bytes(os.urandom(4), "little")
+
+    def note_fallback(self, op, why: str = "") -> None:
+        """A GPU kernel wrapper has no native code for this case (see ``ops/hip_kernels``)."""
+        sess = self.session
+        entry = (op.type, op.name, why)
+        if self.device.type == "cuda" and not sess.config.allow_torch_fallback:
+            from ..ops.hip import HipKernelError
+            raise HipKernelError(
+                "op %s (%s) has no gfx950 kernel for %s; refusing to run torch kernels on the GPU "
+                "(ConfigProto(allow_torch_fallback=True) permits it)" % (op.name, op.type, why))
+        sess.stats["torch_fallbacks"] += 1
+        if len(sess.fallback_log) < 256 and entry not in sess.fallback_log:
+            sess.fallback_log.append(entry)
 
     def nondeterministic_seed(self) -> int:
         self._nd_seed = (self._nd_seed * 1103515245 + 12345) & 0x7FFFFFFF
@@ -276,7 +300,9 @@ class Session:
         self._local_store = (self._runtime.local_store if self._runtime is not None
                              else LocalVariableStore(self.device))
         self._ctx = ExecContext(self)
-        self.stats = {"runs": 0, "graph_replays": 0, "eager_runs": 0, "captures": 0}
+        self.stats = {"runs": 0, "graph_replays": 0, "eager_runs": 0, "captures": 0,
+                      "torch_fallbacks": 0}
+        self.fallback_log: List[Tuple[str, str, str]] = []
 
     # -- context-manager / default-session protocol ---------------------------------------
     def __enter__(self) -> "Session":
@@ -423,6 +449,15 @@ class Session:
             kernel = d.hip_kernel if (use_hip and d.hip_kernel is not None) else d.ref_kernel
             if kernel is None:
                 raise NotImplementedError("op type %r has no kernel" % node.type)
+            if use_hip and d.hip_kernel is None and not d.host_only \
+                    and node.type not in _NO_KERNEL_NEEDED:
+                if not self.config.allow_torch_fallback:
+                    raise NotImplementedError(
+                        "op %s (%s) has no gfx950 kernel; refusing to plan a torch kernel on the "
+                        "GPU (ConfigProto(allow_torch_fallback=True) permits it)"
+                        % (node.name, node.type))
+                self.stats["torch_fallbacks"] += 1
+                self.fallback_log.append((node.type, node.name, "no kernel"))
             ins = [-1] * len(node.inputs)          # -1: a variable reference, not a value
             raw = node.attrs.get("_raw_inputs")
             for i, t in value_inputs(node):

@@ -201,6 +201,60 @@ __global__ __launch_bounds__(BLOCK) void truncated_normal_kernel(float* __restri
   }
 }
 
+// ---- generic cast between the element types a graph can carry --------------------------------
+enum CastKind { K_F32 = 0, K_BF16 = 1, K_I32 = 2, K_I64 = 3, K_BOOL = 4, K_F64 = 5, K_FP8 = 6 };
+
+template <int KIND>
+__device__ __forceinline__ double load_as_double(const void* p, long i) {
+  if (KIND == K_F32) return (double)reinterpret_cast<const float*>(p)[i];
+  if (KIND == K_BF16) return (double)dtf_bf16_to_f32(reinterpret_cast<const unsigned short*>(p)[i]);
+  if (KIND == K_I32) return (double)reinterpret_cast<const int*>(p)[i];
+  if (KIND == K_I64) return (double)reinterpret_cast<const long*>(p)[i];
+  if (KIND == K_BOOL) return reinterpret_cast<const unsigned char*>(p)[i] ? 1.0 : 0.0;
+  if (KIND == K_F64) return reinterpret_cast<const double*>(p)[i];
+  return (double)dtf_e4m3_to_f32(reinterpret_cast<const unsigned char*>(p)[i]);
+}
+
+template <int KIND>
+__device__ __forceinline__ void store_from_double(void* p, long i, double v, long iv) {
+  if (KIND == K_F32) reinterpret_cast<float*>(p)[i] = (float)v;
+  else if (KIND == K_BF16) reinterpret_cast<unsigned short*>(p)[i] = dtf_f32_to_bf16((float)v);
+  else if (KIND == K_I32) reinterpret_cast<int*>(p)[i] = (int)iv;
+  else if (KIND == K_I64) reinterpret_cast<long*>(p)[i] = iv;
+  else if (KIND == K_BOOL) reinterpret_cast<unsigned char*>(p)[i] = (v != 0.0 || iv != 0) ? 1 : 0;
+  else if (KIND == K_F64) reinterpret_cast<double*>(p)[i] = v;
+  else reinterpret_cast<unsigned char*>(p)[i] = dtf_f32_to_e4m3((float)v);
+}
+
+// integer sources keep their exact value on the way to an integer destination (a 64-bit index does
+// not survive a trip through double); floating sources truncate toward zero like a C cast
+template <int SRC, int DST>
+__global__ __launch_bounds__(BLOCK) void cast_generic_kernel(const void* __restrict__ src,
+                                                             void* __restrict__ dst, long n) {
+  for (long i = blockIdx.x * (long)BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * BLOCK) {
+    double v;
+    long iv;
+    if (SRC == K_I64) { iv = reinterpret_cast<const long*>(src)[i]; v = (double)iv; }
+    else if (SRC == K_I32) { iv = reinterpret_cast<const int*>(src)[i]; v = (double)iv; }
+    else { v = load_as_double<SRC>(src, i); iv = (long)v; }
+    store_from_double<DST>(dst, i, v, iv);
+  }
+}
+
+template <int SRC>
+int cast_dispatch_dst(const void* src, void* dst, int dst_kind, long n, hipStream_t stream) {
+  const dim3 grid(grid_for(n, 1)), block(BLOCK);
+  switch (dst_kind) {
+#define DTF_CAST_DST(K) \
+    case K: hipLaunchKernelGGL((cast_generic_kernel<SRC, K>), grid, block, 0, stream, src, dst, n); break;
+    DTF_CAST_DST(K_F32) DTF_CAST_DST(K_BF16) DTF_CAST_DST(K_I32) DTF_CAST_DST(K_I64)
+    DTF_CAST_DST(K_BOOL) DTF_CAST_DST(K_F64) DTF_CAST_DST(K_FP8)
+#undef DTF_CAST_DST
+    default: return DTF_ERR_UNSUPPORTED;
+  }
+  return DTF_OK;
+}
+
 bool aligned(const void* p, unsigned a) { return ((uintptr_t)p & (a - 1)) == 0; }
 
 }  // namespace
@@ -316,6 +370,27 @@ DTF_API int dtf_truncated_normal_f32(float* out, long n, unsigned int seed, unsi
   if (!out) return DTF_ERR_BAD_ARG;
   hipLaunchKernelGGL(truncated_normal_kernel, dim3(grid_for(n, 1)), dim3(BLOCK), 0, stream, out, n,
                      seed, op_seed, mean, stddev);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
+// dst[i] = (dst type) src[i]; kinds: 0 f32, 1 bf16, 2 i32, 3 i64, 4 bool, 5 f64, 6 fp8 e4m3
+DTF_API int dtf_cast_generic(const void* src, int src_kind, void* dst, int dst_kind, long n,
+                             hipStream_t stream) {
+  if (n <= 0) return DTF_OK;
+  if (!src || !dst) return DTF_ERR_BAD_ARG;
+  int rc;
+  switch (src_kind) {
+    case K_F32: rc = cast_dispatch_dst<K_F32>(src, dst, dst_kind, n, stream); break;
+    case K_BF16: rc = cast_dispatch_dst<K_BF16>(src, dst, dst_kind, n, stream); break;
+    case K_I32: rc = cast_dispatch_dst<K_I32>(src, dst, dst_kind, n, stream); break;
+    case K_I64: rc = cast_dispatch_dst<K_I64>(src, dst, dst_kind, n, stream); break;
+    case K_BOOL: rc = cast_dispatch_dst<K_BOOL>(src, dst, dst_kind, n, stream); break;
+    case K_F64: rc = cast_dispatch_dst<K_F64>(src, dst, dst_kind, n, stream); break;
+    case K_FP8: rc = cast_dispatch_dst<K_FP8>(src, dst, dst_kind, n, stream); break;
+    default: return DTF_ERR_UNSUPPORTED;
+  }
+  if (rc != DTF_OK) return rc;
   DTF_LAUNCH_CHECK();
   return DTF_OK;
 }

@@ -358,7 +358,9 @@ def matmul(a, b, transpose_a: bool = False, transpose_b: bool = False, name=None
         k2, n = (sb[1], sb[0]) if transpose_b else sb
     if k1 is not None and k2 is not None and k1 != k2:
         raise ValueError("matmul inner dimensions differ: %s vs %s" % (sa, sb))
-    return _op1("MatMul", [a, b], a.dtype, (m, n), name=name or "MatMul",
+    # fp8 (OCP e4m3) operands accumulate in fp32 on the matrix cores and produce bf16
+    out_dtype = dtypes.bfloat16 if a.dtype == dtypes.float8_e4m3fn else a.dtype
+    return _op1("MatMul", [a, b], out_dtype, (m, n), name=name or "MatMul",
                 transpose_a=bool(transpose_a), transpose_b=bool(transpose_b))
 
 

@@ -99,9 +99,9 @@ class SyntheticRegressionData:
                                       self.features, device=self._device)
                 y = hip.gemm_f32(x, self._w_dev, bias=self._b_dev)
                 if self.noise:
-                    y.add_(hip.philox_window(rows, self.outputs, seed, 2, self._row, 0,
-                                             self.outputs, device=self._device),
-                           alpha=self.noise)
+                    hip.axpby(1.0, y, self.noise,
+                              hip.philox_window(rows, self.outputs, seed, 2, self._row, 0,
+                                                self.outputs, device=self._device), out=y)
                 self._row += rows
                 self._chunk, self._chunk_pos, self._chunk_batch = (x, y), 0, batch_size
             lo = self._chunk_pos

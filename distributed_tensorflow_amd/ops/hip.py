@@ -114,6 +114,7 @@ def _declare(L: ctypes.CDLL) -> None:
         "dtf_absmax_scale": [P, I, LG, F, P, P, P],
         "dtf_cast_to_fp8_dev_scale": [P, I, P, LG, P, P],
         "dtf_truncated_normal_f32": [P, LG, U, U, F, F, P],
+        "dtf_cast_generic": [P, I, P, I, LG, P],
     }
     for name, argtypes in sigs.items():
         fn = getattr(L, name)
@@ -465,6 +466,10 @@ def axpby(alpha: float, x: torch.Tensor, beta: float = 0.0, y: Optional[torch.Te
     return out
 
 
+_CAST_KINDS = {torch.float32: 0, torch.bfloat16: 1, torch.int32: 2, torch.int64: 3, torch.bool: 4,
+               torch.float64: 5, torch.float8_e4m3fn: 6}
+
+
 def cast(x: torch.Tensor, dtype: torch.dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     if x.dtype == dtype and out is None:
         return x
@@ -483,6 +488,10 @@ def cast(x: torch.Tensor, dtype: torch.dtype, out: Optional[torch.Tensor] = None
     elif x.dtype == torch.bool and dtype == torch.float32:
         _check(lib().dtf_cast_bool_to_f32(x.data_ptr(), out.data_ptr(), n, _stream()),
                "cast bool->f32")
+    elif x.dtype in _CAST_KINDS and dtype in _CAST_KINDS:
+        _check(lib().dtf_cast_generic(x.data_ptr(), _CAST_KINDS[x.dtype], out.data_ptr(),
+                                      _CAST_KINDS[dtype], n, _stream()),
+               "cast %s->%s" % (x.dtype, dtype))
     else:
         raise HipKernelError("cast %s -> %s has no HIP kernel" % (x.dtype, dtype))
     return out

@@ -4,9 +4,12 @@ Imported by ``Session`` when its device is a GPU. Importing it loads ``libdtf_hi
 raises if the library has not been built -- a GPU session never silently runs torch kernels
 for an op that has a native one.
 
-Op types without an entry here (shape plumbing such as ``Reshape`` / ``Transpose``, integer
-casts, host-side string ops) keep their reference kernel, which on a GPU tensor is a view or a
-trivial torch op; none of them sits on the training hot path of the reference workloads.
+Op types without an entry here are pure views or host bookkeeping (``Reshape``, ``Identity``,
+``Const`` upload, variable reads, summaries): ``client.session`` lets exactly that list through
+and refuses to plan anything else on a GPU. A kernel here that meets an element type or layout
+it has no native code for does not quietly run torch either: ``_fallback`` raises unless the
+session was created with ``ConfigProto(allow_torch_fallback=True)`` (then the fallback is
+counted in ``Session.stats["torch_fallbacks"]`` and listed in ``Session.fallback_log``).
 """
 from __future__ import annotations
 
@@ -24,9 +27,13 @@ def _is_f32(*tensors) -> bool:
     return all(isinstance(t, torch.Tensor) and t.dtype == _f32 for t in tensors)
 
 
-def _ref(op_type):
+def _fallback(op_type, op, inputs, ctx, why: str = ""):
+    """No native kernel for this case: refuse (default) or, when the session allows it, run
+    the torch reference kernel and record that it happened."""
     from ..framework.op_registry import get_opdef
-    return get_opdef(op_type).ref_kernel
+    ctx.note_fallback(op, why or ", ".join(
+        str(getattr(t, "dtype", type(t).__name__)) for t in inputs))
+    return get_opdef(op_type).ref_kernel(op, inputs, ctx)
 
 
 # -- sources ----------------------------------------------------------------------------
@@ -34,7 +41,7 @@ def _ref(op_type):
 def _random_normal(op, inputs, ctx):
     dt = op.attrs["dtype"].torch
     if dt not in (torch.float32, torch.bfloat16):
-        return _ref("RandomStandardNormal")(op, inputs, ctx)
+        return _fallback("RandomStandardNormal", op, inputs, ctx)
     if op.attrs.get("deterministic", True):
         seed, seed2 = op.attrs["seed"], op.attrs["seed2"]
     else:
@@ -47,7 +54,7 @@ def _random_normal(op, inputs, ctx):
 def _random_uniform(op, inputs, ctx):
     dt = op.attrs["dtype"].torch
     if dt not in (torch.float32, torch.bfloat16):
-        return _ref("RandomUniform")(op, inputs, ctx)
+        return _fallback("RandomUniform", op, inputs, ctx)
     if op.attrs.get("deterministic", True):
         seed, seed2 = op.attrs["seed"], op.attrs["seed2"]
     else:
@@ -59,7 +66,7 @@ def _random_uniform(op, inputs, ctx):
 @hip_kernel("Fill")
 def _fill(op, inputs, ctx):
     if op.attrs["dtype"].torch != _f32:
-        return _ref("Fill")(op, inputs, ctx)
+        return _fallback("Fill", op, inputs, ctx)
     # a small constant fill (the 1.0 seeding backprop, zero biases) is materialised once per
     # session; consumers never write into their inputs (Assign copies into the store)
     cached = ctx.const_cache.get(op)
@@ -74,14 +81,14 @@ def _fill(op, inputs, ctx):
 @hip_kernel("OnesLike")
 def _ones_like(op, inputs, ctx):
     if not _is_f32(inputs[0]):
-        return _ref("OnesLike")(op, inputs, ctx)
+        return _fallback("OnesLike", op, inputs, ctx)
     return [hip.fill(inputs[0].shape, 1.0, ctx.device)]
 
 
 @hip_kernel("ZerosLike")
 def _zeros_like(op, inputs, ctx):
     if not _is_f32(inputs[0]):
-        return _ref("ZerosLike")(op, inputs, ctx)
+        return _fallback("ZerosLike", op, inputs, ctx)
     return [hip.fill(inputs[0].shape, 0.0, ctx.device)]
 
 
@@ -91,12 +98,12 @@ def _register_binary(op_type: str, code: str) -> None:
     def kernel(op, inputs, ctx, _code=code, _type=op_type):
         a, b = inputs
         if not _is_f32(a, b):
-            return _ref(_type)(op, inputs, ctx)
+            return _fallback(_type, op, inputs, ctx)
         try:
             return [hip.binary(_code, a, b)]
         except hip.HipKernelError as e:
             if "trailing-suffix" in str(e):      # general broadcast: rare, keep correctness
-                return _ref(_type)(op, inputs, ctx)
+                return _fallback(_type, op, inputs, ctx)
             raise
 
 
@@ -118,7 +125,7 @@ def _register_compare(op_type: str, code: str) -> None:
             except hip.HipKernelError as e:
                 if "trailing-suffix" not in str(e):
                     raise
-        return _ref(_type)(op, inputs, ctx)
+        return _fallback(_type, op, inputs, ctx)
 
 
 for _t, _c in (("Equal", "eq"), ("NotEqual", "ne"), ("Less", "lt"), ("Greater", "gt")):
@@ -129,7 +136,7 @@ def _register_unary(op_type: str, code: str) -> None:
     @hip_kernel(op_type)
     def kernel(op, inputs, ctx, _code=code, _type=op_type):
         if not _is_f32(inputs[0]):
-            return _ref(_type)(op, inputs, ctx)
+            return _fallback(_type, op, inputs, ctx)
         return [hip.unary(_code, inputs[0])]
 
 
@@ -143,7 +150,7 @@ for _t, _c in (("Neg", "neg"), ("Log", "log"), ("Exp", "exp"), ("Sqrt", "sqrt"),
 def _scale(op, inputs, ctx):
     x = inputs[0]
     if x.dtype not in (torch.float32, torch.bfloat16):
-        return _ref("Scale")(op, inputs, ctx)
+        return _fallback("Scale", op, inputs, ctx)
     return [hip.axpby(op.attrs["alpha"], x)]
 
 
@@ -151,7 +158,7 @@ def _scale(op, inputs, ctx):
 def _axpby(op, inputs, ctx):
     x, y = inputs
     if x.dtype not in (torch.float32, torch.bfloat16) or x.shape != y.shape:
-        return _ref("Axpby")(op, inputs, ctx)
+        return _fallback("Axpby", op, inputs, ctx)
     return [hip.axpby(op.attrs["alpha"], x, op.attrs["beta"], y)]
 
 
@@ -159,7 +166,7 @@ def _axpby(op, inputs, ctx):
 def _add_n(op, inputs, ctx):
     if not _is_f32(*inputs) or any(t.shape != inputs[0].shape for t in inputs) \
             or len(inputs) > 8:
-        return _ref("AddN")(op, inputs, ctx)
+        return _fallback("AddN", op, inputs, ctx)
     return [hip.reduce_partials(list(inputs))]
 
 
@@ -167,18 +174,16 @@ def _add_n(op, inputs, ctx):
 def _cast(op, inputs, ctx):
     x = inputs[0]
     dst = op.attrs["dtype"].torch
-    pairs = {(torch.float32, torch.bfloat16), (torch.bfloat16, torch.float32),
-             (torch.bool, torch.float32)}
-    if (x.dtype, dst) in pairs:
+    if x.dtype in hip._CAST_KINDS and dst in hip._CAST_KINDS:
         return [hip.cast(x, dst)]
-    return _ref("Cast")(op, inputs, ctx)
+    return _fallback("Cast", op, inputs, ctx)
 
 
 @hip_kernel("RowScale")
 def _row_scale(op, inputs, ctx):
     x, s = inputs
     if not _is_f32(x, s) or x.dim() != 2:
-        return _ref("RowScale")(op, inputs, ctx)
+        return _fallback("RowScale", op, inputs, ctx)
     return [hip.row_scale(x, s)]
 
 
@@ -191,14 +196,20 @@ def _matmul(op, inputs, ctx):
         return [hip.gemm_f32(a, b, ta, tb)]
     if a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16:
         return [hip.gemm_bf16(a, b, ta, tb)]
-    return _ref("MatMul")(op, inputs, ctx)
+    if a.dtype == hip.FP8 and b.dtype == hip.FP8 and a.dim() == 2 and b.dim() == 2:
+        # block-scaled fp8 MFMA kernel: both operands K-contiguous (one transpose pass for the
+        # layouts that are not), fp32 accumulate, bf16 result
+        a_kc = hip.transpose2d(a) if ta else a
+        bt_kc = b if tb else hip.transpose2d(b)
+        return [hip.gemm_fp8_nt(a_kc, bt_kc, torch.bfloat16)]
+    return _fallback("MatMul", op, inputs, ctx)
 
 
 @hip_kernel("FusedDense")
 def _fused_dense(op, inputs, ctx):
     x, w, b = inputs
     if not _is_f32(x, w, b):
-        return _ref("FusedDense")(op, inputs, ctx)
+        return _fallback("FusedDense", op, inputs, ctx)
     return [hip.gemm_f32(x, w, bias=b, activation=hip.ACTIVATIONS[op.attrs["activation"]])]
 
 
@@ -207,7 +218,7 @@ def _reduce(op, inputs, ctx, mean: bool, type_name: str):
     x = inputs[0]
     axes = op.attrs["axis"]
     if not _is_f32(x) or op.attrs["keepdims"]:
-        return _ref(type_name)(op, inputs, ctx)
+        return _fallback(type_name, op, inputs, ctx)
     if axes is None or tuple(axes) == tuple(range(x.dim())):
         scale = 1.0 / max(1, x.numel()) if mean else 1.0
         return [hip.reduce_all(x, scale)]
@@ -216,7 +227,7 @@ def _reduce(op, inputs, ctx, mean: bool, type_name: str):
     if x.dim() == 2 and tuple(axes) == (0,):
         out = hip.reduce_cols(x)
         return [hip.axpby(1.0 / x.shape[0], out) if mean else out]
-    return _ref(type_name)(op, inputs, ctx)
+    return _fallback(type_name, op, inputs, ctx)
 
 
 @hip_kernel("Sum")
@@ -234,7 +245,7 @@ def _max(op, inputs, ctx):
     x = inputs[0]
     if _is_f32(x) and x.dim() == 2 and op.attrs["axis"] == (1,) and not op.attrs["keepdims"]:
         return [hip.reduce_rows(x, hip.ROW_MAX)]
-    return _ref("Max")(op, inputs, ctx)
+    return _fallback("Max", op, inputs, ctx)
 
 
 @hip_kernel("ArgMax")
@@ -243,7 +254,7 @@ def _argmax(op, inputs, ctx):
     if _is_f32(x) and x.dim() == 2 and op.attrs["axis"] == 1 \
             and op.outputs[0].dtype.torch == torch.int64:
         return [hip.argmax_rows(x)]
-    return _ref("ArgMax")(op, inputs, ctx)
+    return _fallback("ArgMax", op, inputs, ctx)
 
 
 @hip_kernel("SumToShapeOf")
@@ -253,13 +264,13 @@ def _sum_to_shape_of(op, inputs, ctx):
         return [x]
     if _is_f32(x) and x.dim() == 2 and like.dim() == 1 and like.shape[0] == x.shape[1]:
         return [hip.reduce_cols(x)]
-    return _ref("SumToShapeOf")(op, inputs, ctx)
+    return _fallback("SumToShapeOf", op, inputs, ctx)
 
 
 @hip_kernel("BiasGrad")
 def _bias_grad(op, inputs, ctx):
     if not _is_f32(inputs[0]) or inputs[0].dim() != 2:
-        return _ref("BiasGrad")(op, inputs, ctx)
+        return _fallback("BiasGrad", op, inputs, ctx)
     return [hip.reduce_cols(inputs[0])]
 
 
@@ -267,21 +278,21 @@ def _bias_grad(op, inputs, ctx):
 @hip_kernel("Softmax")
 def _softmax(op, inputs, ctx):
     if not _is_f32(inputs[0]):
-        return _ref("Softmax")(op, inputs, ctx)
+        return _fallback("Softmax", op, inputs, ctx)
     return [hip.softmax_rows(inputs[0])]
 
 
 @hip_kernel("LogSoftmax")
 def _log_softmax(op, inputs, ctx):
     if not _is_f32(inputs[0]):
-        return _ref("LogSoftmax")(op, inputs, ctx)
+        return _fallback("LogSoftmax", op, inputs, ctx)
     return [hip.softmax_rows(inputs[0], log=True)]
 
 
 @hip_kernel("SoftmaxGrad")
 def _softmax_grad(op, inputs, ctx):
     if not _is_f32(*inputs):
-        return _ref("SoftmaxGrad")(op, inputs, ctx)
+        return _fallback("SoftmaxGrad", op, inputs, ctx)
     return [hip.softmax_grad(inputs[0], inputs[1])]
 
 
@@ -289,7 +300,7 @@ def _softmax_grad(op, inputs, ctx):
 def _sxent(op, inputs, ctx):
     logits, labels = inputs
     if not _is_f32(logits, labels) or logits.dim() != 2:
-        return _ref("SoftmaxCrossEntropyWithLogits")(op, inputs, ctx)
+        return _fallback("SoftmaxCrossEntropyWithLogits", op, inputs, ctx)
     _, y, rows = hip.softmax_xent(logits, labels, want_softmax=True, want_rows=True,
                                   want_mean=False)
     # backprop = softmax * rowsum(labels) - labels
@@ -302,7 +313,7 @@ def _sxent(op, inputs, ctx):
 def _softmax_xent_mean(op, inputs, ctx):
     logits, labels = inputs
     if not _is_f32(logits, labels) or logits.dim() != 2:
-        return _ref("SoftmaxXentMean")(op, inputs, ctx)
+        return _fallback("SoftmaxXentMean", op, inputs, ctx)
     mean, y, _ = hip.softmax_xent(logits, labels)
     return [mean, y]
 
@@ -311,7 +322,7 @@ def _softmax_xent_mean(op, inputs, ctx):
 def _softmax_xent_mean_grad(op, inputs, ctx):
     y, labels, dloss = inputs
     if not _is_f32(y, labels, dloss) or y.dim() != 2:
-        return _ref("SoftmaxXentMeanGrad")(op, inputs, ctx)
+        return _fallback("SoftmaxXentMeanGrad", op, inputs, ctx)
     want_bias = bool(op.attrs.get("emit_bias_grad"))
     dz, db = hip.softmax_xent_grad(y, labels, dloss, want_bias)
     return [dz, db] if want_bias else [dz]
@@ -321,7 +332,7 @@ def _softmax_xent_mean_grad(op, inputs, ctx):
 def _dense_grad_sigmoid(op, inputs, ctx):
     da, a = inputs
     if not _is_f32(da, a) or da.dim() != 2:
-        return _ref("DenseGradSigmoid")(op, inputs, ctx)
+        return _fallback("DenseGradSigmoid", op, inputs, ctx)
     dz, db = hip.sigmoid_grad_bias(da, a)
     return [dz, db]
 
@@ -339,7 +350,7 @@ def _classifier_head_train(op, inputs, ctx):
             if not torch.cuda.is_current_stream_capturing():
                 ctx.const_cache[key] = dloss
     if not _is_f32(a, w, b, labels, dloss) or a.dim() != 2:
-        return _ref("ClassifierHeadTrain")(op, inputs, ctx)
+        return _fallback("ClassifierHeadTrain", op, inputs, ctx)
     sig = bool(op.attrs.get("sigmoid_input"))
     want_acc = bool(op.attrs.get("emit_accuracy"))
     if hip.mlp_head_supported(a.shape[0], a.shape[1], w.shape[1]):
@@ -368,8 +379,134 @@ def _classifier_head_train(op, inputs, ctx):
 def _argmax_accuracy(op, inputs, ctx):
     y, labels = inputs
     if not _is_f32(y, labels) or y.dim() != 2:
-        return _ref("ArgmaxAccuracy")(op, inputs, ctx)
+        return _fallback("ArgmaxAccuracy", op, inputs, ctx)
     return [hip.argmax_accuracy(y, labels)]
+
+
+# -- shape plumbing / bookkeeping with real data movement ------------------------------------
+@hip_kernel("Transpose")
+def _transpose(op, inputs, ctx):
+    x = inputs[0]
+    perm = tuple(op.attrs["perm"])
+    if x.dim() == 2 and perm == (1, 0) and x.element_size() in (1, 2, 4):
+        return [hip.transpose2d(x)]
+    if perm == tuple(range(x.dim())):
+        return [x]
+    return _fallback("Transpose", op, inputs, ctx, "perm %s of rank %d" % (perm, x.dim()))
+
+
+@hip_kernel("Sign")
+def _sign(op, inputs, ctx):
+    if not _is_f32(inputs[0]):
+        return _fallback("Sign", op, inputs, ctx)
+    return [hip.sign(inputs[0])]
+
+
+def _mid_extents(shape, axes):
+    """(outer, mid, inner) when ``axes`` is one contiguous run of dimensions of ``shape``."""
+    axes = sorted(axes)
+    if not axes or axes != list(range(axes[0], axes[-1] + 1)):
+        return None
+    outer = mid = inner = 1
+    for i, d in enumerate(shape):
+        if i < axes[0]:
+            outer *= int(d)
+        elif i <= axes[-1]:
+            mid *= int(d)
+        else:
+            inner *= int(d)
+    return outer, mid, inner
+
+
+@hip_kernel("ReduceGrad")
+def _reduce_grad(op, inputs, ctx):
+    g, x = inputs
+    axes = op.attrs["axis"]
+    axes = tuple(range(x.dim())) if axes is None else tuple(axes)
+    ext = _mid_extents(x.shape, axes) if _is_f32(g) and axes else None
+    if ext is None:
+        if _is_f32(g) and not axes:
+            return [g]
+        return _fallback("ReduceGrad", op, inputs, ctx, "axes %s" % (axes,))
+    outer, mid, inner = ext
+    scale = 1.0 / mid if op.attrs["mean"] else 1.0
+    return [hip.broadcast_mid(g, outer, mid, inner, scale, x.shape)]
+
+
+@hip_kernel("BroadcastLike")
+def _broadcast_like(op, inputs, ctx):
+    g, x = inputs
+    if g.shape == x.shape:
+        return [g]
+    if _is_f32(g):
+        gs = [1] * (x.dim() - g.dim()) + list(g.shape)
+        axes = [i for i, (a, b) in enumerate(zip(gs, x.shape)) if a == 1 and b != 1]
+        same = all(a == b for i, (a, b) in enumerate(zip(gs, x.shape)) if i not in axes)
+        ext = _mid_extents(x.shape, axes) if same and axes else None
+        if ext is not None:
+            return [hip.broadcast_mid(g, ext[0], ext[1], ext[2], 1.0, x.shape)]
+    return _fallback("BroadcastLike", op, inputs, ctx, "%s -> %s" % (tuple(g.shape), tuple(x.shape)))
+
+
+@hip_kernel("LogSoftmaxGrad")
+def _log_softmax_grad(op, inputs, ctx):
+    if not _is_f32(*inputs):
+        return _fallback("LogSoftmaxGrad", op, inputs, ctx)
+    return [hip.log_softmax_grad(inputs[0], inputs[1])]
+
+
+@hip_kernel("TruncatedNormal")
+def _truncated_normal(op, inputs, ctx):
+    if op.attrs["dtype"].torch != _f32:
+        return _fallback("TruncatedNormal", op, inputs, ctx, str(op.attrs["dtype"]))
+    if op.attrs.get("deterministic", True):
+        seed, seed2 = op.attrs["seed"], op.attrs["seed2"]
+    else:
+        seed, seed2 = ctx.nondeterministic_seed(), op.attrs["seed2"]
+    return [hip.truncated_normal(op.attrs["shape"], seed, seed2, op.attrs["mean"],
+                                 op.attrs["stddev"], ctx.device)]
+
+
+def _local_f32(ctx, var_op):
+    store = ctx.session._store_for(var_op)
+    fast = getattr(store, "local_tensor", None)
+    p = fast(var_op.name) if fast is not None else None
+    return p if (p is not None and p.is_cuda and p.dtype == _f32 and p.is_contiguous()) else None
+
+
+def _assign_add_kernel(sign: float, type_name: str):
+    def kernel(op, inputs, ctx):
+        var_op, delta = op.inputs[0].op, inputs[1]
+        p = _local_f32(ctx, var_op)
+        if p is not None and _is_f32(delta) and delta.is_cuda \
+                and (delta.shape == p.shape or delta.numel() == 1):
+            return [hip.assign_add(p, delta, sign)]
+        if p is None and not getattr(ctx.session._store_for(var_op), "local_tensor", None):
+            # the variable lives in another process (parameter server): the store ships it
+            return [ctx.var_assign_add(var_op, delta if sign > 0 else -delta)]
+        return _fallback(type_name, op, inputs, ctx)
+    return kernel
+
+
+hip_kernel("AssignAdd")(_assign_add_kernel(1.0, "AssignAdd"))
+hip_kernel("AssignSub")(_assign_add_kernel(-1.0, "AssignSub"))
+
+
+@hip_kernel("Assign")
+def _assign(op, inputs, ctx):
+    """Same-shape re-assignment of a local variable copies into its storage with the block-copy
+    kernel (the address stays put for captured steps); a first assignment hands the value to
+    the store, which takes ownership of it."""
+    var_op, value = op.inputs[0].op, inputs[1]
+    store = ctx.session._store_for(var_op)
+    fast = getattr(store, "local_tensor", None)
+    cur = fast(var_op.name) if fast is not None else None
+    if cur is not None and cur.is_cuda and isinstance(value, torch.Tensor) and value.is_cuda \
+            and cur.shape == value.shape and cur.dtype == value.dtype and cur.is_contiguous() \
+            and value.is_contiguous() and cur.numel() > 0 and cur.data_ptr() != value.data_ptr():
+        hip.copy_2d(value.view(1, -1), cur.view(1, -1))
+        return [cur]
+    return [ctx.var_assign(var_op, value)]
 
 
 # -- optimizer --------------------------------------------------------------------------

@@ -232,6 +232,8 @@ def _matmul(op, inputs, ctx):
         a = a.t()
     if op.attrs["transpose_b"]:
         b = b.t()
+    if a.dtype == torch.float8_e4m3fn:
+        return [(a.float() @ b.float()).to(torch.bfloat16)]
     if a.dtype in (torch.bfloat16, torch.float16) and a.device.type == "cpu":
         return [(a.float() @ b.float()).to(a.dtype)]
     return [a @ b]

@@ -216,7 +216,10 @@ class Server:
                     if world > 1:
                         chief = self._cluster.task_address(self._job_name, 0)
                         chost, _, cport = chief.rpartition(":")
+                        # DTF_COMM_BACKEND=gloo: several ranks rehearsed on ONE GPU (RCCL refuses
+                        # two ranks per device); default: RCCL on GPUs, gloo on CPUs
                         comm = TorchDistComm(
+                            backend=os.environ.get("DTF_COMM_BACKEND") or None,
                             rank=self._task_index, world_size=world, device=self.device,
                             master_addr=os.environ.get("MASTER_ADDR", chost or "127.0.0.1"),
                             master_port=int(os.environ.get("MASTER_PORT", cport)))

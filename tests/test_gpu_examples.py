@@ -263,3 +263,157 @@ def test_fetch_ahead_of_the_optimizer_launch_matches_eager_values():
         assert np.allclose(a[1], b[1], atol=1e-6)            # post-update b2 in both
     assert np.allclose(ga[9], ea[9], atol=1e-6) and ga[10] == ea[10] == 9.0
     assert np.allclose(ga[8][1], ga[9], atol=0)              # the fetched b2 was the final one
+
+
+@pytest.mark.parametrize("shard", ["m", "k", "2d"])
+def test_matmul_example_sharded_over_two_ranks_sharing_the_gpu(shard, tmp_path):
+    """The reference's matmul graph (``tf_distributed_1000Matrix.py:33-48``) with the product
+    sharded over 2 worker processes. The one-GPU box cannot host two RCCL ranks, so both share
+    GPU 0 and the collectives of this rehearsal travel through gloo (staged host copies); the
+    products run on the fp32 MFMA kernel. Row- and 2-D-sharded results must equal the single-rank
+    product bit for bit."""
+    import numpy as np
+
+    def run(workers, mode, tag):
+        dump = str(tmp_path / ("c_%s" % tag))
+        env = dict(os.environ, PYTHONPATH=ROOT, DTF_COMM_BACKEND="gloo")
+        proc = subprocess.run(
+            [sys.executable, "-m", "distributed_tensorflow_amd.launch", "--num_workers",
+             str(workers), "--protocol", "rccl", "--timeout", "200",
+             os.path.join(EX, "tf_distributed_1000Matrix.py"), "--", "--max_steps", "101",
+             "--shard", mode, "--logs_path", str(tmp_path / ("logs_" + tag)),
+             "--dump_result", dump + "_{rank}.npy"],
+            cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+            timeout=240)
+        assert proc.returncode == 0, proc.stdout
+        return proc.stdout, dump
+
+    out1, dump1 = run(1, "none", "w1")
+    out2, dump2 = run(2, shard, "w2")
+    assert out2.count("Sharded variable") >= 2 and out2.count("] done") == 2
+    assert re.search(r"AvgTime:\s*\d+\.\d\dms", out2)
+    ref = np.load(dump1 + "_0.npy")
+    for r in (0, 1):
+        c = np.load(dump2 + "_%d.npy" % r)
+        if shard == "k":
+            assert np.abs(c - ref).max() < 1e-3 * np.abs(ref).max()
+        else:
+            assert np.array_equal(c, ref)
+
+
+def test_example_graphs_select_no_torch_kernel_on_gpu():
+    """Every op of the three example graphs (MNIST training + evaluation, the matrix product,
+    linear regression) is planned onto a hand-written kernel or a pure view; a GPU session that
+    meets anything else raises instead of running torch."""
+    import numpy as np
+    import torch
+    import distributed_tensorflow_amd as tf
+    from distributed_tensorflow_amd.models import linear_regression, mnist_mlp
+
+    def check(sess, fetch_sets):
+        for fetches, feed in fetch_sets:
+            for _ in range(3):                      # eager warm-up, capture, replay
+                sess.run(fetches, feed)
+        assert sess.stats["torch_fallbacks"] == 0 and sess.fallback_log == []
+        for plan in sess._plans.values():
+            for st in plan.steps:
+                from distributed_tensorflow_amd.framework.op_registry import get_opdef
+                d = get_opdef(st.node.type)
+                assert st.kernel is d.hip_kernel or st.node.type in (
+                    "Const", "Identity", "StopGradient", "Reshape", "ReshapeLike", "NoOp",
+                    "Placeholder", "VariableV2", "IsVariableInitialized"), st.node
+
+    for fusion in (True, False):
+        g = tf.Graph()
+        with g.as_default():
+            m = mnist_mlp.build_model()
+            with tf.Session(config=tf.ConfigProto(device="cuda", graph_fusion=fusion)) as sess:
+                sess.run(m.init_op)
+                feed = {m.x: np.random.rand(100, 784).astype(np.float32),
+                        m.y_: np.eye(10, dtype=np.float32)[np.random.randint(0, 10, 100)]}
+                check(sess, [([m.train_op, m.loss, m.summary_op, m.global_step], feed),
+                             (m.accuracy, feed)])
+    g = tf.Graph()
+    with g.as_default():
+        tf.set_random_seed(1)
+        A = tf.Variable(tf.random_normal([1000, 1000]))
+        B = tf.Variable(tf.random_normal([1000, 1000]))
+        C = tf.matmul(A, B)
+        chk = tf.reduce_mean(C)
+        with tf.Session(config=tf.ConfigProto(device="cuda")) as sess:
+            sess.run(tf.global_variables_initializer())
+            check(sess, [(chk, None), (C, None)])
+    g = tf.Graph()
+    with g.as_default():
+        m = linear_regression.build_model(64, 3, learning_rate=0.05)
+        with tf.Session(config=tf.ConfigProto(device="cuda")) as sess:
+            sess.run(m.init_op)
+            feed = {m.x: np.random.rand(32, 64).astype(np.float32),
+                    m.y_: np.random.rand(32, 3).astype(np.float32)}
+            check(sess, [([m.train_op, m.loss, m.global_step], feed)])
+
+
+def test_gpu_session_refuses_ops_without_a_kernel_unless_allowed():
+    import numpy as np
+    import distributed_tensorflow_amd as tf
+    from distributed_tensorflow_amd.ops.hip import HipKernelError
+    g = tf.Graph()
+    with g.as_default():
+        x = tf.placeholder(tf.float32, [2, 3, 4])
+        y = tf.transpose(x, [2, 0, 1])            # rank-3 permutation: no native kernel
+        val = np.arange(24, dtype=np.float32).reshape(2, 3, 4)
+        with tf.Session(config=tf.ConfigProto(device="cuda")) as sess:
+            with pytest.raises(HipKernelError):
+                sess.run(y, {x: val})
+        with tf.Session(config=tf.ConfigProto(device="cuda", allow_torch_fallback=True)) as sess:
+            assert np.array_equal(sess.run(y, {x: val}), val.transpose(2, 0, 1))
+            assert sess.stats["torch_fallbacks"] >= 1
+            assert sess.fallback_log[0][0] == "Transpose"
+
+
+def test_small_ops_run_native_kernels_through_the_session():
+    """AssignAdd / AssignSub, Transpose, Sign, reduction and broadcast gradients, log-softmax
+    gradient, truncated normal, integer casts and an fp8 ``tf.matmul``: all through
+    ``Session.run`` on the GPU with fallbacks forbidden, against numpy."""
+    import numpy as np
+    import torch
+    import distributed_tensorflow_amd as tf
+    rng = np.random.RandomState(0)
+    g = tf.Graph()
+    with g.as_default():
+        tf.set_random_seed(3)
+        x = tf.placeholder(tf.float32, [6, 5])
+        v = tf.Variable(tf.zeros([6, 5]))
+        inc, dec = v.assign_add(x), v.assign_sub(tf.constant(0.5))
+        xt = tf.transpose(x)
+        sg = tf.sign(x)
+        loss = tf.reduce_sum(tf.reduce_mean(tf.nn.log_softmax(x) * x, axis=1)) \
+            + tf.reduce_mean(tf.abs(x)) + tf.reduce_sum(tf.reduce_sum(x, axis=0) * 2.0)
+        gx, = tf.gradients(loss, [x])
+        tn = tf.truncated_normal([4000], stddev=0.1)
+        as_int = tf.cast(tf.cast(x * 10.0, tf.int32), tf.float32)
+        a8 = tf.cast(tf.placeholder(tf.float32, [64, 128], name="a8") , tf.float8_e4m3fn)
+        b8 = tf.cast(tf.placeholder(tf.float32, [128, 32], name="b8"), tf.float8_e4m3fn)
+        c8 = tf.matmul(a8, b8)
+        xv = rng.randn(6, 5).astype(np.float32)
+        with tf.Session(config=tf.ConfigProto(device="cuda")) as sess:
+            sess.run(tf.global_variables_initializer())
+            sess.run(inc, {x: xv})
+            sess.run(inc, {x: xv})
+            sess.run(dec)
+            assert np.allclose(sess.run(v), 2 * xv - 0.5)
+            assert np.array_equal(sess.run(xt, {x: xv}), xv.T)
+            assert np.array_equal(sess.run(sg, {x: xv}), np.sign(xv))
+            xt_ = torch.tensor(xv, requires_grad=True)
+            ref = (torch.log_softmax(xt_, -1) * xt_).mean(1).sum() + xt_.abs().mean() \
+                + (xt_.sum(0) * 2.0).sum()
+            ref.backward()
+            assert np.allclose(sess.run(gx, {x: xv}), xt_.grad.numpy(), atol=1e-5)
+            t = sess.run(tn)
+            assert np.abs(t).max() <= 0.2 + 1e-6 and 0.07 < t.std() < 0.1
+            assert np.array_equal(sess.run(as_int, {x: xv}), np.trunc(xv * 10.0))
+            av = rng.randint(-2, 3, (64, 128)).astype(np.float32)
+            bv = rng.randint(-2, 3, (128, 32)).astype(np.float32)
+            c = sess.run(c8, {g.get_tensor_by_name("a8:0"): av, g.get_tensor_by_name("b8:0"): bv})
+            assert np.array_equal(c, av @ bv)
+            assert sess.stats["torch_fallbacks"] == 0

@@ -544,10 +544,10 @@ def test_gemm_bf16_writes_only_its_output(hip, m, n, k, out_dtype, variant):
     g = torch.Generator().manual_seed(m + n)
     a = torch.randint(-2, 3, (m, k), generator=g).float()
     bt = torch.randint(-2, 3, (n, k), generator=g).float()
-    n_pad = (n + 3) // 4 * 4                    # fast path wants ldc % 4 == 0; ragged n goes generic
+    # a ragged n or a row pitch off the 4-element grid is outside the fast kernels' contract:
+    # the launcher reports that and the wrapper runs the predicated generic kernel on the same
+    # strided view -- the case most likely to overrun, so its band is checked like the others
     big, view, sentinel, origin = _guarded(m, n, out_dtype, pad_cols=4 + (4 - n % 4) % 4)
-    if view.stride(0) % 4 or n_pad != n:
-        pytest.skip("layout not eligible for the fast kernel's strided store")
     hip.gemm_bf16_nt(a.bfloat16().cuda(), bt.bfloat16().cuda(), out_dtype, out=view, variant=variant)
     assert torch.equal(view.float().cpu(), (a @ bt.t()).to(out_dtype).float())
     assert _band_intact(big, (m, n), origin, sentinel)
@@ -648,3 +648,111 @@ def test_pack_f32_completion_word(hip):
         assert view[:3].tolist() == [a[0].item(), a[1].item(), 7.0]
     with pytest.raises(hip.HipKernelError):
         hip.pack_f32([a, b], out, signal=(seq, 2))     # the word would overlap packed values
+
+
+# -- data movement / bookkeeping kernels (csrc/kernels/misc_ops.hip) ------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.uint8])
+@pytest.mark.parametrize("rows,cols,off", [(37, 129, 3), (64, 256, 0), (1, 5, 1), (500, 1000, 500)])
+def test_copy_2d_between_strided_views(hip, dtype, rows, cols, off):
+    src_big = (torch.arange((rows + 2) * (cols + off + 7), device="cuda") % 251).to(dtype) \
+        .view(rows + 2, cols + off + 7)
+    dst_big = torch.full((rows + 4, cols + 9), 99, dtype=dtype, device="cuda")
+    src = src_big[1:1 + rows, off:off + cols]
+    dst = dst_big[2:2 + rows, 4:4 + cols]
+    hip.copy_2d(src, dst)
+    assert torch.equal(dst, src)
+    mask = torch.ones_like(dst_big, dtype=torch.bool)
+    mask[2:2 + rows, 4:4 + cols] = False
+    assert bool((dst_big[mask] == 99).all())
+
+
+def test_assign_add_sign_and_broadcasts(hip):
+    g = torch.Generator().manual_seed(5)
+    var = torch.randn(33, 17, generator=g).cuda()
+    ref = var.clone()
+    delta = torch.randn(33, 17, generator=g).cuda()
+    hip.assign_add(var, delta)
+    hip.assign_add(var, torch.tensor(2.5, device="cuda"), -1.0)
+    assert torch.equal(var, ref + delta - 2.5)
+    x = torch.tensor([-2.0, -0.0, 0.0, 3.0, float("nan")], device="cuda")
+    s = hip.sign(x).cpu()
+    assert s[:4].tolist() == [-1.0, -0.0, 0.0, 1.0] and torch.isnan(s[4])
+    gvec = torch.randn(7, generator=g).cuda()
+    assert torch.equal(hip.broadcast_mid(gvec, 1, 5, 7, 1.0, (5, 7)), gvec.expand(5, 7))
+    gcol = torch.randn(5, generator=g).cuda()
+    assert torch.equal(hip.broadcast_mid(gcol, 5, 7, 1, 0.5, (5, 7)),
+                       (gcol * 0.5).unsqueeze(1).expand(5, 7))
+    y = torch.log_softmax(torch.randn(40, 10, generator=g), dim=-1).cuda()
+    dy = torch.randn(40, 10, generator=g).cuda()
+    ref_dx = dy - torch.exp(y) * dy.sum(dim=-1, keepdim=True)
+    assert (hip.log_softmax_grad(y, dy) - ref_dx).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("src,dst", [(torch.int64, torch.float32), (torch.float32, torch.int32),
+                                     (torch.bool, torch.int64), (torch.float64, torch.bfloat16),
+                                     (torch.float32, torch.float8_e4m3fn),
+                                     (torch.float8_e4m3fn, torch.float32),
+                                     (torch.int32, torch.bool)])
+def test_cast_generic(hip, src, dst):
+    base = torch.tensor([-3.7, -1.0, 0.0, 0.4, 1.0, 2.5, 100.0, 7.0])
+    x = base.to(src).cuda() if src != torch.float8_e4m3fn else base.to(src).cuda()
+    out = hip.cast(x, dst)
+    assert out.dtype == dst
+    ref = x.cpu().to(torch.float64 if src != torch.float8_e4m3fn else torch.float32)
+    ref = (x.cpu().float() if src == torch.float8_e4m3fn else x.cpu()).to(dst)
+    assert torch.equal(out.cpu().float(), ref.float())
+
+
+def test_absmax_and_device_scale_quantisation(hip):
+    g = torch.Generator().manual_seed(9)
+    for dtype in (torch.float32, torch.bfloat16):
+        x = (torch.randn(1000, 333, generator=g) * 3).to(dtype).cuda()
+        stats = hip.absmax_scale(x).cpu()
+        amax = x.float().abs().max().item()
+        assert stats[0].item() == amax
+        assert abs(stats[1].item() - 448.0 / amax) < 1e-6 * 448.0 / amax
+        q, st = hip.quantize_fp8_device(x)
+        q_host, inv = hip.quantize_fp8(x)
+        assert torch.equal(q.view(torch.uint8), q_host.view(torch.uint8))
+        assert abs(st[2].item() - inv) < 1e-6 * inv
+    z = hip.absmax_scale(torch.zeros(10, device="cuda")).cpu()
+    assert z.tolist() == [0.0, 1.0, 1.0]
+
+
+def test_truncated_normal_matches_host_stream(hip):
+    from distributed_tensorflow_amd.ops import philox
+    import math
+    n = 100003
+    out = hip.truncated_normal((n,), 7, 11, 0.5, 2.0, "cuda").cpu().double()
+    u = torch.from_numpy(philox.uniform(n, 7, 11).copy()).double()
+    lo = 0.5 * (1.0 + math.erf(-2.0 / math.sqrt(2.0)))
+    z = math.sqrt(2.0) * torch.erfinv(2.0 * (lo + u * (1.0 - 2.0 * lo)) - 1.0)
+    ref = 0.5 + 2.0 * z
+    assert (out - ref).abs().max().item() < 2e-4
+    assert out.min().item() >= 0.5 - 4.0 - 1e-5 and out.max().item() <= 0.5 + 4.0 + 1e-5
+
+
+@pytest.mark.parametrize("normal", [True, False])
+def test_philox_window_is_a_slice_of_the_whole_stream(hip, normal):
+    """The block a rank generates for a sharded variable equals that block of the tensor a single
+    rank generates (``RandomStandardNormal`` / ``RandomUniform`` kernels)."""
+    rows, cols = 96, 200
+    whole = hip.philox_normal((rows, cols), 1, 3, 0.25, 1.5, torch.float32, "cuda") if normal \
+        else hip.philox_uniform((rows, cols), 1, 3, -1.0, 2.0, torch.float32, "cuda")
+    a, b = (0.25, 1.5) if normal else (-1.0, 3.0)
+    for r0, c0, nr, nc in ((24, 0, 24, cols), (0, 50, rows, 50), (48, 100, 48, 100)):
+        win = hip.philox_window(nr, nc, 1, 3, r0, c0, cols, torch.float32, "cuda", normal, a, b)
+        assert torch.equal(win, whole[r0:r0 + nr, c0:c0 + nc])
+
+
+def test_gemm_f32_accepts_row_strided_blocks(hip):
+    """Column blocks of a larger matrix (K-sharded operands multiplied as views of replicas)
+    and a strided output block go to the kernel with their pitch, without a copy."""
+    g = torch.Generator().manual_seed(2)
+    a = torch.randint(-3, 4, (300, 512), generator=g).float().cuda()
+    b = torch.randint(-3, 4, (512, 260), generator=g).float().cuda()
+    c_big = torch.full((300, 400), 7.0, device="cuda")
+    out = c_big[:, 64:64 + 130]
+    hip.gemm_f32(a[:, 128:384], b[128:384, 130:260], out=out)
+    assert torch.equal(out, a[:, 128:384] @ b[128:384, 130:260])
+    assert bool((c_big[:, :64] == 7.0).all()) and bool((c_big[:, 194:] == 7.0).all())

@@ -63,8 +63,10 @@ class ConfigProto:
     ``strategy`` / ``grad_aggregation`` -- collective runtime options (see ``parallel.runtime``).
     ``capture_collectives`` -- under a collective runtime, capture the step INCLUDING its RCCL
                           calls into the HIP graph (RCCL collectives enqueued during stream
-                          capture become graph nodes). Off by default: a step is then eager
-                          kernel launches around eager collectives.
+                          capture become graph nodes), so a multi-rank step is one graph launch
+                          like a single-GPU one. Default (``None``): on when the communicator's
+                          backend is RCCL (``nccl``), off otherwise (gloo and the loopback world
+                          move data on the host); ``DTF_CAPTURE_COLLECTIVES=0/1`` overrides.
     ``grad_bucket_bytes`` -- under ``allreduce_sync``: gradients are all-reduced in buckets of
                           about this many bytes, each issued as soon as the backward pass has
                           produced its members, so the collectives overlap the rest of the
@@ -90,7 +92,8 @@ class ConfigProto:
     def __init__(self, graph_fusion: bool = True, hip_graphs: bool = True,
                  device: Optional[str] = None, allow_soft_placement: bool = True,
                  log_device_placement: bool = False, strategy: Optional[str] = None,
-                 grad_aggregation: Optional[str] = None, capture_collectives: bool = False,
+                 grad_aggregation: Optional[str] = None,
+                 capture_collectives: Optional[bool] = None,
                  grad_bucket_bytes: Optional[int] = None, matmul_sharding: Optional[str] = None,
                  shard_variables: bool = True, allow_torch_fallback: Optional[bool] = None):
         self.allow_torch_fallback = bool(os.environ.get("DTF_ALLOW_TORCH_FALLBACK")) \
@@ -142,6 +145,7 @@ class ExecContext:
         self.device = session.device
         self.const_cache: Dict[Any, torch.Tensor] = {}
         self.buffers: Dict[Any, torch.Tensor] = {}     # per-node scratch with stable addresses
+        self.out_hint: Optional[Dict[int, torch.Tensor]] = None   # placed outputs of this step
         self._nd_seed = int.from_bytes(os.urandom(4), "little")
 
     def note_fallback(self, op, why: str = "") -> None:
@@ -192,9 +196,13 @@ class ExecContext:
         return sorted(missing, key=lambda n: order.get(n, 0))
 
     # -- gradient synchronisation hooks (synchronous strategies) --------------------------
-    def reduce_gradients(self, grads):
+    def reduce_gradients(self, grads, var_ops=None):
         rt = self.session._runtime
-        return list(grads) if rt is None else rt.reduce_gradients(grads)
+        if rt is None:
+            return list(grads)
+        if var_ops is not None and hasattr(rt, "grad_view"):
+            return rt.reduce_gradients(grads, [v.name for v in var_ops])
+        return rt.reduce_gradients(grads)
 
     def sharded_sgd(self, var_ops, grads, lrs) -> bool:
         rt = self.session._runtime
@@ -206,10 +214,11 @@ class ExecContext:
 # plans
 # ---------------------------------------------------------------------------------------
 class _Step:
-    __slots__ = ("node", "kernel", "in_slots", "out_slots", "host", "buckets")
+    __slots__ = ("node", "kernel", "in_slots", "out_slots", "host", "buckets", "grad_views")
 
     def __init__(self, node, kernel, in_slots, out_slots, host):
         self.buckets = None       # [(bucket id, gradient slots)] complete once this step ran
+        self.grad_views = None    # {output index: variable name}: outputs that ARE gradients
         self.node = node
         self.kernel = kernel
         self.in_slots = in_slots
@@ -496,12 +505,59 @@ class Session:
                                "ShardedVariableInit", "GatherShardedVariable"):
                 plan.capturable = False
         if self._runtime is not None and not self._runtime.capturable and not (
-                self.config.capture_collectives and
+                self._capture_collectives() and
                 getattr(self._runtime, "capturable_with_collectives", False)):
             plan.capturable = False
         if not plan.capturable:
             self._plan_gradient_buckets(plan, {sl: t for t, sl in slot_of.items()})
+        self._plan_gradient_views(plan)
         return plan
+
+    def _plan_gradient_views(self, plan: ExecutionPlan) -> None:
+        """Under a multi-rank collective runtime the gradients the optimizer step consumes are
+        PRODUCED in their slots of the runtime's flat gradient arena (the buffer the collectives
+        run on): the producing step is told which of its outputs go where, kernels with a
+        placeable output write there directly, and the bucketing copy per gradient disappears.
+        Only gradients nobody else reads or fetches are placed (the collective reduces the arena
+        in place)."""
+        rt = self._runtime
+        if rt is None or not hasattr(rt, "grad_view") or rt.comm.world_size < 2 \
+                or plan.grad_buckets:
+            return
+        producer = {sl: (st, idx) for st in plan.steps for idx, sl in enumerate(st.out_slots)}
+        readers: Dict[int, int] = {}
+        for st in plan.steps + plan.host_steps:
+            for sl in st.in_slots:
+                if sl >= 0:
+                    readers[sl] = readers.get(sl, 0) + 1
+        fetched = {sl for sl in plan.fetch_slots if sl is not None} | set(plan.host_input_slots)
+        for st in plan.steps:
+            if st.node.type == "MultiApplySGD":
+                pairs = [(v.name, sl) for v, sl in zip(st.node.attrs["var_ops"], st.in_slots)]
+            elif st.node.type == "ApplyGradientDescent":
+                pairs = [(st.node.inputs[0].op.name, st.in_slots[1])]
+            else:
+                continue
+            for name, sl in pairs:
+                hit = producer.get(sl)
+                if hit is None or sl < 0 or readers.get(sl, 0) != 1 or sl in fetched:
+                    continue
+                src, idx = hit
+                if src.node.type in _VAR_TYPES or src.node.type == "Placeholder":
+                    continue
+                if src.grad_views is None:
+                    src.grad_views = {}
+                src.grad_views[idx] = name
+
+    def _capture_collectives(self) -> bool:
+        want = self.config.capture_collectives
+        env = os.environ.get("DTF_CAPTURE_COLLECTIVES")
+        if want is None and env is not None:
+            want = env not in ("0", "", "false", "False")
+        if want is None:
+            comm = getattr(self._runtime, "comm", None)
+            want = getattr(comm, "backend", "") == "nccl" and self.device.type == "cuda"
+        return bool(want)
 
     def _shard_plan(self):
         """The graph-wide sharding plan of variable x variable products (``parallel/planner``),
@@ -628,7 +684,10 @@ class Session:
                 if self.device.type == "cuda":
                     torch.cuda.synchronize(self.device)
                     t0 = time.perf_counter()
-            outs = s.kernel(s.node, ins, ctx)
+            if s.grad_views is None:
+                outs = s.kernel(s.node, ins, ctx)
+            else:
+                outs = self._run_placed(s, ins, ctx)
             if trace is not None:
                 if self.device.type == "cuda":
                     torch.cuda.synchronize(self.device)
@@ -639,6 +698,37 @@ class Session:
             if s.buckets is not None:
                 for bid, slots in s.buckets:
                     self._runtime.begin_gradient_bucket(bid, [vals[sl] for sl in slots])
+
+    def _run_placed(self, s: _Step, ins: List[Any], ctx: ExecContext) -> List[Any]:
+        """Run a step some of whose outputs are gradients with a slot in the runtime's flat
+        arena: the kernel sees the slots as placement hints; an output that did not land there
+        (a kernel without a placeable output) is moved by one block copy."""
+        views = {}
+        for idx, name in s.grad_views.items():
+            v = self._runtime.grad_view(name)
+            if v is not None:
+                views[idx] = v
+        ctx.out_hint = views or None
+        try:
+            outs = list(s.kernel(s.node, ins, ctx))
+        finally:
+            ctx.out_hint = None
+        for idx, view in views.items():
+            o = outs[idx]
+            if not isinstance(o, torch.Tensor) or o.dtype != view.dtype \
+                    or o.numel() != view.numel():
+                continue
+            if o.data_ptr() != view.data_ptr():
+                dst = view.view(o.shape)
+                if o.is_cuda and o.is_contiguous() and o.numel():
+                    from ..ops import hip
+                    hip.copy_2d(o.reshape(1, -1), dst.view(1, -1))
+                else:
+                    dst.copy_(o)
+                outs[idx] = dst
+            elif o.shape != view.shape:
+                outs[idx] = o
+        return outs
 
     @staticmethod
     def _to_host(value: Any) -> Any:

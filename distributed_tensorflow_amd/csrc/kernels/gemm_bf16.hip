@@ -47,6 +47,9 @@
 #include <cstdlib>
 #include "common.h"
 
+#include <atomic>
+#include <mutex>
+
 namespace {
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -1058,15 +1061,24 @@ __global__ __launch_bounds__(T128_THREADS) void gemm_bf16_nt_t128_kernel(
 
 // workgroups of the persistent ping-pong kernel: one per CU (128 KiB of LDS each), fewer when
 // there are fewer tiles
+// (per device: a process may drive several GPUs, and both the CU count and a kernel's dynamic-LDS
+// opt-in belong to the device that is current at the launch)
+static int dtf_current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  return dev;
+}
+
 static int dtf_pp_grid(int ntiles) {
-  static int cus = 0;
+  static std::atomic<int> cus_of[64];
+  const int dev = dtf_current_device();
+  int cus = cus_of[dev].load(std::memory_order_relaxed);
   if (cus == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
         n <= 0)
       n = 256;
-    cus = n;
+    cus_of[dev].store(cus = n, std::memory_order_relaxed);
   }
   return ntiles < cus ? ntiles : cus;
 }
@@ -1074,6 +1086,22 @@ static int dtf_pp_grid(int ntiles) {
 template <typename KernelT>
 static void dtf_allow_lds(KernelT kernel, size_t lds) {
   hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
+// Runs BODY once per device (the first launcher call made while that device is current); other
+// threads arriving meanwhile wait until the attributes are in place.
+struct DtfPerDeviceOnce {
+  std::mutex mu;
+  unsigned long long done = 0;
+};
+template <typename F>
+static void dtf_once_per_device(DtfPerDeviceOnce& once, F&& body) {
+  const unsigned long long bit = 1ull << dtf_current_device();
+  std::lock_guard<std::mutex> lk(once.mu);
+  if (!(once.done & bit)) {
+    body();
+    once.done |= bit;
+  }
 }
 
 DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int N, int K, long lda,
@@ -1087,8 +1115,7 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
   if (lda * 2 * BM >= (1L << 32) || ldb * 2 * BN >= (1L << 32)) return DTF_ERR_UNSUPPORTED;
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const size_t lds = 2 * BUF_BYTES;   // 128 KiB
-  static bool attr_set = false;
-  if (!attr_set) {
+    { static DtfPerDeviceOnce once__; dtf_once_per_device(once__, [&] {
     dtf_allow_lds(gemm_bf16_nt_kernel<true>, lds);
     dtf_allow_lds(gemm_bf16_nt_kernel<false>, lds);
     dtf_allow_lds(gemm_nt_pp_kernel<true, 0, false>, lds);
@@ -1098,22 +1125,19 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
     dtf_allow_lds(gemm_nt_pp_kernel<false, 2, false>, lds);
     dtf_allow_lds(gemm_nt_pp_kernel<false, 4, false>, lds);
 #endif
-    attr_set = true;
-  }
+  }); }
   dim3 grid(tiles_m * tiles_n), block(NTHREADS);
   const dim3 pp_grid(dtf_pp_grid(tiles_m * tiles_n));
   if ((variant & 15) == 3) {       // four-wave kernel
-    static bool w4_attr = false;
-    const size_t w4_lds = 2 * BUF_BYTES;
-    if (!w4_attr) {
+        const size_t w4_lds = 2 * BUF_BYTES;
+    { static DtfPerDeviceOnce once__; dtf_once_per_device(once__, [&] {
       dtf_allow_lds(gemm_bf16_nt_w4_kernel<true>, w4_lds);
       dtf_allow_lds(gemm_bf16_nt_w4_kernel<false>, w4_lds);
 #ifdef DTF_GEMM_EXPERIMENTS
       dtf_allow_lds(gemm_bf16_nt_w4_kernel<false, 1>, w4_lds);
       dtf_allow_lds(gemm_bf16_nt_w4_kernel<false, 2>, w4_lds);
 #endif
-      w4_attr = true;
-    }
+    }); }
 #ifdef DTF_GEMM_EXPERIMENTS
     if ((variant >> 4) == 1 || (variant >> 4) == 2) {
       if ((variant >> 4) == 1)
@@ -1141,15 +1165,13 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
   }
 #ifdef DTF_GEMM_EXPERIMENTS
   if ((variant & 15) == 4 && (variant >> 4) != 0) {   // timing experiments on the default schedule
-    static bool e_attr = false;
-    if (!e_attr) {
+        { static DtfPerDeviceOnce once__; dtf_once_per_device(once__, [&] {
       dtf_allow_lds(gemm_nt_pp_kernel<false, 8, false, true>, lds + 1024);
       dtf_allow_lds(gemm_nt_pp_kernel<false, 10, false, true>, lds + 1024);
       dtf_allow_lds(gemm_nt_pp_kernel<false, 9, false, true>, lds + 1024);
       dtf_allow_lds(gemm_nt_pp_kernel<false, 16, false, true>, lds);
       dtf_allow_lds(gemm_nt_pp_kernel<false, 32, false, true>, lds);
-      e_attr = true;
-    }
+    }); }
     const int dbg = variant >> 4;
     if (dbg == 8)
       hipLaunchKernelGGL((gemm_nt_pp_kernel<false, 8, false, true>), pp_grid, block, lds + 1024,
@@ -1179,13 +1201,11 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
   // 128x128 tiles (variant 5, or by default when 256x256 tiles would leave CUs idle)
   if ((variant & 15) == 5 ||
       (variant == 0 && tiles_m * tiles_n > 32 && tiles_m * tiles_n < DTF_T128_BELOW_TILES)) {
-    static bool t_attr = false;
-    const size_t t_lds = 2 * T128_BUF_BYTES;
-    if (!t_attr) {
+        const size_t t_lds = 2 * T128_BUF_BYTES;
+    { static DtfPerDeviceOnce once__; dtf_once_per_device(once__, [&] {
       dtf_allow_lds(gemm_bf16_nt_t128_kernel<true>, t_lds);
       dtf_allow_lds(gemm_bf16_nt_t128_kernel<false>, t_lds);
-      t_attr = true;
-    }
+    }); }
     const int tm128 = (M + T128 - 1) / T128, tn128 = (N + T128 - 1) / T128;
     const dim3 t_grid(tm128 * tn128), t_block(T128_THREADS);
     if (out_f32)
@@ -1200,12 +1220,10 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
     return DTF_OK;
   }
   if ((variant & 15) == 4 || variant == 0) {       // ping-pong with two-quadrant phases
-    static bool m_attr = false;
-    if (!m_attr) {
+        { static DtfPerDeviceOnce once__; dtf_once_per_device(once__, [&] {
       dtf_allow_lds(gemm_nt_pp_kernel<true, 0, false, true>, lds);
       dtf_allow_lds(gemm_nt_pp_kernel<false, 0, false, true>, lds);
-      m_attr = true;
-    }
+    }); }
     if (out_f32)
       hipLaunchKernelGGL((gemm_nt_pp_kernel<true, 0, false, true>), pp_grid, block, lds, stream,
                          (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tiles_m,
@@ -1326,11 +1344,9 @@ DTF_API int dtf_gemm_bf16_nt_splitk(const void* A, const void* Bt, void* C, floa
   if (lda * 2 * BM >= (1L << 32) || ldb * 2 * BN >= (1L << 32)) return DTF_ERR_UNSUPPORTED;
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const size_t lds = 2 * BUF_BYTES;
-  static bool attr_set = false;
-  if (!attr_set) {
+    { static DtfPerDeviceOnce once__; dtf_once_per_device(once__, [&] {
     dtf_allow_lds(gemm_nt_pp_kernel<true, 0, false, true>, lds);
-    attr_set = true;
-  }
+  }); }
   const long plane = (long)M * N;
   const dim3 grid(dtf_pp_grid(tiles_m * tiles_n * ksplits)), block(NTHREADS);
   hipLaunchKernelGGL((gemm_nt_pp_kernel<true, 0, false, true>), grid, block, lds, stream,
@@ -1362,17 +1378,14 @@ DTF_API int dtf_gemm_fp8_nt(const void* A, const void* Bt, void* C, int M, int N
   if (lda * BM >= (1L << 32) || ldb * BN >= (1L << 32)) return DTF_ERR_UNSUPPORTED;
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const size_t lds = 2 * BUF_BYTES;
-  static bool attr_set = false;
-  if (!attr_set) {
+    { static DtfPerDeviceOnce once__; dtf_once_per_device(once__, [&] {
     dtf_allow_lds(gemm_nt_pp_kernel<true, 0, true, true>, lds);
     dtf_allow_lds(gemm_nt_pp_kernel<false, 0, true, true>, lds);
-    attr_set = true;
-  }
+  }); }
   const dim3 grid(tiles_m * tiles_n), block(NTHREADS);     // one tile per workgroup (no tile loop)
 #ifdef DTF_GEMM_EXPERIMENTS
   if (getenv("DTF_PP_CHUNK_WALK") && !out_f32) {
-    static bool e_attr = false;
-    if (!e_attr) { dtf_allow_lds(gemm_nt_pp_kernel<false, 16, true, true>, lds); e_attr = true; }
+    { static DtfPerDeviceOnce once__; dtf_once_per_device(once__, [&] { dtf_allow_lds(gemm_nt_pp_kernel<false, 16, true, true>, lds); }); }
     hipLaunchKernelGGL((gemm_nt_pp_kernel<false, 16, true, true>), grid, block, lds, stream,
                        (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tiles_m,
                        tiles_n, alpha, beta, 1, 0L);

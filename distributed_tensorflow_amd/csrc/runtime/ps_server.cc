@@ -19,6 +19,8 @@
 // Updates from different connections interleave freely on the variable bytes (asynchronous,
 // lock-free SGD as in the reference); only the variable TABLE is guarded, by a shared mutex.
 #include <arpa/inet.h>
+#include <math.h>
+#include <netdb.h>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
 #include <poll.h>
@@ -62,11 +64,20 @@ struct Json {
 
 struct JsonParser {
   const char* p;
-  const char* end;
+  const char* end;          // the buffer is NUL-terminated AT `end` (strtod stops there)
   bool ok = true;
+  int depth = 0;            // nesting is capped: a header of '[' * 2^26 must not recurse 2^26 deep
+  static constexpr int kMaxDepth = 32;
   void ws() { while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) ++p; }
   bool eat(char c) { ws(); if (p < end && *p == c) { ++p; return true; } return false; }
   Json parse() {
+    Json j;
+    if (++depth > kMaxDepth) { ok = false; return j; }
+    j = parse_value();
+    --depth;
+    return j;
+  }
+  Json parse_value() {
     Json j;
     ws();
     if (p >= end) { ok = false; return j; }
@@ -105,14 +116,14 @@ struct JsonParser {
         }
       }
       if (p >= end) ok = false; else ++p;
-    } else if (!strncmp(p, "true", 4) && end - p >= 4) { j.kind = Json::BOOL; j.b = true; p += 4; }
-    else if (!strncmp(p, "false", 5) && end - p >= 5) { j.kind = Json::BOOL; p += 5; }
-    else if (!strncmp(p, "null", 4) && end - p >= 4) { p += 4; }
+    } else if (end - p >= 4 && !memcmp(p, "true", 4)) { j.kind = Json::BOOL; j.b = true; p += 4; }
+    else if (end - p >= 5 && !memcmp(p, "false", 5)) { j.kind = Json::BOOL; p += 5; }
+    else if (end - p >= 4 && !memcmp(p, "null", 4)) { p += 4; }
     else {
       char* e = nullptr;
       j.kind = Json::NUM;
-      j.num = strtod(p, &e);
-      if (e == p) ok = false;
+      j.num = strtod(p, &e);            // safe: *end == '\0'
+      if (e == p || e > end) ok = false;
       p = e;
     }
     return j;
@@ -154,13 +165,28 @@ bool parse_specs(const Json* j, std::vector<Spec>& out) {
     if (!d || !sh || d->kind != Json::STR || sh->kind != Json::ARR) return false;
     Spec sp;
     sp.dtype = d->str;
-    size_t count = 1;
-    for (auto& dim : sh->arr) { sp.shape.push_back((int64_t)dim.num); count *= (size_t)dim.num; }
     const size_t es = dtype_size(sp.dtype);
-    if (!es) return false;
-    sp.nbytes = count * es;
+    if (!es || sh->arr.size() > 32) return false;
+    size_t count = 1;
+    for (auto& dim : sh->arr) {
+      // dimensions come off the network: whole numbers in [0, 2^40], products checked
+      if (dim.kind != Json::NUM || !(dim.num >= 0.0) || dim.num > 1099511627776.0 ||
+          dim.num != floor(dim.num))
+        return false;
+      sp.shape.push_back((int64_t)dim.num);
+      if (__builtin_mul_overflow(count, (size_t)dim.num, &count)) return false;
+    }
+    if (__builtin_mul_overflow(count, es, &sp.nbytes)) return false;
     out.push_back(std::move(sp));
   }
+  return true;
+}
+
+// total payload bytes of `specs`, false on overflow
+bool specs_total(const std::vector<Spec>& specs, size_t& total) {
+  total = 0;
+  for (auto& sp : specs)
+    if (__builtin_add_overflow(total, sp.nbytes, &total)) return false;
   return true;
 }
 
@@ -185,7 +211,7 @@ struct Server {
   std::atomic<bool> stop{false};
   std::atomic<long> requests{0}, updates{0}, bytes_in{0}, bytes_out{0};
   std::shared_mutex table_mu;
-  std::map<std::string, std::unique_ptr<Var>> vars;
+  std::map<std::string, std::shared_ptr<Var>> vars;
   std::mutex misc_mu;
   std::condition_variable stop_cv;
   std::set<long> done_workers;
@@ -194,10 +220,12 @@ struct Server {
   std::thread accept_thread;
   std::string last_error;
 
-  Var* find(const std::string& name) {
+  // A reference taken under the table lock: a variable replaced by ASSIGN (new dtype or size)
+  // stays alive until the last connection thread still reading or updating it lets go.
+  std::shared_ptr<Var> find(const std::string& name) {
     std::shared_lock<std::shared_mutex> lk(table_mu);
     auto it = vars.find(name);
-    return it == vars.end() ? nullptr : it->second.get();
+    return it == vars.end() ? nullptr : it->second;
   }
   void request_stop() {
     stop.store(true);
@@ -268,7 +296,7 @@ void axpy(T* w, const T* g, size_t n, double alpha) {
 }
 
 // apply `var += alpha * delta` for the numeric dtypes
-bool add_scaled(Var* v, const char* delta, const Spec& sp, double alpha) {
+bool add_scaled(const std::shared_ptr<Var>& v, const char* delta, const Spec& sp, double alpha) {
   if (sp.nbytes != v->data.size()) return false;
   if (v->dtype == "float32" && sp.dtype == "float32")
     axpy((float*)v->data.data(), (const float*)delta, sp.nbytes / 4, alpha);
@@ -299,14 +327,16 @@ bool handle(Server* s, int fd, uint8_t op, const Json& hdr, const std::vector<ch
     case PULL: {
       std::vector<std::string> names;
       if (!names_of("names", names)) return send_error(fd, "ValueError", "bad PULL header");
+      std::vector<std::shared_ptr<Var>> held;
       std::vector<const Var*> vs;
       std::vector<std::pair<const char*, size_t>> parts;
       for (auto& n : names) {
-        Var* v = s->find(n);
+        auto v = s->find(n);
         if (!v) return send_error(fd, "FailedPreconditionError",
                                   "Attempting to use uninitialized value " + n);
-        vs.push_back(v);
+        vs.push_back(v.get());
         parts.emplace_back(v->data.data(), v->data.size());
+        held.push_back(std::move(v));
       }
       std::string h;
       specs_json(h, vs);
@@ -320,16 +350,16 @@ bool handle(Server* s, int fd, uint8_t op, const Json& hdr, const std::vector<ch
           names.size() != specs.size())
         return send_error(fd, "ValueError", "bad ASSIGN header");
       size_t off = 0;
-      for (auto& sp : specs) off += sp.nbytes;
-      if (off != payload.size()) return send_error(fd, "ValueError", "ASSIGN payload size");
+      if (!specs_total(specs, off) || off != payload.size())
+        return send_error(fd, "ValueError", "ASSIGN payload size");
       off = 0;
       for (size_t i = 0; i < names.size(); ++i) {
-        Var* v = s->find(names[i]);
-        if (v && v->dtype == specs[i].dtype && v->data.size() == specs[i].nbytes) {
+        auto v = s->find(names[i]);
+        if (v && v->dtype == specs[i].dtype && v->data.size() == specs[i].nbytes &&
+            v->shape == specs[i].shape) {
           memcpy(v->data.data(), payload.data() + off, specs[i].nbytes);   // keep the storage
-          v->shape = specs[i].shape;
         } else {
-          auto nv = std::make_unique<Var>();
+          auto nv = std::make_shared<Var>();
           nv->dtype = specs[i].dtype;
           nv->shape = specs[i].shape;
           nv->data.assign(payload.data() + off, payload.data() + off + specs[i].nbytes);
@@ -345,14 +375,16 @@ bool handle(Server* s, int fd, uint8_t op, const Json& hdr, const std::vector<ch
       if (!parse_specs(hdr.get("specs"), specs))
         return send_error(fd, "ValueError", "bad APPLY header");
       size_t total = 0;
-      for (auto& sp : specs) total += sp.nbytes;
-      if (total != payload.size()) return send_error(fd, "ValueError", "APPLY payload size");
+      if (!specs_total(specs, total) || total != payload.size())
+        return send_error(fd, "ValueError", "APPLY payload size");
       size_t k = 0, off = 0;
       if (const Json* sgd = hdr.get("sgd")) {
+        if (sgd->kind != Json::ARR) return send_error(fd, "ValueError", "bad sgd list");
         for (auto& item : sgd->arr) {
-          if (item.kind != Json::ARR || item.arr.size() != 2 || k >= specs.size())
+          if (item.kind != Json::ARR || item.arr.size() != 2 || k >= specs.size() ||
+              item.arr[0].kind != Json::STR || item.arr[1].kind != Json::NUM)
             return send_error(fd, "ValueError", "bad sgd entry");
-          Var* v = s->find(item.arr[0].str);
+          auto v = s->find(item.arr[0].str);
           if (!v) return send_error(fd, "FailedPreconditionError",
                                     "Attempting to use uninitialized value " + item.arr[0].str);
           if (!add_scaled(v, payload.data() + off, specs[k], -item.arr[1].num))
@@ -362,10 +394,11 @@ bool handle(Server* s, int fd, uint8_t op, const Json& hdr, const std::vector<ch
         }
       }
       if (const Json* add = hdr.get("add")) {
+        if (add->kind != Json::ARR) return send_error(fd, "ValueError", "bad add list");
         for (auto& item : add->arr) {
           if (item.kind != Json::STR || k >= specs.size())
             return send_error(fd, "ValueError", "bad add entry");
-          Var* v = s->find(item.str);
+          auto v = s->find(item.str);
           if (!v) return send_error(fd, "FailedPreconditionError",
                                     "Attempting to use uninitialized value " + item.str);
           if (!add_scaled(v, payload.data() + off, specs[k], 1.0))
@@ -375,14 +408,16 @@ bool handle(Server* s, int fd, uint8_t op, const Json& hdr, const std::vector<ch
       }
       std::vector<std::string> want;
       if (!names_of("return", want)) return send_error(fd, "ValueError", "bad return list");
+      std::vector<std::shared_ptr<Var>> held;
       std::vector<const Var*> vs;
       std::vector<std::pair<const char*, size_t>> parts;
       for (auto& n : want) {
-        Var* v = s->find(n);
+        auto v = s->find(n);
         if (!v) return send_error(fd, "FailedPreconditionError",
                                   "Attempting to use uninitialized value " + n);
-        vs.push_back(v);
+        vs.push_back(v.get());
         parts.emplace_back(v->data.data(), v->data.size());
+        held.push_back(std::move(v));
       }
       std::string h;
       specs_json(h, vs);
@@ -448,7 +483,8 @@ void serve(Server* s, int fd) {
     FrameHeader fh;
     if (!recv_exact(fd, &fh, sizeof fh) || memcmp(fh.magic, "DTF1", 4) != 0) break;
     if (fh.hlen > (64u << 20) || fh.plen > (64ull << 30)) break;      // nonsense sizes
-    hbuf.resize(fh.hlen);
+    hbuf.resize((size_t)fh.hlen + 1);
+    hbuf[fh.hlen] = '\0';               // the number parser (strtod) needs a terminator
     payload.resize(fh.plen);
     if (fh.hlen && !recv_exact(fd, hbuf.data(), fh.hlen)) break;
     if (fh.plen && !recv_exact(fd, payload.data(), fh.plen)) break;
@@ -457,7 +493,7 @@ void serve(Server* s, int fd) {
     Json hdr;
     hdr.kind = Json::OBJ;
     if (fh.hlen) {
-      JsonParser jp{hbuf.data(), hbuf.data() + hbuf.size()};
+      JsonParser jp{hbuf.data(), hbuf.data() + fh.hlen};
       hdr = jp.parse();
       if (!jp.ok || hdr.kind != Json::OBJ) {
         if (!send_error(fd, "ValueError", "malformed header")) break;
@@ -502,8 +538,21 @@ DTF_API void* dtf_ps_start(const char* host, int port, int expected_workers) {
   sockaddr_in addr{};
   addr.sin_family = AF_INET;
   addr.sin_port = htons((uint16_t)port);
+  // bind the configured interface only: a name is resolved, never widened to every interface
+  // ("0.0.0.0" has to be asked for explicitly)
   if (!host || !*host || !strcmp(host, "localhost")) host = "127.0.0.1";
-  if (inet_pton(AF_INET, host, &addr.sin_addr) != 1) addr.sin_addr.s_addr = htonl(INADDR_ANY);
+  if (inet_pton(AF_INET, host, &addr.sin_addr) != 1) {
+    addrinfo hints{}, *res = nullptr;
+    hints.ai_family = AF_INET;
+    hints.ai_socktype = SOCK_STREAM;
+    if (getaddrinfo(host, nullptr, &hints, &res) != 0 || !res) {
+      g_error = std::string("cannot resolve host ") + host;
+      close(s->listen_fd);
+      return nullptr;
+    }
+    addr.sin_addr = ((sockaddr_in*)res->ai_addr)->sin_addr;
+    freeaddrinfo(res);
+  }
   if (bind(s->listen_fd, (sockaddr*)&addr, sizeof addr) != 0 || listen(s->listen_fd, 64) != 0) {
     g_error = std::string("cannot bind/listen on ") + host + ":" + std::to_string(port) + ": " +
               strerror(errno);
@@ -561,7 +610,7 @@ DTF_API void dtf_ps_stop(void* h) {
 DTF_API long dtf_ps_read(void* h, const char* name, void* out, long cap, char* meta, long meta_cap) {
   auto* s = (Server*)h;
   if (!s) return -1;
-  Var* v = s->find(name);
+  auto v = s->find(name);
   if (!v) return -1;
   if (out && cap > 0) memcpy(out, v->data.data(), std::min((size_t)cap, v->data.size()));
   if (meta && meta_cap > 0) {

@@ -6,6 +6,14 @@
 // several workers are deliberately lock-free in the server -- the reference's asynchronous
 // update rule -- and are therefore not part of this test.) Values are small integers, so the
 // final state is exact.
+//
+// Two more phases run against the same server: (a) one client re-ASSIGNs a variable with
+// alternating shapes (each time the table entry is replaced by new storage) while other
+// clients PULL it and the hosting process reads it -- the readers must keep the storage they
+// found alive (a use-after-free otherwise, which both sanitizer builds report); (b) malformed
+// frames -- negative, fractional, NaN and overflowing dimensions, a header that is nothing but
+// opening brackets, an unterminated number at the end of the header, non-array "sgd" -- must
+// each come back as an error reply (or a closed connection), never a crash or an over-read.
 #include <arpa/inet.h>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
@@ -147,6 +155,80 @@ static void worker(int port, int id) {
   CHECK(c.call(DONE, "{\"worker\": " + std::to_string(id) + "}", nullptr, 0, &rh, &rp) == OK);
 }
 
+static void reshaper(int port, int rounds) {
+  Client c;
+  CHECK(c.connect_to(port));
+  std::string rh;
+  std::vector<char> rp;
+  std::vector<float> big(4096, 2.0f);
+  for (int i = 0; i < rounds; ++i) {
+    const int n = (i & 1) ? 4096 : 1024;
+    const std::string spec = (i % 3 == 0)
+        ? "{\"dtype\": \"float32\", \"shape\": [" + std::to_string(n) + "]}"
+        : "{\"dtype\": \"float32\", \"shape\": [" + std::to_string(n / 4) + ", 4]}";
+    CHECK(c.call(ASSIGN, "{\"names\": [\"shared\"], \"specs\": [" + spec + "]}", big.data(),
+                 (size_t)n * 4, &rh, &rp) == OK);
+  }
+}
+
+static void puller(int port, int rounds) {
+  Client c;
+  CHECK(c.connect_to(port));
+  std::string rh;
+  std::vector<char> rp;
+  for (int i = 0; i < rounds; ++i) {
+    const int op = c.call(PULL, "{\"names\": [\"shared\"]}", nullptr, 0, &rh, &rp);
+    CHECK(op == OK);
+    CHECK(rp.size() == 4096u * 4 || rp.size() == 1024u * 4);
+    if (!rp.empty()) {
+      float first;
+      memcpy(&first, rp.data(), 4);
+      CHECK(first == 2.0f);
+    }
+  }
+}
+
+static void malformed(int port) {
+  const char* bad_specs[] = {
+      "{\"dtype\": \"float32\", \"shape\": [-1]}",
+      "{\"dtype\": \"float32\", \"shape\": [2.5]}",
+      "{\"dtype\": \"float32\", \"shape\": [1e300]}",
+      "{\"dtype\": \"float32\", \"shape\": [4294967296, 4294967296]}",
+      "{\"dtype\": \"float32\", \"shape\": [4611686018427387904]}",
+      "{\"dtype\": \"float32\", \"shape\": [\"8\"]}",
+      "{\"dtype\": \"float128\", \"shape\": [8]}",
+  };
+  float payload[8] = {0};
+  for (const char* spec : bad_specs) {
+    Client c;
+    CHECK(c.connect_to(port));
+    std::string rh;
+    std::vector<char> rp;
+    const std::string h = std::string("{\"names\": [\"m\"], \"specs\": [") + spec + "]}";
+    CHECK(c.call(ASSIGN, h, payload, sizeof payload, &rh, &rp) == ERR);
+    CHECK(c.call(PING, "{}", nullptr, 0, &rh, &rp) == OK);       // the connection survives
+  }
+  {
+    Client c;                                  // 1 MiB of '[': bounded recursion, error reply
+    CHECK(c.connect_to(port));
+    std::string rh;
+    std::vector<char> rp;
+    CHECK(c.call(PING, std::string(1 << 20, '['), nullptr, 0, &rh, &rp) == ERR);
+    CHECK(c.call(PING, "{\"x\": 12345", nullptr, 0, &rh, &rp) == ERR);    // number at the very end
+    CHECK(c.call(PING, "{\"x\": tru", nullptr, 0, &rh, &rp) == ERR);
+    const std::string spec = "{\"dtype\": \"float32\", \"shape\": [8]}";
+    CHECK(c.call(ASSIGN, "{\"names\": [\"m\"], \"specs\": [" + spec + "]}", payload,
+                 sizeof payload, &rh, &rp) == OK);
+    CHECK(c.call(APPLY, "{\"specs\": [" + spec + "], \"sgd\": 7}", payload, sizeof payload, &rh,
+                 &rp) == ERR);
+    CHECK(c.call(APPLY, "{\"specs\": [" + spec + "], \"sgd\": [[7, \"m\"]]}", payload,
+                 sizeof payload, &rh, &rp) == ERR);
+    CHECK(c.call(APPLY, "{\"specs\": [" + spec + "], \"sgd\": [[\"m\", 0.5]]}", payload,
+                 sizeof payload - 4, &rh, &rp) == ERR);             // payload shorter than the spec
+    CHECK(c.call(PING, "{}", nullptr, 0, &rh, &rp) == OK);
+  }
+}
+
 int main() {
   const int workers = 6;
   void* h = dtf_ps_start("127.0.0.1", 0, workers);
@@ -156,6 +238,28 @@ int main() {
   }
   const int port = dtf_ps_port(h);
   CHECK(port > 0);
+  {
+    // phase (a): storage of "shared" is replaced 400 times under three readers
+    std::vector<float> first(1024, 2.0f);
+    Client c;
+    CHECK(c.connect_to(port));
+    std::string rh;
+    std::vector<char> rp;
+    CHECK(c.call(ASSIGN, "{\"names\": [\"shared\"], \"specs\": [{\"dtype\": \"float32\", "
+                         "\"shape\": [1024]}]}", first.data(), 1024 * 4, &rh, &rp) == OK);
+    std::vector<std::thread> rs;
+    rs.emplace_back(reshaper, port, 400);
+    for (int i = 0; i < 3; ++i) rs.emplace_back(puller, port, 300);
+    for (int i = 0; i < 200; ++i) {
+      float out[4096];
+      char meta[64];
+      const long n = dtf_ps_read(h, "shared", out, sizeof out, meta, sizeof meta);
+      CHECK(n == 4096 * 4 || n == 1024 * 4);
+      CHECK(out[0] == 2.0f);
+    }
+    for (auto& t : rs) t.join();
+  }
+  malformed(port);                                  // phase (b)
   std::vector<std::thread> ts;
   for (int i = 0; i < workers; ++i) ts.emplace_back(worker, port, i);
   // the hosting process polls counters and the table while requests are served

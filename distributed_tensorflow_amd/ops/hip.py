@@ -554,23 +554,35 @@ def reduce_all(x: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
     return out
 
 
-def reduce_cols(x: torch.Tensor) -> torch.Tensor:
+def _out_vec(out: Optional[torch.Tensor], n: int, device, what: str) -> torch.Tensor:
+    """``out`` (a caller-placed contiguous fp32 buffer of n elements, e.g. a gradient's slot in
+    the flat gradient arena) or a fresh vector."""
+    if out is None:
+        return torch.empty((n,), dtype=torch.float32, device=device)
+    if out.dtype != torch.float32 or out.numel() != n or not out.is_contiguous() \
+            or out.device.type != "cuda":
+        raise HipKernelError("%s: bad out tensor" % what)
+    return out
+
+
+def reduce_cols(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     x = _req(x, torch.float32, "reduce_cols x")
     if x.dim() != 2:
         raise HipKernelError("reduce_cols: rank-2 input required")
-    out = torch.empty((x.shape[1],), dtype=torch.float32, device=x.device)
+    out = _out_vec(out, x.shape[1], x.device, "reduce_cols")
     _check(lib().dtf_reduce_cols_f32(x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1],
                                      _stream()), "reduce_cols")
     return out
 
 
-def sigmoid_grad_bias(da: torch.Tensor, a: torch.Tensor, want_bias: bool = True):
+def sigmoid_grad_bias(da: torch.Tensor, a: torch.Tensor, want_bias: bool = True,
+                      db_out: Optional[torch.Tensor] = None):
     da = _req(da, torch.float32, "sigmoid_grad_bias da")
     a = _req(a, torch.float32, "sigmoid_grad_bias a")
     if da.dim() != 2 or da.shape != a.shape:
         raise HipKernelError("sigmoid_grad_bias: need matching rank-2 inputs")
     dz = torch.empty_like(da)
-    db = torch.empty((da.shape[1],), dtype=torch.float32, device=da.device) if want_bias else None
+    db = _out_vec(db_out, da.shape[1], da.device, "sigmoid_grad_bias") if want_bias else None
     _check(lib().dtf_sigmoid_grad_bias_f32(da.data_ptr(), a.data_ptr(), dz.data_ptr(), _ptr(db),
                                            da.shape[0], da.shape[1], _stream()),
            "sigmoid_grad_bias")
@@ -620,7 +632,7 @@ def softmax_xent(logits: torch.Tensor, labels: torch.Tensor, want_softmax: bool 
 
 
 def softmax_xent_grad(y: torch.Tensor, labels: torch.Tensor, dloss: torch.Tensor,
-                      want_bias: bool = True):
+                      want_bias: bool = True, db_out: Optional[torch.Tensor] = None):
     """``dz = (y*rowsum(labels) - labels) * dloss / R`` and its column sum (C <= 64)."""
     y = _req(y, torch.float32, "softmax_xent_grad y")
     labels = _req(labels, torch.float32, "softmax_xent_grad labels")
@@ -632,9 +644,9 @@ def softmax_xent_grad(y: torch.Tensor, labels: torch.Tensor, dloss: torch.Tensor
         dz = binary("sub", binary("mul", y, reduce_rows(labels, ROW_SUM).unsqueeze(1)
                                   .expand_as(y).contiguous()), labels)
         dz = binary("mul", dz, axpby(1.0 / r, dloss.reshape(1)))
-        return dz, (reduce_cols(dz) if want_bias else None)
+        return dz, (reduce_cols(dz, out=db_out) if want_bias else None)
     dz = torch.empty_like(y)
-    db = torch.empty((c,), dtype=torch.float32, device=y.device) if want_bias else None
+    db = _out_vec(db_out, c, y.device, "softmax_xent_grad") if want_bias else None
     fn = lib().dtf_xent_grad_narrow_f32 if c <= 32 else lib().dtf_softmax_xent_grad_f32
     _check(fn(y.data_ptr(), labels.data_ptr(), dloss.data_ptr(), dz.data_ptr(), _ptr(db), r, c,
               _stream()), "softmax_xent_grad")
@@ -646,9 +658,13 @@ def mlp_head_supported(b: int, h: int, c: int) -> bool:
 
 
 def mlp_head_train(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, labels: torch.Tensor,
-                   dloss: torch.Tensor, sigmoid_input: bool, want_accuracy: bool):
+                   dloss: torch.Tensor, sigmoid_input: bool, want_accuracy: bool,
+                   dw_out: Optional[torch.Tensor] = None, db_out: Optional[torch.Tensor] = None,
+                   dbp_out: Optional[torch.Tensor] = None):
     """Fused forward + backward of a small softmax head (B <= 128, H <= 128, C <= 16).
-    Returns ``(loss, y, dw, db, da_or_dz_prev, db_prev_or_None, accuracy_or_None)``."""
+    Returns ``(loss, y, dw, db, da_or_dz_prev, db_prev_or_None, accuracy_or_None)``. The three
+    parameter gradients may be placed by the caller (``*_out``: contiguous fp32 buffers of the
+    right size, e.g. their slots in a flat gradient arena)."""
     a = _req(a, torch.float32, "mlp_head a")
     w = _req(w, torch.float32, "mlp_head w")
     bias = _req(bias, torch.float32, "mlp_head bias")
@@ -675,6 +691,12 @@ def mlp_head_train(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, labels:
     loss, acc = take(1, ()), take(1, ())
     y, dw, db = take(b * c, (b, c)), take(h * c, (h, c)), take(c, (c,))
     da, dbp = take(b * h, (b, h)), take(h, (h,))
+    if dw_out is not None:
+        dw = _out_vec(dw_out.view(-1), h * c, dev, "mlp_head dw").view(h, c)
+    if db_out is not None:
+        db = _out_vec(db_out, c, dev, "mlp_head db")
+    if dbp_out is not None:
+        dbp = _out_vec(dbp_out, h, dev, "mlp_head dbp")
     ws = take(ws_n, (ws_n,))
     _check(lib().dtf_mlp_head_train(a.data_ptr(), w.data_ptr(), bias.data_ptr(),
                                     labels.data_ptr(), dloss.data_ptr(), loss.data_ptr(),

@@ -27,6 +27,22 @@ def _is_f32(*tensors) -> bool:
     return all(isinstance(t, torch.Tensor) and t.dtype == _f32 for t in tensors)
 
 
+def _hint(ctx, index: int, shape, numel=None):
+    """The caller-placed destination for output ``index`` of the step being run (its slot in the
+    runtime's flat gradient arena), shaped like the output -- or ``None``. A kernel that writes
+    there saves the copy the executor would otherwise make."""
+    hints = ctx.out_hint
+    if not hints:
+        return None
+    t = hints.get(index)
+    if t is None or not t.is_cuda or t.dtype != _f32:
+        return None
+    n = 1
+    for d in shape:
+        n *= int(d)
+    return t.view(tuple(shape)) if t.numel() == n and t.is_contiguous() else None
+
+
 def _fallback(op_type, op, inputs, ctx, why: str = ""):
     """No native kernel for this case: refuse (default) or, when the session allows it, run
     the torch reference kernel and record that it happened."""
@@ -193,7 +209,9 @@ def _matmul(op, inputs, ctx):
     a, b = inputs
     ta, tb = op.attrs["transpose_a"], op.attrs["transpose_b"]
     if _is_f32(a, b):
-        return [hip.gemm_f32(a, b, ta, tb)]
+        m = a.shape[1] if ta else a.shape[0]
+        n = b.shape[0] if tb else b.shape[1]
+        return [hip.gemm_f32(a, b, ta, tb, out=_hint(ctx, 0, (m, n)))]
     if a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16:
         return [hip.gemm_bf16(a, b, ta, tb)]
     if a.dtype == hip.FP8 and b.dtype == hip.FP8 and a.dim() == 2 and b.dim() == 2:
@@ -263,7 +281,7 @@ def _sum_to_shape_of(op, inputs, ctx):
     if x.shape == like.shape:
         return [x]
     if _is_f32(x) and x.dim() == 2 and like.dim() == 1 and like.shape[0] == x.shape[1]:
-        return [hip.reduce_cols(x)]
+        return [hip.reduce_cols(x, out=_hint(ctx, 0, (x.shape[1],)))]
     return _fallback("SumToShapeOf", op, inputs, ctx)
 
 
@@ -271,7 +289,7 @@ def _sum_to_shape_of(op, inputs, ctx):
 def _bias_grad(op, inputs, ctx):
     if not _is_f32(inputs[0]) or inputs[0].dim() != 2:
         return _fallback("BiasGrad", op, inputs, ctx)
-    return [hip.reduce_cols(inputs[0])]
+    return [hip.reduce_cols(inputs[0], out=_hint(ctx, 0, (inputs[0].shape[1],)))]
 
 
 # -- nn ---------------------------------------------------------------------------------
@@ -324,7 +342,8 @@ def _softmax_xent_mean_grad(op, inputs, ctx):
     if not _is_f32(y, labels, dloss) or y.dim() != 2:
         return _fallback("SoftmaxXentMeanGrad", op, inputs, ctx)
     want_bias = bool(op.attrs.get("emit_bias_grad"))
-    dz, db = hip.softmax_xent_grad(y, labels, dloss, want_bias)
+    dz, db = hip.softmax_xent_grad(y, labels, dloss, want_bias,
+                                   db_out=_hint(ctx, 1, (y.shape[1],)) if want_bias else None)
     return [dz, db] if want_bias else [dz]
 
 
@@ -333,7 +352,7 @@ def _dense_grad_sigmoid(op, inputs, ctx):
     da, a = inputs
     if not _is_f32(da, a) or da.dim() != 2:
         return _fallback("DenseGradSigmoid", op, inputs, ctx)
-    dz, db = hip.sigmoid_grad_bias(da, a)
+    dz, db = hip.sigmoid_grad_bias(da, a, db_out=_hint(ctx, 1, (da.shape[1],)))
     return [dz, db]
 
 
@@ -354,18 +373,22 @@ def _classifier_head_train(op, inputs, ctx):
     sig = bool(op.attrs.get("sigmoid_input"))
     want_acc = bool(op.attrs.get("emit_accuracy"))
     if hip.mlp_head_supported(a.shape[0], a.shape[1], w.shape[1]):
-        loss, y, dw, db, da, dbp, acc = hip.mlp_head_train(a, w, b, labels, dloss, sig, want_acc)
+        h_, c_ = w.shape
+        loss, y, dw, db, da, dbp, acc = hip.mlp_head_train(
+            a, w, b, labels, dloss, sig, want_acc, dw_out=_hint(ctx, 2, (h_, c_)),
+            db_out=_hint(ctx, 3, (c_,)), dbp_out=_hint(ctx, 5, (h_,)) if sig else None)
     else:
         # batch or layer too large for the one-workgroup kernel: the same math as a chain of
         # the general kernels
         z = hip.gemm_f32(a, w, bias=b)
         loss, y, _ = hip.softmax_xent(z, labels)
-        dz, db = hip.softmax_xent_grad(y, labels, dloss, True)
-        dw = hip.gemm_f32(a, dz, trans_a=True)
+        dz, db = hip.softmax_xent_grad(y, labels, dloss, True,
+                                       db_out=_hint(ctx, 3, (w.shape[1],)))
+        dw = hip.gemm_f32(a, dz, trans_a=True, out=_hint(ctx, 2, tuple(w.shape)))
         da = hip.gemm_f32(dz, w, trans_b=True)
         dbp = None
         if sig:
-            da, dbp = hip.sigmoid_grad_bias(da, a)
+            da, dbp = hip.sigmoid_grad_bias(da, a, db_out=_hint(ctx, 5, (a.shape[1],)))
         acc = hip.argmax_accuracy(y, labels) if want_acc else None
     outs = [loss, y, dw, db, da]
     if sig:
@@ -519,7 +542,7 @@ def _multi_apply_sgd(op, inputs, ctx):
     if ctx.sharded_sgd(var_ops, list(inputs), lrs):      # reduce-scatter / owner update / gather
         inputs, var_ops, lrs = [], [], []
     else:
-        inputs = ctx.reduce_gradients(list(inputs))      # no-op without a synchronous runtime
+        inputs = ctx.reduce_gradients(list(inputs), var_ops)   # no-op without a sync runtime
     local_p, local_g, local_lr, rest = [], [], [], []
     for var_op, lr, g in zip(var_ops, lrs, inputs):
         store = ctx.session._store_for(var_op)
@@ -559,7 +582,7 @@ def _apply_sgd(op, inputs, ctx):
     store = ctx.session._store_for(var_op)
     fast = getattr(store, "local_tensor", None)
     p = fast(var_op.name) if fast is not None else None
-    g = ctx.reduce_gradients([inputs[1]])[0]
+    g = ctx.reduce_gradients([inputs[1]], [var_op])[0]
     if p is not None and p.dtype == _f32 and g.dtype == _f32 and p.is_cuda:
         hip.multi_sgd([p], [g], [op.attrs["learning_rate"]])
         store.update_count += 1

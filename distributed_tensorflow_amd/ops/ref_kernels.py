@@ -124,7 +124,7 @@ def _assign_sub(op, inputs, ctx):
 
 @ref_kernel("ApplyGradientDescent", stateful=True)
 def _apply_sgd(op, inputs, ctx):
-    grad = ctx.reduce_gradients([inputs[1]])[0]
+    grad = ctx.reduce_gradients([inputs[1]], [op.inputs[0].op])[0]
     return [ctx.var_apply_sgd(op.inputs[0].op, op.attrs["learning_rate"], grad)]
 
 
@@ -439,7 +439,7 @@ def _multi_apply_sgd(op, inputs, ctx):
     var_ops = op.attrs["var_ops"]
     lrs = op.attrs["learning_rates"]
     if not ctx.sharded_sgd(var_ops, list(inputs), lrs):
-        for var_op, lr, g in zip(var_ops, lrs, ctx.reduce_gradients(list(inputs))):
+        for var_op, lr, g in zip(var_ops, lrs, ctx.reduce_gradients(list(inputs), var_ops)):
             ctx.var_apply_sgd(var_op, lr, g)
     for var_op, delta in op.attrs.get("counter_increments", []):
         ctx.var_assign_add(var_op, torch.tensor(delta, dtype=var_op.outputs[0].dtype.torch,

@@ -45,11 +45,43 @@ class _Done:
         return True
 
 
+class _Work:
+    """Handle of an asynchronous collective. ``wait()`` turns whatever the backend raises when
+    the collective fails after it was enqueued -- a watchdog timeout, a peer that died, an RCCL
+    asynchronous error -- into :class:`CommError`, the one exception the recovery paths
+    (``Supervisor.run_with_recovery``) look for."""
+
+    __slots__ = ("_work", "_what")
+
+    def __init__(self, work, what: str):
+        self._work, self._what = work, what
+
+    def wait(self, timeout: Optional[float] = None) -> bool:
+        try:
+            if timeout is None:
+                return bool(self._work.wait())
+            import datetime
+            return bool(self._work.wait(datetime.timedelta(seconds=timeout)))
+        except CommError:
+            raise
+        except Exception as e:  # noqa: BLE001 -- RuntimeError, DistBackendError, timeouts
+            raise CommError("%s failed while in flight: %s" % (self._what, e)) from e
+
+    def is_completed(self) -> bool:
+        try:
+            return bool(self._work.is_completed())
+        except Exception as e:  # noqa: BLE001
+            raise CommError("%s failed while in flight: %s" % (self._what, e)) from e
+
+
 class Communicator:
     rank: int = 0
     world_size: int = 1
     device: torch.device = torch.device("cpu")
     backend: str = "single"
+    # all_gather(output, input) accepts ``input`` = this rank's slot of ``output`` (no copy of
+    # the local shard): true for RCCL, the loopback world and a world of one
+    inplace_all_gather = True
 
     def broadcast(self, tensor: torch.Tensor, src: int = 0, async_op: bool = False):
         raise NotImplementedError
@@ -155,12 +187,18 @@ class TorchDistComm(Communicator):
         ops = self._dist.ReduceOp
         return {"sum": ops.SUM, "max": ops.MAX, "min": ops.MIN, "avg": ops.AVG}[op]
 
-    def _wrap(self, fn: Callable, async_op: bool):
+    def _wrap(self, fn: Callable, async_op: bool, what: str = "collective"):
         try:
             work = fn()
-        except RuntimeError as e:          # RCCL async error / watchdog timeout
-            raise CommError(str(e)) from e
-        return work if async_op else None
+        except Exception as e:  # noqa: BLE001 -- RCCL async error / watchdog timeout at enqueue
+            raise CommError("%s failed: %s" % (what, e)) from e
+        if not async_op:
+            return None
+        return _Work(work, what) if work is not None else _Done()
+
+    @property
+    def inplace_all_gather(self) -> bool:      # gloo gathers into a list of chunks
+        return self.backend == "nccl"
 
     def _global(self, group_rank: int) -> int:
         """torch.distributed addresses broadcast sources by global rank."""
@@ -189,7 +227,7 @@ class TorchDistComm(Communicator):
             tensor.copy_(host)
             return _Done() if async_op else None
         return self._wrap(lambda: self._dist.broadcast(tensor, src=src, group=self._group,
-                                                       async_op=async_op), async_op)
+                                                       async_op=async_op), async_op, "broadcast")
 
     def all_reduce(self, tensor, op="sum", async_op=False):
         if self._staged(tensor):
@@ -204,7 +242,7 @@ class TorchDistComm(Communicator):
             return _Done() if async_op else work
         return self._wrap(lambda: self._dist.all_reduce(tensor, op=self._op(op),
                                                         group=self._group, async_op=async_op),
-                          async_op)
+                          async_op, "all_reduce")
 
     def reduce_scatter(self, output, input, op="sum", async_op=False):
         if self._staged(input):
@@ -221,7 +259,8 @@ class TorchDistComm(Communicator):
             output.copy_(tmp.reshape(-1)[self.rank * n:(self.rank + 1) * n].reshape(output.shape))
             return _Done() if async_op else None
         return self._wrap(lambda: self._dist.reduce_scatter_tensor(
-            output, input, op=self._op(op), group=self._group, async_op=async_op), async_op)
+            output, input, op=self._op(op), group=self._group, async_op=async_op), async_op,
+            "reduce_scatter")
 
     def all_gather(self, output, input, async_op=False):
         if self._staged(input):
@@ -234,9 +273,10 @@ class TorchDistComm(Communicator):
         if self.backend == "gloo":
             chunks = list(output.reshape(self.world_size, -1).unbind(0))
             return self._wrap(lambda: self._dist.all_gather(
-                chunks, input.reshape(-1), group=self._group, async_op=async_op), async_op)
+                chunks, input.reshape(-1), group=self._group, async_op=async_op), async_op,
+                "all_gather")
         return self._wrap(lambda: self._dist.all_gather_into_tensor(
-            output, input, group=self._group, async_op=async_op), async_op)
+            output, input, group=self._group, async_op=async_op), async_op, "all_gather")
 
     def barrier(self):
         try:
@@ -244,17 +284,23 @@ class TorchDistComm(Communicator):
                 self._dist.barrier(group=self._group, device_ids=[self.device.index or 0])
             else:
                 self._dist.barrier(group=self._group)
-        except RuntimeError as e:
-            raise CommError(str(e)) from e
+        except Exception as e:  # noqa: BLE001
+            raise CommError("barrier failed: %s" % e) from e
 
     def broadcast_object(self, obj, src=0):
         box = [obj]
-        self._dist.broadcast_object_list(box, src=self._global(src), group=self._group)
+        try:
+            self._dist.broadcast_object_list(box, src=self._global(src), group=self._group)
+        except Exception as e:  # noqa: BLE001
+            raise CommError("broadcast_object failed: %s" % e) from e
         return box[0]
 
     def all_gather_object(self, obj):
         out = [None] * self.world_size
-        self._dist.all_gather_object(out, obj, group=self._group)
+        try:
+            self._dist.all_gather_object(out, obj, group=self._group)
+        except Exception as e:  # noqa: BLE001
+            raise CommError("all_gather_object failed: %s" % e) from e
         return out
 
     def split(self, color, key=None):

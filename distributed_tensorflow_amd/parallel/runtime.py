@@ -178,6 +178,11 @@ class CollectiveRuntime(LocalRuntime):
         self.bytes_reduced = 0
         self.bytes_gathered = 0
         self.sharded_steps = 0             # steps that took the reduce-scatter / owner-update path
+        self.grads_in_place = 0            # gradients found already in their arena slot
+        self.grads_copied = 0              # gradients that had to be copied into it
+        self._grad_views: Optional[Dict[str, torch.Tensor]] = None
+        self._g_shard: Optional[torch.Tensor] = None
+        self._p_stage: Optional[torch.Tensor] = None
         self.shard_plan = None             # parallel.planner.ShardPlan of the session's graph
         self.var_layouts: Dict[str, Any] = {}   # variables stored as blocks: name -> VarLayout
         self.matmul_sharding: Optional[str] = None
@@ -282,6 +287,7 @@ class CollectiveRuntime(LocalRuntime):
             self.var_layouts[n] = lay
         self._flat_params = flat
         self._flat_grads = torch.zeros_like(flat)
+        self._grad_views = None
         self.comm.barrier()
 
     def wait_ready(self, timeout_s: Optional[float] = None) -> None:
@@ -325,28 +331,75 @@ class CollectiveRuntime(LocalRuntime):
         self._pending = []
         return done
 
-    def reduce_gradients(self, grads: Sequence[torch.Tensor]) -> List[torch.Tensor]:
+    def grad_view(self, name: str) -> Optional[torch.Tensor]:
+        """The slot of variable ``name``'s gradient in the flat gradient arena (same offsets as
+        the parameter arena), shaped like the variable; ``None`` for a variable outside it."""
+        views = self._grad_views
+        if views is None:
+            if self._flat_grads is None:
+                return None
+            views = self._grad_views = {
+                n: self._flat_grads[off:off + numel].view(shape)
+                for n, off, numel, shape in self._layout}
+        return views.get(name)
+
+    def _place(self, grads: Sequence[torch.Tensor], names: Optional[Sequence[str]]) -> bool:
+        """Make sure every gradient sits in its arena slot (a gradient the session already had
+        produced there is left alone; anything else is copied in). False when a gradient has no
+        slot or the arena does not exist."""
+        if names is None or self._flat_grads is None:
+            return False
+        for n, g in zip(names, grads):
+            slot = self.grad_view(n)
+            if slot is None or slot.numel() != g.numel() or g.dtype != torch.float32:
+                return False
+        for n, g in zip(names, grads):
+            slot = self.grad_view(n)
+            if g.data_ptr() == slot.data_ptr():
+                self.grads_in_place += 1
+                continue
+            if g.is_cuda and g.is_contiguous() and g.numel():
+                from ..ops import hip
+                hip.copy_2d(g.reshape(1, -1), slot.view(1, -1))
+            else:
+                slot.copy_(g.reshape(slot.shape))
+            self.grads_copied += 1
+        return True
+
+    def reduce_gradients(self, grads: Sequence[torch.Tensor],
+                         names: Optional[Sequence[str]] = None) -> List[torch.Tensor]:
         """All-reduce a list of gradients; returns reduced views. Gradients whose bucket was
-        already issued during the backward pass are only waited for; the rest travel as ONE
-        flat bucket."""
+        already issued during the backward pass are only waited for. The rest travel as ONE
+        collective over the flat gradient arena when their variables (``names``) all have a slot
+        there -- gradients the session had its kernels produce in place need no staging at all --
+        and as one packed bucket otherwise."""
         grads = list(grads)
         if self.comm.world_size == 1 or not grads:
             return grads
+        op = "avg" if self.grad_aggregation == "mean" else "sum"
         if self._pending:
             done = self._collect_buckets()
-            rest = [g for g in grads if id(g) not in done]
-            reduced_rest = iter(self.reduce_gradients(rest)) if rest else iter(())
+            rest = [(i, g) for i, g in enumerate(grads) if id(g) not in done]
+            reduced_rest = iter(self.reduce_gradients(
+                [g for _, g in rest], [names[i] for i, _ in rest] if names else None)) \
+                if rest else iter(())
             return [done[id(g)] if id(g) in done else next(reduced_rest) for g in grads]
+        if self._place(grads, names):
+            flat = self._flat_grads
+            self.comm.all_reduce(flat, op)
+            self.bytes_reduced += flat.numel() * 4
+            return [self.grad_view(n) for n in names]
         total = sum(g.numel() for g in grads)
-        bucket = self._flat_grads[:total] if (self._flat_grads is not None
-                                              and self._flat_grads.numel() >= total
-                                              and grads[0].dtype == torch.float32) \
-            else torch.empty(total, dtype=grads[0].dtype, device=grads[0].device)
+        buf = self._bucket_bufs.get(-1)
+        if buf is None or buf.numel() < total or buf.dtype != grads[0].dtype:
+            buf = self._bucket_bufs[-1] = torch.empty(total, dtype=grads[0].dtype,
+                                                      device=grads[0].device)
+        bucket = buf[:total]
         off = 0
         for g in grads:
             bucket[off:off + g.numel()].copy_(g.reshape(-1))
             off += g.numel()
-        self.comm.all_reduce(bucket, "avg" if self.grad_aggregation == "mean" else "sum")
+        self.comm.all_reduce(bucket, op)
         self.bytes_reduced += bucket.numel() * bucket.element_size()
         out, off = [], 0
         for g in grads:
@@ -356,21 +409,25 @@ class CollectiveRuntime(LocalRuntime):
 
     def sharded_sgd_step(self, names: Sequence[str], grads: Sequence[torch.Tensor],
                          lrs: Sequence[float]) -> bool:
-        """``reduce_scatter_sync``: reduce-scatter the flat gradient to the shard owners, apply
-        SGD on the owned shard only, all-gather the updated parameters. Returns False when the
-        request does not cover the flat arena (caller then falls back to all-reduce)."""
-        if self.strategy != "reduce_scatter_sync" or self._flat_params is None:
+        """``reduce_scatter_sync``: reduce-scatter the flat gradient arena to the shard owners,
+        apply SGD on the owned shard only, all-gather the updated parameters -- the collective
+        image of "variables live on the parameter server, gradients are pushed to it, updated
+        values are pulled back" (reference ``tf_distributed.py:34-36,75-76``). Variables of the
+        arena without a gradient in this step (``global_step`` and other non-trainables) keep a
+        zero gradient slot. Every buffer involved is allocated once. Returns False when a
+        gradient has no slot in the arena or the learning rates differ (the caller then falls
+        back to the all-reduce path)."""
+        if self.strategy != "reduce_scatter_sync" or self._flat_params is None \
+                or len(set(lrs)) != 1 or not grads:
             return False
-        by_name = {n: (g, lr) for n, g, lr in zip(names, grads, lrs)}
-        if set(by_name) != {n for n, _, _, _ in self._layout} or len(set(lrs)) != 1:
+        if not self._place(grads, names):
             return False
         flat_g, flat_p = self._flat_grads, self._flat_params
-        flat_g.zero_()
-        for n, off, numel, _ in self._layout:
-            flat_g[off:off + numel].copy_(by_name[n][0].reshape(-1))
         w, r = self.comm.world_size, self.comm.rank
         shard = flat_p.numel() // w
-        g_shard = torch.empty(shard, dtype=torch.float32, device=self.device)
+        if self._g_shard is None or self._g_shard.numel() != shard:
+            self._g_shard = torch.empty(shard, dtype=torch.float32, device=self.device)
+        g_shard = self._g_shard
         self.comm.reduce_scatter(g_shard, flat_g,
                                  "avg" if self.grad_aggregation == "mean" else "sum")
         p_shard = flat_p[r * shard:(r + 1) * shard]
@@ -379,8 +436,15 @@ class CollectiveRuntime(LocalRuntime):
             hip.multi_sgd([p_shard], [g_shard], [lrs[0]])
         else:
             p_shard.add_(g_shard, alpha=-float(lrs[0]))
-        self.comm.all_gather(flat_p, p_shard.clone())
+        if self.comm.inplace_all_gather:
+            self.comm.all_gather(flat_p, p_shard)            # the shard already is its own slot
+        else:
+            if self._p_stage is None or self._p_stage.numel() != shard:
+                self._p_stage = torch.empty(shard, dtype=torch.float32, device=self.device)
+            self._p_stage.copy_(p_shard)
+            self.comm.all_gather(flat_p, self._p_stage)
         self.bytes_reduced += flat_g.numel() * 4
+        self.sharded_steps += 1
         return True
 
     def shutdown(self) -> None:

@@ -97,6 +97,9 @@ def main() -> int:
         out["w"] = [float(v) for v in sess.run(w).reshape(-1)]
         out["step"] = float(sess.run(step))
         out["buckets_issued"] = getattr(server.runtime, "buckets_issued", 0)
+        out["sharded_steps"] = getattr(server.runtime, "sharded_steps", 0)
+        out["grads_placed"] = (getattr(server.runtime, "grads_in_place", 0)
+                               + getattr(server.runtime, "grads_copied", 0))
     sv.stop()
     server.stop()
     with open(os.path.join(os.environ["DTF_RESULT_DIR"], "rank%d.json" % rank), "w") as fh:

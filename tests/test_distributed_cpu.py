@@ -1,5 +1,6 @@
 """T1 (single process, several "tasks"): communicators, parameter-server transport,
 Supervisor chief/non-chief protocol, async vs sync update semantics, failure injection."""
+import os
 import threading
 import time
 
@@ -292,7 +293,8 @@ def _cluster(num_workers=2):
 
 
 def _worker_job(cluster, task, steps, results, protocol="grpc", comm=None, strategy=None,
-                lr=0.05, logdir=None, start_delay=0.0, bucket_bytes=None):
+                lr=0.05, logdir=None, start_delay=0.0, bucket_bytes=None, save_model_secs=0.2,
+                save_summaries_secs=120.0):
     time.sleep(start_delay)
     g = tf.Graph()
     with g.as_default():
@@ -304,7 +306,8 @@ def _worker_job(cluster, task, steps, results, protocol="grpc", comm=None, strat
             m = mnist_mlp.build_model(learning_rate=lr, seed=1)
         sv = tf.train.Supervisor(is_chief=(task == 0), global_step=m.global_step,
                                  init_op=m.init_op, logdir=logdir, recovery_wait_secs=0.05,
-                                 save_model_secs=0.2, summary_op=None)
+                                 save_model_secs=save_model_secs, summary_op=None,
+                                 save_summaries_secs=save_summaries_secs)
         rng = np.random.RandomState(100 + task)
         from distributed_tensorflow_amd.data.mnist import synthetic_mnist
         images, labels = synthetic_mnist(600, seed=task)
@@ -372,6 +375,12 @@ def test_sync_collective_job_keeps_replicas_identical(strategy):
     assert results[0]["costs"] != results[1]["costs"]    # different data on each worker
     assert np.mean(results[0]["costs"][-5:]) < np.mean(results[0]["costs"][:5])
     assert results[0]["runtime"].bytes_reduced > 0
+    for t in range(world):
+        rt_t = results[t]["runtime"]
+        # every gradient was produced in (or moved to) its slot of the flat arena and the arena
+        # travelled as one collective; the owner-update path really ran under reduce_scatter_sync
+        assert rt_t.grads_in_place + rt_t.grads_copied == 4 * 25
+        assert rt_t.sharded_steps == (25 if strategy == "reduce_scatter_sync" else 0)
     # the flat arena keeps every variable on a 256-byte boundary (the scalar global_step must not
     # push the matrices off the GEMM kernels' 16-byte paths) and its length divides by the world
     rt = results[0]["runtime"]
@@ -380,6 +389,39 @@ def test_sync_collective_job_keeps_replicas_identical(strategy):
     spans = sorted((off, off + numel) for _, off, numel, _ in rt._layout)
     assert all(a_end <= b_start for (_, a_end), (b_start, _) in zip(spans, spans[1:]))
     assert rt._flat_params.numel() % world == 0 and rt._flat_params.numel() >= spans[-1][1]
+
+
+def test_service_threads_do_not_disturb_bucketed_collective_steps(tmp_path):
+    """With a logdir the chief's checkpoint and step-rate threads call ``sess.run`` every few
+    milliseconds while the training loop has gradient buckets in flight. The device phase of
+    ``Session.run`` is serialised per session, so a service-thread run can neither drop the
+    in-flight buckets nor slip an extra collective between them: the job finishes (no rank is
+    left waiting for a collective its peer never posts), the replicas stay bit-identical and
+    equal to the same job without service threads."""
+    world, steps = 2, 60
+    finals = {}
+    for label, logdir in (("quiet", None), ("busy", str(tmp_path / "logdir"))):
+        cluster = tf.train.ClusterSpec({"worker": ["127.0.0.1:%d" % _free_port()
+                                                   for _ in range(world)]})
+        comms = LoopbackComm.create_world(world, timeout_s=30)
+        results = {}
+        threads = [threading.Thread(target=_worker_job, args=(cluster, t, steps, results),
+                                    kwargs=dict(protocol="rccl", comm=comms[t],
+                                                strategy="allreduce_sync", bucket_bytes=4096,
+                                                logdir=logdir, save_model_secs=0.01,
+                                                save_summaries_secs=0.01))
+                   for t in range(world)]
+        [t.start() for t in threads]
+        [t.join(120) for t in threads]
+        assert set(results) == {0, 1}, "a rank hung or died (%s)" % label
+        finals[label] = results
+    busy, quiet = finals["busy"], finals["quiet"]
+    assert busy[0]["grad_buckets"] == 2 and busy[0]["runtime"].buckets_issued == 2 * steps
+    assert any(f.startswith("model.ckpt-") for f in os.listdir(str(tmp_path / "logdir")))
+    for t in range(world):
+        assert np.array_equal(busy[t]["final"]["w1"], quiet[t]["final"]["w1"])
+        assert busy[t]["costs"] == quiet[t]["costs"]
+    assert np.array_equal(busy[0]["final"]["w1"], busy[1]["final"]["w1"])
 
 
 def test_bucketed_gradient_allreduce_overlaps_backward_and_matches_single_bucket():

@@ -124,6 +124,10 @@ def test_gloo_two_process_comm_matmul_and_training(strategy, bucket_bytes, tmp_p
         assert r["step"] == 60.0
         # 8-byte buckets: {b} and {w} are all-reduced asynchronously during the backward pass
         assert r["buckets_issued"] == (120 if bucket_bytes else 0)
+        # reduce_scatter_sync really takes the reduce-scatter / owner-update / all-gather path
+        assert r["sharded_steps"] == (60 if strategy == "reduce_scatter_sync" else 0)
+        if not bucket_bytes:
+            assert r["grads_placed"] == 2 * 60        # w and b, every step, via the flat arena
     assert results[0]["w"] == results[1]["w"]        # bit-identical replicas
 
 

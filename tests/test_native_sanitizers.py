@@ -32,6 +32,26 @@ def test_host_io_selftest_under_asan_ubsan(tmp_path):
 
 
 @pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+def test_ps_server_selftest_under_asan_ubsan(tmp_path):
+    """Same self-test (concurrent clients, storage replaced under readers, malformed frames) with
+    AddressSanitizer + UBSan: a reader left holding freed variable storage, or a frame whose sizes
+    wrap, shows up here as a heap error."""
+    exe = str(tmp_path / "ps_server_selftest_asan")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer",
+           "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-pthread",
+           os.path.join(CSRC, "runtime", "ps_server.cc"),
+           os.path.join(CSRC, "tests", "ps_server_selftest.cc"), "-o", exe]
+    build = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert build.returncode == 0, build.stdout
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0:verify_asan_link_order=0")
+    run = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                         env=env, timeout=180)
+    assert "AddressSanitizer" not in run.stdout and "runtime error" not in run.stdout, run.stdout
+    assert run.returncode == 0, run.stdout
+    assert "ps_server selftest ok" in run.stdout
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
 def test_ps_server_selftest_under_tsan(tmp_path):
     exe = str(tmp_path / "ps_server_selftest")
     cmd = ["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=thread",

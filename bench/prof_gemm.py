@@ -14,6 +14,8 @@ ap.add_argument("--n", type=int, default=8192)
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--variant", type=int, default=0)
 ap.add_argument("--iters", type=int, default=5)
+ap.add_argument("--impl", default="ours", choices=("ours", "torch"),
+                help="torch: the vendor library (hipBLASLt through torch.matmul) on the same operands")
 args = ap.parse_args()
 n = args.n
 if args.dtype == "bf16":
@@ -21,7 +23,10 @@ if args.dtype == "bf16":
     bt = (torch.rand(n, n, device="cuda") * 2 - 1).bfloat16()
     out = torch.empty(n, n, device="cuda", dtype=torch.bfloat16)
     for _ in range(args.iters):
-        hip.gemm_bf16_nt(a, bt, torch.bfloat16, out=out, variant=args.variant)
+        if args.impl == "torch":
+            torch.matmul(a, bt.t(), out=out)
+        else:
+            hip.gemm_bf16_nt(a, bt, torch.bfloat16, out=out, variant=args.variant)
 elif args.dtype == "fp8":
     a = hip.philox_window(n, n, 1, 1, 0, 0, n, torch.float8_e4m3fn, "cuda", False, -1.0, 2.0)
     bt = hip.philox_window(n, n, 1, 2, 0, 0, n, torch.float8_e4m3fn, "cuda", False, -1.0, 2.0)

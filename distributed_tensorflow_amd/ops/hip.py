@@ -115,6 +115,11 @@ def _declare(L: ctypes.CDLL) -> None:
         "dtf_cast_to_fp8_dev_scale": [P, I, P, LG, P, P],
         "dtf_truncated_normal_f32": [P, LG, U, U, F, F, P],
         "dtf_cast_generic": [P, I, P, I, LG, P],
+        "dtf_flags_alloc": [LG, c.POINTER(c.c_void_p), c.c_char_p],
+        "dtf_flags_open": [c.c_char_p, c.POINTER(c.c_void_p)],
+        "dtf_flags_close": [P, I],
+        "dtf_peer_signal": [c.POINTER(c.c_void_p), I, I, P],
+        "dtf_peer_wait": [c.POINTER(c.c_void_p), I, I, LG, P, P],
     }
     for name, argtypes in sigs.items():
         fn = getattr(L, name)
@@ -1024,3 +1029,50 @@ def truncated_normal(shape: Sequence[int], seed: int, op_seed: int, mean: float 
                                           op_seed & 0xFFFFFFFF, float(mean), float(stddev),
                                           _stream()), "truncated_normal")
     return out
+
+
+# ---------------------------------------------------------------------------------------
+# device-side completion flags of the peer-memory collectives (csrc/kernels/peer_sync.hip)
+# ---------------------------------------------------------------------------------------
+def flags_alloc(nbytes: int):
+    """This rank's flag page: ``nbytes`` of zeroed fine-grained device memory on the current
+    device. Returns ``(address, ipc_handle_bytes)``."""
+    ptr = ctypes.c_void_p()
+    handle = ctypes.create_string_buffer(64)
+    code = lib().dtf_flags_alloc(int(nbytes), ctypes.byref(ptr), handle)
+    if code != 0:
+        raise HipKernelError("flags_alloc: code %d" % code)
+    return ptr.value, handle.raw
+
+
+def flags_open(handle: bytes) -> int:
+    """Map a peer's flag page from the 64-byte handle its ``flags_alloc`` returned."""
+    if len(handle) != 64:
+        raise HipKernelError("flags_open: a handle is 64 bytes")
+    ptr = ctypes.c_void_p()
+    code = lib().dtf_flags_open(ctypes.create_string_buffer(handle, 64), ctypes.byref(ptr))
+    if code != 0:
+        raise HipKernelError("flags_open: code %d" % code)
+    return ptr.value
+
+
+def flags_close(address: int, owned: bool) -> None:
+    lib().dtf_flags_close(address, int(bool(owned)))
+
+
+def peer_signal(flag_addresses: Sequence[int], value: int) -> None:
+    """On the current stream: store ``value`` into each flag (system-scope release behind
+    everything the stream did before)."""
+    arr = (ctypes.c_void_p * len(flag_addresses))(*[int(a) for a in flag_addresses])
+    _check(lib().dtf_peer_signal(arr, len(flag_addresses), int(value), _stream()), "peer_signal")
+
+
+def peer_wait(flag_addresses: Sequence[int], value: int, timeout_s: float,
+              status: torch.Tensor) -> None:
+    """On the current stream: wait until every flag has reached ``value``; a flag still behind
+    after ``timeout_s`` puts its position + 1 into the pinned int32 ``status``."""
+    if status.dtype != torch.int32 or not status.is_pinned():
+        raise HipKernelError("peer_wait: status must be a pinned int32 tensor")
+    arr = (ctypes.c_void_p * len(flag_addresses))(*[int(a) for a in flag_addresses])
+    _check(lib().dtf_peer_wait(arr, len(flag_addresses), int(value), int(timeout_s * 1e6),
+                               status.data_ptr(), _stream()), "peer_wait")

@@ -266,8 +266,7 @@ class ShardedMatmul:
                                                       self.peer_transport))
             if s == "k_shard_allreduce_direct":
                 self._sym_partial = SymmetricBuffer(self.comm, (m, n), self.reduce_dtype, dev)
-                self._stage = torch.empty((max(1, w - 1), m // w, n), dtype=self.reduce_dtype,
-                                          device=dev)
+                self._stage = None             # fp32 rows of a mixed-precision reduction
         elif s in ("replicated", "m_shard_allgather", "k_shard_allreduce"):
             self.c = torch.empty((m, n), dtype=dt, device=dev)
         elif s in ("m_shard", "k_shard_reduce_scatter"):
@@ -340,7 +339,11 @@ class ShardedMatmul:
         """Row panels of the local block are computed straight into this rank's rows of the
         symmetric result buffer; the push of panel p to all peers (one copy per peer, each on
         its own stream and link) is queued behind panel p's product and runs while panel p+1
-        is computed. One host synchronisation + barrier per step completes the exchange."""
+        is computed. The exchange is completed on the device (sequence-number flags written
+        behind the copies, one wait kernel on the compute stream); pipelined steps publish
+        their flags at once and wait for the peers' only when the buffer set comes round again,
+        so the compute stream never idles behind a transfer. Without the flag page: one host
+        synchronisation + barrier per step."""
         w, x = self.world, self.recompute_rows
         body = self.m // w - x                 # rows of a block that travel
         base = w * x + self.rank * body        # (x = 0: plain row order)
@@ -358,6 +361,8 @@ class ShardedMatmul:
             # heads of all blocks, computed here while the links carry the bodies
             self._gemm(self.a_heads, self.bt, self.c[:w * x])
         if self.pipelined:
+            if sym.flags is not None:
+                sym.publish()                  # peers learn of the rows now; we wait later
             self._set_works[which] = [True]
         else:
             sym.finish()
@@ -372,15 +377,18 @@ class ShardedMatmul:
         w, r = self.world, self.rank
         per = self.m // w
         part = self._sym_partial
+        part.before_overwrite()                # peers have read the previous step's partials
         self._gemm(self.a, self.bt, part.local)
         part.quiesce()
         mine = self.c[r * per:(r + 1) * per]
         if self.reduce_dtype == self.out_dtype:
-            reduce_scatter_rows(part, mine, r * per, per, self._stage)
+            reduce_scatter_rows(part, mine, r * per, per)
         else:
-            tmp = torch.empty((per, self.n), dtype=self.reduce_dtype, device=self.device)
-            reduce_scatter_rows(part, tmp, r * per, per, self._stage)
-            mine.copy_(tmp)
+            if self._stage is None or self._stage.shape != (per, self.n):
+                self._stage = torch.empty((per, self.n), dtype=self.reduce_dtype,
+                                          device=self.device)
+            reduce_scatter_rows(part, self._stage, r * per, per)
+            mine.copy_(self._stage)
         self._sym_c.push_rows(r * per, per)
         self._sym_c.finish()
         return self.c
@@ -506,6 +514,12 @@ class ShardedMatmul:
                 if self._set_works[which]:
                     sym.finish()
                     self._set_works[which] = []
+            if any(sym.flags is not None for sym in self._sym_sets):
+                # device-side completion: the waits are queued, not run -- drain and look at
+                # the status words (a peer that never signalled shows up here as CommError)
+                torch.cuda.current_stream(self.device).synchronize()
+                for sym in self._sym_sets:
+                    sym.check()
         else:
             for which in range(len(self._set_works)):
                 for wk in self._set_works[which]:

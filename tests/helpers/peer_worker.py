@@ -26,6 +26,33 @@ def main() -> int:
     rank, world = comm.rank, comm.world_size
     res = {"rank": rank, "world": world}
 
+    if os.environ.get("DTF_PEER_TEST") == "dead_peer":
+        # rank 1 stalls and never pushes: rank 0's wait kernel must give up after
+        # DTF_PEER_TIMEOUT_S and the next check must raise CommError (no hang, no host barrier)
+        from distributed_tensorflow_amd.parallel.comm import CommError
+        buf = SymmetricBuffer(comm, (4 * world, 256), torch.float32, dev)
+        res["sync"] = buf.sync
+        import time
+        if rank != 0:
+            with open(os.path.join(out_dir, "rank%d.json" % rank), "w") as fh:
+                json.dump(res, fh)
+            time.sleep(8.0)            # alive (its memory stays mapped) but never pushes
+            os._exit(0)
+        t0 = time.time()
+        buf.push_rows(0, 4)
+        buf.finish()
+        torch.cuda.synchronize()
+        try:
+            buf.check()
+            res["raised"] = False
+        except CommError as e:
+            res["raised"] = True
+            res["message"] = str(e)
+        res["seconds"] = time.time() - t0
+        with open(os.path.join(out_dir, "rank%d.json" % rank), "w") as fh:
+            json.dump(res, fh)
+        os._exit(0)
+
     # all-gather: rank r owns rows [4r, 4r+4)
     buf = SymmetricBuffer(comm, (4 * world, 256), torch.float32, dev)
     buf.local.zero_()
@@ -35,6 +62,8 @@ def main() -> int:
         all_gather_rows(buf, 4)
     want = torch.arange(1, world + 1, dtype=torch.float32, device=dev).repeat_interleave(4)
     res["all_gather_ok"] = bool((buf.local == want[:, None]).all().item())
+    res["sync"] = buf.sync
+    res["host_syncs_all_gather"] = buf.host_syncs
 
     # two-shot all-reduce of bf16 partials
     part = SymmetricBuffer(comm, (8 * world, 128), torch.bfloat16, dev)
@@ -69,6 +98,7 @@ def main() -> int:
     eng.wait()
     torch.cuda.synchronize()
     errs["pipelined_direct"] = (eng.result_dense().float() - want).abs().max().item()
+    res["host_syncs_pipelined"] = sum(sym.host_syncs for sym in eng._sym_sets)
     # recomputed heads: only rows x.. of every block travel; every rank computes the heads itself
     for name, strategy in (("recompute_direct", "m_shard_allgather_direct"),
                            ("recompute_rccl_layout", "m_shard_allgather")):

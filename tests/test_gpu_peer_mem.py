@@ -24,15 +24,50 @@ def _free_port() -> int:
     return port
 
 
-@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
-@pytest.mark.parametrize("world", [2, 4])
-def test_peer_memory_collectives_same_device(world, tmp_path):
+def _spawn(world, tmp_path, **extra_env):
     port = _free_port()
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PYTHONPATH=ROOT,
-                   HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", **extra_env)
+        procs.append(subprocess.Popen([sys.executable, "-u", WORKER, str(tmp_path)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                                      text=True))
+    outs = []
+    try:
+        for p in procs:
+            out, _ = p.communicate(timeout=240)
+            outs.append(out)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return procs, outs
+
+
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
+def test_dead_peer_times_out_into_comm_error(tmp_path):
+    """Device-side completion is bounded: a peer that stalls and never pushes leaves rank 0's
+    wait kernel to give up after the configured time, and the next check raises CommError."""
+    procs, outs = _spawn(2, tmp_path, DTF_PEER_TEST="dead_peer", DTF_PEER_TIMEOUT_S="2")
+    assert procs[0].returncode == 0, outs[0][-3000:]
+    with open(tmp_path / "rank0.json") as fh:
+        res = json.load(fh)
+    assert res["sync"] == "flags"
+    assert res["raised"] is True and "did not signal" in res["message"]
+    assert 1.5 < res["seconds"] < 30.0
+
+
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
+@pytest.mark.parametrize("world,sync", [(2, "flags"), (4, "flags"), (2, "host")])
+def test_peer_memory_collectives_same_device(world, sync, tmp_path):
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PYTHONPATH=ROOT,
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", DTF_PEER_SYNC=sync)
         procs.append(subprocess.Popen([sys.executable, "-u", WORKER, str(tmp_path)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                                       text=True))
@@ -51,6 +86,10 @@ def test_peer_memory_collectives_same_device(world, tmp_path):
         with open(tmp_path / ("rank%d.json" % rank)) as fh:
             res = json.load(fh)
         assert res["world"] == world
+        assert res["sync"] == sync
+        if sync == "flags":
+            # completion is device-side: no host stream synchronisation in any exchange
+            assert res["host_syncs_all_gather"] == 0 and res["host_syncs_pipelined"] == 0
         assert res["all_gather_ok"], res
         assert res["all_reduce_ok"], res
         scale = res["ref_scale"]

@@ -119,7 +119,9 @@ class RunOptions:
 
 
 class RunMetadata:
-    """Receives per-op timings when ``RunOptions(trace_level=FULL_TRACE)`` is passed."""
+    """Receives per-op timings when ``RunOptions(trace_level=FULL_TRACE)`` is passed: one entry
+    per plan step and per collective, timed on the device by HIP events and on the host by the
+    enqueueing code (``utils/tracing.py``)."""
 
     def __init__(self):
         self.step_stats: List[Dict[str, Any]] = []
@@ -127,6 +129,10 @@ class RunMetadata:
     def to_chrome_trace(self) -> Dict[str, Any]:
         from ..utils.tracing import chrome_trace
         return chrome_trace(self.step_stats)
+
+    def summary(self) -> Dict[str, Dict[str, float]]:
+        from ..utils.tracing import summarize
+        return summarize(self.step_stats)
 
 
 def default_device() -> torch.device:
@@ -679,20 +685,13 @@ class Session:
         ctx = self._ctx
         for s in steps:
             ins = [vals[i] if i >= 0 else None for i in s.in_slots]
-            if trace is not None:
-                t0 = time.perf_counter()
-                if self.device.type == "cuda":
-                    torch.cuda.synchronize(self.device)
-                    t0 = time.perf_counter()
+            rec = trace.begin(s.node.name, s.node.type) if trace is not None else None
             if s.grad_views is None:
                 outs = s.kernel(s.node, ins, ctx)
             else:
                 outs = self._run_placed(s, ins, ctx)
-            if trace is not None:
-                if self.device.type == "cuda":
-                    torch.cuda.synchronize(self.device)
-                trace.append({"name": s.node.name, "op": s.node.type, "start": t0,
-                              "end": time.perf_counter(), "device": str(self.device)})
+            if rec is not None:
+                trace.end(rec)
             for sl, o in zip(s.out_slots, outs):
                 vals[sl] = o
             if s.buckets is not None:
@@ -762,7 +761,10 @@ class Session:
                 plan = self._build_plan(flat, [t for t, _ in fed_pairs])
                 self._plans[key] = plan
         self.stats["runs"] += 1
-        trace = [] if (options is not None and options.trace_level) else None
+        trace = None
+        if options is not None and options.trace_level:
+            from ..utils.tracing import StepTracer
+            trace = StepTracer(self.device)      # HIP events per step: no sync between steps
 
         self._run_lock.acquire()
         token = None
@@ -778,7 +780,11 @@ class Session:
                 vals: List[Any] = [None] * plan.num_slots
                 for (_, sl), v in zip(plan.feed_slots, feeds):
                     vals[sl] = v
-                self._run_steps(plan.steps, vals, trace)
+                if trace is not None:
+                    with trace.collectives(getattr(self._runtime, "comm", None)):
+                        self._run_steps(plan.steps, vals, trace)
+                else:
+                    self._run_steps(plan.steps, vals, trace)
                 self.stats["eager_runs"] += 1
                 slot_vals = {sl: vals[sl] for sl in plan.fetch_slots if sl is not None}
                 slot_vals.update((sl, vals[sl]) for sl in plan.host_input_slots)
@@ -800,8 +806,10 @@ class Session:
             for s in plan.host_steps:
                 for sl in s.out_slots:
                     host_out[sl] = hv[sl]
-        if run_metadata is not None and trace is not None:
-            run_metadata.step_stats.extend(trace)
+        if trace is not None:
+            stats = trace.finish()               # the one synchronisation of a traced run
+            if run_metadata is not None:
+                run_metadata.step_stats.extend(stats)
         results = [None if sl is None else
                    (host_out[sl] if sl in host_out else self._to_host(slot_vals[sl]))
                    for sl in plan.fetch_slots]

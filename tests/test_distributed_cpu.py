@@ -586,3 +586,55 @@ def test_peer_memory_strategies_need_a_gpu():
                         strategy="m_shard_allgather_direct", device=torch.device("cpu"))
     with pytest.raises(PeerMemError):
         eng.init_operands()
+
+
+def test_traced_collective_step_records_collectives_with_payload(tmp_path):
+    """A traced synchronous step lists its collectives next to its ops: name, payload bytes and
+    a duration each; the Chrome trace puts them on their own track."""
+    world = 2
+    cluster = tf.train.ClusterSpec({"worker": ["127.0.0.1:%d" % _free_port()
+                                               for _ in range(world)]})
+    comms = LoopbackComm.create_world(world, timeout_s=30)
+    out = {}
+
+    def job(task):
+        g = tf.Graph()
+        with g.as_default():
+            config = tf.ConfigProto(device="cpu", strategy="reduce_scatter_sync")
+            server = tf.train.Server(cluster, job_name="worker", task_index=task,
+                                     protocol="rccl", config=config, comm=comms[task])
+            with tf.device(tf.train.replica_device_setter(
+                    worker_device="/job:worker/task:%d" % task, cluster=cluster)):
+                m = mnist_mlp.build_model(learning_rate=0.05, seed=1)
+            sv = tf.train.Supervisor(is_chief=(task == 0), global_step=m.global_step,
+                                     init_op=m.init_op, recovery_wait_secs=0.05, summary_op=None)
+            rng = np.random.RandomState(task)
+            feed = {m.x: rng.rand(20, 784).astype(np.float32),
+                    m.y_: np.eye(10, dtype=np.float32)[rng.randint(0, 10, 20)]}
+            with sv.prepare_or_wait_for_session(server.target, config=config) as sess:
+                sess.run(m.train_op, feed)
+                md = tf.RunMetadata()
+                sess.run(m.train_op, feed,
+                         options=tf.RunOptions(trace_level=tf.RunOptions.FULL_TRACE),
+                         run_metadata=md)
+                sess.run(m.train_op, feed)          # the communicator is untouched afterwards
+                out[task] = md
+            sv.stop()
+            server.stop()
+
+    threads = [threading.Thread(target=job, args=(t,)) for t in range(world)]
+    [t.start() for t in threads]
+    [t.join(60) for t in threads]
+    assert set(out) == {0, 1}
+    md = out[0]
+    colls = [s for s in md.step_stats if s["cat"] == "collective"]
+    assert [c["op"] for c in colls] == ["reduce_scatter", "all_gather"]
+    arena = comms[0].world_size and colls[0]["args"]["bytes"]
+    assert arena >= 79510 * 4 and colls[1]["args"]["bytes"] == arena
+    assert all(c["end"] >= c["start"] for c in colls)
+    summary = md.summary()
+    assert summary["reduce_scatter"]["count"] == 1 and summary["reduce_scatter"]["bytes"] == arena
+    trace = md.to_chrome_trace()
+    tracks = {e["tid"] for e in trace["traceEvents"]}
+    assert any("collectives" in t for t in tracks) and any("kernels" in t for t in tracks)
+    assert "all_reduce" not in comms[0].__dict__          # instance wrappers were removed

@@ -417,3 +417,47 @@ def test_small_ops_run_native_kernels_through_the_session():
             c = sess.run(c8, {g.get_tensor_by_name("a8:0"): av, g.get_tensor_by_name("b8:0"): bv})
             assert np.array_equal(c, av @ bv)
             assert sess.stats["torch_fallbacks"] == 0
+
+
+def test_traced_step_uses_hip_events_and_does_not_synchronise_between_steps(monkeypatch):
+    """``RunOptions(trace_level=FULL_TRACE)`` on the GPU: every plan step carries a device-side
+    duration from HIP events, the host's enqueue time is recorded separately, and the whole traced
+    run synchronises the device twice (when the tracer takes its base time stamp and when it
+    resolves the events) -- not once or twice per step."""
+    import numpy as np
+    import torch
+    import distributed_tensorflow_amd as tf
+    from distributed_tensorflow_amd.models import mnist_mlp
+    g = tf.Graph()
+    with g.as_default():
+        m = mnist_mlp.build_model()
+        with tf.Session(config=tf.ConfigProto(device="cuda")) as sess:
+            sess.run(m.init_op)
+            feed = {m.x: np.random.rand(100, 784).astype(np.float32),
+                    m.y_: np.eye(10, dtype=np.float32)[np.random.randint(0, 10, 100)]}
+            fetches = [m.train_op, m.loss, m.global_step]
+            for _ in range(3):
+                sess.run(fetches, feed)
+            calls = {"n": 0}
+            real_sync = torch.cuda.synchronize
+
+            def counting_sync(*a, **k):
+                calls["n"] += 1
+                return real_sync(*a, **k)
+            monkeypatch.setattr(torch.cuda, "synchronize", counting_sync)
+            md = tf.RunMetadata()
+            sess.run(fetches, feed, options=tf.RunOptions(trace_level=tf.RunOptions.FULL_TRACE),
+                     run_metadata=md)
+            monkeypatch.setattr(torch.cuda, "synchronize", real_sync)
+    stats = md.step_stats
+    assert len(stats) >= 4 and calls["n"] == 2
+    assert all(s["clock"] == "hip_event" for s in stats)
+    kernels = [s for s in stats if s["op"] in ("FusedDense", "ClassifierHeadTrain", "MatMul",
+                                               "MultiApplySGD")]
+    assert len(kernels) >= 3
+    assert all(0.0 < s["end"] - s["start"] < 5e-3 for s in kernels)
+    # steps follow each other on the device in plan order, without a host round trip in between
+    starts = [s["start"] for s in stats]
+    assert starts == sorted(starts)
+    trace = md.to_chrome_trace()
+    assert {"host enqueue"} <= {e["tid"] for e in trace["traceEvents"]}

@@ -15,7 +15,11 @@ pruned subgraph before execution:
 * a linear output layer + softmax cross-entropy + their whole backward (logits gradient, weight
   and bias gradients, the gradient into -- and through -- a preceding sigmoid layer, and the
   accuracy of the same predictions) -> ``ClassifierHeadTrain``, one kernel for small heads;
-* every ``ApplyGradientDescent`` (+ the ``global_step`` increment) -> one ``MultiApplySGD``.
+* every ``ApplyGradientDescent`` (+ the ``global_step`` increment) -> one ``MultiApplySGD``;
+* a whole SGD step of a two-layer sigmoid/softmax classifier whose four parameters live on this
+  device (first layer, head, weight-gradient product and update -- the reference's model and
+  train_op, ``tf_distributed.py:58-76``) -> one ``MLPTrainStep`` node: three launches, the
+  first-layer weight gradient applied in the epilogue of its own product.
 
 Rewrites are expressed as *tensor replacements* (``original tensor -> output k of a fused
 node``) and *op replacements* (for control edges). The original ops stay in the graph; after
@@ -61,6 +65,19 @@ class Rewrite:
     def __init__(self):
         self.tensor_map: Dict[Tensor, Tensor] = {}      # original tensor -> fused output
         self.op_map: Dict[Operation, FusedNode] = {}    # original op -> fused node (control)
+        # a whole-step node that MAY replace several fused nodes at once: (node, tensor
+        # replacements, op replacements, the nodes it makes redundant). The session applies it
+        # and keeps it only if none of the redundant nodes is still reachable from the fetches.
+        self.step_candidate = None
+
+    def with_candidate(self) -> "Rewrite":
+        node, tmap, omap, _internal = self.step_candidate
+        rw = Rewrite()
+        rw.tensor_map = dict(self.tensor_map)
+        rw.tensor_map.update(tmap)
+        rw.op_map = dict(self.op_map)
+        rw.op_map.update(omap)
+        return rw
 
     def resolve(self, t: Tensor) -> Tensor:
         seen = 0
@@ -245,9 +262,64 @@ def _plan_sharding(graph: Graph, ops: Sequence[Operation], fed: Set[Tensor],
             rw.tensor_map[t] = node.outputs[0]
 
 
+def _match_mlp_step(graph, alive, fed, fetched, rw, heads, sgd_node, applies):
+    """The whole training step of a two-layer classifier: ``FusedDense(sigmoid)`` feeding a
+    ``ClassifierHeadTrain`` that carries the gradient back through the sigmoid, the first layer's
+    weight gradient ``MatMul(x, dz1, transpose_a)`` and a ``MultiApplySGD`` over exactly the four
+    parameters. Returns ``(node, tensor replacements, op replacements, redundant nodes)``."""
+    if sgd_node is None or len(heads) != 1 or len(applies) != 4:
+        return None
+    hnode, loss_t, soft_t, acc_t = heads[0]
+    if not hnode.attrs["sigmoid_input"] or hnode.attrs["dloss_const"] is None \
+            or len(hnode.inputs) != 4:
+        return None
+    a_t, w2_t, b2_t, labels = hnode.inputs
+    mapped = rw.tensor_map.get(a_t)
+    if mapped is None or getattr(mapped.op, "type", "") != "FusedDense":
+        return None
+    dense = mapped.op
+    x, w1_t, b1_t = dense.inputs
+    params = [w1_t, b1_t, w2_t, b2_t]
+    if any(t.op.type != "VariableV2" or t.dtype != dtypes.float32 or t in fed for t in params):
+        return None
+    if len({t.op for t in params}) != 4 or x.dtype != dtypes.float32 \
+            or labels.dtype != dtypes.float32:
+        return None
+    by_var = {a.inputs[0].op: a for a in applies}
+    if set(by_var) != {t.op for t in params}:
+        return None
+    g_w1 = by_var[w1_t.op].inputs[1]
+    dw1_op = g_w1.op
+    if dw1_op not in alive or dw1_op.type != "MatMul" or g_w1 in fetched or g_w1 in fed \
+            or not dw1_op.attrs["transpose_a"] or dw1_op.attrs["transpose_b"] \
+            or dw1_op.inputs[0] is not x \
+            or rw.tensor_map.get(dw1_op.inputs[1]) is not hnode.outputs[4]:
+        return None
+    if rw.tensor_map.get(by_var[b1_t.op].inputs[1]) is not hnode.outputs[5] \
+            or rw.tensor_map.get(by_var[w2_t.op].inputs[1]) is not hnode.outputs[2] \
+            or rw.tensor_map.get(by_var[b2_t.op].inputs[1]) is not hnode.outputs[3]:
+        return None
+    outs = [(loss_t.dtype, loss_t.shape), (soft_t.dtype, soft_t.shape)]
+    if acc_t is not None:
+        outs.append((acc_t.dtype, acc_t.shape))
+    node = FusedNode(graph, "MLPTrainStep", "fused_train_step", [x, labels], outs,
+                     {"var_ops": [t.op for t in params],
+                      "learning_rates": [by_var[t.op].attrs["learning_rate"] for t in params],
+                      "counter_increments": list(sgd_node.attrs["counter_increments"]),
+                      "dloss_const": float(hnode.attrs["dloss_const"]),
+                      "emit_accuracy": acc_t is not None,
+                      "parts": (dense, hnode, dw1_op, sgd_node)},
+                     control_inputs=sgd_node.control_inputs, device=sgd_node.device)
+    tmap = {loss_t: node.outputs[0], soft_t: node.outputs[1]}
+    if acc_t is not None:
+        tmap[acc_t] = node.outputs[2]
+    omap = {op: node for op, target in rw.op_map.items() if target is sgd_node}
+    return node, tmap, omap, (dense, hnode, dw1_op, sgd_node)
+
+
 def build_rewrite(graph: Graph, ops: Sequence[Operation], fed: Set[Tensor],
                   fetched: Set[Tensor] = frozenset(), shard_plan=None,
-                  stored_layouts=None, fuse: bool = True) -> Rewrite:
+                  stored_layouts=None, fuse: bool = True, step_fusion: bool = False) -> Rewrite:
     """Find fusable patterns among ``ops`` (the pruned, topologically ordered subgraph)."""
     rw = Rewrite()
     alive = set(ops)
@@ -258,6 +330,7 @@ def build_rewrite(graph: Graph, ops: Sequence[Operation], fed: Set[Tensor],
         return rw
     grad_map = graph.grad_map
     dense_of: Dict[Tensor, FusedNode] = {}     # dense output tensor -> its FusedDense node
+    heads: List[Tuple] = []                    # (ClassifierHeadTrain node, loss, softmax, accuracy)
 
     def only_consumer(t: Tensor, op: Operation) -> bool:
         return all(c is op for c in consumers.get(t, []))
@@ -383,6 +456,8 @@ def build_rewrite(graph: Graph, ops: Sequence[Operation], fed: Set[Tensor],
                     rw.tensor_map[da_t] = hnode.outputs[4]
                 if acc_op is not None:
                     rw.tensor_map[acc_op.outputs[0]] = hnode.outputs[len(outs) - 1]
+                heads.append((hnode, loss_t, soft_t,
+                              acc_op.outputs[0] if acc_op is not None else None))
 
     # -- metric: argmax-compare-mean --------------------------------------------------------
     for op in ops:
@@ -416,4 +491,7 @@ def build_rewrite(graph: Graph, ops: Sequence[Operation], fed: Set[Tensor],
                 delta = src.attrs["value"]
                 node.attrs["counter_increments"].append((op.inputs[0].op, float(delta)))
                 rw.op_map[op] = node
+        if step_fusion and not shard_plan and not stored_layouts:
+            rw.step_candidate = _match_mlp_step(graph, alive, fed, fetched, rw, heads, node,
+                                                applies)
     return rw

@@ -21,6 +21,7 @@ in single-process and collective modes).
 from __future__ import annotations
 
 import contextlib
+import functools
 import os
 import threading
 import time
@@ -86,6 +87,19 @@ class ConfigProto:
                           On (or ``DTF_ALLOW_TORCH_FALLBACK=1``): such a case runs the torch
                           reference kernel and is counted in ``stats["torch_fallbacks"]`` and
                           listed in ``Session.fallback_log``.
+    ``step_fusion``    -- let the planner replace a whole training step it recognises (the
+                          two-layer classifier of the reference: both layers, loss, backward and
+                          the SGD update) by one node of three launches. Default (``None``): on
+                          for GPU sessions; needs ``graph_fusion`` and variables in plain local
+                          storage (no parameter server, no gradient exchange).
+    ``deferred_fetches`` -- captured GPU steps only. Off (default): ``run`` returns when the
+                          step's small results have reached the host, as TensorFlow does. On (or
+                          ``DTF_DEFERRED_FETCHES=1``): ``run`` returns as soon as the step is
+                          enqueued and the small fp32 results (loss, step counter, accuracy) come
+                          back as ``DeferredValue`` objects that wait for the step only when they
+                          are looked at (``float(v)``, ``np.asarray(v)``, arithmetic, printing):
+                          the host prepares the following steps while the GPU runs this one, up
+                          to a ring of 16 steps ahead.
     ``allow_soft_placement`` / ``log_device_placement`` -- accepted for compatibility.
     """
 
@@ -95,7 +109,11 @@ class ConfigProto:
                  grad_aggregation: Optional[str] = None,
                  capture_collectives: Optional[bool] = None,
                  grad_bucket_bytes: Optional[int] = None, matmul_sharding: Optional[str] = None,
-                 shard_variables: bool = True, allow_torch_fallback: Optional[bool] = None):
+                 shard_variables: bool = True, allow_torch_fallback: Optional[bool] = None,
+                 step_fusion: Optional[bool] = None, deferred_fetches: Optional[bool] = None):
+        self.step_fusion = step_fusion
+        self.deferred_fetches = bool(os.environ.get("DTF_DEFERRED_FETCHES")) \
+            if deferred_fetches is None else bool(deferred_fetches)
         self.allow_torch_fallback = bool(os.environ.get("DTF_ALLOW_TORCH_FALLBACK")) \
             if allow_torch_fallback is None else bool(allow_torch_fallback)
         self.matmul_sharding = matmul_sharding
@@ -152,6 +170,12 @@ class ExecContext:
         self.const_cache: Dict[Any, torch.Tensor] = {}
         self.buffers: Dict[Any, torch.Tensor] = {}     # per-node scratch with stable addresses
         self.out_hint: Optional[Dict[int, torch.Tensor]] = None   # placed outputs of this step
+        # while a step is being captured: its ring (ops.hip.RingArgs), the table entry of every
+        # fed tensor that is read through the ring instead of being gathered, and the request of
+        # the session to have the step's small results gathered by the node that ends the step
+        self.ring = None
+        self.ring_feeds: Dict[int, int] = {}
+        self.pack_request = None
         self._nd_seed = int.from_bytes(os.urandom(4), "little")
 
     def note_fallback(self, op, why: str = "") -> None:
@@ -248,27 +272,154 @@ class ExecutionPlan:
         self.runs = 0
 
 
+class _StepRing:
+    """Host side of a captured step's ring (``csrc/kernels/step_ring.h``): per slot the feed
+    addresses of one replay (pinned table the kernels read) and its packed small results
+    (pinned buffer the step's last kernel writes and stamps). ``launched`` counts replays and is,
+    in stream order, what the device's own counter holds: replay ``n`` uses slot ``n % SLOTS``."""
+
+    SLOTS = 16
+
+    def __init__(self, device: torch.device):
+        from ..ops import hip
+        n = self.SLOTS
+        self.table = torch.zeros(n * hip.RING_FEEDS, dtype=torch.int64).pin_memory()
+        self.table_np = self.table.numpy().reshape(n, hip.RING_FEEDS)
+        self.out = torch.zeros(n * hip.RING_WORDS, dtype=torch.float32).pin_memory()
+        self.out_np = self.out.numpy().reshape(n, hip.RING_WORDS)
+        self.ctr = torch.zeros(2, dtype=torch.int32, device=device)
+        self.args = hip.RingArgs(self.table, self.ctr, self.out, n)
+        self.words = hip.RING_WORDS
+        self.launched = 0
+        self.pending: List[Optional["_PendingStep"]] = [None] * n
+        self.live: List[Any] = [None] * n         # feed sources of the replay in each slot
+        self.skip_spin = 0                        # replays left that block without polling
+
+    @staticmethod
+    def stamp(n: int) -> float:
+        return float((n & 0x7fffff) + 1)
+
+
+class _PendingStep:
+    """The small results of replay ``n``: still in the ring until ``resolve`` copies them out."""
+
+    __slots__ = ("ring", "n", "slot", "words", "stream", "snap", "lock")
+
+    def __init__(self, ring: _StepRing, n: int, slot: int, words: int, stream):
+        self.ring, self.n, self.slot, self.words, self.stream = ring, n, slot, words, stream
+        self.snap = None
+        self.lock = threading.Lock()
+
+    def resolve(self):
+        if self.snap is not None:
+            return self.snap
+        with self.lock:
+            if self.snap is not None:
+                return self.snap
+            ring = self.ring
+            row, want = ring.out_np[self.slot], _StepRing.stamp(self.n)
+            last = ring.words - 1
+            done = row[last] == want
+            if ring.skip_spin > 0:
+                ring.skip_spin -= 1              # a long step: block right away for a while
+            elif not done and not _NO_SPIN_FETCH:
+                # the step's last kernel stamps the slot behind the packed values: poll it for a
+                # bounded time (a short step finishes well inside it; the wake-up of a stream
+                # synchronisation costs several microseconds)
+                deadline = time.perf_counter() + _SPIN_SECS
+                while True:
+                    if row[last] == want:
+                        done = True
+                        break
+                    if time.perf_counter() > deadline:
+                        ring.skip_spin = 64
+                        break
+            if not done:
+                self.stream.synchronize()
+                if row[last] != want:
+                    raise RuntimeError("captured step %d finished without stamping its results "
+                                       "(slot %d holds %r, expected %r)"
+                                       % (self.n, self.slot, float(row[last]), want))
+            self.snap = row[:self.words].copy()  # one copy out of the pinned buffer
+            return self.snap
+
+    def value(self, off: int, n: int, shape: tuple):
+        snap = self.resolve()
+        return snap[off:off + n].reshape(shape) if shape else snap[off]
+
+
+class _PackRequest:
+    """What the session asks of a node that ends a captured step and can gather the step's small
+    results itself: ``parts_for`` lists them (fp32, at most 64 words each), ``claim`` says the
+    node does it -- the session then adds no gather launch of its own."""
+
+    def __init__(self, want: List[int], vals: List[Any], step: "_Step", limit: int):
+        self.want, self.vals, self.step, self.limit = want, vals, step, limit
+        self.claimed = False
+        self.packed: List[Tuple[int, int, tuple, torch.Tensor]] = []
+        self._candidate: List[Tuple[int, int, tuple, torch.Tensor]] = []
+
+    def parts_for(self, node, outs: Sequence[Any]) -> Optional[List[torch.Tensor]]:
+        if node is not self.step.node:
+            return None
+        mine = dict(zip(self.step.out_slots, outs))
+        self._candidate = _packable([(sl, self.vals[sl] if self.vals[sl] is not None
+                                      else mine.get(sl)) for sl in dict.fromkeys(self.want)],
+                                    self.limit)
+        return [p[3] for p in self._candidate]
+
+    def claim(self) -> None:
+        self.packed, self.claimed = self._candidate, True
+
+
+def _packable(pairs, limit: int):
+    """(slot, offset, shape, tensor) of the values that travel in a ring slot: small contiguous
+    fp32 GPU tensors, up to 16 of them, ``limit`` words in all."""
+    packed, off = [], 0
+    for sl, v in pairs:
+        if (isinstance(v, torch.Tensor) and v.is_cuda and v.dtype == torch.float32
+                and v.is_contiguous() and 0 < v.numel() <= 64 and off + v.numel() <= limit
+                and len(packed) < 16):
+            packed.append((sl, off, tuple(v.shape), v))
+            off += v.numel()
+    return packed
+
+
 class _CapturedStep:
     """One HIP-graph instantiation of a plan for fixed feed shapes."""
 
     def __init__(self):
         self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.ring: Optional[_StepRing] = None
         self.static_feeds: List[torch.Tensor] = []
-        self.host_buf: Optional[torch.Tensor] = None      # pinned staging for packed scalars
-        self.host_np = None                               # numpy view of host_buf
+        self.use_table = False                            # feeds travel as addresses in the ring
+        self.pinned: List[Any] = []                       # staging of host feeds
+        self.h2d_done: Optional[torch.cuda.Event] = None
         self.host_words = 0
         self.layout: List[Tuple[int, int, tuple, int]] = []   # (slot, offset, shape, numel)
         self.slot_values: List[Any] = []
         self.generation = 0                               # variable-store generation at capture
-        self.feed_table: Optional[torch.Tensor] = None    # pinned int64: current feed addresses
-        self.feed_table_np = None
-        self.live_feeds: Any = None
-        self.table_read: Optional[torch.cuda.Event] = None
-        self.seq: Optional[torch.Tensor] = None           # pinned word: number of the replay
-        self.seq_np = None
-        self.seq_val = 0
-        self.signalled = False                            # the gather kernel echoes seq
-        self.skip_spin = 0                                # replays left that block without polling
+        self.launches = 0                                 # kernel launches recorded per replay
+
+
+class _DeferredHost:
+    """The host phase (summaries) of a step whose inputs are still on their way."""
+
+    def __init__(self, session: "Session", plan: ExecutionPlan, slot_vals: Dict[int, Any]):
+        self.session, self.plan, self.slot_vals = session, plan, slot_vals
+        self.out: Optional[Dict[int, Any]] = None
+        self.lock = threading.Lock()
+
+    def get(self, sl: int):
+        with self.lock:
+            if self.out is None:
+                self.out = self.session._run_host_phase(self.plan, self.slot_vals, None)
+                self.slot_vals = None
+        return self.out[sl]
+
+
+_DEFERRABLE_HOST_OPS = frozenset(("ScalarSummary", "MergeSummary"))
+_RING_READERS = frozenset(("MLPTrainStep",))   # node types that read fed tensors through the ring
 
 
 _default_session = threading.local()
@@ -355,6 +506,8 @@ class Session:
             fn(self)
         self._closed = True
         for plan in self._plans.values():
+            for cap in plan.graphs.values():
+                self._retire(cap)        # results still in a ring outlive the session
             plan.graphs.clear()
         self._plans.clear()
 
@@ -443,9 +596,18 @@ class Session:
         if self.config.graph_fusion or shard_plan or stored:
             rw = fusion.build_rewrite(self.graph, sorted(order, key=lambda o: o.id), fed_set,
                                       fetched_tensors, shard_plan=shard_plan,
-                                      stored_layouts=stored, fuse=self.config.graph_fusion)
+                                      stored_layouts=stored, fuse=self.config.graph_fusion,
+                                      step_fusion=self._step_fusion())
             if rw.tensor_map or rw.op_map:
                 order = prune(rw)
+            if rw.step_candidate is not None:
+                # a whole-step node stands only if it makes every node it replaces unreachable
+                # (nothing fetched, and no other op, still needs one of their values)
+                rw2 = rw.with_candidate()
+                order2 = prune(rw2)
+                redundant = set(rw.step_candidate[3])
+                if not any(n in redundant for n in order2):
+                    rw, order = rw2, order2
 
         plan = ExecutionPlan()
         slot_of: Dict[Tensor, int] = {}
@@ -554,6 +716,19 @@ class Session:
                 if src.grad_views is None:
                     src.grad_views = {}
                 src.grad_views[idx] = name
+
+    def _step_fusion(self) -> bool:
+        """Whole-step nodes update variables in place with their own kernels: only where every
+        variable is plain local storage (no parameter server, no gradient exchange)."""
+        want = self.config.step_fusion
+        if want is None:
+            want = self.device.type == "cuda"
+        if not (self.config.graph_fusion and want):
+            return False
+        if self._runtime is None:
+            return True
+        from ..parallel.runtime import LocalRuntime
+        return type(self._runtime) is LocalRuntime
 
     def _capture_collectives(self) -> bool:
         want = self.config.capture_collectives
@@ -799,13 +974,16 @@ class Session:
 
         host_out: Dict[int, Any] = {}
         if plan.host_steps:
-            hv: List[Any] = [None] * plan.num_slots
-            for sl in plan.host_input_slots:
-                hv[sl] = self._to_host(slot_vals[sl])
-            self._run_steps(plan.host_steps, hv, trace)
-            for s in plan.host_steps:
-                for sl in s.out_slots:
-                    host_out[sl] = hv[sl]
+            from .deferred import DeferredValue
+            if (any(isinstance(slot_vals[sl], DeferredValue) for sl in plan.host_input_slots)
+                    and trace is None
+                    and all(st.node.type in _DEFERRABLE_HOST_OPS for st in plan.host_steps)):
+                lazy = _DeferredHost(self, plan, slot_vals)
+                for st in plan.host_steps:
+                    for sl in st.out_slots:
+                        host_out[sl] = DeferredValue(functools.partial(lazy.get, sl))
+            else:
+                host_out = self._run_host_phase(plan, slot_vals, trace)
         if trace is not None:
             stats = trace.finish()               # the one synchronisation of a traced run
             if run_metadata is not None:
@@ -814,6 +992,15 @@ class Session:
                    (host_out[sl] if sl in host_out else self._to_host(slot_vals[sl]))
                    for sl in plan.fetch_slots]
         return self._unflatten(structure, results)
+
+    def _run_host_phase(self, plan: ExecutionPlan, slot_vals: Dict[int, Any],
+                        trace) -> Dict[int, Any]:
+        from .deferred import resolve
+        hv: List[Any] = [None] * plan.num_slots
+        for sl in plan.host_input_slots:
+            hv[sl] = self._to_host(resolve(slot_vals[sl]))
+        self._run_steps(plan.host_steps, hv, trace)
+        return {sl: hv[sl] for st in plan.host_steps for sl in st.out_slots}
 
     def _fetch_ahead_addends(self, sgd_node, parts: List[torch.Tensor],
                              fetched: List[Any]) -> Optional[List[float]]:
@@ -903,19 +1090,19 @@ class Session:
 
     # -- HIP-graph path --------------------------------------------------------------------
     def _run_captured(self, plan: ExecutionPlan, feeds: List[Any]):
-        # every input already in GPU memory: the graph's first node gathers them itself from a
-        # table of source addresses in pinned memory -- no runtime copy in front of the launch
-        # (small host inputs ride the same way: they are staged in pinned memory, whose address
-        # goes into the table, and the kernel reads them over PCIe -- no copy call either; large
-        # host inputs keep the DMA path)
+        # every input already in GPU memory (or small enough to be read over PCIe from pinned
+        # staging): the step finds them through the ring's address table -- no runtime copy in
+        # front of the launch; large host inputs keep the DMA path
         use_table = (0 < len(feeds) <= 8 and not os.environ.get("DTF_NO_FEED_TABLE")
                      and all((f.numel() > 0) if isinstance(f, torch.Tensor)
                              else (0 < f.nbytes <= _TABLE_HOST_BYTES) for f in feeds))
-        sig = tuple((tuple(f.shape), f.dtype) for f in feeds) + (use_table,)
+        sig = tuple((tuple(f.shape), f.dtype, isinstance(f, torch.Tensor)) for f in feeds) \
+            + (use_table,)
         cap = plan.graphs.get(sig)
         generation = self._local_store.generation
         if cap is not None and cap.generation != generation:
-            cap = None                  # a variable moved to new storage since the capture
+            self._retire(cap)           # a variable moved to new storage since the capture
+            cap = None
         if cap is None:
             dev_feeds = [f if isinstance(f, torch.Tensor) else
                          torch.from_numpy(np.ascontiguousarray(f).reshape(f.shape)).to(self.device)
@@ -923,182 +1110,194 @@ class Session:
             cap = self._capture(plan, dev_feeds, use_table)
             plan.graphs[sig] = cap
             self.stats["captures"] += 1
-        if cap.feed_table is not None:
-            if cap.table_read is not None:
-                cap.table_read.synchronize()     # the previous replay has read its addresses
-            table = cap.feed_table_np
+        ring = cap.ring
+        n = ring.launched
+        slot = n % ring.SLOTS
+        prev = ring.pending[slot]
+        if prev is not None:
+            prev.resolve()                   # replay n - SLOTS is done with this slot: keep its results
+            ring.pending[slot] = None
+        if cap.use_table:
+            row = ring.table_np[slot]
             for i, f in enumerate(feeds):
                 if isinstance(f, torch.Tensor):
-                    table[i] = f.data_ptr()
+                    row[i] = f.data_ptr()
+                    continue
+                pins = cap.pinned[i]
+                if pins is None:
+                    pins = cap.pinned[i] = [None] * ring.SLOTS
+                pin = pins[slot]
+                if pin is None:
+                    static = cap.static_feeds[i]
+                    t = torch.empty(static.shape, dtype=static.dtype, pin_memory=True)
+                    pin = pins[slot] = (t, t.numpy(), t.data_ptr())
+                np.copyto(pin[1], f)
+                row[i] = pin[2]
+            ring.live[slot] = feeds          # the sources stay alive until the slot is reused
+        elif feeds:
+            if cap.h2d_done is not None:
+                cap.h2d_done.synchronize()   # last step's copies have left the pinned buffers
+            staged = False
+            for i, (static, f) in enumerate(zip(cap.static_feeds, feeds)):
+                if isinstance(f, torch.Tensor):
+                    static.copy_(f, non_blocking=True)
                     continue
                 pin = cap.pinned[i]
                 if pin is None:
-                    static = cap.static_feeds[i]
-                    pin = torch.empty(static.shape, dtype=static.dtype, pin_memory=True)
-                    pin = cap.pinned[i] = (pin, pin.numpy(), pin.data_ptr())
-                np.copyto(pin[1], f)
-                table[i] = pin[2]
-            cap.live_feeds = feeds               # the sources stay alive until the step has run
-            feeds = ()
-        if cap.h2d_done is not None:
-            cap.h2d_done.synchronize()       # last step's copies have left the pinned buffers
-        staged = False
-        for i, (static, f) in enumerate(zip(cap.static_feeds, feeds)):
-            if isinstance(f, torch.Tensor):
-                static.copy_(f, non_blocking=True)
-                continue
-            pin = cap.pinned[i]
-            if pin is None:
-                pin = cap.pinned[i] = torch.empty(static.shape, dtype=static.dtype,
-                                                  pin_memory=True)
-            np.copyto(pin.numpy(), f)
-            static.copy_(pin, non_blocking=True)
-            staged = True
-        if staged:
-            if cap.h2d_done is None:
-                cap.h2d_done = torch.cuda.Event()
-            cap.h2d_done.record()
-        if cap.signalled:
-            cap.seq_val = cap.seq_val % 1000000 + 1
-            cap.seq_np[0] = cap.seq_val
+                    pin = cap.pinned[i] = torch.empty(static.shape, dtype=static.dtype,
+                                                      pin_memory=True)
+                np.copyto(pin.numpy(), f)
+                static.copy_(pin, non_blocking=True)
+                staged = True
+            if staged:
+                if cap.h2d_done is None:
+                    cap.h2d_done = torch.cuda.Event()
+                cap.h2d_done.record()
         cap.graph.replay()
+        ring.launched = n + 1
         self.stats["graph_replays"] += 1
-        if cap.feed_table is not None and cap.host_buf is None:
-            # nothing below waits for this step: remember when the table may be rewritten
-            if cap.table_read is None:
-                cap.table_read = torch.cuda.Event()
-            cap.table_read.record()
+        pend = _PendingStep(ring, n, slot, cap.host_words,
+                            torch.cuda.current_stream(self.device))
+        ring.pending[slot] = pend
         out: Dict[int, Any] = {}
-        if cap.host_buf is not None:
-            done = False
-            if cap.skip_spin > 0:
-                cap.skip_spin -= 1               # a long step: block right away for a while
-            elif cap.signalled and not _NO_SPIN_FETCH:
-                # the step's last kernel stores this replay's number behind the packed values:
-                # poll it in pinned memory for a bounded time (a short step finishes well
-                # inside it; the wake-up of a stream synchronisation costs several microseconds)
-                flag, want = cap.host_np, cap.seq_val
-                deadline = time.perf_counter() + _SPIN_SECS
-                while True:
-                    if flag[_PACK_WORDS - 1] == want:
-                        done = True
-                        break
-                    if time.perf_counter() > deadline:
-                        cap.skip_spin = 64
-                        break
-            if not done:
-                torch.cuda.current_stream(self.device).synchronize()
-            snap = cap.host_np[:cap.host_words].copy()      # one copy out of the pinned buffer
-            for slot_idx, off, shape, n in cap.layout:
-                out[slot_idx] = snap[off:off + n].reshape(shape) if shape else snap[off]
+        if cap.layout:
+            if self.config.deferred_fetches:
+                from .deferred import DeferredValue
+                for slot_idx, off, shape, cnt in cap.layout:
+                    out[slot_idx] = DeferredValue(functools.partial(pend.value, off, cnt, shape))
+            else:
+                for slot_idx, off, shape, cnt in cap.layout:
+                    out[slot_idx] = pend.value(off, cnt, shape)
         for sl in list(plan.fetch_slots) + plan.host_input_slots:
             if sl is not None and sl not in out:
                 out[sl] = cap.slot_values[sl]
         return out
 
+    def _retire(self, cap: _CapturedStep) -> None:
+        """Take every outstanding result out of a captured step's ring (before the step is
+        dropped or the session closes)."""
+        if cap.ring is None:
+            return
+        for i, p in enumerate(cap.ring.pending):
+            if p is not None:
+                p.resolve()
+                cap.ring.pending[i] = None
+
     def _capture(self, plan: ExecutionPlan, feeds: List[torch.Tensor],
                  use_table: bool = False) -> _CapturedStep:
+        from ..ops import hip
         cap = _CapturedStep()
         cap.static_feeds = [torch.empty_like(f) for f in feeds]
         cap.pinned = [None] * len(feeds)
-        cap.h2d_done = None
+        cap.use_table = use_table
         for static, f in zip(cap.static_feeds, feeds):
             static.copy_(f)
-        if use_table:
-            cap.feed_table = torch.zeros(8, dtype=torch.int64).pin_memory()
-            cap.feed_table_np = cap.feed_table.numpy()
-            for i, f in enumerate(feeds):        # valid addresses while the capture warms up
-                cap.feed_table_np[i] = f.data_ptr()
-            cap.live_feeds = feeds
-        # small fp32 results (loss, step, accuracy ...) are packed into one pinned buffer by a
-        # gather kernel inside the graph, so a step needs a single stream synchronisation. The
-        # pinned buffer is allocated before capture starts (host allocation is not capturable).
+        ring = cap.ring = _StepRing(self.device)
         want = [sl for sl in plan.fetch_slots if sl is not None] + plan.host_input_slots
-        host_buf = torch.zeros(_PACK_WORDS, dtype=torch.float32).pin_memory()
-        cap.seq = torch.zeros(1, dtype=torch.float32).pin_memory()
+        # feeds that only ring-aware nodes read are not gathered at all: those nodes take the
+        # batch straight from where it lies, through the ring's table
+        feed_slots = [sl for _, sl in plan.feed_slots]
+        direct = bool(use_table and feeds and not os.environ.get("DTF_NO_RING_READS")
+                      and not any(sl in want for sl in feed_slots)
+                      and all(st.node.type in _RING_READERS for st in plan.steps
+                              if any(sl in st.in_slots for sl in feed_slots)))
+        ctx = self._ctx
         torch.cuda.synchronize(self.device)
         graph = torch.cuda.CUDAGraph()
         vals: List[Any] = [None] * plan.num_slots
+        packed: List[Tuple[int, int, tuple, torch.Tensor]] = []
+        limit = ring.words - 1
         # (thread-local capture mode: a service thread's host allocation or copy during this
         # capture must not invalidate it)
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-            if cap.feed_table is not None:
-                from ..ops import hip
-                hip.gather_feeds(cap.feed_table, cap.static_feeds)
-            for (_, sl), v in zip(plan.feed_slots, cap.static_feeds):
-                vals[sl] = v
-            # A step that ends in the fused optimizer launch: nothing that is fetched depends on
-            # it except the step counters it bumps, and their new value is known beforehand
-            # (old + increment). The gather of the small results -- with that increment added --
-            # then runs BEFORE the optimizer launch: the host has its results while the GPU still
-            # applies the update, and prepares the next step in that time.
-            # (Variable reads scheduled behind the update return the live storage; they may run
-            # first as long as that is what they return.)
-            k = max((i for i, st in enumerate(plan.steps) if st.node.type == "MultiApplySGD"),
-                    default=-1)
-            held = None                              # (optimizer step, reads behind it)
-            if (k >= 0 and not _NO_FETCH_AHEAD
-                    and all(st.node.type == "VariableV2" for st in plan.steps[k + 1:])):
-                # the gather can move further up: behind the last step that produces something
-                # fetched, provided nothing between there and the optimizer writes in place
-                reads = plan.steps[k + 1:]
-                from_reads = {sl for st in reads for sl in st.out_slots}
-                made_at = {sl: i for i, st in enumerate(plan.steps[:k]) for sl in st.out_slots}
-                j = 1 + max((made_at.get(sl, -1) for sl in want if sl not in from_reads),
-                            default=-1)
-                if any(st.node.type in _MUTATING_OPS for st in plan.steps[j:k]):
-                    j = k
-                held = (plan.steps[k], reads, plan.steps[j:k])
-                self._run_steps(plan.steps[:j], vals)
-                self._run_steps(reads, vals)
-            else:
-                self._run_steps(plan.steps, vals)
-            packed = []
-            off = 0
-            for sl in dict.fromkeys(want):
-                v = vals[sl]
-                if (isinstance(v, torch.Tensor) and v.dtype == torch.float32
-                        and v.numel() <= 64 and off + v.numel() <= _PACK_WORDS):
-                    packed.append((sl, off, v.shape, v.dtype, v))
-                    off += v.numel()
-            packed = packed[:16]
-            adds = None
-            if held is not None:
-                live_reads = True
-                for st in held[1]:
-                    fast = getattr(self._store_for(st.node), "local_tensor", None)
-                    live = fast(st.node.name) if fast is not None else None
-                    out_t = vals[st.out_slots[0]] if st.out_slots else None
-                    if live is None or not isinstance(out_t, torch.Tensor) \
-                            or out_t.data_ptr() != live.data_ptr():
-                        live_reads = False
-                if live_reads:
-                    adds = self._fetch_ahead_addends(held[0].node, [p[4] for p in packed],
-                                                     [vals[sl] for sl in dict.fromkeys(want)])
-                if adds is None:       # something fetched is touched by the update: usual order
-                    self._run_steps(held[2], vals)
-                    self._run_steps([held[0]], vals)
-                    self._run_steps(held[1], vals)
-                    packed = [(sl, o, shape, dt, vals[sl]) for sl, o, shape, dt, _ in packed]
-            if packed:
-                from ..ops import hip
-                off = sum(p[4].numel() for p in packed)
-                # one gather launch whose stores go straight into the pinned host buffer
-                # (the last word of the buffer is the completion word the host polls)
-                hip.pack_f32([p[4] for p in packed], host_buf,
-                             signal=(cap.seq, _PACK_WORDS - 1) if off < _PACK_WORDS else None,
-                             adds=adds)
-            if adds is not None:
-                self._run_steps(held[2], vals)
-                self._run_steps([held[0]], vals)
-            if packed:
-                cap.signalled = off < _PACK_WORDS
-                cap.seq_np = cap.seq.numpy()
-                cap.host_buf = host_buf
-                cap.host_np = host_buf.numpy()
-                cap.host_words = off
-                cap.layout = [(sl, o, tuple(shape), int(v.numel()))
-                              for sl, o, shape, _dt, v in packed]
+        try:
+            ctx.ring = ring.args
+            ctx.ring_feeds = {t.data_ptr(): i for i, t in enumerate(cap.static_feeds)} \
+                if direct else {}
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                if use_table and not direct:
+                    hip.gather_feeds_ring(ring.args, cap.static_feeds)
+                for (_, sl), v in zip(plan.feed_slots, cap.static_feeds):
+                    vals[sl] = v
+                steps = plan.steps
+                # trailing variable reads return the live storage; they may run ahead of a step
+                # that ends the plan by updating those variables
+                k = max((i for i, st in enumerate(steps) if st.node.type != "VariableV2"),
+                        default=-1)
+                reads = steps[k + 1:]
+
+                def live_reads() -> bool:
+                    for st in reads:
+                        fast = getattr(self._store_for(st.node), "local_tensor", None)
+                        live = fast(st.node.name) if fast is not None else None
+                        out_t = vals[st.out_slots[0]] if st.out_slots else None
+                        if live is None or not isinstance(out_t, torch.Tensor) \
+                                or out_t.data_ptr() != live.data_ptr():
+                            return False
+                    return True
+
+                done = False
+                if k >= 0 and steps[k].node.type in _RING_READERS and not _NO_FETCH_AHEAD:
+                    # a whole-step node ends the plan: it gathers the small results itself,
+                    # in the workgroup that finishes loss, accuracy and the step counters
+                    self._run_steps(steps[:k], vals)
+                    self._run_steps(reads, vals)
+                    if live_reads():
+                        req = ctx.pack_request = _PackRequest(want, vals, steps[k], limit)
+                        try:
+                            self._run_steps([steps[k]], vals)
+                        finally:
+                            ctx.pack_request = None
+                        if req.claimed:
+                            packed = req.packed
+                        else:
+                            packed = _packable([(sl, vals[sl]) for sl in dict.fromkeys(want)],
+                                               limit)
+                            hip.pack_f32_ring([p[3] for p in packed], ring.args)
+                    else:
+                        self._run_steps([steps[k]], vals)
+                        self._run_steps(reads, vals)
+                        packed = _packable([(sl, vals[sl]) for sl in dict.fromkeys(want)], limit)
+                        hip.pack_f32_ring([p[3] for p in packed], ring.args)
+                    done = True
+                elif k >= 0 and steps[k].node.type == "MultiApplySGD" and not _NO_FETCH_AHEAD:
+                    # A step that ends in the fused optimizer launch: nothing that is fetched
+                    # depends on it except the step counters it bumps, and their new value is
+                    # known beforehand (old + increment). The gather of the small results -- with
+                    # that increment added -- then runs BEFORE the optimizer launch: the host has
+                    # its results while the GPU still applies the update. The gather can move
+                    # further up: behind the last step that produces something fetched, provided
+                    # nothing between there and the optimizer writes in place.
+                    from_reads = {sl for st in reads for sl in st.out_slots}
+                    made_at = {sl: i for i, st in enumerate(steps[:k]) for sl in st.out_slots}
+                    j = 1 + max((made_at.get(sl, -1) for sl in want if sl not in from_reads),
+                                default=-1)
+                    if any(st.node.type in _MUTATING_OPS for st in steps[j:k]):
+                        j = k
+                    self._run_steps(steps[:j], vals)
+                    self._run_steps(reads, vals)
+                    adds = None
+                    if live_reads():
+                        packed = _packable([(sl, vals[sl]) for sl in dict.fromkeys(want)], limit)
+                        adds = self._fetch_ahead_addends(steps[k].node, [p[3] for p in packed],
+                                                         [vals[sl] for sl in dict.fromkeys(want)])
+                    if adds is not None:
+                        hip.pack_f32_ring([p[3] for p in packed], ring.args, adds=adds)
+                        self._run_steps(steps[j:k + 1], vals)
+                        done = True
+                    else:             # something fetched is touched by the update: usual order
+                        self._run_steps(steps[j:k + 1], vals)
+                        self._run_steps(reads, vals)
+                else:
+                    self._run_steps(steps, vals)
+                if not done:
+                    packed = _packable([(sl, vals[sl]) for sl in dict.fromkeys(want)], limit)
+                    hip.pack_f32_ring([p[3] for p in packed], ring.args)
+        finally:
+            ctx.ring = None
+            ctx.ring_feeds = {}
+            ctx.pack_request = None
+        cap.host_words = sum(p[3].numel() for p in packed)
+        cap.layout = [(sl, off, shape, int(v.numel())) for sl, off, shape, v in packed]
         cap.graph = graph
         cap.slot_values = vals
         cap.generation = self._local_store.generation

@@ -1,0 +1,543 @@
+// Body of the fp32 MFMA GEMM (see gemm_f32.hip for the design): one workgroup's share of
+// C = act(op(A) * op(B) + bias) as a device function, so that kernels which do more than one
+// thing per launch -- the MLP step kernels in mlp_step.hip run a weight-gradient product next to
+// the small-parameter update -- use the same code, instruction for instruction, as the plain
+// product.
+#pragma once
+
+#include <type_traits>
+
+#include "common.h"
+
+namespace dtf_gemm {
+
+constexpr int BK = 16;
+constexpr int NTHREADS = 256;
+
+struct GemmF32Args {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;
+  int M, N, K;
+  long lda, ldb, ldc;
+  int a_vec, b_vec, act, tiles_n, ntiles, splits, kchunk;
+  float* partial;
+  float lr;            // EPI == 1 only
+};
+
+
+template <int BT, bool KCONTIG>
+struct Loader {
+  static constexpr int LD = KCONTIG ? BT + 2 : BT;
+  static constexpr int PER_THREAD = (BT * BK / 4) / NTHREADS;
+  static_assert(PER_THREAD >= 1, "tile too small for 256 threads");
+
+  // X(t, k) = X[t * ld + k] when KCONTIG, X[k * ld + t] otherwise
+  __device__ static void fetch(f32x4 (&regs)[PER_THREAD], const float* __restrict__ X, long ld,
+                               int t0, int k0, int T, int K, bool vec_ok, int tid) {
+#pragma unroll
+    for (int i = 0; i < PER_THREAD; ++i) {
+      const int idx = tid + i * NTHREADS;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (KCONTIG) {
+        const int t = idx >> 2, k4 = idx & 3;
+        const int gt = t0 + t, gk = k0 + 4 * k4;
+        if (gt < T && gk < K) {
+          const float* p = X + (long)gt * ld + gk;
+          if (vec_ok && gk + 3 < K) {
+            v = *reinterpret_cast<const f32x4*>(p);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (gk + j < K) v[j] = p[j];
+          }
+        }
+      } else {
+        constexpr int V = BT / 4;
+        const int k = idx / V, t4 = idx % V;
+        const int gk = k0 + k, gt = t0 + 4 * t4;
+        if (gk < K && gt < T) {
+          const float* p = X + (long)gk * ld + gt;
+          if (vec_ok && gt + 3 < T) {
+            v = *reinterpret_cast<const f32x4*>(p);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (gt + j < T) v[j] = p[j];
+          }
+        }
+      }
+      regs[i] = v;
+    }
+  }
+
+  // Branch-free fetch for 16-byte-aligned operands (ld % 4 == 0, aligned base, K % 4 == 0 when
+  // KCONTIG, T % 4 == 0 otherwise): every lane loads one aligned f32x4 from a CLAMPED address --
+  // rows / k-rows past the edge re-read the last valid one -- and elements with k >= k_end are
+  // zeroed by selects. Out-of-range rows only feed outputs the epilogue drops. With no branch
+  // around the loads the compiler can count them (s_waitcnt vmcnt(N)), which is what lets
+  // loads stay in flight across several K-tiles.
+  __device__ static void fetch_fast(f32x4 (&regs)[PER_THREAD], const float* __restrict__ X,
+                                    long ld, int t0, int k0, int T, int k_end, int tid) {
+#pragma unroll
+    for (int i = 0; i < PER_THREAD; ++i) {
+      const int idx = tid + i * NTHREADS;
+      if (KCONTIG) {
+        const int t = idx >> 2, k4 = idx & 3;
+        int gt = t0 + t;
+        gt = gt < T - 1 ? gt : T - 1;
+        const int gk = k0 + 4 * k4;                      // multiple of 4; k_end is too
+        const int ck = gk < k_end - 4 ? gk : k_end - 4;
+        f32x4 v = *reinterpret_cast<const f32x4*>(X + (long)gt * ld + ck);
+        regs[i] = gk < k_end ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      } else {
+        constexpr int V = BT / 4;
+        const int k = idx / V, t4 = idx % V;
+        int gt = t0 + 4 * t4;
+        gt = gt < T - 4 ? gt : T - 4;
+        const int gk = k0 + k;
+        const int ck = gk < k_end - 1 ? gk : k_end - 1;
+        f32x4 v = *reinterpret_cast<const f32x4*>(X + (long)ck * ld + gt);
+        regs[i] = gk < k_end ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  }
+
+  // Interior K-tiles (k0 + BK <= k_end) of aligned operands need neither the k clamp nor the
+  // zero select, and what is left of the address -- the lane's row (clamped at the edge) times
+  // the leading dimension plus its 16-byte column -- does not change from tile to tile. The
+  // lane part is computed once as a 32-bit byte offset and the tile part is a wave-uniform base
+  // advanced on the scalar unit, so an interior fetch is a buffer load with no vector ALU work
+  // (recomputing row * ld in 64 bits per tile cost more issue time than the tile's MFMAs leave).
+  // Needs BT * ld * 4 (KCONTIG) or BK * ld * 4 bytes below 4 GiB.
+  __device__ static void lane_offsets(unsigned (&voff)[PER_THREAD], long ld, int t0, int T,
+                                      int tid) {
+#pragma unroll
+    for (int i = 0; i < PER_THREAD; ++i) {
+      const int idx = tid + i * NTHREADS;
+      if (KCONTIG) {
+        const int t = idx >> 2, k4 = idx & 3;
+        int gt = t0 + t;
+        gt = gt < T - 1 ? gt : T - 1;
+        voff[i] = (unsigned)(gt - t0) * (unsigned)(ld * 4) + 16u * k4;
+      } else {
+        constexpr int V = BT / 4;
+        const int k = idx / V, t4 = idx % V;
+        const int tb = t0 < T - 4 ? t0 : T - 4;
+        int gt = t0 + 4 * t4;
+        gt = gt < T - 4 ? gt : T - 4;
+        voff[i] = (unsigned)k * (unsigned)(ld * 4) + 4u * (gt - tb);
+      }
+    }
+  }
+
+  // wave-uniform address of element (row t0, k = k0) -- KCONTIG -- or (k-row k0, column
+  // min(t0, T - 4)) of the tile
+  __device__ static const float* tile_base(const float* __restrict__ X, long ld, int t0, int T,
+                                           int k0) {
+    if (KCONTIG) return X + (long)t0 * ld + k0;
+    return X + (long)k0 * ld + (t0 < T - 4 ? t0 : T - 4);
+  }
+
+  __device__ static void fetch_interior(f32x4 (&regs)[PER_THREAD], const float* base,
+                                        const unsigned (&voff)[PER_THREAD]) {
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0xffffffff, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < PER_THREAD; ++i) {
+      const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[i], 0, 0);
+      regs[i] = __builtin_bit_cast(f32x4, v);
+    }
+  }
+
+  __device__ static void stash(const f32x4 (&regs)[PER_THREAD], float* __restrict__ Xs, int tid) {
+#pragma unroll
+    for (int i = 0; i < PER_THREAD; ++i) {
+      const int idx = tid + i * NTHREADS;
+      if (KCONTIG) {
+        const int t = idx >> 2, k4 = idx & 3;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Xs[(4 * k4 + j) * LD + t] = regs[i][j];
+      } else {
+        constexpr int V = BT / 4;
+        const int k = idx / V, t4 = idx % V;
+        *reinterpret_cast<f32x4*>(&Xs[k * LD + 4 * t4]) = regs[i];
+      }
+    }
+  }
+};
+
+// ABL (timing experiments, -DDTF_GEMM_EXPERIMENTS only; results are wrong when set): bit 0 = no
+// global loads in the K loop, bit 1 = no LDS stash, bit 2 = no barrier, bit 3 = no fragment reads
+// EPI: 0 = C = act(acc + bias) (or the split's partial plane), 1 = C = fma(-lr, acc, C): the
+// product is a gradient and C the variable it updates in place (plain SGD in the epilogue).
+template <int BM, int BN, bool A_KC, bool B_KC, int ABL = 0, int EPI = 0>
+__device__ __forceinline__ void gemm_f32_block(const GemmF32Args& p, const int bid) {
+  const float* __restrict__ A = p.A;
+  const float* __restrict__ B = p.B;
+  float* __restrict__ C = p.C;
+  const float* __restrict__ bias = p.bias;
+  const int M = p.M, N = p.N, K = p.K;
+  const long lda = p.lda, ldb = p.ldb, ldc = p.ldc;
+  const int a_vec = p.a_vec, b_vec = p.b_vec, act = p.act, tiles_n = p.tiles_n;
+  const int ntiles = p.ntiles, splits = p.splits, kchunk = p.kchunk;
+  float* __restrict__ partial = p.partial;
+  using LA = Loader<BM, A_KC>;
+  using LB = Loader<BN, B_KC>;
+  constexpr int WM = BM / 2, WN = BN / 2;     // per-wave tile
+  constexpr int TM = WM / 32, TN = WN / 32;   // 32x32 MFMA tiles per wave
+  __shared__ __attribute__((aligned(16))) float smem[2 * BK * (LA::LD + LB::LD)];
+  constexpr int A_BUF = BK * LA::LD, B_BUF = BK * LB::LD;   // floats per buffer
+  float* const As = smem;                                   // As[buf][k][m]
+  float* const Bs = smem + 2 * A_BUF;                       // Bs[buf][k][n]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int split = bid / ntiles;
+  // XCD-aware remap (each XCD's L2 sees a contiguous chunk of the walk) + grouped walk: the
+  // ~32-64 tiles resident on one XCD form a block GROUP tile-rows deep, so they share A and B
+  // panels instead of streaming a whole tile-row of B each
+  const int tile = dtf_xcd_remap(bid % ntiles, ntiles);
+  constexpr int GROUP = 8;
+  const int tiles_m = ntiles / tiles_n;
+  const int per_group = GROUP * tiles_n;
+  const int first_m = (tile / per_group) * GROUP;
+  const int gsize = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
+  const int m0 = (first_m + (tile % per_group) % gsize) * BM;
+  const int n0 = ((tile % per_group) / gsize) * BN;
+  const int k_begin = split * kchunk;                 // kchunk is a multiple of BK
+  const int k_end = (k_begin + kchunk < K) ? k_begin + kchunk : K;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // A wave with a single 32x32 output tile would issue every MFMA on the accumulator the one
+  // before it is still writing; two accumulators (even / odd k-pairs, summed before the epilogue)
+  // keep consecutive MFMAs independent.
+  f32x16 acc_odd[1];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc_odd[0][r] = 0.f;
+
+  const int nkt = (k_end - k_begin + BK - 1) / BK;
+  const int lrow = lane & 31, lk = lane >> 5;
+  // aligned operands take the branch-free loads (block-uniform choice, made once)
+  const bool fast = a_vec != 0 && b_vec != 0 && k_end - k_begin >= 4 &&
+                    lda * 4 * (A_KC ? BM : BK) < (1L << 32) &&
+                    ldb * 4 * (B_KC ? BN : BK) < (1L << 32) &&
+                    (A_KC ? (K & 3) == 0 : ((M & 3) == 0 && M >= 4)) &&
+                    (B_KC ? (K & 3) == 0 : ((N & 3) == 0 && N >= 4));
+
+  // The K loop, instantiated twice (FAST: branch-free loads; otherwise fully predicated ones).
+  auto k_loop = [&](auto fast_tag) {
+    constexpr bool FAST = decltype(fast_tag)::value;
+    constexpr int DEPTH = (BM == 128) ? 3 : 4;        // register sets = K-tiles in flight
+    f32x4 ra[DEPTH][LA::PER_THREAD], rb[DEPTH][LB::PER_THREAD];
+    unsigned voff_a[LA::PER_THREAD], voff_b[LB::PER_THREAD];
+    if (FAST) {
+      LA::lane_offsets(voff_a, lda, m0, M, tid);
+      LB::lane_offsets(voff_b, ldb, n0, N, tid);
+    }
+    // any tile: clamped addresses, zeros beyond k_end (K tail, prefetches past the end)
+    auto fetch_tile = [&](f32x4 (&qa)[LA::PER_THREAD], f32x4 (&qb)[LB::PER_THREAD], int kt) {
+      const int k0 = k_begin + kt * BK;
+      if (FAST) {
+        LA::fetch_fast(qa, A, lda, m0, k0, M, k_end, tid);
+        LB::fetch_fast(qb, B, ldb, n0, k0, N, k_end, tid);
+      } else {
+        LA::fetch(qa, A, lda, m0, k0, M, k_end, a_vec != 0, tid);
+        LB::fetch(qb, B, ldb, n0, k0, N, k_end, b_vec != 0, tid);
+      }
+    };
+    // a tile that lies wholly inside [k_begin, k_end) of aligned operands
+    auto fetch_interior_tile = [&](f32x4 (&qa)[LA::PER_THREAD], f32x4 (&qb)[LB::PER_THREAD],
+                                   int kt) {
+      const int k0 = k_begin + kt * BK;
+      LA::fetch_interior(qa, LA::tile_base(A, lda, m0, M, k0), voff_a);
+      LB::fetch_interior(qb, LB::tile_base(B, ldb, n0, N, k0), voff_b);
+    };
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u) fetch_tile(ra[u], rb[u], u);   // tiles past the end: zeros
+    LA::stash(ra[0], As, tid);
+    LB::stash(rb[0], Bs, tid);
+    __syncthreads();
+
+    // MFMA fragments run through a register ring PD k-pairs ahead of the MFMAs and straight
+    // across K-tile boundaries. With one 32x32 tile per wave (64x64 block tile) a k-pair is a
+    // single 64-cycle MFMA, less than an LDS round trip with four waves reading: PD = 3. The
+    // barrier of a K-tile sits PD k-pairs before its end -- the last point before the ring reads
+    // the next tile's buffer -- so the waves meet in mid-stream with MFMAs still queued, not at
+    // an empty pipe followed by a cold fragment read.
+    constexpr int KP = BK / 2;                        // k-pairs per K-tile
+    constexpr int PD = (BM == 128) ? 1 : 3;
+    constexpr int RING = PD + 1;                      // divides KP: slots line up across tiles
+    static_assert(KP % RING == 0, "fragment ring must divide the K-tile");
+    float a[RING][TM], b[RING][TN];
+    auto read_frag = [&](int slot, const float* as, const float* bs, int kp) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[slot][i] = as[(2 * kp + lk) * LA::LD + 32 * i];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[slot][j] = bs[(2 * kp + lk) * LB::LD + 32 * j];
+    };
+#pragma unroll
+    for (int p = 0; p < PD; ++p) read_frag(p, As + wr * WM + lrow, Bs + wc * WN + lrow, p);
+
+    // DEPTH consecutive K-tiles (ring slots 0..DEPTH-1). INTERIOR: every tile of the group, and
+    // the tile each one prefetches, lies wholly inside the K range -- the loads are then buffer
+    // loads with loop-invariant lane offsets. The two kinds of fetch live in separate loops: a
+    // join of paths that issue different loads makes the compiler drain vmcnt to zero before
+    // the next LDS stash, which empties the prefetch ring once per group.
+    auto group = [&](auto interior_tag, int kt0) {
+      constexpr bool INTERIOR = decltype(interior_tag)::value;
+#pragma unroll
+      for (int u = 0; u < DEPTH; ++u) {
+        const int kt = kt0 + u;
+        if (!INTERIOR && kt >= nkt) break;
+        const int cur = kt & 1;
+        // set u held tile kt, already in LDS: refill it with tile kt + DEPTH
+        if (!(ABL & 1)) {
+          if (INTERIOR) fetch_interior_tile(ra[u], rb[u], kt + DEPTH);
+          else fetch_tile(ra[u], rb[u], kt + DEPTH);
+        }
+        const float* as = As + cur * A_BUF + wr * WM + lrow;
+        const float* bs = Bs + cur * B_BUF + wc * WN + lrow;
+        const float* asn = As + (cur ^ 1) * A_BUF + wr * WM + lrow;
+        const float* bsn = Bs + (cur ^ 1) * B_BUF + wc * WN + lrow;
+#pragma unroll
+        for (int kk = 0; kk < KP; ++kk) {
+          if (kk == (KP - PD) / 2 && !(ABL & 2)) {
+            // tile kt+1 (loaded DEPTH-1 tiles ago; zeros past the end) goes into the other LDS
+            // buffer, whose last readers finished before the previous tile's barrier. Neither
+            // this nor the ring's reads below are skipped on the last tile: a branch around LDS
+            // operations would force the compiler to drain lgkmcnt to zero at the join instead
+            // of counting, and every MFMA would then wait for the newest fragment read.
+            LA::stash(ra[(u + 1) % DEPTH], As + (cur ^ 1) * A_BUF, tid);
+            LB::stash(rb[(u + 1) % DEPTH], Bs + (cur ^ 1) * B_BUF, tid);
+          }
+          if (kk == KP - PD && !(ABL & 4)) __syncthreads();
+          {
+            const int pf = kk + PD;
+            if (ABL & 8) {}
+            else if (pf < KP) read_frag(pf % RING, as, bs, pf);
+            else read_frag(pf % RING, asn, bsn, pf - KP);
+          }
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              if (TM * TN == 1 && (kk & 1))
+                acc_odd[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk % RING][i], b[kk % RING][j],
+                                                                  acc_odd[0], 0, 0, 0);
+              else
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk % RING][i], b[kk % RING][j],
+                                                                 acc[i][j], 0, 0, 0);
+            }
+        }
+      }
+    };
+    int kt0 = 0;
+    if constexpr (FAST) {
+      const int n_full = (k_end - k_begin) / BK;
+      for (; kt0 + 2 * DEPTH <= n_full; kt0 += DEPTH) group(std::true_type{}, kt0);
+    }
+    for (; kt0 < nkt; kt0 += DEPTH) group(std::false_type{}, kt0);
+  };
+  if (fast) k_loop(std::true_type{});
+  else k_loop(std::false_type{});
+
+  if (TM * TN == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][0][r] += acc_odd[0][r];
+  }
+  // C/D fragment: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  if (splits > 1) {
+    const long plane = (long)M * N;
+    float* const mine = partial + split * plane;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wc * WN + 32 * j + lrow;
+        if (col >= N) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wr * WM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk;
+          if (row < M) mine[(long)row * N + col] = acc[i][j][r];
+        }
+      }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wc * WN + 32 * j + lrow;
+      if (col >= N) continue;
+      const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wr * WM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (row >= M) continue;
+        float* const c = C + (long)row * ldc + col;
+        if (EPI == 1) *c = __builtin_fmaf(-p.lr, acc[i][j][r], *c);
+        else *c = dtf_apply_act(acc[i][j][r] + bv, act);
+      }
+    }
+}
+
+
+// ---- small products: one 16x16 output tile per workgroup, K split over its four waves ----------
+// A product with few outputs and a long or short K -- a dense layer on a batch of 100, the weight
+// gradient of such a layer -- does not fill the chip with 64x64 tiles, and cutting K into
+// workgroups costs a second launch and a round trip of partial planes through memory. Here a
+// workgroup owns ONE 16x16 tile of C (100x100 outputs: 49 workgroups; 784x100: 343) and its four
+// waves each take a contiguous quarter of K, in units of 16, on the exact-fp32
+// v_mfma_f32_16x16x4_f32 (A[m = l&15][k = l>>4], B[k = l>>4][n = l&15], one VGPR each). Operands
+// go from memory straight into MFMA registers, four 16-wide K-blocks in flight ahead of the
+// MFMAs; there is no LDS staging to wait for and no barrier in the loop. A K-contiguous A is read
+// 16 bytes per lane: lane (m, q) takes A[m][k0 + 4q .. 4q+3] and MFMA j of the block multiplies
+// element j of every lane, i.e. the k's {4q + j}; B is read to match, B[k0 + 4q + j][n]. An
+// M-contiguous A (the transposed operand of a weight gradient) is read one word per lane,
+// A[k0 + 4j + q][m]. The four partial tiles meet in LDS and are summed in wave order, then bias
+// and activation (EPI 0) or the in-place SGD update C = fma(-lr, acc, C) (EPI 1) follow, C's old
+// value having been requested before the K loop. Every sum has a fixed order: results are
+// bit-identical from launch to launch.
+constexpr int SK_T = 16;            // tile edge
+constexpr int SK_U = 4;             // K-blocks of 16 in flight per wave
+
+struct SkinnyFrag {
+  float a[4], b[4];
+};
+
+// B_KC: B is stored [N, K] (the caller's transposed operand)
+template <bool A_KC, bool B_KC>
+__device__ __forceinline__ void skinny_load(SkinnyFrag& f, const float* __restrict__ A,
+                                            const float* __restrict__ B, long lda, long ldb,
+                                            int am, int bn, int kq, int k0, int k_end, bool a_vec,
+                                            bool b_vec) {
+  if (A_KC) {
+    // element j of the lane is k = k0 + 4 kq + j
+    const int k = k0 + 4 * kq;
+    const float* pa = A + (long)am * lda + k;
+    if (a_vec && k + 3 < k_end) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(pa);
+      f.a[0] = v[0]; f.a[1] = v[1]; f.a[2] = v[2]; f.a[3] = v[3];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) f.a[j] = k + j < k_end ? pa[j] : 0.f;
+    }
+    if (B_KC) {
+      const float* pb = B + (long)bn * ldb + k;
+      if (b_vec && k + 3 < k_end) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(pb);
+        f.b[0] = v[0]; f.b[1] = v[1]; f.b[2] = v[2]; f.b[3] = v[3];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f.b[j] = k + j < k_end ? pb[j] : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) f.b[j] = k + j < k_end ? B[(long)(k + j) * ldb + bn] : 0.f;
+    }
+  } else {
+    // element j of the lane is k = k0 + 4 j + kq
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + 4 * j + kq;
+      f.a[j] = k < k_end ? A[(long)k * lda + am] : 0.f;
+      f.b[j] = k < k_end ? (B_KC ? B[(long)bn * ldb + k] : B[(long)k * ldb + bn]) : 0.f;
+    }
+  }
+}
+
+struct SkinnyArgs {
+  const float* A;      // [M, K] (A_KC) or [K, M]
+  const float* B;      // [K, N], or [N, K] (B_KC)
+  float* C;            // [M, N]
+  const float* bias;   // [N] or null (EPI 0)
+  int M, N, K;
+  long lda, ldb, ldc;
+  int act;             // EPI 0
+  float lr;            // EPI 1
+  int tiles_n;
+};
+
+// NW: waves per workgroup (4 or 16). With a long K sixteen waves each take a sixteenth: every wave
+// then has all of its operands in flight at once, one memory round trip instead of several.
+template <bool A_KC, bool B_KC, int EPI, int NW = 4>
+__device__ __forceinline__ void gemm_f32_skinny_block(const SkinnyArgs& p, const int bid) {
+  __shared__ float red[NW][SK_T][SK_T + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = (bid / p.tiles_n) * SK_T, n0 = (bid % p.tiles_n) * SK_T;
+  const int lm = lane & 15, kq = lane >> 4;
+  // rows / columns past the edge re-read the last valid one; their results are dropped
+  const int am = m0 + lm < p.M ? m0 + lm : p.M - 1;
+  const int bn = n0 + lm < p.N ? n0 + lm : p.N - 1;
+  const bool a_vec = A_KC && (p.lda % 4 == 0) && ((uintptr_t)p.A % 16 == 0);
+  const bool b_vec = B_KC && (p.ldb % 4 == 0) && ((uintptr_t)p.B % 16 == 0);
+
+  // the output element this thread finishes: (row, col) = (tid / 16, tid % 16) of the tile
+  const int orow = m0 + ((tid >> 4) & 15), ocol = n0 + (tid & 15);
+  const bool oin = tid < SK_T * SK_T && orow < p.M && ocol < p.N;
+  float c_old = 0.f, bv = 0.f;
+  if (EPI == 1) c_old = oin ? p.C[(long)orow * p.ldc + ocol] : 0.f;
+  else bv = (p.bias && oin) ? p.bias[ocol] : 0.f;
+
+  const int nkb = (p.K + 15) / 16;
+  const int per = (nkb + NW - 1) / NW;
+  const int kb0 = wave * per;
+  const int kb1 = kb0 + per < nkb ? kb0 + per : nkb;
+
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  SkinnyFrag cur[SK_U], nxt[SK_U];
+#pragma unroll
+  for (int u = 0; u < SK_U; ++u)
+    skinny_load<A_KC, B_KC>(cur[u], p.A, p.B, p.lda, p.ldb, am, bn, kq, (kb0 + u) * 16,
+                            kb0 + u < kb1 ? p.K : 0, a_vec, b_vec);
+  for (int kb = kb0; kb < kb1; kb += SK_U) {
+#pragma unroll
+    for (int u = 0; u < SK_U; ++u)
+      skinny_load<A_KC, B_KC>(nxt[u], p.A, p.B, p.lda, p.ldb, am, bn, kq, (kb + SK_U + u) * 16,
+                              kb + SK_U + u < kb1 ? p.K : 0, a_vec, b_vec);
+#pragma unroll
+    for (int u = 0; u < SK_U; ++u) {
+      // (blocks past the wave's range hold zeros: fma(0, 0, acc) leaves acc as it is)
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[u].a[0], cur[u].b[0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[u].a[1], cur[u].b[1], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[u].a[2], cur[u].b[2], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[u].a[3], cur[u].b[3], acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < SK_U; ++u) cur[u] = nxt[u];
+  }
+  // C/D fragment: col = lane & 15, row = 4 * (lane >> 4) + i
+#pragma unroll
+  for (int i = 0; i < 4; ++i) red[wave][4 * kq + i][lm] = acc0[i] + acc1[i];
+  __syncthreads();
+  if (tid >= SK_T * SK_T || !oin) return;
+  const int r = tid >> 4, c = tid & 15;
+  float v = red[0][r][c];                          // wave order
+#pragma unroll
+  for (int w = 1; w < NW; ++w) v += red[w][r][c];
+  float* const out = p.C + (long)orow * p.ldc + ocol;
+  if (EPI == 1) *out = __builtin_fmaf(-p.lr, v, c_old);
+  else *out = dtf_apply_act(v + bv, p.act);
+}
+
+// waves per workgroup the small-product kernel runs with for a given K
+__host__ __device__ inline int gemm_f32_skinny_waves(long K) { return K > 256 ? 16 : 4; }
+
+// 1 when the small-product kernel is the better plan for C[M,N] = op(A)[M,K] * B[K,N]: the
+// 64x64 tiling would leave most of the chip idle and K is short enough for four waves
+__host__ __device__ inline bool gemm_f32_skinny_fits(long M, long N, long K) {
+  const long tiles64 = ((M + 63) / 64) * ((N + 63) / 64);
+  return tiles64 <= 32 && K <= 4096 && M >= 1 && N >= 1 && K >= 1;
+}
+
+}  // namespace dtf_gemm

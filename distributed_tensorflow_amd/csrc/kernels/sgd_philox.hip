@@ -10,6 +10,7 @@
 // * reduce_partials: out = sum of up to 8 partial buffers (the local reduction step of a
 //   direct reduce-scatter over peer-mapped buffers, and of K-sharded GEMM partial sums).
 #include "common.h"
+#include "step_ring.h"
 
 namespace {
 
@@ -40,10 +41,19 @@ __global__ __launch_bounds__(BLOCK) void multi_sgd_kernel(SgdArgs args) {
     const long n4 = t.n >> 2;
     f32x4* w4 = reinterpret_cast<f32x4*>(t.w);
     const f32x4* g4 = reinterpret_cast<const f32x4*>(t.g);
-    for (long i = start; i < n4; i += step) w4[i] -= g4[i] * t.lr;
-    for (long i = (n4 << 2) + start; i < t.n; i += step) t.w[i] -= t.lr * t.g[i];
+    // w = fma(-lr, g, w), one rounding: the update is spelled the same wherever it is applied
+    // (here, and in the epilogues of the kernels that apply a gradient they have just computed)
+    for (long i = start; i < n4; i += step) {
+      const f32x4 g = g4[i];
+      f32x4 w = w4[i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w[j] = __builtin_fmaf(-t.lr, g[j], w[j]);
+      w4[i] = w;
+    }
+    for (long i = (n4 << 2) + start; i < t.n; i += step)
+      t.w[i] = __builtin_fmaf(-t.lr, t.g[i], t.w[i]);
   } else {
-    for (long i = start; i < t.n; i += step) t.w[i] -= t.lr * t.g[i];
+    for (long i = start; i < t.n; i += step) t.w[i] = __builtin_fmaf(-t.lr, t.g[i], t.w[i]);
   }
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < args.num_counters)
     args.counter[threadIdx.x][0] += args.delta[threadIdx.x];
@@ -205,13 +215,25 @@ struct PackArgs {
 // going through a stream synchronisation (whose wake-up costs several microseconds).
 __global__ __launch_bounds__(BLOCK) void pack_f32_kernel(PackArgs args, float* __restrict__ dst,
                                                          const float* __restrict__ seq_src,
-                                                         float* __restrict__ seq_dst) {
+                                                         float* __restrict__ seq_dst,
+                                                         DtfStepRing ring, int ring_first) {
+  // in a ring step the words go to this replay's slot of the ring, the slot's last word is the
+  // replay's stamp, and the launch is the LAST ring kernel of the step: it opens the next replay
+  unsigned seq = 0;
+  if (ring.ctr) {
+    seq = ring_first ? ring.ctr[1] : dtf_ring_current(ring);
+    dst = dtf_ring_out(ring, seq);
+  }
   for (int i = 0; i < args.count; ++i) {
     const int n = args.offset[i + 1] - args.offset[i];
     const float add = args.add[i];
     for (int j = threadIdx.x; j < n; j += BLOCK) dst[args.offset[i] + j] = args.src[i][j] + add;
   }
-  if (seq_dst != nullptr) {
+  if (ring.ctr) {
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) dtf_ring_finish(ring, seq);
+  } else if (seq_dst != nullptr) {
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -237,11 +259,14 @@ struct FeedDst {
 constexpr int FEED_BYTES_PER_BLOCK = BLOCK * 16 * 4;
 
 __global__ __launch_bounds__(BLOCK) void gather_feeds_kernel(
-    const unsigned long long* __restrict__ table, FeedDst args) {
+    const unsigned long long* __restrict__ table, FeedDst args, DtfStepRing ring) {
   int seg = 0;
   while (seg + 1 < args.count && (long)blockIdx.x >= args.first_block[seg + 1]) ++seg;
-  const char* src = reinterpret_cast<const char*>(
-      __builtin_nontemporal_load(table + seg));          // host memory: never from a stale line
+  // in a ring step this is the FIRST kernel of the replay and the table is the ring's
+  const char* src = ring.ctr
+      ? reinterpret_cast<const char*>(dtf_ring_feed(ring, dtf_ring_begin(ring), seg))
+      : reinterpret_cast<const char*>(
+            __builtin_nontemporal_load(table + seg));      // host memory: never from a stale line
   char* dst = args.dst[seg];
   const long n = args.bytes[seg];
   const long base = ((long)blockIdx.x - args.first_block[seg]) * FEED_BYTES_PER_BLOCK;
@@ -301,9 +326,9 @@ DTF_API int dtf_multi_sgd_f32(int count, float* const* w, const float* const* g,
 // dst[i][0..bytes[i]) = (*table[i])[0..bytes[i]) for count <= 8 inputs: `table` holds the source
 // ADDRESSES (64-bit, in pinned host memory or device memory) and is read when the kernel runs,
 // not when it is launched or captured.
-DTF_API int dtf_gather_feeds(const void* table, int count, void* const* dst, const long* bytes,
-                             hipStream_t stream) {
-  if (!table || count < 1 || count > MAX_FEEDS) return DTF_ERR_BAD_ARG;
+static int gather_feeds_launch(const void* table, const DtfStepRing& ring, int count,
+                               void* const* dst, const long* bytes, hipStream_t stream) {
+  if (count < 1 || count > MAX_FEEDS) return DTF_ERR_BAD_ARG;
   FeedDst args = {};
   long blocks = 0;
   for (int i = 0; i < count; ++i) {
@@ -317,12 +342,29 @@ DTF_API int dtf_gather_feeds(const void* table, int count, void* const* dst, con
   args.count = count;
   if (blocks > 0x7fffffffL) return DTF_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(gather_feeds_kernel, dim3((unsigned)blocks), dim3(BLOCK), 0, stream,
-                     (const unsigned long long*)table, args);
+                     (const unsigned long long*)table, args, ring);
   DTF_LAUNCH_CHECK();
   return DTF_OK;
 }
 
-// out[i] = mean + stddev * N(0,1) for stream elements offset .. offset+n (bf16_out: 0/1)
+DTF_API int dtf_gather_feeds(const void* table, int count, void* const* dst, const long* bytes,
+                             hipStream_t stream) {
+  if (!table) return DTF_ERR_BAD_ARG;
+  return gather_feeds_launch(table, DtfStepRing{nullptr, nullptr, nullptr, 0}, count, dst, bytes,
+                             stream);
+}
+
+// The same gather as the FIRST kernel of a ring step (step_ring.h): the source addresses are
+// those of the replay's slot of the ring's table.
+DTF_API int dtf_gather_feeds_ring(const void* ring_table, void* ring_ctr, void* ring_out, int ring,
+                                  int count, void* const* dst, const long* bytes,
+                                  hipStream_t stream) {
+  if (!ring_table || !ring_ctr || ring < 1 || (ring & (ring - 1))) return DTF_ERR_BAD_ARG;
+  const DtfStepRing r{(const unsigned long long*)ring_table, (unsigned*)ring_ctr, (float*)ring_out,
+                      ring};
+  return gather_feeds_launch(ring_table, r, count, dst, bytes, stream);
+}
+
 DTF_API int dtf_philox_normal(void* out, long n, unsigned int seed, unsigned int op_seed,
                               long offset, float mean, float stddev, int bf16_out,
                               hipStream_t stream) {
@@ -398,7 +440,37 @@ DTF_API int dtf_pack_f32_signal(int count, const float* const* src, const int* s
   args.offset[count] = off;
   args.count = count;
   hipLaunchKernelGGL(pack_f32_kernel, dim3(1), dim3(BLOCK), 0, stream, args, dst, seq_src,
-                     seq_dst);
+                     seq_dst, DtfStepRing{nullptr, nullptr, nullptr, 0}, 0);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
+// The same gather as the LAST ring kernel of a captured step (step_ring.h): the words go to the
+// replay's slot of the ring's result buffer, which is then stamped, and the next replay is
+// opened. count may be 0 (a step that returns nothing small still stamps its slot: the host
+// learns from the stamp when the slot's table entries may be rewritten). ring_first: no earlier
+// kernel of the step has published the replay number.
+DTF_API int dtf_pack_f32_ring(int count, const float* const* src, const int* sizes,
+                              const float* adds, const void* ring_table, void* ring_ctr,
+                              void* ring_out, int ring, int ring_first, hipStream_t stream) {
+  if (count < 0 || count > MAX_PACK || !ring_ctr || !ring_out || ring < 1 || (ring & (ring - 1)))
+    return DTF_ERR_BAD_ARG;
+  PackArgs args = {};
+  int off = 0;
+  for (int i = 0; i < count; ++i) {
+    if (!src[i] || sizes[i] < 0) return DTF_ERR_BAD_ARG;
+    args.src[i] = src[i];
+    args.offset[i] = off;
+    args.add[i] = adds ? adds[i] : 0.f;
+    off += sizes[i];
+  }
+  if (off > DTF_RING_WORDS - 1) return DTF_ERR_BAD_ARG;
+  args.offset[count] = off;
+  args.count = count;
+  const DtfStepRing r{(const unsigned long long*)ring_table, (unsigned*)ring_ctr, (float*)ring_out,
+                      ring};
+  hipLaunchKernelGGL(pack_f32_kernel, dim3(1), dim3(BLOCK), 0, stream, args, nullptr, nullptr,
+                     nullptr, r, ring_first);
   DTF_LAUNCH_CHECK();
   return DTF_OK;
 }

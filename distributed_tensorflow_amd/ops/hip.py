@@ -60,6 +60,7 @@ def _declare(L: ctypes.CDLL) -> None:
     sigs = {
         "dtf_gemm_f32": [P, P, P, P, I, I, I, LG, LG, LG, I, I, I, P, I, I, P],
         "dtf_gemm_f32_splits": [I, I, I, P],
+        "dtf_gemm_f32_tile": [I, I, I],
         "dtf_gemm_bf16_nt": [P, P, P, I, I, I, LG, LG, LG, F, F, I, I, P],
         "dtf_gemm_bf16_splits": [I, I, I],
         "dtf_gemm_bf16_nt_splitk": [P, P, P, P, I, I, I, LG, LG, LG, F, F, I, I, P],
@@ -105,6 +106,10 @@ def _declare(L: ctypes.CDLL) -> None:
         "dtf_pack_f32": [I, P, P, P, P],
         "dtf_pack_f32_signal": [I, P, P, P, P, P, P, P],
         "dtf_gather_feeds": [P, I, P, P, P],
+        "dtf_pack_f32_ring": [I, P, P, P, P, P, P, I, I, P],
+        "dtf_gather_feeds_ring": [P, P, P, I, I, P, P, P],
+        "dtf_mlp_step_supported": [LG, LG, LG, LG],
+        "dtf_mlp_step_train": [P, P],
         "dtf_philox_fill_2d": [P, LG, LG, LG, U, U, LG, LG, LG, F, F, I, I, P],
         "dtf_copy_2d": [P, P, LG, LG, LG, LG, P],
         "dtf_assign_add_f32": [P, P, LG, LG, F, P],
@@ -179,9 +184,11 @@ def _aligned(t: torch.Tensor) -> torch.Tensor:
 def gemm_f32(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool = False,
              bias: Optional[torch.Tensor] = None, activation: int = ACT_NONE,
              out: Optional[torch.Tensor] = None, splits: Optional[int] = None,
-             tile: int = 0) -> torch.Tensor:
-    """``act(op(a) @ op(b) + bias)`` on the fp32 MFMA kernel. ``a`` is [M,K] ([K,M] when
-    ``trans_a``), ``b`` is [K,N] ([N,K] when ``trans_b``)."""
+             tile: int = 0, plan_mnk: Optional[Sequence[int]] = None) -> torch.Tensor:
+    """``act(op(a) @ op(b) + bias)`` on the fp32 MFMA kernels. ``a`` is [M,K] ([K,M] when
+    ``trans_a``), ``b`` is [K,N] ([N,K] when ``trans_b``). ``plan_mnk``: choose tile and K split
+    as for a product of THAT shape (with the same K): a row or column block of a larger product
+    then comes out bit-identical to the same block of the whole result."""
     if getattr(a, "dim", lambda: 0)() != 2 or getattr(b, "dim", lambda: 0)() != 2:
         raise HipKernelError("gemm_f32: operands must be rank 2")
     a = _req_rows(a, torch.float32, "gemm_f32 a")
@@ -209,6 +216,12 @@ def gemm_f32(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: b
     ldb = b.stride(0) if b.shape[0] > 1 else b.shape[1]
     ldc = out.stride(0) if m > 1 else n
     partial = None
+    if plan_mnk is not None:
+        pm, pn, pk = (int(v) for v in plan_mnk)
+        if pk != k:
+            raise HipKernelError("gemm_f32: plan_mnk must have the product's own K")
+        tile = L.dtf_gemm_f32_tile(pm, pn, pk)
+        splits = L.dtf_gemm_f32_splits(pm, pn, pk, None)
     if splits is None:
         splits = L.dtf_gemm_f32_splits(m, n, k, None)
     splits = max(1, min(int(splits), 64))
@@ -896,6 +909,214 @@ def gather_feeds(table: torch.Tensor, dsts: Sequence[torch.Tensor]) -> None:
     dst = (ctypes.c_void_p * n)(*[d.data_ptr() for d in dsts])
     nbytes = (ctypes.c_long * n)(*[d.numel() * d.element_size() for d in dsts])
     _check(lib().dtf_gather_feeds(table.data_ptr(), n, dst, nbytes, _stream()), "gather_feeds")
+
+
+RING_FEEDS, RING_WORDS = 8, 256      # step_ring.h: inputs and result words per ring slot
+
+
+class RingArgs:
+    """The device-visible parts of a step ring (``csrc/kernels/step_ring.h``): pinned address
+    table ``[slots, 8]`` int64, device counters ``[2]`` int32, pinned results ``[slots, 256]``
+    fp32. ``first_taken`` records, while a step is being captured, whether an earlier kernel of
+    the step already publishes the replay number."""
+
+    def __init__(self, table: torch.Tensor, ctr: torch.Tensor, out: torch.Tensor, slots: int):
+        if slots < 1 or slots & (slots - 1):
+            raise HipKernelError("step ring: the number of slots must be a power of two")
+        if table.dtype != torch.int64 or not table.is_pinned() or table.numel() != slots * RING_FEEDS \
+                or out.dtype != torch.float32 or not out.is_pinned() \
+                or out.numel() != slots * RING_WORDS or ctr.dtype != torch.int32 \
+                or not ctr.is_cuda or ctr.numel() != 2:
+            raise HipKernelError("step ring: bad buffers")
+        self.table, self.ctr, self.out, self.slots = table, ctr, out, slots
+        self.first_taken = False
+
+    def take_first(self) -> int:
+        first = not self.first_taken
+        self.first_taken = True
+        return int(first)
+
+
+def pack_f32_ring(parts: Sequence[torch.Tensor], ring: RingArgs,
+                  adds: Optional[Sequence[float]] = None) -> List[int]:
+    """``pack_f32`` as the last ring kernel of a captured step: the words go to the replay's
+    slot of ``ring.out``, the slot is stamped and the next replay opened. ``parts`` may be empty."""
+    if len(parts) > 16:
+        raise HipKernelError("pack_f32_ring: at most 16 parts")
+    parts = [_req(p, torch.float32, "pack_f32 part") for p in parts]
+    if sum(p.numel() for p in parts) > RING_WORDS - 1:
+        raise HipKernelError("pack_f32_ring: more than %d words" % (RING_WORDS - 1))
+    n = max(len(parts), 1)
+    src = (ctypes.c_void_p * n)(*[p.data_ptr() for p in parts])
+    sizes = (ctypes.c_int * n)(*[p.numel() for p in parts])
+    add_arr = None
+    if adds is not None:
+        if len(adds) != len(parts):
+            raise HipKernelError("pack_f32_ring: one addend per part")
+        add_arr = (ctypes.c_float * n)(*[float(a) for a in adds])
+    _check(lib().dtf_pack_f32_ring(len(parts), src, sizes, add_arr, ring.table.data_ptr(),
+                                   ring.ctr.data_ptr(), ring.out.data_ptr(), ring.slots,
+                                   ring.take_first(), _stream()), "pack_f32_ring")
+    offsets, off = [], 0
+    for p in parts:
+        offsets.append(off)
+        off += p.numel()
+    return offsets
+
+
+def gather_feeds_ring(ring: RingArgs, dsts: Sequence[torch.Tensor]) -> None:
+    """``gather_feeds`` as the first kernel of a ring step: input i is copied from the address in
+    entry i of the replay's slot of ``ring.table``."""
+    dsts = list(dsts)
+    if not 1 <= len(dsts) <= RING_FEEDS:
+        raise HipKernelError("gather_feeds_ring: 1..8 destinations")
+    for d in dsts:
+        if not (isinstance(d, torch.Tensor) and d.device.type == "cuda" and d.is_contiguous()
+                and d.numel() > 0 and d.data_ptr() % 16 == 0):
+            raise HipKernelError("gather_feeds_ring: destinations must be non-empty contiguous "
+                                 "16-byte aligned GPU tensors")
+    if ring.first_taken:
+        raise HipKernelError("gather_feeds_ring: must be the first ring kernel of the step")
+    ring.first_taken = True
+    n = len(dsts)
+    dst = (ctypes.c_void_p * n)(*[d.data_ptr() for d in dsts])
+    nbytes = (ctypes.c_long * n)(*[d.numel() * d.element_size() for d in dsts])
+    _check(lib().dtf_gather_feeds_ring(ring.table.data_ptr(), ring.ctr.data_ptr(),
+                                       ring.out.data_ptr(), ring.slots, n, dst, nbytes, _stream()),
+           "gather_feeds_ring")
+
+
+class _MlpStep(ctypes.Structure):
+    _fields_ = [("x", ctypes.c_void_p), ("labels", ctypes.c_void_p), ("w1", ctypes.c_void_p),
+                ("b1", ctypes.c_void_p), ("w2", ctypes.c_void_p), ("b2", ctypes.c_void_p),
+                ("B", ctypes.c_long), ("D", ctypes.c_long), ("H", ctypes.c_long),
+                ("C", ctypes.c_long),
+                ("lr_w1", ctypes.c_float), ("lr_b1", ctypes.c_float), ("lr_w2", ctypes.c_float),
+                ("lr_b2", ctypes.c_float), ("dloss", ctypes.c_float),
+                ("loss", ctypes.c_void_p), ("accuracy", ctypes.c_void_p), ("y", ctypes.c_void_p),
+                ("a", ctypes.c_void_p), ("dz1", ctypes.c_void_p),
+                ("head_ws", ctypes.c_void_p),
+                ("ncounters", ctypes.c_int), ("counter", ctypes.c_void_p * 4),
+                ("delta", ctypes.c_float * 4),
+                ("npack", ctypes.c_int), ("pack_src", ctypes.c_void_p * 16),
+                ("pack_size", ctypes.c_int * 16), ("pack_dst", ctypes.c_void_p),
+                ("seq_src", ctypes.c_void_p), ("seq_dst", ctypes.c_void_p),
+                ("ring_table", ctypes.c_void_p), ("ring_ctr", ctypes.c_void_p),
+                ("ring_out", ctypes.c_void_p), ("ring", ctypes.c_int),
+                ("x_index", ctypes.c_int), ("labels_index", ctypes.c_int),
+                ("ring_first", ctypes.c_int), ("ring_last", ctypes.c_int)]
+
+
+def mlp_step_supported(b: int, d: int, h: int, c: int) -> bool:
+    return bool(lib().dtf_mlp_step_supported(b, d, h, c))
+
+
+def mlp_step_scratch(b: int, d: int, h: int, c: int, device) -> dict:
+    """Buffers one two-layer training step needs besides the model: results (loss, accuracy,
+    softmax) and scratch (hidden activations, dz1, the head's per-block shares). Allocate once and pass to every ``mlp_step_train`` call of that shape."""
+    L = lib()
+    ws_n = int(L.dtf_mlp_head_workspace(b, h, c))
+    buf = torch.zeros(2 + b * c + 2 * b * h + ws_n, dtype=torch.float32, device=device)
+    off = 0
+    out = {}
+    for name, n, shape in (("loss", 1, ()), ("accuracy", 1, ()), ("y", b * c, (b, c)),
+                           ("a", b * h, (b, h)), ("dz1", b * h, (b, h)),
+                           ("head_ws", ws_n, (ws_n,))):
+        out[name] = buf[off:off + n].view(shape)
+        off += n
+    return out
+
+
+def mlp_step_train(x: Optional[torch.Tensor], labels: Optional[torch.Tensor], w1: torch.Tensor,
+                   b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, lrs: Sequence[float],
+                   scratch: dict, dims: Sequence[int], dloss: float = 1.0,
+                   want_accuracy: bool = True, want_softmax: bool = False,
+                   counters: Sequence[torch.Tensor] = (), deltas: Sequence[float] = (),
+                   pack: Sequence[torch.Tensor] = (), pack_out: Optional[torch.Tensor] = None,
+                   signal=None, ring: Optional[RingArgs] = None, x_index: int = -1,
+                   labels_index: int = -1, ring_last: bool = True) -> None:
+    """One SGD step of ``softmax(sigmoid(x w1 + b1) w2 + b2)`` under cross-entropy in three
+    launches (``csrc/kernels/mlp_step.hip``): parameters are updated in place
+    (``lrs = (lr_w1, lr_b1, lr_w2, lr_b2)``), ``counters[j] += deltas[j]``, loss / accuracy /
+    softmax land in ``scratch``. ``dims = (B, D, H, C)``. ``pack``: small fp32 tensors gathered
+    at the end of the step into ``pack_out`` (pinned host or GPU memory; ``signal = (seq, index)``
+    echoes the host's step number behind them as in ``pack_f32``) or, with a ``ring``, into the
+    replay's slot of the ring. With a ring, ``x_index`` / ``labels_index`` >= 0 name the table
+    entries the batch is read through (``x`` / ``labels`` may then be ``None``), and
+    ``ring_last`` says that this step's last launch is the last ring kernel of the captured step
+    (it gathers ``pack`` into the ring, stamps the slot and opens the next replay)."""
+    b, d, h, c = (int(v) for v in dims)
+    if not mlp_step_supported(b, d, h, c):
+        raise HipKernelError("mlp_step_train: unsupported shape B=%d D=%d H=%d C=%d" % (b, d, h, c))
+
+    def need(t, shape, what):
+        t = _req(t, torch.float32, "mlp_step " + what)
+        if tuple(t.shape) != tuple(shape) or not t.is_contiguous():
+            raise HipKernelError("mlp_step_train: %s must be contiguous %s, got %s"
+                                 % (what, tuple(shape), tuple(t.shape)))
+        return t
+
+    w1, b1 = need(w1, (d, h), "w1"), need(b1, (h,), "b1")
+    w2, b2 = need(w2, (h, c), "w2"), need(b2, (c,), "b2")
+    a = _MlpStep()
+    if ring is None or x_index < 0:
+        a.x = need(x, (b, d), "x").data_ptr()
+        x_index = -1
+    if ring is None or labels_index < 0:
+        a.labels = need(labels, (b, c), "labels").data_ptr()
+        labels_index = -1
+    a.w1, a.b1, a.w2, a.b2 = w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr()
+    a.B, a.D, a.H, a.C = b, d, h, c
+    a.lr_w1, a.lr_b1, a.lr_w2, a.lr_b2 = (float(v) for v in lrs)
+    a.dloss = float(dloss)
+    if tuple(scratch["a"].shape) != (b, h) or tuple(scratch["y"].shape) != (b, c) \
+            or scratch["a"].device != w1.device:
+        raise HipKernelError("mlp_step_train: scratch was made for another shape or device")
+    a.loss = scratch["loss"].data_ptr()
+    a.accuracy = scratch["accuracy"].data_ptr() if want_accuracy else None
+    a.y = scratch["y"].data_ptr() if want_softmax else None
+    a.a, a.dz1 = scratch["a"].data_ptr(), scratch["dz1"].data_ptr()
+    a.head_ws = scratch["head_ws"].data_ptr()
+    if len(counters) != len(deltas) or len(counters) > 4:
+        raise HipKernelError("mlp_step_train: at most 4 counters, one delta each")
+    a.ncounters = len(counters)
+    for j, (t, dl) in enumerate(zip(counters, deltas)):
+        if t.dtype != torch.float32 or t.numel() != 1 or not t.is_cuda:
+            raise HipKernelError("mlp_step_train: counters must be fp32 GPU scalars")
+        a.counter[j] = t.data_ptr()
+        a.delta[j] = float(dl)
+    if len(pack) > 16:
+        raise HipKernelError("mlp_step_train: at most 16 packed parts")
+    total = 0
+    a.npack = len(pack)
+    for i, t in enumerate(pack):
+        t = _req(t, torch.float32, "mlp_step packed part")
+        a.pack_src[i] = t.data_ptr()
+        a.pack_size[i] = t.numel()
+        total += t.numel()
+    if total > RING_WORDS - 1:
+        raise HipKernelError("mlp_step_train: more than %d packed words" % (RING_WORDS - 1))
+    if ring is not None:
+        a.ring_table, a.ring_ctr = ring.table.data_ptr(), ring.ctr.data_ptr()
+        a.ring_out, a.ring = ring.out.data_ptr(), ring.slots
+        a.x_index, a.labels_index = x_index, labels_index
+        a.ring_first = ring.take_first()
+        a.ring_last = int(bool(ring_last))
+        if pack and not ring_last:
+            raise HipKernelError("mlp_step_train: a ring gather needs ring_last")
+    else:
+        a.x_index = a.labels_index = -1
+        if pack:
+            if pack_out is None or pack_out.dtype != torch.float32 or pack_out.numel() < total \
+                    or not (pack_out.is_cuda or pack_out.is_pinned()):
+                raise HipKernelError("mlp_step_train: bad pack_out")
+            a.pack_dst = pack_out.data_ptr()
+            if signal is not None:
+                seq, index = signal
+                if seq.numel() != 1 or seq.dtype != torch.float32 or not total <= index < pack_out.numel():
+                    raise HipKernelError("mlp_step_train: bad signal")
+                a.seq_src, a.seq_dst = seq.data_ptr(), pack_out.data_ptr() + 4 * int(index)
+    _check(lib().dtf_mlp_step_train(ctypes.byref(a), _stream()), "mlp_step_train")
 
 
 def philox_window(rows: int, cols: int, seed: int, op_seed: int, row0: int, col0: int,

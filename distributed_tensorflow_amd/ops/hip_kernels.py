@@ -576,6 +576,93 @@ def _multi_apply_sgd(op, inputs, ctx):
     return []
 
 
+def _spans_overlap(a: torch.Tensor, b: torch.Tensor) -> bool:
+    a0, b0 = a.data_ptr(), b.data_ptr()
+    return a0 < b0 + b.numel() * b.element_size() and b0 < a0 + a.numel() * a.element_size()
+
+
+@hip_kernel("MLPTrainStep")
+def _mlp_train_step(op, inputs, ctx):
+    """The whole training step of the two-layer classifier. Small shapes (batch and hidden layer
+    up to 128, up to 16 classes) run the three-launch step (``csrc/kernels/mlp_step.hip``):
+    inside a captured step it reads the batch through the step ring when the session left the
+    feeds ungathered, and it takes over the gather of the step's small results when asked to.
+    Other shapes run the same math as the chain of general kernels."""
+    x, labels = inputs
+    var_ops, lrs = op.attrs["var_ops"], op.attrs["learning_rates"]
+    params = []
+    for v in var_ops:
+        store = ctx.session._store_for(v)
+        fast = getattr(store, "local_tensor", None)
+        p = fast(v.name) if fast is not None else None
+        if p is None or p.dtype != _f32 or not p.is_cuda or not p.is_contiguous():
+            raise hip.HipKernelError("MLPTrainStep: variable %s is not local fp32 GPU storage"
+                                     % v.name)
+        params.append(p)
+        store.update_count += 1
+    counters, deltas = [], []
+    for v, delta in op.attrs.get("counter_increments", []):
+        store = ctx.session._store_for(v)
+        fast = getattr(store, "local_tensor", None)
+        t = fast(v.name) if fast is not None else None
+        if t is None or t.dtype != _f32 or not t.is_cuda or t.numel() != 1 or len(counters) >= 4:
+            raise hip.HipKernelError("MLPTrainStep: counter %s is not a local fp32 GPU scalar"
+                                     % v.name)
+        counters.append(t)
+        deltas.append(delta)
+    if not _is_f32(x, labels) or x.dim() != 2 or labels.dim() != 2:
+        return _fallback("MLPTrainStep", op, inputs, ctx)
+    w1, b1, w2, b2 = params
+    b, d = x.shape
+    h, c = w2.shape
+    want_acc = bool(op.attrs.get("emit_accuracy"))
+    dloss = float(op.attrs["dloss_const"])
+    if hip.mlp_step_supported(b, d, h, c):
+        key = (op, "scratch", b)
+        scratch = ctx.buffers.get(key)
+        if scratch is None:
+            scratch = ctx.buffers[key] = hip.mlp_step_scratch(b, d, h, c, ctx.device)
+        outs = [scratch["loss"], scratch["y"]] + ([scratch["accuracy"]] if want_acc else [])
+        ring = ctx.ring
+        pack, req, claimed = (), ctx.pack_request, False
+        if ring is not None and req is not None:
+            # the step's small results ride on the last launch unless one of them is a parameter
+            # that launch is still updating in other workgroups
+            parts = req.parts_for(op, outs)
+            if parts is not None and not any(_spans_overlap(t, p) for t in parts
+                                             for p in (w2, b2, b1, w1)):
+                pack, claimed = parts, True
+                req.claim()
+        xi = li = -1
+        if ring is not None:
+            xi = ctx.ring_feeds.get(x.data_ptr(), -1)
+            li = ctx.ring_feeds.get(labels.data_ptr(), -1)
+        hip.mlp_step_train(x, labels, w1, b1, w2, b2, lrs, scratch, (b, d, h, c), dloss=dloss,
+                           want_accuracy=want_acc, want_softmax=True, counters=counters,
+                           deltas=deltas, pack=pack,
+                           ring=ring if (claimed or xi >= 0 or li >= 0) else None,
+                           x_index=xi, labels_index=li, ring_last=claimed)
+        return outs
+    # larger batch or layers: the chain of general kernels
+    key = ("scalar", dloss)
+    dl = ctx.const_cache.get(key)
+    if dl is None:
+        dl = hip.fill((), dloss, ctx.device)
+        if not torch.cuda.is_current_stream_capturing():
+            ctx.const_cache[key] = dl
+    a = hip.gemm_f32(x, w1, bias=b1, activation=hip.ACT_SIGMOID)
+    z = hip.gemm_f32(a, w2, bias=b2)
+    loss, y, _ = hip.softmax_xent(z, labels)
+    dz, db2 = hip.softmax_xent_grad(y, labels, dl, True)
+    dw2 = hip.gemm_f32(a, dz, trans_a=True)
+    da = hip.gemm_f32(dz, w2, trans_b=True)
+    dz1, db1 = hip.sigmoid_grad_bias(da, a)
+    dw1 = hip.gemm_f32(x, dz1, trans_a=True)
+    acc = hip.argmax_accuracy(y, labels) if want_acc else None
+    hip.multi_sgd([w1, b1, w2, b2], [dw1, db1, dw2, db2], lrs, counters, deltas)
+    return [loss, y] + ([acc] if want_acc else [])
+
+
 @hip_kernel("ApplyGradientDescent")
 def _apply_sgd(op, inputs, ctx):
     var_op = op.inputs[0].op

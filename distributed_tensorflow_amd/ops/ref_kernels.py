@@ -429,6 +429,26 @@ def _classifier_head_train(op, inputs, ctx):
     return outs
 
 
+@ref_kernel("MLPTrainStep", stateful=True)
+def _mlp_train_step(op, inputs, ctx):
+    """(x, labels) -> (loss, softmax[, accuracy]) and, in place, one SGD step on the four
+    parameters ``attrs["var_ops"] = (W1, b1, W2, b2)`` plus the step-counter increments: the
+    nodes it replaces (``attrs["parts"]``: first layer, head, dW1 product, optimizer), run one
+    after the other."""
+    x, labels = inputs
+    dense, head, _dw1_op, sgd = op.attrs["parts"]
+    w1_op, b1_op, w2_op, b2_op = op.attrs["var_ops"]
+    w1, b1, w2, b2 = (ctx.var_read(v) for v in (w1_op, b1_op, w2_op, b2_op))
+    a = _fused_dense(dense, [x, w1, b1], ctx)[0]
+    h = _classifier_head_train(head, [a, w2, b2, labels], ctx)
+    grads = {w1_op: x.t() @ h[4], b1_op: h[5], w2_op: h[2], b2_op: h[3]}
+    _multi_apply_sgd(sgd, [grads[v] for v in sgd.attrs["var_ops"]], ctx)
+    outs = [h[0], h[1]]
+    if op.attrs.get("emit_accuracy"):
+        outs.append(h[6])
+    return outs
+
+
 @ref_kernel("BiasGrad")
 def _bias_grad(op, inputs, ctx):
     return [inputs[0].sum(dim=0)]

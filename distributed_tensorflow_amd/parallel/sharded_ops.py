@@ -71,10 +71,8 @@ def _gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, full_mnk) -> None
     if a.is_cuda:
         from ..ops import hip
         if a.dtype == torch.float32:
-            m, n, k = full_mnk
-            splits = hip.lib().dtf_gemm_f32_splits(int(m), int(n), int(k), None) \
-                if k == a.shape[1] else None
-            hip.gemm_f32(a, b, out=out, splits=splits)
+            hip.gemm_f32(a, b, out=out,
+                         plan_mnk=full_mnk if full_mnk[2] == a.shape[1] else None)
         elif a.dtype == torch.bfloat16:
             hip.gemm_bf16(a, b, out=out)
         else:

@@ -170,7 +170,7 @@ def test_captured_step_gathers_device_feeds_through_the_address_table():
             assert abs(got - want) <= 1e-4 * abs(want), (i, got, want)
         assert sess.stats["graph_replays"] >= 10
         cap = next(iter(next(p for p in sess._plans.values() if p.graphs).graphs.values()))
-        assert cap.feed_table is not None
+        assert cap.use_table and cap.ring.launched >= 10
         # steps without a fetch: back-to-back replays must each see their own batch
         total = 0.0
         for i in range(8):
@@ -193,7 +193,7 @@ def test_captured_step_gathers_device_feeds_through_the_address_table():
             got = sess.run(out, {x: big_x, y: big_y})
         want = ref.run(out, {x: big_x, y: big_y})
         assert abs(got - want) <= 1e-3 * abs(want)
-        kinds = {c.feed_table is not None for p in sess._plans.values() for c in p.graphs.values()}
+        kinds = {c.use_table for p in sess._plans.values() for c in p.graphs.values()}
         assert kinds == {True, False}
 
 
@@ -215,13 +215,13 @@ def test_captured_step_completion_polling_and_blocking_fallback(monkeypatch):
         got = [float(sess.run(total, {x: batch * (i + 1)})) for i in range(6)]
         assert got == [20.0, 60.0, 120.0, 200.0, 300.0, 420.0]
         cap = next(iter(next(p for p in sess._plans.values() if p.graphs).graphs.values()))
-        assert cap.signalled and cap.seq_val >= 4 and cap.skip_spin == 0
+        assert cap.layout and cap.ring.launched >= 4 and cap.ring.skip_spin == 0
         monkeypatch.setattr(S, "_SPIN_SECS", -1.0)       # no polling budget
         got = [float(sess.run(total, {x: batch})) for i in range(3)]
         assert got == [440.0, 460.0, 480.0]
-        cap.skip_spin = 2                                  # as after a step that outlasted it
+        cap.ring.skip_spin = 2                             # as after a step that outlasted it
         got = [float(sess.run(total, {x: batch})) for i in range(3)]
-        assert got == [500.0, 520.0, 540.0] and cap.skip_spin == 0
+        assert got == [500.0, 520.0, 540.0] and cap.ring.skip_spin == 0
 
 
 def test_fetch_ahead_of_the_optimizer_launch_matches_eager_values():
@@ -431,7 +431,7 @@ def test_traced_step_uses_hip_events_and_does_not_synchronise_between_steps(monk
     g = tf.Graph()
     with g.as_default():
         m = mnist_mlp.build_model()
-        with tf.Session(config=tf.ConfigProto(device="cuda")) as sess:
+        with tf.Session(config=tf.ConfigProto(device="cuda", step_fusion=False)) as sess:
             sess.run(m.init_op)
             feed = {m.x: np.random.rand(100, 784).astype(np.float32),
                     m.y_: np.eye(10, dtype=np.float32)[np.random.randint(0, 10, 100)]}
@@ -461,3 +461,75 @@ def test_traced_step_uses_hip_events_and_does_not_synchronise_between_steps(monk
     assert starts == sorted(starts)
     trace = md.to_chrome_trace()
     assert {"host enqueue"} <= {e["tid"] for e in trace["traceEvents"]}
+
+
+def _mnist_run(config, steps, device_feeds=True, look=True):
+    """``steps`` training steps of the MNIST MLP on fixed synthetic batches; returns the fetched
+    (loss, summary, global_step) per step, the final variables and the session's plans."""
+    import numpy as np
+    import torch
+    import distributed_tensorflow_amd as tf
+    from distributed_tensorflow_amd.models import mnist_mlp
+    rng = np.random.RandomState(11)
+    batches = [(rng.rand(100, 784).astype(np.float32),
+                np.eye(10, dtype=np.float32)[rng.randint(0, 10, 100)]) for _ in range(5)]
+    if device_feeds:
+        batches = [(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()) for x, y in batches]
+    g = tf.Graph()
+    with g.as_default():
+        m = mnist_mlp.build_model(seed=1)
+        with tf.Session(config=config) as sess:
+            sess.run(m.init_op)
+            hist = []
+            for i in range(steps):
+                bx, by = batches[i % len(batches)]
+                out = sess.run([m.train_op, m.loss, m.summary_op, m.global_step],
+                               feed_dict={m.x: bx, m.y_: by})[1:]
+                hist.append([float(out[0]), bytes(out[1]), float(out[2])] if look else out)
+            acc = float(sess.run(m.accuracy, feed_dict={m.x: batches[0][0], m.y_: batches[0][1]}))
+            variables = sess.run([m.w1, m.b1, m.w2, m.b2])
+            plans = [([st.node.type for st in p.steps if st.node.type != "VariableV2"],
+                      [(c.use_table, bool(c.layout), c.ring.launched) for c in p.graphs.values()])
+                     for p in sess._plans.values() if p.mutates_state and p.feed_slots]
+            stats = dict(sess.stats)
+    return hist, variables, acc, plans, stats
+
+
+def test_mnist_step_fusion_is_one_node_and_bit_equal_to_the_kernel_chain_for_100_steps():
+    """The MNIST training step through the facade with the whole-step node (three launches: layer
+    1, head, update) and with the chain of fused kernels it replaces: loss, summary bytes, step
+    counter, accuracy and all four variables are bit-equal after 100 steps, with feeds resident in
+    GPU memory (read through the step ring, no gather launch) and with numpy feeds."""
+    import numpy as np
+    import distributed_tensorflow_amd as tf
+    ref = _mnist_run(tf.ConfigProto(device="cuda", step_fusion=False), 100)
+    for device_feeds in (True, False):
+        new = _mnist_run(tf.ConfigProto(device="cuda"), 100, device_feeds=device_feeds)
+        assert new[0] == ref[0]
+        assert new[2] == ref[2]
+        for p, q in zip(ref[1], new[1]):
+            assert np.array_equal(p, q)
+        types, caps = new[3][0]
+        assert types == ["MLPTrainStep"]
+        use_table, has_layout, launched = caps[0]
+        assert has_layout and use_table and launched >= 98
+        assert new[4]["torch_fallbacks"] == 0
+    assert np.isfinite(ref[0][-1][0]) and ref[0][-1][2] == 100.0
+
+
+def test_deferred_fetches_return_the_blocking_values_without_blocking():
+    """``deferred_fetches``: ``run`` hands back DeferredValue objects and never waits; 50 steps
+    are issued without looking at any result (more than three times round the 16-slot ring), and
+    afterwards every value -- loss, merged summary, step counter -- equals the blocking run's."""
+    import distributed_tensorflow_amd as tf
+    from distributed_tensorflow_amd.client.deferred import DeferredValue
+    ref = _mnist_run(tf.ConfigProto(device="cuda"), 50)
+    new = _mnist_run(tf.ConfigProto(device="cuda", deferred_fetches=True), 50, look=False)
+    assert all(isinstance(v, DeferredValue) for v in new[0][-1])
+    got = [[float(o[0]), bytes(o[1]), float(o[2])] for o in new[0]]
+    assert got == ref[0]
+    assert new[2] == ref[2]
+    # the chain of fused kernels (generic gather launch) defers the same way
+    chain = _mnist_run(tf.ConfigProto(device="cuda", deferred_fetches=True, step_fusion=False),
+                       50, look=False)
+    assert [[float(o[0]), bytes(o[1]), float(o[2])] for o in chain[0]] == ref[0]

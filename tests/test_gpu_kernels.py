@@ -756,3 +756,49 @@ def test_gemm_f32_accepts_row_strided_blocks(hip):
     hip.gemm_f32(a[:, 128:384], b[128:384, 130:260], out=out)
     assert torch.equal(out, a[:, 128:384] @ b[128:384, 130:260])
     assert bool((c_big[:, :64] == 7.0).all()) and bool((c_big[:, 194:] == 7.0).all())
+
+
+def _mlp_reference_step(hip, x, labels, w1, b1, w2, b2, lr, dloss, step):
+    """The same training step as the chain of general kernels the three-launch step replaces."""
+    a = hip.gemm_f32(x, w1, bias=b1, activation=hip.ACT_SIGMOID)
+    loss, y, dw2, db2, dz1, db1, acc = hip.mlp_head_train(a, w2, b2, labels, dloss, True, True)
+    dw1 = hip.gemm_f32(x, dz1, trans_a=True)
+    hip.multi_sgd([w1, b1, w2, b2], [dw1, db1, dw2, db2], [lr] * 4, [step], [1.0])
+    return loss, acc, y
+
+
+@pytest.mark.parametrize("dims", [(100, 784, 100, 10), (37, 50, 33, 7), (128, 260, 128, 16)])
+def test_mlp_step_three_launches_match_the_kernel_chain_bitwise(dims):
+    """100 SGD steps of the two-layer classifier through ``mlp_step_train`` (three launches) and
+    through the chain of general kernels: parameters, loss, accuracy and softmax stay bit-equal,
+    and the values gathered at the end of the step are the step's own."""
+    import torch
+    from distributed_tensorflow_amd.ops import hip
+    b, d, h, c = dims
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(3)
+    batches = [(torch.rand(b, d, generator=g).to(dev),
+                torch.eye(c)[torch.randint(0, c, (b,), generator=g)].to(dev)) for _ in range(4)]
+    init = [torch.randn(d, h, generator=g), torch.zeros(h), torch.randn(h, c, generator=g),
+            torch.zeros(c)]
+    ref = [t.clone().to(dev) for t in init]
+    new = [t.clone().to(dev) for t in init]
+    step_ref, step_new = torch.zeros((), device=dev), torch.zeros((), device=dev)
+    dloss = torch.ones((), device=dev)
+    scratch = hip.mlp_step_scratch(b, d, h, c, dev)
+    packed = torch.zeros(8, device=dev)
+    lr = 0.05
+    for i in range(100):
+        x, labels = batches[i % 4]
+        loss, acc, y = _mlp_reference_step(hip, x, labels, *ref, lr, dloss, step_ref)
+        hip.mlp_step_train(x, labels, *new, [lr] * 4, scratch, dims, want_softmax=True,
+                           counters=[step_new], deltas=[1.0],
+                           pack=[scratch["loss"], step_new, scratch["accuracy"]],
+                           pack_out=packed)
+        assert torch.equal(scratch["loss"], loss), i
+        assert torch.equal(scratch["accuracy"], acc), i
+        assert torch.equal(scratch["y"], y), i
+        for p, q in zip(ref, new):
+            assert torch.equal(p, q), i
+        assert packed[:3].tolist() == [float(loss), float(i + 1), float(acc)]
+    assert torch.isfinite(loss)

@@ -194,6 +194,60 @@ def test_fused_and_unfused_plans_agree_bitwise_on_cpu():
     assert [h[1] for h in outs[0][0]] == [1.0, 2.0, 3.0, 4.0]
 
 
+def test_step_fusion_replaces_the_whole_mlp_step_and_changes_no_bit_on_cpu():
+    """With ``step_fusion`` the training step of the two-layer classifier is ONE plan node; its
+    results and parameters equal the four-node plan's bit for bit. The node is not used when
+    something it would swallow is fetched (the first layer's weight gradient here)."""
+    m = mnist_mlp.build_model(learning_rate=0.05)
+    rng = np.random.RandomState(5)
+    bx = (rng.rand(100, 784) * 0.1).astype(np.float32)
+    by = np.eye(10, dtype=np.float32)[rng.randint(0, 10, 100)]
+    outs = []
+    for step_fusion in (False, True):
+        with _session(step_fusion=step_fusion) as sess:
+            sess.run(m.init_op)
+            hist = [sess.run([m.train_op, m.loss, m.global_step, m.accuracy],
+                             {m.x: bx, m.y_: by})[1:] for _ in range(5)]
+            outs.append((hist, sess.run([m.w1, m.b1, m.w2, m.b2])))
+            plan = [p for p in sess._plans.values() if p.mutates_state and p.feed_slots][0]
+            types = [st.node.type for st in plan.steps if st.node.type != "VariableV2"]
+            if step_fusion:
+                assert types == ["MLPTrainStep"]
+                dw1 = tf.gradients(m.loss, [m.w1])[0]
+                sess.run([m.train_op, dw1], {m.x: bx, m.y_: by})
+                other = [p for p in sess._plans.values() if p is not plan and p.mutates_state
+                         and p.feed_slots][0]
+                assert "MLPTrainStep" not in [st.node.type for st in other.steps]
+            else:
+                assert types == ["FusedDense", "ClassifierHeadTrain", "MatMul", "MultiApplySGD"]
+    assert outs[0][0] == outs[1][0]
+    for p, q in zip(outs[0][1], outs[1][1]):
+        assert np.array_equal(p, q)
+
+
+def test_deferred_value_behaves_as_the_value_it_stands_for():
+    from distributed_tensorflow_amd.client.deferred import DeferredValue, resolve
+    calls = []
+
+    def thunk():
+        calls.append(1)
+        return np.float32(2.5)
+
+    v = DeferredValue(thunk)
+    assert not v.ready and calls == []
+    assert float(v) == 2.5 and v.ready and calls == [1]
+    assert "%.2f" % v == "2.50" and "{:.1f}".format(v) == "2.5" and str(v) == "2.5"
+    assert v + 1 == 3.5 and 2 * v == 5.0 and v > 2 and not v < 2 and int(v) == 2
+    assert np.isfinite(v) and np.asarray(v).dtype == np.float32 and v.dtype == np.float32
+    assert np.allclose([v, v], 2.5) and resolve(v) == np.float32(2.5) and resolve(7) == 7
+    assert calls == [1]
+    arr = DeferredValue(lambda: np.arange(6, dtype=np.float32).reshape(2, 3))
+    assert arr.shape == (2, 3) and len(arr) == 2 and arr[1][2] == 5.0 and float(arr.sum()) == 15.0
+    assert np.concatenate([arr, arr]).shape == (4, 3)
+    blob = DeferredValue(lambda: b"abc")
+    assert bytes(blob) == b"abc"
+
+
 def test_gradients_of_assorted_ops_match_torch():
     x = tf.placeholder(tf.float32, [4, 3])
     w = tf.Variable(tf.random_normal([3, 5], seed=7))

@@ -3,8 +3,8 @@
 
 * ``mnist``: the MNIST MLP training step of ``tf_distributed.py:111`` -- ``sess.run([train_op,
   cross_entropy, summary_op, global_step], feed_dict=batch of 100)`` -- as the reference's
-  AvgTime (ms per step) and steps/s, with HIP-graph replay on and off, plus the 10 000-image
-  evaluation pass of ``:126``.
+  AvgTime (ms per step) and steps/s, with HIP-graph replay on and off, the whole-step node on
+  and off, blocking and deferred fetches, plus the 10 000-image evaluation pass of ``:126``.
 * ``matmul``: ``sess.run`` of the 1000 x 1000 fp32 product of ``tf_distributed_1000Matrix.py:48``
   (operands resident in HBM) as ms per step and GFLOP/s.
 
@@ -33,7 +33,8 @@ def _sync(device: str) -> None:
 
 
 def bench_mnist(device: str, steps: int, warmup: int, hip_graphs: bool, fusion: bool,
-                batch: int = 100, device_data: bool = False) -> dict:
+                batch: int = 100, device_data: bool = False, step_fusion: bool = True,
+                deferred: bool = False) -> dict:
     g = tf.Graph()
     with g.as_default():
         model = mnist_mlp.build_model(seed=1)
@@ -46,7 +47,9 @@ def bench_mnist(device: str, steps: int, warmup: int, hip_graphs: bool, fusion: 
             batches = [(torch.from_numpy(bx).to(device), torch.from_numpy(by).to(device))
                        for bx, by in batches]
             test_x, test_y = torch.from_numpy(test_x).to(device), torch.from_numpy(test_y).to(device)
-        cfg = tf.ConfigProto(device=device, hip_graphs=hip_graphs, graph_fusion=fusion)
+        cfg = tf.ConfigProto(device=device, hip_graphs=hip_graphs, graph_fusion=fusion,
+                             step_fusion=step_fusion and device.startswith("cuda"),
+                             deferred_fetches=deferred)
         with tf.Session(config=cfg) as sess:
             sess.run(model.init_op)
             fetches = [model.train_op, model.loss, model.summary_op, model.global_step]
@@ -61,6 +64,7 @@ def bench_mnist(device: str, steps: int, warmup: int, hip_graphs: bool, fusion: 
             t0 = time.perf_counter()
             for i in range(steps):
                 out = one(i)
+            final_cost = float(out[1])       # (deferred fetches: waits for the last step)
             _sync(device)
             train_ms = (time.perf_counter() - t0) * 1e3 / steps
             fd = {model.x: test_x, model.y_: test_y}
@@ -75,9 +79,11 @@ def bench_mnist(device: str, steps: int, warmup: int, hip_graphs: bool, fusion: 
             stats = dict(getattr(sess, "stats", {}))
     return {"bench": "mnist_mlp_train_step", "device": device, "batch": batch,
             "hip_graphs": hip_graphs, "fusion": fusion, "device_data": device_data,
+            "step_fusion": bool(step_fusion and fusion and device.startswith("cuda")),
+            "deferred_fetches": deferred,
             "ms_per_step": round(train_ms, 4),
             "steps_per_s": round(1e3 / train_ms, 1), "eval_10k_ms": round(eval_ms, 3),
-            "final_cost": float(out[1]), "global_step": float(out[3]), "accuracy": float(acc),
+            "final_cost": final_cost, "global_step": float(out[3]), "accuracy": float(acc),
             "session_stats": {k: v for k, v in stats.items() if isinstance(v, (int, float))}}
 
 
@@ -123,12 +129,15 @@ def main() -> None:
     args = ap.parse_args()
     rows = []
     if "mnist" in args.which:
-        for graphs, fusion, dev_data in ((True, True, True), (True, True, False),
-                                         (False, True, False), (False, False, False)):
+        # (HIP graphs, fusion, data resident in HBM, whole-step node, deferred fetches)
+        for graphs, fusion, dev_data, step, deferred in (
+                (True, True, True, True, True), (True, True, True, True, False),
+                (True, True, True, False, False), (True, True, False, True, False),
+                (False, True, False, True, False), (False, False, False, False, False)):
             if (graphs or dev_data) and not args.device.startswith("cuda"):
                 continue
             rows.append(bench_mnist(args.device, args.steps, args.warmup, graphs, fusion,
-                                    device_data=dev_data))
+                                    device_data=dev_data, step_fusion=step, deferred=deferred))
             print(json.dumps(rows[-1]), flush=True)
     if "matmul" in args.which:
         for graphs in ((True, False) if args.device.startswith("cuda") else (False,)):

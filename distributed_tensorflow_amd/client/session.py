@@ -48,6 +48,7 @@ _TABLE_HOST_BYTES = 1 << 20      # host inputs up to this size are read by the g
 _SPIN_SECS = 300e-6              # how long a step's completion word is polled before blocking
 _NO_SPIN_FETCH = bool(os.environ.get("DTF_NO_SPIN_FETCH"))
 _NO_FETCH_AHEAD = bool(os.environ.get("DTF_NO_FETCH_AHEAD"))
+_NO_DIRECT_STEP = bool(os.environ.get("DTF_NO_DIRECT_STEP"))
 # ops that write a variable in place (a gather must not move across them)
 _MUTATING_OPS = frozenset(("Assign", "AssignAdd", "AssignSub", "ApplyGradientDescent",
                            "MultiApplySGD"))
@@ -176,6 +177,7 @@ class ExecContext:
         self.ring = None
         self.ring_feeds: Dict[int, int] = {}
         self.pack_request = None
+        self.direct_call = None     # set by a node whose whole work is one prepared library call
         self._nd_seed = int.from_bytes(os.urandom(4), "little")
 
     def note_fallback(self, op, why: str = "") -> None:
@@ -303,10 +305,10 @@ class _StepRing:
 class _PendingStep:
     """The small results of replay ``n``: still in the ring until ``resolve`` copies them out."""
 
-    __slots__ = ("ring", "n", "slot", "words", "stream", "snap", "lock")
+    __slots__ = ("ring", "n", "slot", "words", "snap", "lock")
 
-    def __init__(self, ring: _StepRing, n: int, slot: int, words: int, stream):
-        self.ring, self.n, self.slot, self.words, self.stream = ring, n, slot, words, stream
+    def __init__(self, ring: _StepRing, n: int, slot: int, words: int):
+        self.ring, self.n, self.slot, self.words = ring, n, slot, words
         self.snap = None
         self.lock = threading.Lock()
 
@@ -335,7 +337,7 @@ class _PendingStep:
                         ring.skip_spin = 64
                         break
             if not done:
-                self.stream.synchronize()
+                torch.cuda.synchronize(ring.ctr.device)
                 if row[last] != want:
                     raise RuntimeError("captured step %d finished without stamping its results "
                                        "(slot %d holds %r, expected %r)"
@@ -399,7 +401,8 @@ class _CapturedStep:
         self.layout: List[Tuple[int, int, tuple, int]] = []   # (slot, offset, shape, numel)
         self.slot_values: List[Any] = []
         self.generation = 0                               # variable-store generation at capture
-        self.launches = 0                                 # kernel launches recorded per replay
+        self.direct = None          # (library function, prepared argument block) of a step that
+                                    # is a single library call: issued directly, not replayed
 
 
 class _DeferredHost:
@@ -439,6 +442,7 @@ class Session:
         self._closed = False
         self._close_hooks: List[Any] = []
         self._plans: Dict[Tuple, ExecutionPlan] = {}
+        self._call_cache: Dict[Tuple, Tuple] = {}
         self._eager_buf = self._eager_seq = self._eager_np = None   # pinned staging of _fetch_small
         self._eager_count = 0
         self._fetch_lock = threading.Lock()
@@ -510,6 +514,7 @@ class Session:
                 self._retire(cap)        # results still in a ring outlive the session
             plan.graphs.clear()
         self._plans.clear()
+        self._call_cache.clear()
 
     # -- variable routing ------------------------------------------------------------------
     def _store_for(self, var_op):
@@ -922,19 +927,40 @@ class Session:
         if self._closed:
             raise RuntimeError("Attempted to use a closed Session.")
         feed_dict = feed_dict or {}
-        fed_pairs: List[Tuple[Tensor, Any]] = []
-        for k, v in feed_dict.items():
-            t = self.graph.as_graph_element(k, allow_operation=False)
-            fed_pairs.append((t, v))
-        fed_pairs.sort(key=lambda p: (p[0].op.id, p[0].value_index))
-        flat, structure = self._flatten(fetches)
-        key = (tuple(id(f) for f in flat), tuple(id(t) for t, _ in fed_pairs),
-               self.graph.version if not self.graph.finalized else -1)
-        with self._lock:
-            plan = self._plans.get(key)
-            if plan is None:
-                plan = self._build_plan(flat, [t for t, _ in fed_pairs])
-                self._plans[key] = plan
+        # A training loop calls run() with the same fetch list and the same placeholders every
+        # step: what they resolve to (graph elements, feed order, plan, result structure) is
+        # remembered under the identities of the objects passed. The entry keeps those objects
+        # alive, so an identity cannot come back meaning something else.
+        ck = None
+        tf_ = type(fetches)
+        if tf_ is list or tf_ is tuple:
+            ck = (tf_, tuple(map(id, fetches)), tuple(map(id, feed_dict)))
+        ent = self._call_cache.get(ck) if ck is not None else None
+        if ent is not None and ent[0] == (self.graph.version if not self.graph.finalized else -1):
+            _, _keep, feed_order, plan, structure = ent
+            fed_pairs = [(t, feed_dict[k]) for k, t in feed_order]
+        else:
+            fed_pairs = []
+            keys = {}
+            for k, v in feed_dict.items():
+                t = self.graph.as_graph_element(k, allow_operation=False)
+                fed_pairs.append((t, v))
+                keys[t] = k
+            fed_pairs.sort(key=lambda p: (p[0].op.id, p[0].value_index))
+            flat, structure = self._flatten(fetches)
+            version = self.graph.version if not self.graph.finalized else -1
+            key = (tuple(id(f) for f in flat), tuple(id(t) for t, _ in fed_pairs), version)
+            with self._lock:
+                plan = self._plans.get(key)
+                if plan is None:
+                    plan = self._build_plan(flat, [t for t, _ in fed_pairs])
+                    self._plans[key] = plan
+                if ck is not None and all(not isinstance(f, (list, tuple, dict)) and f is not None
+                                          for f in fetches):
+                    if len(self._call_cache) > 256:
+                        self._call_cache.clear()
+                    self._call_cache[ck] = (version, (list(fetches), list(feed_dict)),
+                                            [(keys[t], t) for t, _ in fed_pairs], plan, structure)
         self.stats["runs"] += 1
         trace = None
         if options is not None and options.trace_level:
@@ -1153,11 +1179,18 @@ class Session:
                 if cap.h2d_done is None:
                     cap.h2d_done = torch.cuda.Event()
                 cap.h2d_done.record()
-        cap.graph.replay()
+        if cap.direct is not None:
+            # the whole step is one prepared call into the kernel library (its launches cost
+            # less host time issued directly than as a graph of so few nodes)
+            fn, block = cap.direct
+            rc = fn(block, torch._C._cuda_getCurrentRawStream(self.device.index))
+            if rc != 0:
+                raise RuntimeError("captured step: direct launch failed with code %d" % rc)
+        else:
+            cap.graph.replay()
         ring.launched = n + 1
         self.stats["graph_replays"] += 1
-        pend = _PendingStep(ring, n, slot, cap.host_words,
-                            torch.cuda.current_stream(self.device))
+        pend = _PendingStep(ring, n, slot, cap.host_words)
         ring.pending[slot] = pend
         out: Dict[int, Any] = {}
         if cap.layout:
@@ -1249,6 +1282,10 @@ class Session:
                             ctx.pack_request = None
                         if req.claimed:
                             packed = req.packed
+                            call = ctx.direct_call
+                            if (call is not None and direct and not _NO_DIRECT_STEP and all(
+                                    st.node.type == "VariableV2" for st in steps[:k])):
+                                cap.direct = call
                         else:
                             packed = _packable([(sl, vals[sl]) for sl in dict.fromkeys(want)],
                                                limit)
@@ -1296,6 +1333,7 @@ class Session:
             ctx.ring = None
             ctx.ring_feeds = {}
             ctx.pack_request = None
+            ctx.direct_call = None
         cap.host_words = sum(p[3].numel() for p in packed)
         cap.layout = [(sl, off, shape, int(v.numel())) for sl, off, shape, v in packed]
         cap.graph = graph

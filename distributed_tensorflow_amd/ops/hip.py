@@ -1034,7 +1034,7 @@ def mlp_step_train(x: Optional[torch.Tensor], labels: Optional[torch.Tensor], w1
                    counters: Sequence[torch.Tensor] = (), deltas: Sequence[float] = (),
                    pack: Sequence[torch.Tensor] = (), pack_out: Optional[torch.Tensor] = None,
                    signal=None, ring: Optional[RingArgs] = None, x_index: int = -1,
-                   labels_index: int = -1, ring_last: bool = True) -> None:
+                   labels_index: int = -1, ring_last: bool = True):
     """One SGD step of ``softmax(sigmoid(x w1 + b1) w2 + b2)`` under cross-entropy in three
     launches (``csrc/kernels/mlp_step.hip``): parameters are updated in place
     (``lrs = (lr_w1, lr_b1, lr_w2, lr_b2)``), ``counters[j] += deltas[j]``, loss / accuracy /
@@ -1044,7 +1044,10 @@ def mlp_step_train(x: Optional[torch.Tensor], labels: Optional[torch.Tensor], w1
     replay's slot of the ring. With a ring, ``x_index`` / ``labels_index`` >= 0 name the table
     entries the batch is read through (``x`` / ``labels`` may then be ``None``), and
     ``ring_last`` says that this step's last launch is the last ring kernel of the captured step
-    (it gathers ``pack`` into the ring, stamps the slot and opens the next replay)."""
+    (it gathers ``pack`` into the ring, stamps the slot and opens the next replay).
+
+    Returns the argument block of the call: ``lib().dtf_mlp_step_train(ctypes.byref(block),
+    stream)`` issues the same step again (every tensor named here must still be alive)."""
     b, d, h, c = (int(v) for v in dims)
     if not mlp_step_supported(b, d, h, c):
         raise HipKernelError("mlp_step_train: unsupported shape B=%d D=%d H=%d C=%d" % (b, d, h, c))
@@ -1117,6 +1120,7 @@ def mlp_step_train(x: Optional[torch.Tensor], labels: Optional[torch.Tensor], w1
                     raise HipKernelError("mlp_step_train: bad signal")
                 a.seq_src, a.seq_dst = seq.data_ptr(), pack_out.data_ptr() + 4 * int(index)
     _check(lib().dtf_mlp_step_train(ctypes.byref(a), _stream()), "mlp_step_train")
+    return a
 
 
 def philox_window(rows: int, cols: int, seed: int, op_seed: int, row0: int, col0: int,

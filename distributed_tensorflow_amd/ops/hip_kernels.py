@@ -637,11 +637,16 @@ def _mlp_train_step(op, inputs, ctx):
         if ring is not None:
             xi = ctx.ring_feeds.get(x.data_ptr(), -1)
             li = ctx.ring_feeds.get(labels.data_ptr(), -1)
-        hip.mlp_step_train(x, labels, w1, b1, w2, b2, lrs, scratch, (b, d, h, c), dloss=dloss,
-                           want_accuracy=want_acc, want_softmax=True, counters=counters,
-                           deltas=deltas, pack=pack,
-                           ring=ring if (claimed or xi >= 0 or li >= 0) else None,
-                           x_index=xi, labels_index=li, ring_last=claimed)
+        block = hip.mlp_step_train(
+            x, labels, w1, b1, w2, b2, lrs, scratch, (b, d, h, c), dloss=dloss,
+            want_accuracy=want_acc, want_softmax=True, counters=counters, deltas=deltas,
+            pack=pack, ring=ring if (claimed or xi >= 0 or li >= 0) else None,
+            x_index=xi, labels_index=li, ring_last=claimed)
+        if claimed and xi >= 0 and li >= 0:
+            # the whole captured step is this one library call: the session may issue it directly
+            import ctypes
+            ctx.direct_call = (hip.lib().dtf_mlp_step_train, ctypes.byref(block))
+            ctx.buffers[(op, "call", b)] = block       # the block outlives this call
         return outs
     # larger batch or layers: the chain of general kernels
     key = ("scalar", dloss)

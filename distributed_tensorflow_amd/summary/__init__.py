@@ -249,7 +249,9 @@ class EventFileWriter:
             with self._lock:
                 items, self._pending = self._pending, []
             for item in items:
-                self._file.write(item)
+                # an event whose summary was still on its way from the GPU when it was added is
+                # encoded now (this waits for its step if it has not finished yet)
+                self._file.write(item() if callable(item) else item)
 
     def _run(self) -> None:
         next_flush = time.time() + self._flush_secs
@@ -260,7 +262,9 @@ class EventFileWriter:
                     self._file.flush()
                 next_flush = time.time() + self._flush_secs
 
-    def add_event(self, event: bytes) -> None:
+    def add_event(self, event) -> None:
+        """``event``: a serialized ``Event``, or a callable returning one (called once, by
+        whichever thread writes it out)."""
         if self._closed:
             return
         with self._lock:
@@ -306,6 +310,22 @@ class FileWriter:
         ``None`` (the fetch of a ``None`` summary op) is ignored."""
         if summary is None:
             return
+        from ..client.deferred import DeferredValue, resolve
+        if (isinstance(summary, DeferredValue) and not summary.ready) or (
+                isinstance(global_step, DeferredValue) and not global_step.ready):
+            # results of a step that is still running (ConfigProto(deferred_fetches=True)): the
+            # event is put together when it is written, not here -- the loop does not wait
+            wall = time.time()
+
+            def late(summary=summary, global_step=global_step, wall=wall) -> bytes:
+                sm = resolve(summary)
+                if isinstance(sm, np.ndarray):
+                    sm = sm.item()
+                gs = resolve(global_step)
+                return encode_event(wall, step=None if gs is None else int(gs), summary=bytes(sm))
+            self.event_writer.add_event(late)
+            return
+        summary, global_step = resolve(summary), resolve(global_step)
         if isinstance(summary, np.ndarray):
             summary = summary.item()
         step = None if global_step is None else int(global_step)

@@ -68,6 +68,9 @@ def define_flags(default_job=DEFAULT_JOB, default_epochs=DEFAULT_EPOCHS):
                                 "into the HIP graph together with its kernels")
     tf.app.flags.DEFINE_boolean("device_data", True, "keep the data set resident in GPU memory "
                                 "(GPU tasks only) so feeds are device-to-device copies")
+    tf.app.flags.DEFINE_boolean("deferred_fetches", False, "GPU tasks: sess.run returns as soon as "
+                                "the step is enqueued; cost / summary / step are waited for only "
+                                "when looked at (every 100 steps here)")
     return tf.app.flags.FLAGS
 
 
@@ -90,7 +93,8 @@ def main(argv=None, default_num_workers=DEFAULT_NUM_WORKERS):
     if "WORLD_SIZE" in os.environ and FLAGS.protocol == "rccl" and not FLAGS.worker_hosts:
         FLAGS.job_name, FLAGS.task_index = tf.train.task_from_env()
     config = tf.ConfigProto(device=FLAGS.device or None, strategy=FLAGS.strategy,
-                            capture_collectives=FLAGS.capture_collectives)
+                            capture_collectives=FLAGS.capture_collectives,
+                            deferred_fetches=FLAGS.deferred_fetches)
 
     # start a server for a specific task
     server = tf.train.Server(cluster, job_name=FLAGS.job_name, task_index=FLAGS.task_index,

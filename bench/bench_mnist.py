@@ -126,15 +126,20 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--which", default="mnist,matmul")
     ap.add_argument("--out", default="")
+    ap.add_argument("--rows", default="", help="comma-separated indices of the mnist "
+                    "configurations to run (default: all)")
     args = ap.parse_args()
     rows = []
     if "mnist" in args.which:
         # (HIP graphs, fusion, data resident in HBM, whole-step node, deferred fetches)
-        for graphs, fusion, dev_data, step, deferred in (
+        only = {int(v) for v in args.rows.split(",") if v != ""}
+        for idx, (graphs, fusion, dev_data, step, deferred) in enumerate((
                 (True, True, True, True, True), (True, True, True, True, False),
                 (True, True, True, False, False), (True, True, False, True, False),
-                (False, True, False, True, False), (False, False, False, False, False)):
+                (False, True, False, True, False), (False, False, False, False, False))):
             if (graphs or dev_data) and not args.device.startswith("cuda"):
+                continue
+            if only and idx not in only:
                 continue
             rows.append(bench_mnist(args.device, args.steps, args.warmup, graphs, fusion,
                                     device_data=dev_data, step_fusion=step, deferred=deferred))

@@ -1181,9 +1181,13 @@ class Session:
                 cap.h2d_done.record()
         if cap.direct is not None:
             # the whole step is one prepared call into the kernel library (its launches cost
-            # less host time issued directly than as a graph of so few nodes)
-            fn, block = cap.direct
-            rc = fn(block, torch._C._cuda_getCurrentRawStream(self.device.index))
+            # less host time issued directly than as a graph of so few nodes): the batch's
+            # addresses and the replay number go into the argument block, so the kernels start
+            # without a round trip to the ring's table
+            fn, ref, block, xi, li = cap.direct
+            block.x, block.labels = int(row[xi]), int(row[li])
+            block.host_seq = n & 0x7fffffff
+            rc = fn(ref, torch._C._cuda_getCurrentRawStream(self.device.index))
             if rc != 0:
                 raise RuntimeError("captured step: direct launch failed with code %d" % rc)
         else:
@@ -1286,6 +1290,7 @@ class Session:
                             if (call is not None and direct and not _NO_DIRECT_STEP and all(
                                     st.node.type == "VariableV2" for st in steps[:k])):
                                 cap.direct = call
+                                call[2].x_index = call[2].labels_index = -1
                         else:
                             packed = _packable([(sl, vals[sl]) for sl in dict.fromkeys(want)],
                                                limit)

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_step_update_kernel(SkinnyArgs g,
                                                                    int a_index, int tail_blocks,
                                                                    int ring_last) {
   if ((int)blockIdx.x < tail_blocks) {
-    step_tail(p, t, ring_last ? ring : DtfStepRing{nullptr, nullptr, nullptr, 0}, blockIdx.x);
+    step_tail(p, t, ring_last ? ring : DtfStepRing{nullptr, nullptr, nullptr, 0, -1}, blockIdx.x);
     return;
   }
   if (ring.ctr && a_index >= 0)
@@ -193,6 +193,8 @@ struct DtfMlpStep {
   int ring_first;              // this step's first launch is the first kernel of the replay
   int ring_last;               // its last launch gathers into the ring, stamps the slot and opens
                                // the next replay (otherwise a later kernel of the step does)
+  long host_seq;               // >= 0: the replay number, for a step issued directly (the device
+                               // counters are then not used); -1: read it from the counters
 };
 
 DTF_API int dtf_mlp_step_supported(long B, long D, long H, long C) {
@@ -217,7 +219,7 @@ DTF_API int dtf_mlp_step_train(const DtfMlpStep* s, hipStream_t stream) {
     return DTF_ERR_BAD_ARG;
   const int B = (int)s->B, D = (int)s->D, H = (int)s->H, C = (int)s->C;
   const DtfStepRing ring{(const unsigned long long*)s->ring_table, (unsigned*)s->ring_ctr,
-                         (float*)s->ring_out, s->ring};
+                         (float*)s->ring_out, s->ring, s->host_seq};
 
   TailArgs tail = {};
   tail.w2 = s->w2;

@@ -350,7 +350,7 @@ static int gather_feeds_launch(const void* table, const DtfStepRing& ring, int c
 DTF_API int dtf_gather_feeds(const void* table, int count, void* const* dst, const long* bytes,
                              hipStream_t stream) {
   if (!table) return DTF_ERR_BAD_ARG;
-  return gather_feeds_launch(table, DtfStepRing{nullptr, nullptr, nullptr, 0}, count, dst, bytes,
+  return gather_feeds_launch(table, DtfStepRing{nullptr, nullptr, nullptr, 0, -1}, count, dst, bytes,
                              stream);
 }
 
@@ -361,7 +361,7 @@ DTF_API int dtf_gather_feeds_ring(const void* ring_table, void* ring_ctr, void* 
                                   hipStream_t stream) {
   if (!ring_table || !ring_ctr || ring < 1 || (ring & (ring - 1))) return DTF_ERR_BAD_ARG;
   const DtfStepRing r{(const unsigned long long*)ring_table, (unsigned*)ring_ctr, (float*)ring_out,
-                      ring};
+                      ring, -1};
   return gather_feeds_launch(ring_table, r, count, dst, bytes, stream);
 }
 
@@ -440,7 +440,7 @@ DTF_API int dtf_pack_f32_signal(int count, const float* const* src, const int* s
   args.offset[count] = off;
   args.count = count;
   hipLaunchKernelGGL(pack_f32_kernel, dim3(1), dim3(BLOCK), 0, stream, args, dst, seq_src,
-                     seq_dst, DtfStepRing{nullptr, nullptr, nullptr, 0}, 0);
+                     seq_dst, DtfStepRing{nullptr, nullptr, nullptr, 0, -1}, 0);
   DTF_LAUNCH_CHECK();
   return DTF_OK;
 }
@@ -468,7 +468,7 @@ DTF_API int dtf_pack_f32_ring(int count, const float* const* src, const int* siz
   args.offset[count] = off;
   args.count = count;
   const DtfStepRing r{(const unsigned long long*)ring_table, (unsigned*)ring_ctr, (float*)ring_out,
-                      ring};
+                      ring, -1};
   hipLaunchKernelGGL(pack_f32_kernel, dim3(1), dim3(BLOCK), 0, stream, args, nullptr, nullptr,
                      nullptr, r, ring_first);
   DTF_LAUNCH_CHECK();

@@ -28,19 +28,25 @@ struct DtfStepRing {
   unsigned* ctr;                     // null: not a ring step (arguments are direct pointers)
   float* out;                        // pinned [ring][DTF_RING_WORDS]
   int ring;
+  long host_seq;                     // >= 0: the replay number, given by the host at launch (a
+                                     // step issued directly, not replayed from a graph): the
+                                     // counters are neither read nor written
 };
 
 __device__ __forceinline__ unsigned dtf_ring_stamp(unsigned seq) { return (seq & 0x7fffffu) + 1u; }
 
 // first kernel of the step: every workgroup learns the replay number, workgroup 0 publishes it
 __device__ __forceinline__ unsigned dtf_ring_begin(const DtfStepRing& r) {
+  if (r.host_seq >= 0) return (unsigned)r.host_seq;
   const unsigned seq = r.ctr[1];
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) r.ctr[0] = seq;
   return seq;
 }
 
 // later kernels of the step
-__device__ __forceinline__ unsigned dtf_ring_current(const DtfStepRing& r) { return r.ctr[0]; }
+__device__ __forceinline__ unsigned dtf_ring_current(const DtfStepRing& r) {
+  return r.host_seq >= 0 ? (unsigned)r.host_seq : r.ctr[0];
+}
 
 // address of input `index` of replay `seq` (pinned host memory: never from a stale cache line)
 __device__ __forceinline__ const void* dtf_ring_feed(const DtfStepRing& r, unsigned seq, int index) {
@@ -59,5 +65,5 @@ __device__ __forceinline__ float* dtf_ring_out(const DtfStepRing& r, unsigned se
 __device__ __forceinline__ void dtf_ring_finish(const DtfStepRing& r, unsigned seq) {
   __hip_atomic_store(dtf_ring_out(r, seq) + (DTF_RING_WORDS - 1), (float)dtf_ring_stamp(seq),
                      __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  r.ctr[1] = seq + 1u;
+  if (r.host_seq < 0) r.ctr[1] = seq + 1u;
 }

@@ -1004,7 +1004,8 @@ class _MlpStep(ctypes.Structure):
                 ("ring_table", ctypes.c_void_p), ("ring_ctr", ctypes.c_void_p),
                 ("ring_out", ctypes.c_void_p), ("ring", ctypes.c_int),
                 ("x_index", ctypes.c_int), ("labels_index", ctypes.c_int),
-                ("ring_first", ctypes.c_int), ("ring_last", ctypes.c_int)]
+                ("ring_first", ctypes.c_int), ("ring_last", ctypes.c_int),
+                ("host_seq", ctypes.c_long)]
 
 
 def mlp_step_supported(b: int, d: int, h: int, c: int) -> bool:
@@ -1062,6 +1063,7 @@ def mlp_step_train(x: Optional[torch.Tensor], labels: Optional[torch.Tensor], w1
     w1, b1 = need(w1, (d, h), "w1"), need(b1, (h,), "b1")
     w2, b2 = need(w2, (h, c), "w2"), need(b2, (c,), "b2")
     a = _MlpStep()
+    a.host_seq = -1
     if ring is None or x_index < 0:
         a.x = need(x, (b, d), "x").data_ptr()
         x_index = -1

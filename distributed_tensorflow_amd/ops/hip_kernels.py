@@ -645,7 +645,7 @@ def _mlp_train_step(op, inputs, ctx):
         if claimed and xi >= 0 and li >= 0:
             # the whole captured step is this one library call: the session may issue it directly
             import ctypes
-            ctx.direct_call = (hip.lib().dtf_mlp_step_train, ctypes.byref(block))
+            ctx.direct_call = (hip.lib().dtf_mlp_step_train, ctypes.byref(block), block, xi, li)
             ctx.buffers[(op, "call", b)] = block       # the block outlives this call
         return outs
     # larger batch or layers: the chain of general kernels

@@ -110,6 +110,7 @@ def result_line(args, world: int, strategy: str, engine: ShardedMatmul, elapsed:
                    "parallelism": par, "panels": engine.panels,
                    "pipelined_steps": bool(engine.pipelined),
                    "recompute_rows": engine.recompute_rows,
+                   "fp8_scaling": engine.scaling if args.dtype == "fp8" else None,
                    "peer_transport": engine.peer_transport
                    if strategy.endswith("_direct") else None,
                    "result": "full C on every rank" if strategy in
@@ -179,6 +180,9 @@ def main() -> None:
     ap.add_argument("--n", type=int, default=16384)
     ap.add_argument("--k", type=int, default=16384)
     ap.add_argument("--dtype", default="bf16", choices=sorted(DTYPES))
+    ap.add_argument("--fp8-scaling", default="tensor", choices=("tensor", "mx"),
+                    help="--dtype fp8 only: 'mx' = block-scaled operands (one E8M0 scale per 32 k, "
+                         "applied by the matrix instruction)")
     ap.add_argument("--strategy", default="auto")
     ap.add_argument("--panels", type=int, default=None)
     ap.add_argument("--no-pipeline", action="store_true",
@@ -230,6 +234,10 @@ def main() -> None:
               file=sys.stderr)
 
     dtype = DTYPES[args.dtype]
+    if args.dtype != "fp8":
+        args.fp8_scaling = "tensor"
+    if args.fp8_scaling == "mx":
+        args.no_recompute = True          # block-scaled operands stay on the rank that made them
     secured = Secured(rank, result_fd)
 
     def say(msg: str) -> None:
@@ -241,7 +249,8 @@ def main() -> None:
         eng = ShardedMatmul(args.m, args.n, args.k, comm, dtype=dtype, strategy=strategy,
                             panels=args.panels, seed=1, device=device,
                             distribution=args.distribution, pipelined=not args.no_pipeline,
-                            recompute_rows=recompute_rows, peer_transport=args.peer_transport)
+                            recompute_rows=recompute_rows, peer_transport=args.peer_transport,
+                            scaling=args.fp8_scaling)
         eng.init_operands()
         return eng
 

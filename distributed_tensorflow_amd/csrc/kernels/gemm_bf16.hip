@@ -231,21 +231,29 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const char* base) {
   return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0xffffffff, 0x00020000);
 }
 
+// SHARED_HALVES: the second 128-row half of an operand tile is staged with the FIRST half's
+// per-lane offsets plus a wave-uniform 128 * ld bytes in the scalar offset -- valid when no row of
+// the tile is clamped at the matrix edge (M and N multiples of the tile) -- so that only
+// voff[0] (A) and voff[1] (Bt) stay live across the K loop: four registers instead of eight.
+template <bool SHARED_HALVES = false>
 __device__ __forceinline__ void stage_half(__amdgpu_buffer_rsrc_t a_tile,
                                            __amdgpu_buffer_rsrc_t b_tile,
                                            const unsigned (&voff)[4][2], int h, int nkt, int kind,
-                                           int buf, char* smem, int wave) {
+                                           int buf, char* smem, int wave, int a_half_bytes = 0,
+                                           int b_half_bytes = 0) {
   int t = h >> 2;
   t = t < nkt ? t : nkt - 1;        // past the end: restage a dead slot with valid memory
   const bool is_a = (kind == 0 || kind == 3);
   const int half = (kind >= 2) ? 1 : 0;
-  const int k0 = t * 128;           // 128 bytes of k per K-tile
+  int k0 = t * 128;                 // 128 bytes of k per K-tile
+  if (SHARED_HALVES && half) k0 += is_a ? a_half_bytes : b_half_bytes;
+  const int vk = SHARED_HALVES ? (is_a ? 0 : 1) : kind;
   char* dst = smem + buf * BUF_BYTES + (is_a ? 0 : TILE_BYTES) + half * (TILE_BYTES / 2);
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int piece = wave * 2 + j;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(is_a ? a_tile : b_tile,
-                                             (lds_void*)(dst + piece * 1024), 16, voff[kind][j],
+                                             (lds_void*)(dst + piece * 1024), 16, voff[vk][j],
                                              k0, 0, 0);
   }
 }
@@ -305,11 +313,28 @@ __device__ __forceinline__ void pp_tile_of_block(int bid, int tiles_m, int tiles
 //   8-register operands) and spills with the few more the tile loop keeps live, so it runs one
 //   tile per workgroup; a spill inside the K loop would also add scratch loads to the vmcnt
 //   stream the counted waits rely on.
-template <bool OUT_F32, int DBG, bool FP8, bool MERGE = false>
+// MX = true (FP8 only): block-scaled operands in the OCP MX manner -- every 32 consecutive k of a
+//   row share one E8M0 scale (a power of two), applied by the MFMA itself. The instruction takes
+//   the scale of (row r, 32-block b of its 128 k) from lane 16 b + r of a scale register, one byte
+//   selected by an immediate. Scales are stored ready for that (dtf_quantize_mx_fp8 writes them
+//   so): per K-tile and 256-row block tile 256 dwords; a wave's lane l = 16 b + r finds in ONE
+//   dword the four scales it needs for a half of the tile -- for A the rows (MH, wr, i = 0..3,
+//   r), byte i; for Bt the rows (NH, wc, j, r), byte 2 NH + j. Per K-tile a wave moves three such
+//   dwords per lane (A half 0, A half 1, Bt) into a private LDS strip with three 4-byte LDS-DMA
+//   instructions, one K-tile ahead of their use, and reads them back with ds_read_b32 next to the
+//   fragment reads. The three instructions enter the counted vmcnt waits of the phases that issue
+//   them (they sit in the queue before that phase's tile DMA, so those phases wait for
+//   vmcnt(9) instead of vmcnt(6)).
+template <bool OUT_F32, int DBG, bool FP8, bool MERGE = false, bool MX = false>
 __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
     const char* __restrict__ A, const char* __restrict__ Bt,
     void* __restrict__ C, int M, int N, int K, long lda, long ldb, long ldc, int tiles_m,
-    int tiles_n, float alpha, float beta, int ksplits, long plane) {
+    int tiles_n, float alpha, float beta, int ksplits, long plane,
+    const unsigned* __restrict__ sa, const unsigned* __restrict__ sb, int sa_pair = 0,
+    int sb_kt = 0) {
+  // sa_pair / sb_kt: bytes from one K-tile pair (A) / K-tile (Bt) of scales to the next -- the
+  // row-tile count of the matrix the scales were made for, which may be taller than this call's
+  static_assert(!MX || (FP8 && MERGE), "block scales: fp8 operands, merged schedule");
   // ksplits > 1 (few output tiles, long K): work item (split, tile) multiplies K-range `split`
   // of K / ksplits columns and writes its partial tile to C + split * plane (elements); a
   // second kernel sums the planes in split order.
@@ -360,13 +385,51 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
   unsigned seg[4][6] = {};
   unsigned voff[4][2];
   stage_offsets<ESIZE>(voff, lda, ldb, m0, n0, M, N, wave, lane);
+  // (MX: tiles never straddle the matrix edge; the halves share their per-lane offsets)
+  const int a_half_bytes = (int)(128 * lda * ESIZE), b_half_bytes = (int)(128 * ldb * ESIZE);
   __amdgpu_buffer_rsrc_t a_tile = tile_rsrc(A + ((long)m0 * lda + (long)split * ksub) * ESIZE);
   __amdgpu_buffer_rsrc_t b_tile = tile_rsrc(Bt + ((long)n0 * ldb + (long)split * ksub) * ESIZE);
+
+  // block scales: this wave's strip of LDS,
+  //   A: [pair parity][64 lanes][16 bytes = (K-tile & 1, A half, i)]   2 x 1 KiB, one 16-byte
+  //      LDS-DMA per PAIR of K-tiles;
+  //   Bt: [K-tile parity][64 lanes][4 bytes = (Bt half, j)]            2 x 256 B, one 4-byte
+  //      LDS-DMA per K-tile.
+  // A per-lane register serves as LDS address of the lane's slot and as the DMA's per-lane offset
+  // (the buffer base is set back by the strip's offset to make up for it).
+  constexpr int SC_WAVE = 2 * 1024 + 2 * 256;
+  const int sc_strip = 2 * BUF_BYTES + wave * SC_WAVE;
+  const unsigned sca_lane = (unsigned)sc_strip + (unsigned)lane * 16u;
+  const unsigned scb_lane = (unsigned)(sc_strip + 2048) + (unsigned)lane * 4u;
+  __amdgpu_buffer_rsrc_t sa_tile = a_tile, sb_tile = b_tile;
+  // stage the A scales of K-tile pair p and the Bt scales of K-tile t (clamped at the end: a
+  // dead slot is refilled)
+  auto stage_scales_a = [&](int pr) {
+    const int last = (nkt - 1) >> 1;
+    const int pc = (pr < last ? pr : last) + split * ((nkt + 1) >> 1);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(sa_tile, (lds_void*)(smem + sc_strip + (pr & 1) * 1024),
+                                             16, sca_lane, pc * sa_pair, 0, 0);
+  };
+  auto stage_scales_b = [&](int t) {
+    const int tc = (t < nkt ? t : nkt - 1) + split * nkt;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(sb_tile,
+                                             (lds_void*)(smem + sc_strip + 2048 + (t & 1) * 256), 4,
+                                             scb_lane, tc * sb_kt, 0, 0);
+  };
+  if constexpr (MX) {
+    sa_tile = tile_rsrc(reinterpret_cast<const char*>(sa) + (long)(m0 / BM) * 2048 + wr * 1024 -
+                        sc_strip);
+    sb_tile = tile_rsrc(reinterpret_cast<const char*>(sb) + (long)(n0 / BN) * 1024 + wc * 256 -
+                        (sc_strip + 2048));
+    stage_scales_a(0);             // in front of the prologue's DMA: landed with half-tile 0
+    stage_scales_b(0);
+  }
+  unsigned sc_a = 0x7f7f7f7fu, sc_b = 0x7f7f7f7fu;     // the scales of the running phase
 
   // prologue of the first tile: half-tiles 0..5 in flight
 #pragma unroll
   for (int h = 0; h < 6; ++h)
-    stage_half(a_tile, b_tile, voff, h, nkt, h & 3, (h >> 2) & 1, smem, wave);
+    stage_half<MX>(a_tile, b_tile, voff, h, nkt, h & 3, (h >> 2) & 1, smem, wave, a_half_bytes, b_half_bytes);
   bool first = true;
 
   for (;;) {
@@ -400,13 +463,17 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
       bf[NH][j][s2] = *reinterpret_cast<const i32x4*>(smem + (BUFI) * BUF_BYTES + (NH) * 16384 + \
                                                       b_wave + j * 2048 +                       \
                                                       (s2 ? lane_off1 : lane_off0));
+// (the scale-byte selectors of the block-scaled MFMA are immediates: one macro per tile)
+#define DTF_MFMA_F8(MH, NH, I, J)                                                                \
+  acc[MH][NH][I][J] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(                          \
+      __builtin_shufflevector(bf[NH][J][0], bf[NH][J][1], 0, 1, 2, 3, 4, 5, 6, 7),               \
+      __builtin_shufflevector(af[I][0], af[I][1], 0, 1, 2, 3, 4, 5, 6, 7), acc[MH][NH][I][J], 0, \
+      0, MX ? 2 * (NH) + (J) : 0, sc_b, MX ? (I) : 0, sc_a);
 #define DTF_MFMA_QUAD(MH, NH)                                                                    \
   if constexpr (FP8) {                                                                           \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)  \
-        acc[MH][NH][i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(                    \
-            __builtin_shufflevector(bf[NH][j][0], bf[NH][j][1], 0, 1, 2, 3, 4, 5, 6, 7),         \
-            __builtin_shufflevector(af[i][0], af[i][1], 0, 1, 2, 3, 4, 5, 6, 7),                 \
-            acc[MH][NH][i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);                              \
+    DTF_MFMA_F8(MH, NH, 0, 0) DTF_MFMA_F8(MH, NH, 0, 1) DTF_MFMA_F8(MH, NH, 1, 0)                \
+    DTF_MFMA_F8(MH, NH, 1, 1) DTF_MFMA_F8(MH, NH, 2, 0) DTF_MFMA_F8(MH, NH, 2, 1)                \
+    DTF_MFMA_F8(MH, NH, 3, 0) DTF_MFMA_F8(MH, NH, 3, 1)                                          \
   } else {                                                                                       \
     _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) _Pragma("unroll") for (int i = 0; i < 4;    \
                                                                             ++i)                 \
@@ -420,8 +487,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
   {                                                                                              \
     READS;                                                                                       \
     if (!(dbg & 1))                                                                              \
-      stage_half(a_tile, b_tile, voff, (dbg & 2) ? 0 : g0 + (P) + 6, nkt, ((P) + 2) & 3,         \
-                 (((P) + 6) >> 2) & 1, smem, wave);                                              \
+      stage_half<MX>(a_tile, b_tile, voff, (dbg & 2) ? 0 : g0 + (P) + 6, nkt, ((P) + 2) & 3,         \
+                 (((P) + 6) >> 2) & 1, smem, wave, a_half_bytes, b_half_bytes);                                              \
     if (!(dbg & 4)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                             \
     __builtin_amdgcn_sched_barrier(0);                                                           \
     __builtin_amdgcn_s_barrier();                                                                \
@@ -441,14 +508,27 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0;                     \
     if constexpr ((dbg & 8) != 0) ts0 = __builtin_amdgcn_s_memtime();                            \
     READS;                                                                                       \
+    if constexpr (MX) {                                                                          \
+      /* K-tile of this phase: (g0 >> 2) + (P >> 1), of pair g0 >> 3; its A half is P & 1 */     \
+      sc_a = *reinterpret_cast<const unsigned*>(smem + sca_lane + ((g0 >> 3) & 1) * 1024 +       \
+                                                ((P) >> 1) * 8 + ((P) & 1) * 4);                 \
+      if (((P) & 1) == 0)                                                                        \
+        sc_b = *reinterpret_cast<const unsigned*>(smem + scb_lane + ((P) >> 1) * 256);           \
+      if ((P) == 0) stage_scales_a((g0 >> 3) + 1);                                               \
+      if (((P) & 1) == 0) stage_scales_b((g0 >> 2) + ((P) >> 1) + 1);                            \
+    }                                                                                            \
     if (!(dbg & 1)) {                                                                            \
-      stage_half(a_tile, b_tile, voff, (dbg & 2) ? 0 : g0 + 2 * (P) + 6, nkt,                    \
-                 (2 * (P) + 2) & 3, ((2 * (P) + 6) >> 2) & 1, smem, wave);                       \
-      stage_half(a_tile, b_tile, voff, (dbg & 2) ? 0 : g0 + 2 * (P) + 7, nkt,                    \
-                 (2 * (P) + 3) & 3, ((2 * (P) + 7) >> 2) & 1, smem, wave);                       \
+      stage_half<MX>(a_tile, b_tile, voff, (dbg & 2) ? 0 : g0 + 2 * (P) + 6, nkt,                    \
+                 (2 * (P) + 2) & 3, ((2 * (P) + 6) >> 2) & 1, smem, wave, a_half_bytes, b_half_bytes);                       \
+      stage_half<MX>(a_tile, b_tile, voff, (dbg & 2) ? 0 : g0 + 2 * (P) + 7, nkt,                    \
+                 (2 * (P) + 3) & 3, ((2 * (P) + 7) >> 2) & 1, smem, wave, a_half_bytes, b_half_bytes);                       \
     }                                                                                            \
     if constexpr ((dbg & 8) != 0) ts1 = __builtin_amdgcn_s_memtime();                            \
-    if (!(dbg & 4)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                             \
+    if (!(dbg & 4)) {                                                                            \
+      if (MX && (P) == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                       \
+      else if (MX && (P) == 2) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");                  \
+      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                      \
+    }                                                                                            \
     if constexpr ((dbg & 8) != 0) ts2 = __builtin_amdgcn_s_memtime();                            \
     __builtin_amdgcn_sched_barrier(0);                                                           \
     __builtin_amdgcn_s_barrier();                                                                \
@@ -506,6 +586,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
 #undef DTF_PHASE2
 #undef DTF_PHASE
 #undef DTF_MFMA_QUAD
+#undef DTF_MFMA_F8
 #undef DTF_READ_A
 #undef DTF_READ_B
   if (wr == 0) __builtin_amdgcn_s_barrier();          // every wave has passed the same count
@@ -527,7 +608,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
     b_tile = tile_rsrc(Bt + ((long)n0 * ldb + (long)split * ksub) * ESIZE);
 #pragma unroll
     for (int h = 0; h < 6; ++h)
-      stage_half(a_tile, b_tile, voff, h, nkt, h & 3, (h >> 2) & 1, smem, wave);
+      stage_half<MX>(a_tile, b_tile, voff, h, nkt, h & 3, (h >> 2) & 1, smem, wave, a_half_bytes, b_half_bytes);
   }
   // epilogue: lane holds C[row = frow][col = 4*fq + r] of each 16x16 tile. The lane's row and
   // column pass through an opaque copy so that the address arithmetic stays HERE: hoisted out
@@ -1176,23 +1257,23 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
     if (dbg == 8)
       hipLaunchKernelGGL((gemm_nt_pp_kernel<false, 8, false, true>), pp_grid, block, lds + 1024,
                          stream, (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc,
-                         tiles_m, tiles_n, alpha, beta, 1, 0L);
+                         tiles_m, tiles_n, alpha, beta, 1, 0L, nullptr, nullptr);
     else if (dbg == 10)
       hipLaunchKernelGGL((gemm_nt_pp_kernel<false, 10, false, true>), pp_grid, block, lds + 1024,
                          stream, (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc,
-                         tiles_m, tiles_n, alpha, beta, 1, 0L);
+                         tiles_m, tiles_n, alpha, beta, 1, 0L, nullptr, nullptr);
     else if (dbg == 9)
       hipLaunchKernelGGL((gemm_nt_pp_kernel<false, 9, false, true>), pp_grid, block, lds + 1024,
                          stream, (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc,
-                         tiles_m, tiles_n, alpha, beta, 1, 0L);
+                         tiles_m, tiles_n, alpha, beta, 1, 0L, nullptr, nullptr);
     else if (dbg == 16)
       hipLaunchKernelGGL((gemm_nt_pp_kernel<false, 16, false, true>), pp_grid, block, lds, stream,
                          (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tiles_m,
-                         tiles_n, alpha, beta, 1, 0L);
+                         tiles_n, alpha, beta, 1, 0L, nullptr, nullptr);
     else if (dbg == 32)
       hipLaunchKernelGGL((gemm_nt_pp_kernel<false, 32, false, true>), grid, block, lds, stream,
                          (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tiles_m,
-                         tiles_n, alpha, beta, 1, 0L);
+                         tiles_n, alpha, beta, 1, 0L, nullptr, nullptr);
     else return DTF_ERR_UNSUPPORTED;
     DTF_LAUNCH_CHECK();
     return DTF_OK;
@@ -1227,11 +1308,11 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
     if (out_f32)
       hipLaunchKernelGGL((gemm_nt_pp_kernel<true, 0, false, true>), pp_grid, block, lds, stream,
                          (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tiles_m,
-                         tiles_n, alpha, beta, 1, 0L);
+                         tiles_n, alpha, beta, 1, 0L, nullptr, nullptr);
     else
       hipLaunchKernelGGL((gemm_nt_pp_kernel<false, 0, false, true>), pp_grid, block, lds, stream,
                          (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tiles_m,
-                         tiles_n, alpha, beta, 1, 0L);
+                         tiles_n, alpha, beta, 1, 0L, nullptr, nullptr);
     DTF_LAUNCH_CHECK();
     return DTF_OK;
   }
@@ -1240,7 +1321,7 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
 #define DTF_PP_LAUNCH(F32, DBGV)                                                                  \
   hipLaunchKernelGGL((gemm_nt_pp_kernel<F32, DBGV, false>), pp_grid, block, lds, stream,             \
                      (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tiles_m,         \
-                     tiles_n, alpha, beta, 1, 0L)
+                     tiles_n, alpha, beta, 1, 0L, nullptr, nullptr)
     const int dbg = variant >> 4;
     if (dbg == 0) {
       if (out_f32) DTF_PP_LAUNCH(true, 0); else DTF_PP_LAUNCH(false, 0);
@@ -1351,7 +1432,7 @@ DTF_API int dtf_gemm_bf16_nt_splitk(const void* A, const void* Bt, void* C, floa
   const dim3 grid(dtf_pp_grid(tiles_m * tiles_n * ksplits)), block(NTHREADS);
   hipLaunchKernelGGL((gemm_nt_pp_kernel<true, 0, false, true>), grid, block, lds, stream,
                      (const char*)A, (const char*)Bt, (void*)workspace, M, N, K, lda, ldb,
-                     (long)N, tiles_m, tiles_n, 1.0f, 0.0f, ksplits, plane);
+                     (long)N, tiles_m, tiles_n, 1.0f, 0.0f, ksplits, plane, nullptr, nullptr);
   const long work = plane / 4;
   const int blocks = (int)((work + 255) / 256 > 2048 ? 2048 : (work + 255) / 256);
   if (out_f32)
@@ -1388,7 +1469,7 @@ DTF_API int dtf_gemm_fp8_nt(const void* A, const void* Bt, void* C, int M, int N
     { static DtfPerDeviceOnce once__; dtf_once_per_device(once__, [&] { dtf_allow_lds(gemm_nt_pp_kernel<false, 16, true, true>, lds); }); }
     hipLaunchKernelGGL((gemm_nt_pp_kernel<false, 16, true, true>), grid, block, lds, stream,
                        (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tiles_m,
-                       tiles_n, alpha, beta, 1, 0L);
+                       tiles_n, alpha, beta, 1, 0L, nullptr, nullptr);
     DTF_LAUNCH_CHECK();
     return DTF_OK;
   }
@@ -1396,11 +1477,54 @@ DTF_API int dtf_gemm_fp8_nt(const void* A, const void* Bt, void* C, int M, int N
   if (out_f32)
     hipLaunchKernelGGL((gemm_nt_pp_kernel<true, 0, true, true>), grid, block, lds, stream,
                        (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tiles_m,
-                       tiles_n, alpha, beta, 1, 0L);
+                       tiles_n, alpha, beta, 1, 0L, nullptr, nullptr);
   else
     hipLaunchKernelGGL((gemm_nt_pp_kernel<false, 0, true, true>), grid, block, lds, stream,
                        (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tiles_m,
-                       tiles_n, alpha, beta, 1, 0L);
+                       tiles_n, alpha, beta, 1, 0L, nullptr, nullptr);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
+// Block-scaled fp8 (OCP MX: e4m3 elements, one E8M0 scale per 32 consecutive k of a row), both
+// operands quantised by dtf_quantize_mx_fp8 (which also lays the scales out the way the kernel
+// reads them: sa with role 0 for A, sb with role 1 for Bt):
+// C[M,N] (bf16 or fp32) = alpha * (A o SA)[M,K] * (Bt o SB)[N,K]^T, fp32 accumulate.
+// Contract: M % 256 == N % 256 == 0, K % 128 == 0, lda/ldb % 16 == 0, 16-byte aligned A/Bt.
+DTF_API int dtf_gemm_fp8_mx_nt(const void* A, const void* Bt, void* C, const void* sa,
+                               const void* sb, int M, int N, int K, long lda, long ldb, long ldc,
+                               long sa_row_tiles, long sb_row_tiles, float alpha, float beta,
+                               int out_f32, hipStream_t stream) {
+  if (!A || !Bt || !C || !sa || !sb || M <= 0 || N <= 0 || K <= 0) return DTF_ERR_BAD_ARG;
+  if (lda < K || ldb < K || ldc < N) return DTF_ERR_BAD_ARG;
+  if (M % BM || N % BN || K % 128 || lda % 16 || ldb % 16 || ldc % 4 || ((uintptr_t)A & 15) ||
+      ((uintptr_t)Bt & 15) || ((uintptr_t)sa & 15) || ((uintptr_t)sb & 3) ||
+      ((uintptr_t)C & (out_f32 ? 15 : 7)))
+    return DTF_ERR_UNSUPPORTED;
+  if (lda * BM >= (1L << 32) || ldb * BN >= (1L << 32)) return DTF_ERR_UNSUPPORTED;
+  const int tiles_m = M / BM, tiles_n = N / BN;
+  // the scales may belong to a taller matrix of which A / Bt is a block of whole row tiles
+  if (sa_row_tiles < tiles_m || sb_row_tiles < tiles_n) return DTF_ERR_BAD_ARG;
+  if ((long)(K / 128 + 1) * (sa_row_tiles > sb_row_tiles ? sa_row_tiles : sb_row_tiles) * 1024 >=
+      (1L << 31))
+    return DTF_ERR_UNSUPPORTED;
+  const size_t lds = 2 * BUF_BYTES + (NTHREADS / 64) * 2560;
+  { static DtfPerDeviceOnce once__; dtf_once_per_device(once__, [&] {
+    dtf_allow_lds(gemm_nt_pp_kernel<true, 0, true, true, true>, lds);
+    dtf_allow_lds(gemm_nt_pp_kernel<false, 0, true, true, true>, lds);
+  }); }
+  const dim3 grid(tiles_m * tiles_n), block(NTHREADS);
+  const int sa_pair = (int)(sa_row_tiles * 2048), sb_kt = (int)(sb_row_tiles * 1024);
+  if (out_f32)
+    hipLaunchKernelGGL((gemm_nt_pp_kernel<true, 0, true, true, true>), grid, block, lds, stream,
+                       (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tiles_m,
+                       tiles_n, alpha, beta, 1, 0L, (const unsigned*)sa, (const unsigned*)sb,
+                       sa_pair, sb_kt);
+  else
+    hipLaunchKernelGGL((gemm_nt_pp_kernel<false, 0, true, true, true>), grid, block, lds, stream,
+                       (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tiles_m,
+                       tiles_n, alpha, beta, 1, 0L, (const unsigned*)sa, (const unsigned*)sb,
+                       sa_pair, sb_kt);
   DTF_LAUNCH_CHECK();
   return DTF_OK;
 }

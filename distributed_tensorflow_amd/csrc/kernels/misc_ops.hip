@@ -394,3 +394,115 @@ DTF_API int dtf_cast_generic(const void* src, int src_kind, void* dst, int dst_k
   DTF_LAUNCH_CHECK();
   return DTF_OK;
 }
+
+// ---- MX block-scaled fp8 quantisation ------------------------------------------------------------
+// x[R, K] (fp32 or bf16, row pitch ld) -> q[R, K] OCP e4m3 (row pitch ldq) + one E8M0 scale per 32
+// consecutive k of a row: scale = 2^e with e the smallest exponent for which the block's largest
+// magnitude still fits e4m3 (|x| / 2^e <= 448), so nothing saturates; an all-zero block gets
+// scale 1. Eight lanes share a block (four elements each, one 16-byte load per lane for fp32).
+//
+// Scales are written in the order the block-scaled GEMM (gemm_bf16.hip, MX) reads them. With r the
+// row inside its 256-row tile, kb the index of the 32-block, kt = kb / 4 its K-tile of 128 k and
+// lane = 16 (kb % 4) + r % 16:
+//   role 0 (the GEMM's A operand): per PAIR of K-tiles and row tile 2 KiB;
+//       byte offset 1024 ((r / 64) % 2) + 16 lane + 8 (kt % 2) + 4 (r / 128) + (r / 16) % 4
+//   role 1 (its Bt operand): per K-tile and row tile 1 KiB;
+//       byte offset 256 ((r / 32) % 4) + 4 lane + 2 (r / 128) + (r / 16) % 2 `scales_rm` (optional)
+// receives the same bytes in plain row-major [R, K / 32] order.
+namespace {
+
+template <bool BF16_IN>
+__global__ __launch_bounds__(256) void quantize_mx_kernel(const void* __restrict__ x_, long R, long K,
+                                                          long ld, unsigned char* __restrict__ q,
+                                                          long ldq, unsigned char* __restrict__ sc,
+                                                          unsigned char* __restrict__ sc_rm,
+                                                          int role, long row_tiles) {
+  const long kblocks = K >> 5;
+  const long gb = (long)blockIdx.x * 32 + (threadIdx.x >> 3);     // (row, 32-block) of this octet
+  const int l8 = threadIdx.x & 7;
+  const bool in = gb < R * kblocks;
+  const long row = in ? gb / kblocks : 0, kb = in ? gb % kblocks : 0;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  if (in) {
+    if (BF16_IN) {
+      const unsigned short* p = reinterpret_cast<const unsigned short*>(x_) + row * ld + kb * 32 + l8 * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = dtf_bf16_to_f32(p[j]);
+    } else {
+      const float* p = reinterpret_cast<const float*>(x_) + row * ld + kb * 32 + l8 * 4;
+      if ((((uintptr_t)p) & 15) == 0) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+        v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = p[j];
+      }
+    }
+  }
+  float amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+  amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+  amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+  // e8 - 127 = ceil(log2(amax / 448)): exponent field of amax / 448, plus one unless the
+  // mantissa is zero; clamped to the E8M0 range that has an fp32 reciprocal
+  int e8 = 127;
+  if (amax > 0.f && amax < INFINITY) {
+    const unsigned bits = __float_as_uint(amax * (1.0f / 448.0f));
+    e8 = (int)((bits >> 23) & 255u) + ((bits & 0x7fffffu) ? 1 : 0);
+    e8 = e8 < 1 ? 1 : (e8 > 253 ? 253 : e8);
+  }
+  const float inv = __uint_as_float((unsigned)(254 - e8) << 23);      // 2^-(e8 - 127)
+  if (!in) return;
+  unsigned packed = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) packed |= (unsigned)dtf_f32_to_e4m3(v[j] * inv) << (8 * j);
+  *reinterpret_cast<unsigned*>(q + row * ldq + kb * 32 + l8 * 4) = packed;
+  if (l8 == 0) {
+    const long kt = kb >> 2, tile = row >> 8;
+    const int r = (int)(row & 255), ln = 16 * (int)(kb & 3) + (r & 15);
+    long off;
+    if (role == 0)
+      off = ((kt >> 1) * row_tiles + tile) * 2048 + 1024 * ((r >> 6) & 1) + 16 * ln +
+            8 * (int)(kt & 1) + 4 * (r >> 7) + ((r >> 4) & 3);
+    else
+      off = (kt * row_tiles + tile) * 1024 + 256 * ((r >> 5) & 3) + 4 * ln + 2 * (r >> 7) +
+            ((r >> 4) & 1);
+    sc[off] = (unsigned char)e8;
+    if (sc_rm) sc_rm[row * kblocks + kb] = (unsigned char)e8;
+  }
+}
+
+}  // namespace
+
+// bytes of the GEMM-ordered scale buffer for an [R, K] operand (R rounded up to whole 256-row
+// tiles, K % 128 == 0)
+DTF_API long dtf_mx_scale_bytes(long R, long K) {
+  if (R <= 0 || K <= 0 || K % 128) return 0;
+  return ((K / 128 + 1) / 2 * 2) * ((R + 255) / 256) * 1024;    // whole pairs of K-tiles
+}
+
+// src_kind 0: fp32, 1: bf16. q: [R, K] bytes with row pitch ldq (ldq % 4 == 0). scales:
+// dtf_mx_scale_bytes(R, K) bytes, 4-byte aligned (rows past R in the last tile keep what the
+// buffer held: the caller zero-fills or ignores them). scales_rm may be null.
+DTF_API int dtf_quantize_mx_fp8(const void* x, int src_kind, long R, long K, long ld, void* q,
+                                long ldq, void* scales, void* scales_rm, int role,
+                                hipStream_t stream) {
+  if (!x || !q || !scales || R <= 0 || K <= 0 || ld < K || ldq < K || (role != 0 && role != 1) ||
+      (src_kind != 0 && src_kind != 1))
+    return DTF_ERR_BAD_ARG;
+  if (K % 128 || ldq % 4 || ((uintptr_t)q & 3) || (src_kind == 1 && (ld % 2)))
+    return DTF_ERR_UNSUPPORTED;
+  const long blocks = (R * (K / 32) + 31) / 32;
+  if (blocks > 0x7fffffffL) return DTF_ERR_UNSUPPORTED;
+  const long row_tiles = (R + 255) / 256;
+  if (src_kind == 1)
+    hipLaunchKernelGGL(quantize_mx_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, x, R,
+                       K, ld, (unsigned char*)q, ldq, (unsigned char*)scales,
+                       (unsigned char*)scales_rm, role, row_tiles);
+  else
+    hipLaunchKernelGGL(quantize_mx_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, x,
+                       R, K, ld, (unsigned char*)q, ldq, (unsigned char*)scales,
+                       (unsigned char*)scales_rm, role, row_tiles);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}

@@ -67,6 +67,8 @@ def _declare(L: ctypes.CDLL) -> None:
         "dtf_gemm_bf16_generic": [P, P, P, I, I, I, LG, LG, LG, LG, LG, F, F, I, P],
         "dtf_gemm_fp8_nt": [P, P, P, I, I, I, LG, LG, LG, F, F, I, P],
         "dtf_gemm_fp8_generic": [P, P, P, I, I, I, LG, LG, LG, LG, LG, F, F, I, P],
+        "dtf_gemm_fp8_mx_nt": [P, P, P, P, P, I, I, I, LG, LG, LG, LG, LG, F, F, I, P],
+        "dtf_quantize_mx_fp8": [P, I, LG, LG, LG, P, LG, P, P, I, P],
         "dtf_cast_to_fp8": [P, I, P, LG, F, P],
         "dtf_transpose": [P, P, LG, LG, LG, LG, I, P],
         "dtf_cast_from_fp8": [P, P, I, LG, F, P],
@@ -132,6 +134,8 @@ def _declare(L: ctypes.CDLL) -> None:
         fn.restype = c.c_int
     L.dtf_absmax_workspace.argtypes = [LG]
     L.dtf_absmax_workspace.restype = LG
+    L.dtf_mx_scale_bytes.argtypes = [LG, LG]
+    L.dtf_mx_scale_bytes.restype = LG
 
 
 # ---------------------------------------------------------------------------------------
@@ -325,6 +329,110 @@ def gemm_fp8_nt(a: torch.Tensor, bt: torch.Tensor, out_dtype: torch.dtype = torc
                                           a.stride(0), 1, 1, bt.stride(0), out.stride(0),
                                           float(alpha), float(beta), out_f32, _stream())
     _check(code, "gemm_fp8_nt")
+    return out
+
+
+class MxFp8:
+    """A matrix in block-scaled fp8 (OCP MX: e4m3 elements, one power-of-two E8M0 scale per 32
+    consecutive elements of a row). ``q`` [R, K] fp8; ``scales`` the scale bytes of the matrix it
+    was quantised as (``row_tiles`` 256-row tiles) in the order the GEMM reads them for an operand
+    of this ``role`` (0: left operand, 1: the K-contiguous right operand), ``scale_offset`` the
+    byte at which this (block of the) matrix starts in them; ``scales_rm`` (optional) the scale
+    bytes as a plain [R, K/32] matrix. ``mx[r0:r1]`` is the block of rows r0..r1 (multiples of
+    256) sharing the parent's storage."""
+
+    __slots__ = ("q", "scales", "scales_rm", "role", "scale_offset", "row_tiles")
+
+    def __init__(self, q, scales, scales_rm, role, scale_offset=0, row_tiles=None):
+        self.q, self.scales, self.scales_rm, self.role = q, scales, scales_rm, role
+        self.scale_offset = int(scale_offset)
+        self.row_tiles = int(row_tiles) if row_tiles is not None else (q.shape[0] + 255) // 256
+
+    @property
+    def shape(self):
+        return self.q.shape
+
+    @property
+    def dtype(self):
+        return self.q.dtype
+
+    def __getitem__(self, key) -> "MxFp8":
+        if not isinstance(key, slice) or key.step not in (None, 1):
+            raise HipKernelError("MxFp8: only row slices mx[r0:r1] are supported")
+        r0, r1, _ = key.indices(self.q.shape[0])
+        if r0 % 256 or (r1 % 256 and r1 != self.q.shape[0]) or r1 <= r0:
+            raise HipKernelError("MxFp8: row blocks start and end on multiples of 256")
+        per_tile = 2048 if self.role == 0 else 1024
+        return MxFp8(self.q[r0:r1], self.scales,
+                     None if self.scales_rm is None else self.scales_rm[r0:r1], self.role,
+                     self.scale_offset + (r0 // 256) * per_tile, self.row_tiles)
+
+    def dequantize(self) -> torch.Tensor:
+        """fp32 values (needs ``scales_rm``); a torch reference for tests, not a kernel."""
+        if self.scales_rm is None:
+            raise HipKernelError("MxFp8.dequantize: quantise with want_rowmajor=True")
+        r, k = self.q.shape
+        f = torch.pow(2.0, self.scales_rm.to(torch.float32) - 127.0)
+        return (self.q.to(torch.float32).view(r, k // 32, 32) * f.view(r, k // 32, 1)).view(r, k)
+
+
+def quantize_mx_fp8(x: torch.Tensor, role: int, want_rowmajor: bool = False) -> MxFp8:
+    """Quantise the rows of ``x`` [R, K] (fp32 or bf16, K % 128 == 0) to block-scaled fp8: per
+    32 consecutive k the smallest power-of-two scale under which the block fits e4m3 without
+    saturating. ``role`` 0 for the left operand of ``gemm_fp8_mx_nt``, 1 for the right one."""
+    if not isinstance(x, torch.Tensor) or x.device.type != "cuda" or x.dim() != 2 \
+            or x.dtype not in (torch.float32, torch.bfloat16):
+        raise HipKernelError("quantize_mx_fp8: need a rank-2 fp32 or bf16 GPU tensor")
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    r, k = x.shape
+    if r == 0 or k == 0 or k % 128:
+        raise HipKernelError("quantize_mx_fp8: K must be a positive multiple of 128, got %s"
+                             % (tuple(x.shape),))
+    if role not in (0, 1):
+        raise HipKernelError("quantize_mx_fp8: role is 0 (left operand) or 1 (right operand)")
+    q = torch.empty((r, k), dtype=FP8, device=x.device)
+    nbytes = int(lib().dtf_mx_scale_bytes(r, k))
+    # rows past R in the last 256-row tile: unit scales
+    scales = torch.full((nbytes,), 127, dtype=torch.uint8, device=x.device)
+    rm = torch.empty((r, k // 32), dtype=torch.uint8, device=x.device) if want_rowmajor else None
+    _check(lib().dtf_quantize_mx_fp8(x.data_ptr(), int(x.dtype == torch.bfloat16), r, k,
+                                     x.stride(0), q.data_ptr(), k, scales.data_ptr(), _ptr(rm),
+                                     int(role), _stream()), "quantize_mx_fp8")
+    return MxFp8(q, scales, rm, role)
+
+
+def gemm_fp8_mx_nt(a: MxFp8, bt: MxFp8, out_dtype: torch.dtype = torch.bfloat16,
+                   alpha: float = 1.0, out: Optional[torch.Tensor] = None,
+                   beta: float = 0.0) -> torch.Tensor:
+    """``alpha * A @ Bt.T (+ beta * out)`` of two block-scaled fp8 matrices (``a`` quantised with
+    role 0, ``bt`` [N, K] with role 1): the scales are applied by the matrix instruction
+    (``v_mfma_scale_f32_16x16x128_f8f6f4``), fp32 accumulate, bf16 or fp32 result. M and N must
+    be multiples of 256, K of 128."""
+    if not isinstance(a, MxFp8) or not isinstance(bt, MxFp8) or a.role != 0 or bt.role != 1:
+        raise HipKernelError("gemm_fp8_mx_nt: operands must be MxFp8 with roles 0 and 1")
+    m, k = a.q.shape
+    n = bt.q.shape[0]
+    if bt.q.shape[1] != k:
+        raise HipKernelError("gemm_fp8_mx_nt: inner dimensions differ")
+    if out_dtype not in (torch.bfloat16, torch.float32):
+        raise HipKernelError("gemm_fp8_mx_nt: out dtype must be bf16 or fp32")
+    if m % 256 or n % 256 or k % 128:
+        raise HipKernelError("gemm_fp8_mx_nt: M and N must be multiples of 256 and K of 128 "
+                             "(got %d x %d x %d)" % (m, n, k))
+    if beta != 0.0 and out is None:
+        raise HipKernelError("gemm_fp8_mx_nt: beta needs an out tensor to accumulate into")
+    if out is None:
+        out = torch.empty((m, n), dtype=out_dtype, device=a.q.device)
+    elif out.shape != (m, n) or out.dtype != out_dtype or out.stride(1) != 1:
+        raise HipKernelError("gemm_fp8_mx_nt: bad out tensor")
+    _check(lib().dtf_gemm_fp8_mx_nt(a.q.data_ptr(), bt.q.data_ptr(), out.data_ptr(),
+                                    a.scales.data_ptr() + a.scale_offset,
+                                    bt.scales.data_ptr() + bt.scale_offset, m, n, k,
+                                    a.q.stride(0), bt.q.stride(0), out.stride(0), a.row_tiles,
+                                    bt.row_tiles, float(alpha), float(beta),
+                                    int(out_dtype == torch.float32), _stream()),
+           "gemm_fp8_mx_nt")
     return out
 
 

@@ -117,7 +117,7 @@ class ShardedMatmul:
                  device: Optional[torch.device] = None,
                  reduce_dtype: Optional[torch.dtype] = None, distribution: str = "uniform",
                  pipelined: bool = False, recompute_rows: int = 0,
-                 peer_transport: str = "copy"):
+                 peer_transport: str = "copy", scaling: str = "tensor"):
         if strategy not in STRATEGIES:
             raise ValueError("unknown strategy %r (choose from %s)" % (strategy, STRATEGIES))
         self.m, self.n, self.k = int(m), int(n), int(k)
@@ -125,6 +125,18 @@ class ShardedMatmul:
         self.rank, self.world = self.comm.rank, self.comm.world_size
         self.device = torch.device(device) if device is not None else self.comm.device
         self.dtype = dtype
+        # fp8 operands: "tensor" = unit scales (the generated operands fit e4m3 as they are),
+        # "mx" = block-scaled (one E8M0 scale per 32 k of a row, applied by the matrix
+        # instruction): operands are generated in bf16 and quantised by the MX kernel
+        if scaling not in ("tensor", "mx"):
+            raise ValueError("scaling is 'tensor' or 'mx'")
+        self.scaling = scaling
+        if scaling == "mx":
+            if dtype != torch.float8_e4m3fn:
+                raise ValueError("scaling='mx' applies to fp8 operands")
+            if strategy == "summa_2d" or recompute_rows:
+                raise ValueError("scaling='mx': operands must stay on their rank (no summa_2d, "
+                                 "no recompute_rows)")
         # fp8 operands produce bf16 results (fp32 accumulate inside the kernel)
         self.out_dtype = torch.bfloat16 if dtype == torch.float8_e4m3fn else dtype
         self.strategy = strategy
@@ -210,6 +222,11 @@ class ShardedMatmul:
         normal = self.distribution == "normal"
         a, b = (0.0, 1.0) if normal else (-1.0, 2.0)     # N(0,1) or U(-1,1)
         if self.on_gpu:
+            if self.scaling == "mx":
+                src = self._hip.philox_window(rows, cols, self.seed, op_seed, row0, col0,
+                                              global_cols, torch.bfloat16, self.device, normal,
+                                              a, b)
+                return self._hip.quantize_mx_fp8(src, 0 if which == "a" else 1)
             return self._hip.philox_window(rows, cols, self.seed, op_seed, row0, col0,
                                            global_cols, self.dtype, self.device, normal, a, b)
         host = philox.window(rows, cols, self.seed, op_seed, row0, col0, global_cols, normal)
@@ -297,7 +314,9 @@ class ShardedMatmul:
         (CPU)."""
         if self.on_gpu:
             beta = 1.0 if accumulate else 0.0
-            if a.dtype == torch.bfloat16:
+            if self.scaling == "mx":
+                self._hip.gemm_fp8_mx_nt(a, bt, out.dtype, out=out, beta=beta)
+            elif a.dtype == torch.bfloat16:
                 self._hip.gemm_bf16_nt(a, bt, out.dtype, out=out, beta=beta)
             elif a.dtype == torch.float8_e4m3fn:
                 self._hip.gemm_fp8_nt(a, bt, out.dtype, out=out, beta=beta)
@@ -575,6 +594,19 @@ class ShardedMatmul:
                            for i in rows])
         b_rows = np.stack([philox.window(1, self.k, self.seed, 2, int(j), 0, self.k, normal)[0]
                            for j in cols])
+        if self.scaling == "mx":
+            # what the MX quantiser keeps: bf16 source, per 32 k the smallest power-of-two scale
+            # under which the block fits e4m3, elements rounded to e4m3
+            def mx(x):
+                x = x.to(torch.bfloat16).float().view(x.shape[0], -1, 32)
+                amax = x.abs().amax(dim=2, keepdim=True)
+                e = torch.ceil(torch.log2(torch.clamp(amax, min=1e-30) / 448.0))
+                scale = torch.where(amax > 0, torch.pow(2.0, e), torch.ones_like(amax))
+                q = (x / scale).to(torch.float8_e4m3fn).float() * scale
+                return q.view(q.shape[0], -1).double()
+            at = mx(torch.from_numpy(a_rows) * b + a)
+            bt = mx(torch.from_numpy(b_rows) * b + a)
+            return at @ bt.t()
         at = (torch.from_numpy(a_rows) * b + a).to(self.dtype).double()
         bt = (torch.from_numpy(b_rows) * b + a).to(self.dtype).double()
         # (torch's fp8 cast rounds to nearest even like the device fill; U(-1,1) and N(0,1)

@@ -361,6 +361,33 @@ def test_sharded_matmul_fp8_single_gpu(hip):
     assert (s2.step().double().cpu()[rows][:, cols] - ref).abs().max().item() < 1e-3
 
 
+def test_sharded_matmul_mx_fp8_single_gpu(hip):
+    """``ShardedMatmul(dtype=fp8, scaling="mx")``: operands generated in bf16, quantised to
+    block-scaled fp8 by the MX kernel, multiplied with the scales applied by the matrix
+    instruction -- whole product, row panels of an all-gather strategy and K shards agree with the
+    host's fp64 product of the MX-quantised streams."""
+    from distributed_tensorflow_amd.parallel.sharded_matmul import ShardedMatmul
+    dev = torch.device("cuda")
+    rows, cols = np.arange(0, 1024, 61), np.arange(0, 512, 41)
+    ref = None
+    for strategy, panels in (("replicated", None), ("m_shard_allgather", 2),
+                             ("k_shard_allreduce", None)):
+        sm = ShardedMatmul(1024, 512, 2048, dtype=FP8, strategy=strategy, device=dev,
+                           scaling="mx", distribution="normal", panels=panels)
+        c = sm.step()
+        if hasattr(sm, "wait"):
+            sm.wait()
+        assert c.dtype == torch.bfloat16
+        if ref is None:
+            ref = sm.reference(rows, cols)
+        got = c.double().cpu()[rows][:, cols]
+        assert (got - ref).abs().max().item() < 0.02 * ref.abs().max().item() + 0.5, strategy
+    with pytest.raises(ValueError):
+        ShardedMatmul(512, 512, 1024, dtype=FP8, strategy="summa_2d", device=dev, scaling="mx")
+    with pytest.raises(ValueError):
+        ShardedMatmul(512, 512, 1024, dtype=torch.bfloat16, device=dev, scaling="mx")
+
+
 # -- small-shape paths of the training step ------------------------------------------------------
 @pytest.mark.parametrize("m,n,k,ta,tb", [(100, 100, 784, False, False), (100, 10, 1000, False, False),
                                           (64, 64, 4096, False, True), (100, 100, 784, True, False),
@@ -802,3 +829,133 @@ def test_mlp_step_three_launches_match_the_kernel_chain_bitwise(dims):
             assert torch.equal(p, q), i
         assert packed[:3].tolist() == [float(loss), float(i + 1), float(acc)]
     assert torch.isfinite(loss)
+
+
+def test_mx_quantise_picks_the_smallest_power_of_two_scale_that_does_not_saturate():
+    import torch
+    from distributed_tensorflow_amd.ops import hip
+    g = torch.Generator().manual_seed(2)
+    x = (torch.randn(300, 256, generator=g) * torch.exp(3 * torch.randn(300, 8, generator=g))
+         .repeat_interleave(32, dim=1)).cuda()
+    x[5, 32:64] = 0.0                                    # an all-zero block: unit scale
+    for src in (x, x.to(torch.bfloat16)):
+        for role in (0, 1):
+            mx = hip.quantize_mx_fp8(src, role, want_rowmajor=True)
+            xf = src.float()
+            amax = xf.view(300, 8, 32).abs().amax(dim=2)
+            e = mx.scales_rm.to(torch.int32) - 127
+            scale = torch.pow(2.0, e.float())
+            assert torch.all(amax <= 448 * scale)                         # nothing saturates
+            nz = amax > 0
+            assert torch.all((amax > 224 * scale)[nz])                    # and no smaller scale would do
+            assert int(e[5, 1]) == 0
+            back = mx.dequantize()
+            # e4m3 keeps 3 mantissa bits: relative error at most 2^-4 of the block's scale range
+            assert torch.all((back - xf).abs() <= amax.repeat_interleave(32, dim=1) / 16 + 1e-30)
+            # the GEMM-ordered bytes are the row-major ones, permuted (2 row tiles, 2 K-tiles)
+            for (row, kb) in ((0, 0), (17, 3), (100, 5), (255, 7), (256, 1), (299, 6)):
+                r, kt, tile = row % 256, kb // 4, row // 256
+                ln = 16 * (kb % 4) + r % 16
+                if role == 0:
+                    off = ((kt // 2) * 2 + tile) * 2048 + 1024 * ((r // 64) % 2) + 16 * ln \
+                        + 8 * (kt % 2) + 4 * (r // 128) + (r // 16) % 4
+                else:
+                    off = (kt * 2 + tile) * 1024 + 256 * ((r // 32) % 4) + 4 * ln \
+                        + 2 * (r // 128) + (r // 16) % 2
+                assert int(mx.scales[off]) == int(mx.scales_rm[row, kb])
+
+
+@pytest.mark.parametrize("shape", [(256, 256, 128), (512, 768, 1024), (256, 512, 4096)])
+def test_mx_fp8_gemm_matches_the_dequantised_product(shape):
+    """The block-scaled GEMM against fp64 of the dequantised operands (what the hardware is meant
+    to compute); blocks get wildly different magnitudes so that a misplaced scale cannot hide."""
+    import torch
+    from distributed_tensorflow_amd.ops import hip
+    m, n, k = shape
+    g = torch.Generator().manual_seed(4)
+
+    def operand(rows):
+        mag = torch.exp(2.5 * torch.randn(rows, k // 32, generator=g)).repeat_interleave(32, dim=1)
+        return (torch.randn(rows, k, generator=g) * mag).cuda()
+
+    a, bt = operand(m), operand(n)
+    qa = hip.quantize_mx_fp8(a, 0, want_rowmajor=True)
+    qb = hip.quantize_mx_fp8(bt, 1, want_rowmajor=True)
+    ref = qa.dequantize().double() @ qb.dequantize().double().t()
+    for dt in (torch.float32, torch.bfloat16):
+        out = hip.gemm_fp8_mx_nt(qa, qb, dt)
+        err = (out.double() - ref).abs().max() / ref.abs().max()
+        # (the instruction's own accumulation is a little short of fp32: ~1e-4 of the largest term)
+        assert err < (2e-4 if dt == torch.float32 else 6e-3), (dt, float(err))
+    acc = torch.ones(m, n, device="cuda")
+    hip.gemm_fp8_mx_nt(qa, qb, torch.float32, alpha=0.5, out=acc, beta=2.0)
+    assert ((acc.double() - (0.5 * ref + 2.0)).abs().max() / ref.abs().max()) < 2e-4
+
+
+def test_mx_fp8_gemm_with_unit_scales_is_the_exact_integer_product():
+    import torch
+    from distributed_tensorflow_amd.ops import hip
+    g = torch.Generator().manual_seed(6)
+    a = torch.randint(-8, 9, (256, 512), generator=g).float().cuda()
+    bt = torch.randint(-8, 9, (512, 512), generator=g).float().cuda()
+    # every block's maximum is 256, in (224, 448]: scale exactly 1; the 256s meet zeros in the
+    # other operand, so the sums stay small integers the instruction adds without rounding
+    a[:, 0::32], bt[:, 0::32] = 256.0, 0.0
+    a[:, 1::32], bt[:, 1::32] = 0.0, 256.0
+    qa, qb = hip.quantize_mx_fp8(a, 0, True), hip.quantize_mx_fp8(bt, 1, True)
+    assert torch.all(qa.scales_rm == 127) and torch.all(qb.scales_rm == 127)
+    assert torch.equal(qa.dequantize(), a) and torch.equal(qb.dequantize(), bt)
+    ref = a.double() @ bt.double().t()
+    out = hip.gemm_fp8_mx_nt(qa, qb, torch.float32)
+    assert torch.equal(out.double(), ref)
+    assert torch.equal(out, hip.gemm_fp8_nt(qa.q, qb.q, torch.float32))
+
+
+def test_mx_fp8_is_more_accurate_than_per_tensor_fp8_when_blocks_differ_in_magnitude():
+    """16384-long dot products against fp64. e4m3 is a floating-point format: on plain N(0,1)
+    data one scale per tensor already keeps every value in its normal range and the error is that
+    of the 3-bit mantissa either way (parity, checked below). Block scaling pays when magnitudes
+    differ ACROSS blocks by more than e4m3's own range (outlier channels, per-block spread of
+    e^(+-12) here): one scale per tensor then flushes the small blocks towards zero, one scale per
+    32 values does not -- the error is at least halved."""
+    import torch
+    from distributed_tensorflow_amd.ops import hip
+    g = torch.Generator().manual_seed(8)
+    k = 16384
+    bt = torch.randn(256, k, generator=g).cuda()
+
+    def errors(a):
+        # rows are normalised so that every output weighs the same
+        ref = a.double() @ bt.double().t()
+        mx = hip.gemm_fp8_mx_nt(hip.quantize_mx_fp8(a, 0), hip.quantize_mx_fp8(bt, 1),
+                                torch.float32)
+        qa, ia = hip.quantize_fp8(a)
+        qb, ib = hip.quantize_fp8(bt)
+        pt = hip.gemm_fp8_nt(qa, qb, torch.float32, alpha=ia * ib)
+        # error of a row's outputs relative to what that row's SMALL blocks contribute
+        return ((mx.double() - ref).abs().mean(), (pt.double() - ref).abs().mean(), ref)
+
+    plain = torch.randn(256, k, generator=g).cuda()
+    e_mx, e_pt, ref = errors(plain)
+    assert 0.8 < float(e_mx / e_pt) < 1.25                  # parity on N(0,1)
+    assert float(e_mx / ref.abs().mean()) < 0.05
+    # per-block spread: compare on the part of the product the small blocks carry, i.e. against
+    # the same data with the LARGE blocks removed from both the product and its reference
+    spread = torch.exp(4.0 * torch.randn(256, k // 32, generator=g)).repeat_interleave(32, dim=1)
+    small = (spread < 1e-2).cuda()
+    a = (torch.randn(256, k, generator=g) * spread).cuda()
+    a_small = torch.where(small, a, torch.zeros_like(a))
+    ref_small = a_small.double() @ bt.double().t()
+    qb_mx = hip.quantize_mx_fp8(bt, 1)
+    qa_mx = hip.quantize_mx_fp8(a, 0, want_rowmajor=True)
+    qa_pt, ia = hip.quantize_fp8(a)
+    qb_pt, ib = hip.quantize_fp8(bt)
+    # what each quantisation kept of the small blocks
+    kept_mx = torch.where(small, qa_mx.dequantize(), torch.zeros_like(a))
+    kept_pt = torch.where(small, hip.dequantize_fp8(qa_pt, ia).float(), torch.zeros_like(a))
+    err_mx = float((kept_mx.double() @ bt.double().t() - ref_small).abs().mean())
+    err_pt = float((kept_pt.double() @ bt.double().t() - ref_small).abs().mean())
+    assert err_mx * 2 <= err_pt, (err_mx, err_pt)
+    # and the whole product is no worse
+    e_mx, e_pt, _ = errors(a)
+    assert float(e_mx) <= float(e_pt) * 1.05

@@ -694,8 +694,11 @@ class Session:
         Only gradients nobody else reads or fetches are placed (the collective reduces the arena
         in place)."""
         rt = self._runtime
-        if rt is None or not hasattr(rt, "grad_view") or rt.comm.world_size < 2 \
-                or plan.grad_buckets:
+        if rt is None or not hasattr(rt, "grad_view") or plan.grad_buckets:
+            return
+        # (a world of one reduces nothing -- except under reduce_scatter_sync, whose owner-update
+        # path runs on the arena whatever the world size)
+        if rt.comm.world_size < 2 and getattr(rt, "strategy", "") != "reduce_scatter_sync":
             return
         producer = {sl: (st, idx) for st in plan.steps for idx, sl in enumerate(st.out_slots)}
         readers: Dict[int, int] = {}

@@ -103,6 +103,54 @@ def test_collective_runtime_trains_like_local_session(nccl_comm, strategy, captu
     assert np.allclose(got[1], ref[1], rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("strategy", ["allreduce_sync", "reduce_scatter_sync"])
+def test_captured_collective_steps_equal_eager_ones_bit_for_bit(nccl_comm, strategy):
+    """The same 30 training steps under the collective runtime (RCCL, world of one) run eagerly
+    and as replayed HIP graphs with the RCCL calls captured: losses, step counter and every
+    variable are bit-equal, and no gradient is copied on its way to the collective."""
+    import distributed_tensorflow_amd as tf
+    from distributed_tensorflow_amd.models import mnist_mlp
+    from distributed_tensorflow_amd.train.server import _free_port
+    rng = np.random.RandomState(4)
+    batches = [(rng.rand(100, 784).astype(np.float32),
+                np.eye(10, dtype=np.float32)[rng.randint(0, 10, 100)]) for _ in range(6)]
+
+    def run(graphs):
+        g = tf.Graph()
+        with g.as_default():
+            cfg = tf.ConfigProto(device="cuda:0", strategy=strategy, hip_graphs=graphs,
+                                 capture_collectives=graphs)
+            cluster = tf.train.ClusterSpec({"worker": ["127.0.0.1:%d" % _free_port()]})
+            server = tf.train.Server(cluster, job_name="worker", task_index=0, protocol="rccl",
+                                     config=cfg, comm=nccl_comm)
+            with tf.device(tf.train.replica_device_setter(cluster=cluster)):
+                model = mnist_mlp.build_model(learning_rate=0.01, seed=1)
+            sv = tf.train.Supervisor(is_chief=True, global_step=model.global_step,
+                                     init_op=model.init_op)
+            sess = sv.prepare_or_wait_for_session(server.target, config=cfg)
+            hist = []
+            for i in range(30):
+                bx, by = batches[i % len(batches)]
+                _, l, st = sess.run([model.train_op, model.loss, model.global_step],
+                                    {model.x: bx, model.y_: by})
+                hist.append((float(l), float(st)))
+            variables = sess.run([model.w1, model.b1, model.w2, model.b2])
+            stats = dict(sess.stats)
+            rt = server.runtime
+            placed = (rt.grads_in_place, rt.grads_copied)
+            sess.close()
+            sv.stop()
+        return hist, variables, stats, placed
+
+    eager, captured = run(False), run(True)
+    assert eager[2]["graph_replays"] == 0 and captured[2]["graph_replays"] >= 25
+    assert eager[0] == captured[0]
+    for p, q in zip(eager[1], captured[1]):
+        assert np.array_equal(p, q)
+    for placed in (eager[3], captured[3]):
+        assert placed[1] == 0, placed          # no gradient was copied into the arena
+
+
 def test_bench_contract_one_json_line_on_stdout():
     """bench.py under the real RCCL backend (world 1): stdout is exactly one JSON line with the
     contract's keys -- RCCL's version banner and every note go to stderr."""

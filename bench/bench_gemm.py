@@ -39,8 +39,9 @@ def main() -> None:
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     rows = []
-    for n in [int(s) for s in args.sizes.split(",")]:
-        m = k = n
+    for size in args.sizes.split(","):
+        # "4096" = a cube, "2048x16384x16384" = M x N x K (a rank's share of a row-sharded product)
+        m, n, k = (int(v) for v in size.split("x")) if "x" in size else (int(size),) * 3
         flops = 2.0 * m * n * k
         if args.dtype == "bf16":
             a = (torch.rand(m, k, device="cuda") * 2 - 1).bfloat16()
@@ -48,7 +49,7 @@ def main() -> None:
             out = torch.empty(m, n, device="cuda", dtype=torch.bfloat16)
             ours = timeit(lambda: hip.gemm_bf16_nt(a, bt, torch.bfloat16, out=out, variant=args.variant), args.iters)
             ref = None if args.no_torch else timeit(lambda: torch.matmul(a, bt.t()), args.iters)
-            if n <= 4096:
+            if max(m, n, k) <= 4096:
                 err = (out.float() - a.float() @ bt.float().t()).abs().max().item()
             else:
                 err = (out[:256].float() - a[:256].float() @ bt.float().t()).abs().max().item()
@@ -73,7 +74,8 @@ def main() -> None:
             ours = timeit(lambda: hip.gemm_f32(a, b, out=out), args.iters)
             ref = None if args.no_torch else timeit(lambda: torch.matmul(a, b), args.iters)
             err = (out[:128].double() - a[:128].double() @ b.double()).abs().max().item()
-        row = {"dtype": args.dtype, "variant": args.variant, "n": n, "ms": round(ours, 4),
+        row = {"dtype": args.dtype, "variant": args.variant, "m": m, "n": n, "k": k,
+               "ms": round(ours, 4),
                "tflops": round(flops / ours / 1e9, 1), "max_err": err}
         if ref is not None:
             row["torch_ms"] = round(ref, 4)

@@ -331,8 +331,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
     void* __restrict__ C, int M, int N, int K, long lda, long ldb, long ldc, int tiles_m,
     int tiles_n, float alpha, float beta, int ksplits, long plane,
     const unsigned* __restrict__ sa, const unsigned* __restrict__ sb, int sa_pair = 0,
-    int sb_kt = 0) {
-  // sa_pair / sb_kt: bytes from one K-tile pair (A) / K-tile (Bt) of scales to the next -- the
+    int sb_quad = 0) {
+  // sa_pair / sb_quad: bytes from one K-tile pair (A) / quad (Bt) of scales to the next -- the
   // row-tile count of the matrix the scales were made for, which may be taller than this call's
   static_assert(!MX || (FP8 && MERGE), "block scales: fp8 operands, merged schedule");
   // ksplits > 1 (few output tiles, long K): work item (split, tile) multiplies K-range `split`
@@ -390,37 +390,36 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
   __amdgpu_buffer_rsrc_t a_tile = tile_rsrc(A + ((long)m0 * lda + (long)split * ksub) * ESIZE);
   __amdgpu_buffer_rsrc_t b_tile = tile_rsrc(Bt + ((long)n0 * ldb + (long)split * ksub) * ESIZE);
 
-  // block scales: this wave's strip of LDS,
-  //   A: [pair parity][64 lanes][16 bytes = (K-tile & 1, A half, i)]   2 x 1 KiB, one 16-byte
-  //      LDS-DMA per PAIR of K-tiles;
-  //   Bt: [K-tile parity][64 lanes][4 bytes = (Bt half, j)]            2 x 256 B, one 4-byte
-  //      LDS-DMA per K-tile.
-  // A per-lane register serves as LDS address of the lane's slot and as the DMA's per-lane offset
-  // (the buffer base is set back by the strip's offset to make up for it).
-  constexpr int SC_WAVE = 2 * 1024 + 2 * 256;
+  // block scales: this wave's strip of LDS, 16 bytes per lane and buffer,
+  //   A:  [pair parity][64 lanes][(K-tile & 1, A half, i)]    one 16-byte LDS-DMA per PAIR of K-tiles
+  //   Bt: [quad parity][64 lanes][(K-tile & 3, Bt half, j)]   one 16-byte LDS-DMA per FOUR K-tiles
+  // ONE per-lane register, sc_lane = strip offset + 16 * lane, serves as LDS address of the
+  // lane's slot (plus constants) and as the DMA's per-lane offset (the buffer bases are set back
+  // by the strip's offset to make up for it).
+  constexpr int SC_WAVE = 4 * 1024;
   const int sc_strip = 2 * BUF_BYTES + wave * SC_WAVE;
-  const unsigned sca_lane = (unsigned)sc_strip + (unsigned)lane * 16u;
-  const unsigned scb_lane = (unsigned)(sc_strip + 2048) + (unsigned)lane * 4u;
+  const unsigned sc_lane = (unsigned)sc_strip + (unsigned)lane * 16u;
   __amdgpu_buffer_rsrc_t sa_tile = a_tile, sb_tile = b_tile;
-  // stage the A scales of K-tile pair p and the Bt scales of K-tile t (clamped at the end: a
-  // dead slot is refilled)
+  // stage the A scales of K-tile pair pr / the Bt scales of K-tile quad qd (clamped at the end:
+  // a dead slot is refilled)
   auto stage_scales_a = [&](int pr) {
     const int last = (nkt - 1) >> 1;
     const int pc = (pr < last ? pr : last) + split * ((nkt + 1) >> 1);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(sa_tile, (lds_void*)(smem + sc_strip + (pr & 1) * 1024),
-                                             16, sca_lane, pc * sa_pair, 0, 0);
+                                             16, sc_lane, pc * sa_pair, 0, 0);
   };
-  auto stage_scales_b = [&](int t) {
-    const int tc = (t < nkt ? t : nkt - 1) + split * nkt;
+  auto stage_scales_b = [&](int qd) {
+    const int last = (nkt - 1) >> 2;
+    const int qc = (qd < last ? qd : last) + split * ((nkt + 3) >> 2);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(sb_tile,
-                                             (lds_void*)(smem + sc_strip + 2048 + (t & 1) * 256), 4,
-                                             scb_lane, tc * sb_kt, 0, 0);
+                                             (lds_void*)(smem + sc_strip + 2048 + (qd & 1) * 1024),
+                                             16, sc_lane, qc * sb_quad, 0, 0);
   };
   if constexpr (MX) {
     sa_tile = tile_rsrc(reinterpret_cast<const char*>(sa) + (long)(m0 / BM) * 2048 + wr * 1024 -
                         sc_strip);
-    sb_tile = tile_rsrc(reinterpret_cast<const char*>(sb) + (long)(n0 / BN) * 1024 + wc * 256 -
-                        (sc_strip + 2048));
+    sb_tile = tile_rsrc(reinterpret_cast<const char*>(sb) + (long)(n0 / BN) * 4096 + wc * 1024 -
+                        sc_strip);
     stage_scales_a(0);             // in front of the prologue's DMA: landed with half-tile 0
     stage_scales_b(0);
   }
@@ -509,13 +508,16 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
     if constexpr ((dbg & 8) != 0) ts0 = __builtin_amdgcn_s_memtime();                            \
     READS;                                                                                       \
     if constexpr (MX) {                                                                          \
-      /* K-tile of this phase: (g0 >> 2) + (P >> 1), of pair g0 >> 3; its A half is P & 1 */     \
-      sc_a = *reinterpret_cast<const unsigned*>(smem + sca_lane + ((g0 >> 3) & 1) * 1024 +       \
+      /* K-tile of this phase: kt = (g0 >> 2) + (P >> 1), of pair g0 >> 3 and quad g0 >> 4;     \
+         its A half is P & 1 */                                                                  \
+      sc_a = *reinterpret_cast<const unsigned*>(smem + sc_lane + ((g0 >> 3) & 1) * 1024 +        \
                                                 ((P) >> 1) * 8 + ((P) & 1) * 4);                 \
-      if (((P) & 1) == 0)                                                                        \
-        sc_b = *reinterpret_cast<const unsigned*>(smem + scb_lane + ((P) >> 1) * 256);           \
-      if ((P) == 0) stage_scales_a((g0 >> 3) + 1);                                               \
-      if (((P) & 1) == 0) stage_scales_b((g0 >> 2) + ((P) >> 1) + 1);                            \
+      sc_b = *reinterpret_cast<const unsigned*>(smem + sc_lane + 2048 + ((g0 >> 4) & 1) * 1024 + \
+                                                ((g0 >> 3) & 1) * 8 + ((P) >> 1) * 4);           \
+      if ((P) == 0) {                                                                            \
+        stage_scales_a((g0 >> 3) + 1);                                                           \
+        if ((g0 >> 3) & 1) stage_scales_b((g0 >> 4) + 1);                                        \
+      }                                                                                          \
     }                                                                                            \
     if (!(dbg & 1)) {                                                                            \
       stage_half<MX>(a_tile, b_tile, voff, (dbg & 2) ? 0 : g0 + 2 * (P) + 6, nkt,                    \
@@ -525,9 +527,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
     }                                                                                            \
     if constexpr ((dbg & 8) != 0) ts1 = __builtin_amdgcn_s_memtime();                            \
     if (!(dbg & 4)) {                                                                            \
-      if (MX && (P) == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                       \
-      else if (MX && (P) == 2) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");                  \
-      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                      \
+      if (MX && (P) == 0) {                                                                      \
+        if ((g0 >> 3) & 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                      \
+        else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");                                    \
+      } else {                                                                                   \
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                         \
+      }                                                                                          \
     }                                                                                            \
     if constexpr ((dbg & 8) != 0) ts2 = __builtin_amdgcn_s_memtime();                            \
     __builtin_amdgcn_sched_barrier(0);                                                           \
@@ -562,6 +567,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
       DTF_PHASE2(3, DTF_READ_A(1, 1), 1, 1, 0)
     }
     if (nkt & 1) {
+      // (the lane's LDS offsets are recomputed for this tail from the execution mask: kept
+      // live across the main loop for it, they would not fit the register budget)
+      int t_lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+      asm volatile("" : "+v"(t_lane));
+      const int lane_off0 = chunk_off(t_lane & 15, t_lane >> 4);
+      const int lane_off1 = chunk_off(t_lane & 15, 4 + (t_lane >> 4));
+      const unsigned sc_lane = (unsigned)sc_strip + (unsigned)t_lane * 16u;
       DTF_PHASE2(0, DTF_READ_B(0, 0) DTF_READ_A(0, 0) DTF_READ_B(1, 0), 0, 0, 1)
       DTF_PHASE2(1, DTF_READ_A(1, 0), 1, 1, 0)
     }
@@ -614,8 +626,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
   // column pass through an opaque copy so that the address arithmetic stays HERE: hoisted out
   // of the tile loop it would occupy ~20 VGPRs across the K loop (the fp8 instantiation then
   // spills, and scratch reloads inside the K loop would also break its counted vmcnt waits).
-  int e_frow = frow, e_fq = fq;
-  asm volatile("" : "+v"(e_frow), "+v"(e_fq));
+  // (the lane id is recomputed from the execution mask here rather than kept in a register
+  // across the K loop)
+  int e_lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  asm volatile("" : "+v"(e_lane));
+  const int e_frow = e_lane & 15, e_fq = e_lane >> 4;
 #pragma unroll
   for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
@@ -1505,26 +1520,26 @@ DTF_API int dtf_gemm_fp8_mx_nt(const void* A, const void* Bt, void* C, const voi
   const int tiles_m = M / BM, tiles_n = N / BN;
   // the scales may belong to a taller matrix of which A / Bt is a block of whole row tiles
   if (sa_row_tiles < tiles_m || sb_row_tiles < tiles_n) return DTF_ERR_BAD_ARG;
-  if ((long)(K / 128 + 1) * (sa_row_tiles > sb_row_tiles ? sa_row_tiles : sb_row_tiles) * 1024 >=
+  if ((long)(K / 128 + 3) * (sa_row_tiles > sb_row_tiles ? sa_row_tiles : sb_row_tiles) * 1024 >=
       (1L << 31))
     return DTF_ERR_UNSUPPORTED;
-  const size_t lds = 2 * BUF_BYTES + (NTHREADS / 64) * 2560;
+  const size_t lds = 2 * BUF_BYTES + (NTHREADS / 64) * 4096;      // all 160 KiB of the CU
   { static DtfPerDeviceOnce once__; dtf_once_per_device(once__, [&] {
     dtf_allow_lds(gemm_nt_pp_kernel<true, 0, true, true, true>, lds);
     dtf_allow_lds(gemm_nt_pp_kernel<false, 0, true, true, true>, lds);
   }); }
   const dim3 grid(tiles_m * tiles_n), block(NTHREADS);
-  const int sa_pair = (int)(sa_row_tiles * 2048), sb_kt = (int)(sb_row_tiles * 1024);
+  const int sa_pair = (int)(sa_row_tiles * 2048), sb_quad = (int)(sb_row_tiles * 4096);
   if (out_f32)
     hipLaunchKernelGGL((gemm_nt_pp_kernel<true, 0, true, true, true>), grid, block, lds, stream,
                        (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tiles_m,
                        tiles_n, alpha, beta, 1, 0L, (const unsigned*)sa, (const unsigned*)sb,
-                       sa_pair, sb_kt);
+                       sa_pair, sb_quad);
   else
     hipLaunchKernelGGL((gemm_nt_pp_kernel<false, 0, true, true, true>), grid, block, lds, stream,
                        (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tiles_m,
                        tiles_n, alpha, beta, 1, 0L, (const unsigned*)sa, (const unsigned*)sb,
-                       sa_pair, sb_kt);
+                       sa_pair, sb_quad);
   DTF_LAUNCH_CHECK();
   return DTF_OK;
 }

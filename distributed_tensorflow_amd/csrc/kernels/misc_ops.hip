@@ -406,8 +406,8 @@ DTF_API int dtf_cast_generic(const void* src, int src_kind, void* dst, int dst_k
 // lane = 16 (kb % 4) + r % 16:
 //   role 0 (the GEMM's A operand): per PAIR of K-tiles and row tile 2 KiB;
 //       byte offset 1024 ((r / 64) % 2) + 16 lane + 8 (kt % 2) + 4 (r / 128) + (r / 16) % 4
-//   role 1 (its Bt operand): per K-tile and row tile 1 KiB;
-//       byte offset 256 ((r / 32) % 4) + 4 lane + 2 (r / 128) + (r / 16) % 2 `scales_rm` (optional)
+//   role 1 (its Bt operand): per FOUR K-tiles and row tile 4 KiB;
+//       byte offset 1024 ((r / 32) % 4) + 16 lane + 4 (kt % 4) + 2 (r / 128) + (r / 16) % 2 `scales_rm` (optional)
 // receives the same bytes in plain row-major [R, K / 32] order.
 namespace {
 
@@ -465,8 +465,8 @@ __global__ __launch_bounds__(256) void quantize_mx_kernel(const void* __restrict
       off = ((kt >> 1) * row_tiles + tile) * 2048 + 1024 * ((r >> 6) & 1) + 16 * ln +
             8 * (int)(kt & 1) + 4 * (r >> 7) + ((r >> 4) & 3);
     else
-      off = (kt * row_tiles + tile) * 1024 + 256 * ((r >> 5) & 3) + 4 * ln + 2 * (r >> 7) +
-            ((r >> 4) & 1);
+      off = ((kt >> 2) * row_tiles + tile) * 4096 + 1024 * ((r >> 5) & 3) + 16 * ln +
+            4 * (int)(kt & 3) + 2 * (r >> 7) + ((r >> 4) & 1);
     sc[off] = (unsigned char)e8;
     if (sc_rm) sc_rm[row * kblocks + kb] = (unsigned char)e8;
   }
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(256) void quantize_mx_kernel(const void* __restrict
 // tiles, K % 128 == 0)
 DTF_API long dtf_mx_scale_bytes(long R, long K) {
   if (R <= 0 || K <= 0 || K % 128) return 0;
-  return ((K / 128 + 1) / 2 * 2) * ((R + 255) / 256) * 1024;    // whole pairs of K-tiles
+  return ((K / 128 + 3) / 4 * 4) * ((R + 255) / 256) * 1024;    // whole groups of four K-tiles
 }
 
 // src_kind 0: fp32, 1: bf16. q: [R, K] bytes with row pitch ldq (ldq % 4 == 0). scales:

@@ -362,7 +362,7 @@ class MxFp8:
         r0, r1, _ = key.indices(self.q.shape[0])
         if r0 % 256 or (r1 % 256 and r1 != self.q.shape[0]) or r1 <= r0:
             raise HipKernelError("MxFp8: row blocks start and end on multiples of 256")
-        per_tile = 2048 if self.role == 0 else 1024
+        per_tile = 2048 if self.role == 0 else 4096
         return MxFp8(self.q[r0:r1], self.scales,
                      None if self.scales_rm is None else self.scales_rm[r0:r1], self.role,
                      self.scale_offset + (r0 // 256) * per_tile, self.row_tiles)

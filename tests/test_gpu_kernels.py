@@ -860,8 +860,8 @@ def test_mx_quantise_picks_the_smallest_power_of_two_scale_that_does_not_saturat
                     off = ((kt // 2) * 2 + tile) * 2048 + 1024 * ((r // 64) % 2) + 16 * ln \
                         + 8 * (kt % 2) + 4 * (r // 128) + (r // 16) % 4
                 else:
-                    off = (kt * 2 + tile) * 1024 + 256 * ((r // 32) % 4) + 4 * ln \
-                        + 2 * (r // 128) + (r // 16) % 2
+                    off = ((kt // 4) * 2 + tile) * 4096 + 1024 * ((r // 32) % 4) + 16 * ln \
+                        + 4 * (kt % 4) + 2 * (r // 128) + (r // 16) % 2
                 assert int(mx.scales[off]) == int(mx.scales_rm[row, kb])
 
 

@@ -81,6 +81,34 @@ def test_file_writer_events(tmp_path, monkeypatch, use_native):
         S.read_events(path)
 
 
+def test_file_writer_encodes_deferred_summaries_when_it_writes_them(tmp_path):
+    """A summary / step that are still ``DeferredValue``s when ``add_summary`` is called are not
+    waited for there: the event is put together when the writer drains its queue, in order with
+    the events around it."""
+    from distributed_tensorflow_amd.client.deferred import DeferredValue
+    resolved = []
+
+    def late(value, tag):
+        def thunk():
+            resolved.append(tag)
+            return value
+        return DeferredValue(thunk)
+
+    writer = tf.summary.FileWriter(str(tmp_path))
+    writer.add_summary(S.encode_scalar_summary("cost", 3.0), 1)
+    writer.add_summary(late(S.encode_scalar_summary("cost", 2.0), "summary"),
+                       late(np.float32(2.0), "step"))
+    assert resolved == []                         # nothing looked at the values yet
+    writer.add_summary(S.encode_scalar_summary("cost", 1.0), 3)
+    writer.close()
+    assert sorted(resolved) == ["step", "summary"]
+    files = [f for f in os.listdir(tmp_path) if f.startswith("events.out.tfevents.")]
+    events = [e for e in S.read_events(os.path.join(tmp_path, files[0])) if "summary" in e]
+    assert [e["step"] for e in events] == [1, 2, 3]
+    assert [e["summary"][0][1] for e in events] == [pytest.approx(3.0), pytest.approx(2.0),
+                                                    pytest.approx(1.0)]
+
+
 def test_merge_all_none_without_summaries():
     assert tf.summary.merge_all() is None
 

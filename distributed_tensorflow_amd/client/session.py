@@ -735,8 +735,14 @@ class Session:
             return False
         if self._runtime is None:
             return True
-        from ..parallel.runtime import LocalRuntime
-        return type(self._runtime) is LocalRuntime
+        from ..parallel.runtime import CollectiveRuntime, LocalRuntime
+        rt = self._runtime
+        if type(rt) is LocalRuntime:
+            return True
+        # a collective world of ONE rank under all-reduce exchanges nothing: its variables are
+        # plain local storage too (views of the parameter arena)
+        return (type(rt) is CollectiveRuntime and rt.comm.world_size == 1
+                and rt.strategy == "allreduce_sync" and not rt.has_sharded_storage())
 
     def _capture_collectives(self) -> bool:
         want = self.config.capture_collectives

@@ -274,7 +274,9 @@ def main() -> None:
         # HBM): SUMMA on the P x Q grid, C left 2-D sharded
         strategy = args.strategy
         if strategy == "auto":
-            strategy = "replicated" if world == 1 else "summa_2d"
+            # (block-scaled operands stay on the rank that quantised them: row blocks + all-gather)
+            strategy = "replicated" if world == 1 else (
+                "m_shard_allgather" if args.fp8_scaling == "mx" else "summa_2d")
         engine, elapsed = measure(strategy)
         secured.offer(result_line(args, world, strategy, engine, elapsed), elapsed)
         secured.emit()

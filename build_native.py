@@ -99,7 +99,7 @@ def build_host(force: bool = False) -> str:
     if force or _newer(out, sources + headers):
         _run([cxx, "-O2", "-fPIC", "-shared", "-std=c++17", "-msse4.2", "-pthread",
               "-fvisibility=hidden", "-Wall", "-I" + os.path.join(CSRC, "io"),
-              "-I" + os.path.join(CSRC, "runtime"), "-o", out] + sources)
+              "-I" + os.path.join(CSRC, "runtime"), "-o", out] + sources + ["-ldl"])
     return out
 
 

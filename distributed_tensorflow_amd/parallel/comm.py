@@ -321,6 +321,19 @@ class TorchDistComm(Communicator):
             self._owns_pg = False
 
 
+def make_communicator(device: Optional[torch.device] = None, backend: Optional[str] = None,
+                      **kwargs) -> Communicator:
+    """The job's communicator for this process: ``backend`` (default: ``DTF_COMM_BACKEND``, then
+    ``nccl`` on a GPU / ``gloo`` on a CPU) is ``nccl`` or ``gloo`` (``torch.distributed``) or
+    ``rccl_native`` (``parallel/rccl_native.py``: own rendezvous and RCCL calls). Rank, world
+    size and rendezvous address come from the launcher's environment unless passed."""
+    backend = backend or os.environ.get("DTF_COMM_BACKEND") or None
+    if backend == "rccl_native":
+        from .rccl_native import RcclComm
+        return RcclComm(device=device, **kwargs)
+    return TorchDistComm(device=device, backend=backend, **kwargs)
+
+
 # ---------------------------------------------------------------------------------------
 # in-process loopback (threads)
 # ---------------------------------------------------------------------------------------

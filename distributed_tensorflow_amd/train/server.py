@@ -211,14 +211,15 @@ class Server:
                 comm = self._comm
                 self._owns_comm = comm is None
                 if comm is None:
-                    from ..parallel.comm import SingleComm, TorchDistComm
+                    from ..parallel.comm import SingleComm, make_communicator
                     world = self._cluster.num_tasks(self._job_name)
                     if world > 1:
                         chief = self._cluster.task_address(self._job_name, 0)
                         chost, _, cport = chief.rpartition(":")
                         # DTF_COMM_BACKEND=gloo: several ranks rehearsed on ONE GPU (RCCL refuses
-                        # two ranks per device); default: RCCL on GPUs, gloo on CPUs
-                        comm = TorchDistComm(
+                        # two ranks per device); =rccl_native: own rendezvous + RCCL calls;
+                        # default: torch.distributed with RCCL on GPUs, gloo on CPUs
+                        comm = make_communicator(
                             backend=os.environ.get("DTF_COMM_BACKEND") or None,
                             rank=self._task_index, world_size=world, device=self.device,
                             master_addr=os.environ.get("MASTER_ADDR", chost or "127.0.0.1"),

@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import threading
 from typing import Optional
 
 _LIB: Optional[ctypes.CDLL] = None
@@ -18,12 +19,22 @@ _HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOST_LIB_PATH = os.path.join(_HERE, "lib", "libdtf_host.so")
 
 
+_LOAD_LOCK = threading.Lock()
+
+
 def load() -> Optional[ctypes.CDLL]:
+    if _TRIED:
+        return _LIB
+    with _LOAD_LOCK:             # (threads of one process may ask at the same time)
+        return _load_locked()
+
+
+def _load_locked() -> Optional[ctypes.CDLL]:
     global _LIB, _TRIED
     if _TRIED:
         return _LIB
-    _TRIED = True
     if os.environ.get("DTF_DISABLE_NATIVE_HOST") == "1" or not os.path.exists(HOST_LIB_PATH):
+        _TRIED = True
         return None
     lib = ctypes.CDLL(HOST_LIB_PATH)
     c = ctypes
@@ -80,7 +91,42 @@ def load() -> Optional[ctypes.CDLL]:
                                     c.c_long]
         lib.dtf_ps_names.restype = c.c_long
         lib.dtf_ps_names.argtypes = [c.c_void_p, c.c_char_p, c.c_long]
+    # control-plane rendezvous + native RCCL communicator
+    if hasattr(lib, "dtf_rdzv_create"):
+        lib.dtf_rdzv_create.restype = c.c_void_p
+        lib.dtf_rdzv_create.argtypes = [c.c_char_p, c.c_int, c.c_int, c.c_int, c.c_double,
+                                        c.POINTER(c.c_int)]
+        lib.dtf_rdzv_all_gather.restype = c.c_int
+        lib.dtf_rdzv_all_gather.argtypes = [c.c_void_p, c.c_char_p, c.c_long, c.c_char_p]
+        lib.dtf_rdzv_broadcast.restype = c.c_int
+        lib.dtf_rdzv_broadcast.argtypes = [c.c_void_p, c.c_char_p, c.c_long, c.c_int]
+        lib.dtf_rdzv_barrier.restype = c.c_int
+        lib.dtf_rdzv_barrier.argtypes = [c.c_void_p]
+        lib.dtf_rdzv_set_timeout.restype = None
+        lib.dtf_rdzv_set_timeout.argtypes = [c.c_void_p, c.c_double]
+        lib.dtf_rdzv_destroy.restype = None
+        lib.dtf_rdzv_destroy.argtypes = [c.c_void_p]
+    if hasattr(lib, "dtf_rccl_available"):
+        P, I, LG = c.c_void_p, c.c_int, c.c_long
+        lib.dtf_rccl_available.restype = I
+        lib.dtf_rccl_version.restype = I
+        lib.dtf_rccl_has_split.restype = I
+        lib.dtf_rccl_error_string.restype = c.c_char_p
+        lib.dtf_rccl_error_string.argtypes = [I]
+        lib.dtf_rccl_unique_id.argtypes = [c.c_char_p]
+        lib.dtf_rccl_init.argtypes = [c.POINTER(P), I, c.c_char_p, I]
+        lib.dtf_rccl_destroy.argtypes = [P, I]
+        lib.dtf_rccl_async_error.argtypes = [P, c.POINTER(I)]
+        lib.dtf_rccl_split.argtypes = [P, I, I, c.POINTER(P)]
+        lib.dtf_rccl_all_reduce.argtypes = [P, P, P, LG, I, I, P]
+        lib.dtf_rccl_reduce_scatter.argtypes = [P, P, P, LG, I, I, P]
+        lib.dtf_rccl_all_gather.argtypes = [P, P, P, LG, I, P]
+        lib.dtf_rccl_broadcast.argtypes = [P, P, LG, I, I, P]
+        for name in ("unique_id", "init", "destroy", "async_error", "split", "all_reduce",
+                     "reduce_scatter", "all_gather", "broadcast"):
+            getattr(lib, "dtf_rccl_" + name).restype = I
     _LIB = lib
+    _TRIED = True                # only now: a concurrent caller must not see "tried, nothing"
     return _LIB
 
 

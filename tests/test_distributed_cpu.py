@@ -638,3 +638,53 @@ def test_traced_collective_step_records_collectives_with_payload(tmp_path):
     tracks = {e["tid"] for e in trace["traceEvents"]}
     assert any("collectives" in t for t in tracks) and any("kernels" in t for t in tracks)
     assert "all_reduce" not in comms[0].__dict__          # instance wrappers were removed
+
+
+def test_native_rendezvous_gathers_and_broadcasts_byte_strings_between_ranks():
+    """The C++ control-plane rendezvous (``csrc/runtime/rendezvous.cc``) with four ranks as
+    threads: all-gather of byte strings of different lengths, broadcast from a non-zero root,
+    barrier; a rank that never shows up makes the others fail with CommError, not hang."""
+    import threading
+    from distributed_tensorflow_amd.parallel.comm import CommError
+    from distributed_tensorflow_amd.parallel.rccl_native import Rendezvous
+    from distributed_tensorflow_amd.train.server import _free_port
+    port, world = _free_port(), 4
+    out, errors = {}, []
+
+    def run(rank):
+        try:
+            r = Rendezvous(rank, world, "127.0.0.1", port, timeout_s=20.0)
+            table = r.all_gather_bytes(b"x" * (rank * 3) + bytes([rank]))
+            root_says = r.broadcast_bytes(b"from two" if rank == 2 else None, src=2)
+            r.barrier()
+            big = r.all_gather_bytes(bytes([rank]) * 100000)
+            out[rank] = (table, root_says, [len(b) for b in big], big[3][:2])
+            r.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append((rank, e))
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in (3, 1, 0, 2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(30)
+    assert not errors, errors
+    want = [b"x" * (r * 3) + bytes([r]) for r in range(world)]
+    for rank in range(world):
+        assert out[rank] == (want, b"from two", [100000] * 4, bytes([3, 3]))
+    # a missing peer: bounded failure on the ranks that did come
+    port = _free_port()
+    failed = []
+
+    def lonely(rank):
+        try:
+            Rendezvous(rank, 3, "127.0.0.1", port, timeout_s=1.0)
+        except CommError as e:
+            failed.append((rank, str(e)))
+
+    threads = [threading.Thread(target=lonely, args=(r,)) for r in (0, 1)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(15)
+    assert len(failed) >= 1 and all("rendezvous" in m for _, m in failed)

@@ -55,6 +55,10 @@ _MUTATING_OPS = frozenset(("Assign", "AssignAdd", "AssignSub", "ApplyGradientDes
 _PACK_WORDS = 256     # fp32 words of pinned staging per captured step for small fetches
 
 
+class SessionClosedError(RuntimeError):
+    """``run`` on a session that has been closed."""
+
+
 class ConfigProto:
     """Session options (the subset that means something here).
 
@@ -934,7 +938,7 @@ class Session:
             options: Optional[RunOptions] = None,
             run_metadata: Optional[RunMetadata] = None):
         if self._closed:
-            raise RuntimeError("Attempted to use a closed Session.")
+            raise SessionClosedError("Attempted to use a closed Session.")
         feed_dict = feed_dict or {}
         # A training loop calls run() with the same fetch list and the same placeholders every
         # step: what they resolve to (graph elements, feed order, plan, result structure) is

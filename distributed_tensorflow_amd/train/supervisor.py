@@ -416,9 +416,13 @@ class _Looper(threading.Thread):
         self._coord, self._interval, self._fn = coord, interval, fn
 
     def run(self) -> None:
+        from ..client.session import SessionClosedError
         with self._coord.stop_on_exception():
             while not self._coord.wait_for_stop(self._interval):
-                self._fn()
+                try:
+                    self._fn()
+                except SessionClosedError:
+                    return          # the job closed its session while this round was under way
 
 
 class _StepRate(threading.Thread):
@@ -429,13 +433,21 @@ class _StepRate(threading.Thread):
         self._sv, self._sess = sv, sess
 
     def run(self) -> None:
+        from ..client.session import SessionClosedError
         sv = self._sv
         with sv.coord.stop_on_exception():
-            last_t, last_step = time.time(), sv._step_value(self._sess)
-            while not sv.coord.wait_for_stop(sv._save_summaries_secs):
-                now, step = time.time(), sv._step_value(self._sess)
-                rate = (step - last_step) / max(now - last_t, 1e-9)
-                if sv.summary_writer is not None:
-                    sv.summary_writer.add_summary(
-                        summary_lib.encode_scalar_summary("global_step/sec", rate), step)
-                last_t, last_step = now, step
+            try:
+                self._loop()
+            except SessionClosedError:
+                return              # the job closed its session while this round was under way
+
+    def _loop(self) -> None:
+        sv = self._sv
+        last_t, last_step = time.time(), sv._step_value(self._sess)
+        while not sv.coord.wait_for_stop(sv._save_summaries_secs):
+            now, step = time.time(), sv._step_value(self._sess)
+            rate = (step - last_step) / max(now - last_t, 1e-9)
+            if sv.summary_writer is not None:
+                sv.summary_writer.add_summary(
+                    summary_lib.encode_scalar_summary("global_step/sec", rate), step)
+            last_t, last_step = now, step

@@ -19,6 +19,9 @@ every step's result is complete before the timed region ends (``--no-pipeline`` 
 Rank 0 prints ONE JSON line. On more than one GPU ``--strategy auto`` (default) is a measured
 choice in two phases:
 
+0. the product with no data exchange (every rank computes all of C), kept as a fallback line:
+   reported only if no sharded strategy completes (first contact with hardware this code has not
+   run on must not end without a number).
 A. the plain RCCL strategies -- row-sharded A + all-gather of C, K-sharded operands +
    all-reduce of partial sums -- are each measured in full (W warm-up steps, K timed steps
    between barriers). From here on a valid result line exists.
@@ -134,6 +137,7 @@ class Secured:
         self.rank, self.result_fd = rank, result_fd
         self.line = None
         self.elapsed = None
+        self.fallback = None          # reported only if no sharded measurement was completed
         self.lock = threading.Lock()
         self.deadline = None
         self.done = False
@@ -145,20 +149,29 @@ class Secured:
                 return True
             return False
 
+    def offer_fallback(self, line: str) -> None:
+        with self.lock:
+            self.fallback = line
+
+    @property
+    def have_result(self) -> bool:
+        return self.line is not None or self.fallback is not None
+
     def emit(self) -> None:
         with self.lock:
             if self.done:
                 return
             self.done = True
-            if self.rank == 0 and self.line is not None:
-                os.write(self.result_fd, (self.line + "\n").encode())
+            line = self.line if self.line is not None else self.fallback
+            if self.rank == 0 and line is not None:
+                os.write(self.result_fd, (line + "\n").encode())
 
     def bail(self, why: str) -> None:
         print("note: rank %d leaves the optional candidates (%s); reporting the measurement "
               "already taken" % (self.rank, why), file=sys.stderr)
         sys.stderr.flush()
         self.emit()
-        os._exit(0 if self.line is not None else 3)
+        os._exit(0 if self.have_result else 3)
 
     def arm(self, seconds: float) -> None:
         self.deadline = time.monotonic() + seconds
@@ -200,6 +213,9 @@ def main() -> None:
     ap.add_argument("--recompute-rows", type=int, default=None,
                     help="time this many recomputed rows per peer block instead of the values "
                          "around the measured balance point")
+    ap.add_argument("--phase-a-budget", type=float, default=300.0,
+                    help="seconds the fully measured RCCL strategies may take before the job "
+                         "reports the measurement it already has")
     ap.add_argument("--probe-budget", type=float, default=60.0,
                     help="seconds the optional candidates of --strategy auto may take in total; "
                          "past it every rank reports the RCCL measurement already taken")
@@ -284,10 +300,30 @@ def main() -> None:
         return
 
     # ---- world > 1, measured choice -----------------------------------------------------------
-    # Phase A: the plain RCCL strategies, measured in full. After it a valid result exists.
+    # Phase 0: the product with no data exchange at all (every rank computes all of C): a valid,
+    # if unsharded, measurement that exists before the first collective carrying data is issued.
+    # Whatever happens to a communicating strategy on hardware this code has not met before --
+    # an error on one rank, a collective that never completes -- the job still reports a number.
+    try:
+        eng, elapsed = measure("replicated")
+        say("candidate %-28s %8.3f ms/step (%d timed steps)"
+            % ("replicated", elapsed * 1e3 / args.steps, args.steps))
+        secured.offer_fallback(result_line(args, world, "replicated", eng, elapsed))
+        del eng
+        torch.cuda.empty_cache()
+    except Exception as e:  # noqa: BLE001
+        say("note: replicated baseline failed: %s" % str(e)[:200])
+    secured.arm(args.phase_a_budget)
+
+    # Phase A: the plain RCCL strategies, measured in full. After it a sharded result exists.
     best_ag = None                    # (engine, elapsed) of the RCCL all-gather variant
     for cand in FULL_RESULT_STRATEGIES:
-        eng, elapsed = measure(cand)
+        try:
+            eng, elapsed = measure(cand)
+        except Exception as e:  # noqa: BLE001 -- peers may be inside the collective: do not rejoin
+            if not secured.have_result:
+                raise
+            secured.bail("%s failed on rank %d: %s" % (cand, rank, str(e)[:160]))
         say("candidate %-28s %8.3f ms/step (%d timed steps)"
             % (cand, elapsed * 1e3 / args.steps, args.steps))
         secured.offer(result_line(args, world, cand, eng, elapsed), elapsed)
@@ -296,6 +332,8 @@ def main() -> None:
         else:
             del eng
             torch.cuda.empty_cache()
+    if best_ag is None:
+        secured.bail("no all-gather measurement")
 
     # Phase B: optional candidates under a deadline. Every stage ends in a vote over a separate
     # gloo group (bounded wait): a failure on any rank drops the candidate on all of them; ranks

@@ -1360,6 +1360,27 @@ class Session:
         return cap
 
     # -- conveniences ----------------------------------------------------------------------
+    def make_callable(self, fetches, feed_list: Optional[Sequence[Any]] = None,
+                      accept_options: bool = False):
+        """``f = sess.make_callable(fetches, feed_list)``; ``f(*feed_values)`` is
+        ``sess.run(fetches, dict(zip(feed_list, feed_values)))`` with the lookups of ``run`` (graph
+        elements, feed order, plan) done once. With ``accept_options`` the callable also takes
+        ``options=`` and ``run_metadata=``."""
+        feed_list = list(feed_list or [])
+        fetches_t = tuple(fetches) if isinstance(fetches, (list, tuple)) else fetches
+        keys = tuple(feed_list)
+        as_list = isinstance(fetches, list)
+
+        def call(*values, options=None, run_metadata=None):
+            if len(values) != len(keys):
+                raise TypeError("expected %d feed values, got %d" % (len(keys), len(values)))
+            if not accept_options and (options is not None or run_metadata is not None):
+                raise TypeError("this callable was made without accept_options")
+            out = self.run(fetches_t, dict(zip(keys, values)), options=options,
+                           run_metadata=run_metadata)
+            return list(out) if as_list else out
+        return call
+
     def list_devices(self) -> List[str]:
         spec = DeviceSpec(job="localhost", replica=0, task=0,
                           device_type="GPU" if self.device.type == "cuda" else "CPU",

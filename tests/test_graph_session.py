@@ -310,3 +310,26 @@ def test_run_metadata_trace():
     trace = md.to_chrome_trace()
     assert any(e["cat"] in ("FusedDense", "MatMul") for e in trace["traceEvents"])
     assert all(e["dur"] >= 0 for e in trace["traceEvents"])
+
+
+def test_make_callable_runs_the_same_plan_as_run():
+    x = tf.placeholder(tf.float32, [None, 3])
+    w = tf.Variable(tf.fill([3, 2], 0.5))
+    y = tf.matmul(x, w)
+    total = tf.reduce_sum(y)
+    with _session() as sess:
+        sess.run(tf.global_variables_initializer())
+        f = sess.make_callable([y, total], feed_list=[x])
+        bx = np.arange(6, dtype=np.float32).reshape(2, 3)
+        got = f(bx)
+        want = sess.run([y, total], {x: bx})
+        assert isinstance(got, list) and np.array_equal(got[0], want[0]) and got[1] == want[1]
+        assert len(sess._plans) == 2                      # init + the one training plan, shared
+        g = sess.make_callable(total, [x], accept_options=True)
+        md = tf.RunMetadata()
+        assert g(bx, options=tf.RunOptions(trace_level=tf.RunOptions.FULL_TRACE),
+                 run_metadata=md) == want[1] and md.step_stats
+        with pytest.raises(TypeError):
+            f(bx, bx)
+        with pytest.raises(TypeError):
+            f(bx, options=tf.RunOptions())

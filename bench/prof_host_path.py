@@ -20,7 +20,7 @@ with g.as_default():
     batches = [(torch.from_numpy(rng.rand(100, 784).astype(np.float32)).cuda(),
                 torch.from_numpy(np.eye(10, dtype=np.float32)[rng.randint(0, 10, 100)]).cuda())
                for _ in range(16)]
-    with tf.Session(config=tf.ConfigProto(device="cuda", deferred_fetches=True)) as sess:
+    with tf.Session(config=tf.ConfigProto(device="cuda", deferred_fetches=bool(int(os.environ.get("DEFERRED", "1"))))) as sess:
         sess.run(m.init_op)
         fetches = [m.train_op, m.loss, m.summary_op, m.global_step]
         for i in range(50):

@@ -38,6 +38,9 @@ else:
     b = torch.rand(n, n, device="cuda") * 2 - 1
     out = torch.empty(n, n, device="cuda")
     for _ in range(args.iters):
-        hip.gemm_f32(a, b, out=out)
+        if args.impl == "torch":
+            torch.matmul(a, b, out=out)
+        else:
+            hip.gemm_f32(a, b, out=out)
 torch.cuda.synchronize()
 print("done")

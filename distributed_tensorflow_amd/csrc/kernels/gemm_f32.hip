@@ -7,7 +7,9 @@
 // [B,100]x[100,10] (tf_distributed.py:62,64) and their NT / TN gradient products.
 //
 // Structure: 256 threads = 4 waves in a 2x2 grid over a BMxBN block tile (128x128 for large
-// problems, 64x64 when that is what it takes to put a workgroup on every CU), BK = 16.
+// problems, 64x64 when that is what it takes to put a workgroup on every CU; the largest
+// products run 256x256 tiles with a hand-dealt instruction order, gemm_f32_big_block in
+// gemm_f32_body.h), BK = 16.
 // Both operand tiles are staged K-major in LDS (As[k][m], Bs[k][n]) so the MFMA fragment read
 // -- lane l takes A[m = l&31][k = l>>5], B[k = l>>5][n = l&31] -- is 32 consecutive words per
 // half-wave: conflict-free ds_read_b32. An operand that is K-contiguous in memory is
@@ -42,6 +44,12 @@ using namespace dtf_gemm;
 template <int BM, int BN, bool A_KC, bool B_KC, int ABL = 0>
 __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmF32Args p) {
   gemm_f32_block<BM, BN, A_KC, B_KC, ABL, 0>(p, blockIdx.x);
+}
+
+// large products: 256x256 tiles, one wave per SIMD (gemm_f32_body.h)
+template <bool A_KC, bool B_KC, int ABL = 0>
+__global__ __launch_bounds__(NTHREADS) void gemm_f32_big_kernel(GemmF32Args p) {
+  gemm_f32_big_block<A_KC, B_KC, ABL>(p, blockIdx.x);
 }
 
 // C = act(op(A) op(B) + bias) for small outputs: one 16x16 tile per workgroup (gemm_f32_body.h)
@@ -88,6 +96,49 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
+template <int BM, int BN, bool AKC, bool BKC, int ABL>
+void launch_kernel(dim3 grid, dim3 block, hipStream_t stream, const GemmF32Args& args) {
+  hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, AKC, BKC, ABL>), grid, block, 0, stream, args);
+}
+
+// 256x256 tiles (gemm_f32_big_block); its staging buffers are dynamic LDS, just over the 64 KiB a
+// kernel may use without asking
+template <bool AKC, bool BKC, int ABL>
+void launch_big_kernel(dim3 grid, hipStream_t stream, const GemmF32Args& args) {
+  constexpr size_t lds = gemm_f32_big_lds_bytes(AKC, BKC);
+  static bool allowed = false;
+  if (!allowed) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_big_kernel<AKC, BKC, ABL>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    allowed = true;
+  }
+  hipLaunchKernelGGL((gemm_f32_big_kernel<AKC, BKC, ABL>), grid, dim3(NTHREADS), lds, stream, args);
+}
+
+int launch_big(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
+               long lda, long ldb, long ldc, int trans_a, int trans_b, int act,
+               float* partial, hipStream_t stream) {
+  const int tiles_m = (M + BIG_T - 1) / BIG_T, tiles_n = (N + BIG_T - 1) / BIG_T;
+  const int ntiles = tiles_m * tiles_n;
+  const GemmF32Args args{A, B, C, bias, M, N, K, lda, ldb, ldc, 1, 1, act, tiles_n, ntiles,
+                         1, K, partial, 0.f};
+  dim3 grid(ntiles);
+#ifdef DTF_GEMM_EXPERIMENTS
+  if (const char* e = getenv("DTF_F32_ABL")) {
+    if (atoi(e) == 16 && !trans_a && !trans_b) {
+      launch_big_kernel<true, false, 16>(grid, stream, args);
+      return DTF_OK;
+    }
+  }
+#endif
+  if (!trans_a && !trans_b) launch_big_kernel<true, false, 0>(grid, stream, args);
+  else if (!trans_a && trans_b) launch_big_kernel<true, true, 0>(grid, stream, args);
+  else if (trans_a && !trans_b) launch_big_kernel<false, false, 0>(grid, stream, args);
+  else launch_big_kernel<false, true, 0>(grid, stream, args);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
 template <int BM, int BN>
 int launch(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
            long lda, long ldb, long ldc, int trans_a, int trans_b, int act, int splits,
@@ -100,19 +151,17 @@ int launch(const float* A, const float* B, float* C, const float* bias, int M, i
   const GemmF32Args args{A, B, C, bias, M, N, K, lda, ldb, ldc, a_vec, b_vec, act, tiles_n, ntiles,
                          splits, kchunk, partial, 0.f};
   // op(A)(m,k): stored [M,K] -> K-contiguous; stored [K,M] (trans_a) -> M-contiguous
-#define DTF_GEMM_CASE(AKC, BKC)                                                               \
-  hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, AKC, BKC>), grid, block, 0, stream, args)
+#define DTF_GEMM_CASE(AKC, BKC) launch_kernel<BM, BN, AKC, BKC, 0>(grid, block, stream, args)
 #ifdef DTF_GEMM_EXPERIMENTS
   if (const char* e = getenv("DTF_F32_ABL")) {
     const int abl = atoi(e);
 #define DTF_ABL_CASE(V)                                                                       \
   if (abl == V) {                                                                             \
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, false, V>), grid, block, 0, stream,     \
-                       args);                                                                 \
+    launch_kernel<BM, BN, true, false, V>(grid, block, stream, args);                         \
     return DTF_OK;                                                                            \
   }
     DTF_ABL_CASE(1) DTF_ABL_CASE(2) DTF_ABL_CASE(4) DTF_ABL_CASE(8) DTF_ABL_CASE(6)
-    DTF_ABL_CASE(7) DTF_ABL_CASE(15) DTF_ABL_CASE(14)
+    DTF_ABL_CASE(7) DTF_ABL_CASE(15) DTF_ABL_CASE(14) DTF_ABL_CASE(16)
 #undef DTF_ABL_CASE
   }
 #endif
@@ -133,12 +182,21 @@ int launch(const float* A, const float* B, float* C, const float* bias, int M, i
 
 }  // namespace
 
-// Block tile for an M x N x K product, from measurements on MI355X: the 128x128 tile (2x2 MFMA
-// tiles per wave, half the LDS reads per flop) wins from 4096^2 outputs on (4096^3: 136 vs 131
-// TF, 8192^3: 140 vs 139 TF); below that the 64x64 tile keeps more workgroups per CU in flight
-// and is faster (3072^3: 120 vs 96 TF, 2048^3: 128 vs 113 TF).
+// Block tile for an M x N x K product, from measurements on MI355X. 256x256 (one wave per SIMD,
+// every other instruction in the shadow of an MFMA; 8192^3: 150 TF against 140 for the smaller
+// tiles) when K is long enough to amortise a tile's unoverlapped first loads and 256 KiB of
+// stores and the grid fills whole rounds of the 256 CUs -- a workgroup has its CU to itself, so
+// a last round that is a quarter full costs as much as a full one (6144^3: 576 tiles, 109 TF).
+// Otherwise 128x128 (2x2 MFMA tiles per wave, half the LDS reads per flop of 64x64) from 4096^2
+// outputs on; below that the 64x64 tile keeps more workgroups per CU in flight and is faster
+// (3072^3: 120 vs 96 TF, 2048^3: 128 vs 113 TF).
 DTF_API int dtf_gemm_f32_tile(int M, int N, int K) {
   if (gemm_f32_skinny_fits(M, N, K)) return 16;       // one 16x16 tile per workgroup, no split
+  const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
+  if (K >= 2048 && t256 >= 256) {
+    const long rounds = (t256 + 255) / 256;
+    if (t256 * 100 >= rounds * 256 * 93) return 256;
+  }
   const long big_tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
   return big_tiles >= 1024 ? 128 : 64;
 }
@@ -186,7 +244,7 @@ DTF_API int dtf_gemm_f32(const float* A, const float* B, float* C, const float* 
                          float* partial, int splits, int tile, hipStream_t stream) {
   if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return DTF_ERR_BAD_ARG;
   if (lda < (trans_a ? M : K) || ldb < (trans_b ? K : N) || ldc < N) return DTF_ERR_BAD_ARG;
-  if (tile != 16 && tile != 64 && tile != 128) tile = dtf_gemm_f32_tile(M, N, K);
+  if (tile != 16 && tile != 64 && tile != 128 && tile != 256) tile = dtf_gemm_f32_tile(M, N, K);
   if (tile == 16) {
     const int tiles_m = (M + SK_T - 1) / SK_T, tiles_n = (N + SK_T - 1) / SK_T;
     const SkinnyArgs args{A, B, C, bias, M, N, K, lda, ldb, ldc, act, 0.f, tiles_n};
@@ -214,6 +272,12 @@ DTF_API int dtf_gemm_f32(const float* A, const float* B, float* C, const float* 
   } else {
     kchunk = ((K + splits - 1) / splits + BK - 1) / BK * BK;
     splits = (K + kchunk - 1) / kchunk;          // never more than the caller allotted
+  }
+  if (tile == 256) {
+    if (gemm_f32_big_ok(A, B, M, N, K, lda, ldb, !trans_a, trans_b != 0))
+      return launch_big(A, B, C, bias, M, N, K, lda, ldb, ldc, trans_a, trans_b, act, partial,
+                        stream);
+    tile = 128;                                  // operands the large-tile loads cannot take
   }
   if (tile == 128)
     return launch<128, 128>(A, B, C, bias, M, N, K, lda, ldb, ldc, trans_a, trans_b, act, splits,

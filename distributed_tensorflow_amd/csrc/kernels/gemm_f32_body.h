@@ -14,6 +14,9 @@ namespace dtf_gemm {
 constexpr int BK = 16;
 constexpr int NTHREADS = 256;
 
+// staging buffers of the 256x256 tile (just over the 64 KiB a kernel may declare statically)
+extern __shared__ __attribute__((aligned(16))) float gemm_f32_dyn_lds[];
+
 struct GemmF32Args {
   const float* A;
   const float* B;
@@ -151,25 +154,30 @@ struct Loader {
     }
   }
 
+  // register i of a tile's set into its place in the LDS tile
+  __device__ static void stash_one(const f32x4& reg, int i, float* __restrict__ Xs, int tid) {
+    const int idx = tid + i * NTHREADS;
+    if (KCONTIG) {
+      const int t = idx >> 2, k4 = idx & 3;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) Xs[(4 * k4 + j) * LD + t] = reg[j];
+    } else {
+      constexpr int V = BT / 4;
+      const int k = idx / V, t4 = idx % V;
+      *reinterpret_cast<f32x4*>(&Xs[k * LD + 4 * t4]) = reg;
+    }
+  }
+
   __device__ static void stash(const f32x4 (&regs)[PER_THREAD], float* __restrict__ Xs, int tid) {
 #pragma unroll
-    for (int i = 0; i < PER_THREAD; ++i) {
-      const int idx = tid + i * NTHREADS;
-      if (KCONTIG) {
-        const int t = idx >> 2, k4 = idx & 3;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) Xs[(4 * k4 + j) * LD + t] = regs[i][j];
-      } else {
-        constexpr int V = BT / 4;
-        const int k = idx / V, t4 = idx % V;
-        *reinterpret_cast<f32x4*>(&Xs[k * LD + 4 * t4]) = regs[i];
-      }
-    }
+    for (int i = 0; i < PER_THREAD; ++i) stash_one(regs[i], i, Xs, tid);
   }
 };
 
 // ABL (timing experiments, -DDTF_GEMM_EXPERIMENTS only; results are wrong when set): bit 0 = no
-// global loads in the K loop, bit 1 = no LDS stash, bit 2 = no barrier, bit 3 = no fragment reads
+// global loads in the K loop, bit 1 = no LDS stash, bit 2 = no barrier, bit 3 = no fragment reads,
+// bit 4 = every wave sums the shader-clock cycles each k-pair of its interior K-tiles took and
+// leaves the means in p.partial[(workgroup * 4 + wave) * 16 + k-pair] (slot 15: tiles counted)
 // EPI: 0 = C = act(acc + bias) (or the split's partial plane), 1 = C = fma(-lr, acc, C): the
 // product is a gradient and C the variable it updates in place (plain SGD in the epilogue).
 template <int BM, int BN, bool A_KC, bool B_KC, int ABL = 0, int EPI = 0>
@@ -293,6 +301,8 @@ __device__ __forceinline__ void gemm_f32_block(const GemmF32Args& p, const int b
     // loads with loop-invariant lane offsets. The two kinds of fetch live in separate loops: a
     // join of paths that issue different loads makes the compiler drain vmcnt to zero before
     // the next LDS stash, which empties the prefetch ring once per group.
+    unsigned long long t_prev = 0, t_sum[KP] = {};
+    int t_count = 0;
     auto group = [&](auto interior_tag, int kt0) {
       constexpr bool INTERIOR = decltype(interior_tag)::value;
 #pragma unroll
@@ -311,14 +321,31 @@ __device__ __forceinline__ void gemm_f32_block(const GemmF32Args& p, const int b
         const float* bsn = Bs + (cur ^ 1) * B_BUF + wc * WN + lrow;
 #pragma unroll
         for (int kk = 0; kk < KP; ++kk) {
-          if (kk == (KP - PD) / 2 && !(ABL & 2)) {
+          if ((ABL & 16) && INTERIOR) {
+            // slot kk: from the start of k-pair kk-1 to the start of k-pair kk
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            if (t_prev != 0) t_sum[(kk + KP - 1) % KP] += now - t_prev;
+            t_prev = now;
+            if (kk == 0) ++t_count;
+          }
+          if (!(ABL & 2)) {
             // tile kt+1 (loaded DEPTH-1 tiles ago; zeros past the end) goes into the other LDS
-            // buffer, whose last readers finished before the previous tile's barrier. Neither
-            // this nor the ring's reads below are skipped on the last tile: a branch around LDS
-            // operations would force the compiler to drain lgkmcnt to zero at the join instead
-            // of counting, and every MFMA would then wait for the newest fragment read.
-            LA::stash(ra[(u + 1) % DEPTH], As + (cur ^ 1) * A_BUF, tid);
-            LB::stash(rb[(u + 1) % DEPTH], Bs + (cur ^ 1) * B_BUF, tid);
+            // buffer, whose last readers finished before the previous tile's barrier: one
+            // register of each operand's set per k-pair, in the k-pairs before the barrier. (All
+            // of a 256x256 tile's 20 LDS writes in one place, from four waves at once, held the
+            // waves -- and the MFMAs queued behind the writes -- for 500 cycles per K-tile.)
+            // Neither this nor the ring's reads below are skipped on the last tile: a branch
+            // around LDS operations would force the compiler to drain lgkmcnt to zero at the
+            // join instead of counting, and every MFMA would then wait for the newest fragment
+            // read.
+            constexpr int SLICES = LA::PER_THREAD > LB::PER_THREAD ? LA::PER_THREAD : LB::PER_THREAD;
+            constexpr int S0 = (KP - PD - SLICES) / 2 > 0 ? (KP - PD - SLICES) / 2 : 0;
+            static_assert(S0 + SLICES <= KP - PD, "stash must end before the barrier");
+            const int si = kk - S0;
+            if (si >= 0 && si < LA::PER_THREAD)
+              LA::stash_one(ra[(u + 1) % DEPTH][si], si, As + (cur ^ 1) * A_BUF, tid);
+            if (si >= 0 && si < LB::PER_THREAD)
+              LB::stash_one(rb[(u + 1) % DEPTH][si], si, Bs + (cur ^ 1) * B_BUF, tid);
           }
           if (kk == KP - PD && !(ABL & 4)) __syncthreads();
           {
@@ -347,6 +374,12 @@ __device__ __forceinline__ void gemm_f32_block(const GemmF32Args& p, const int b
       for (; kt0 + 2 * DEPTH <= n_full; kt0 += DEPTH) group(std::true_type{}, kt0);
     }
     for (; kt0 < nkt; kt0 += DEPTH) group(std::false_type{}, kt0);
+    if ((ABL & 16) && lane == 0 && partial) {
+#pragma unroll
+      for (int kk = 0; kk < KP; ++kk)
+        partial[(bid * 4 + wave) * 16 + kk] = (float)t_sum[kk] / (float)(t_count > 0 ? t_count : 1);
+      partial[(bid * 4 + wave) * 16 + 15] = (float)t_count;
+    }
   };
   if (fast) k_loop(std::true_type{});
   else k_loop(std::false_type{});
@@ -389,6 +422,220 @@ __device__ __forceinline__ void gemm_f32_block(const GemmF32Args& p, const int b
         else *c = dtf_apply_act(acc[i][j][r] + bv, act);
       }
     }
+}
+
+
+// ---- large products: 256x256 block tile, four waves of 128x128 outputs, one wave per SIMD -----
+// The exact-fp32 MFMA needs so little operand traffic (a 32x32x2 step is 64 cycles on two
+// registers) that a large product is limited by nothing but how often the matrix pipe is left
+// without its next instruction. With 128x128 tiles and two waves per SIMD it idled 11 % of the
+// time: each K-tile's 20 LDS writes, its barrier and the waits in front of them sat between MFMAs
+// that had nothing queued behind them. Here every wave owns 256 accumulators (4x4 MFMA tiles), a
+// K-tile of 16 is 128 MFMAs = 8192 cycles per wave, and everything else is dealt out one
+// instruction per MFMA so that it issues in the shadow of the 64 cycles the MFMA before it runs:
+//
+//   k-pair kk of a K-tile (16 MFMAs):  slots 0..7   the 8 fragment reads of k-pair kk+1
+//                                      slots 8..15  kk == 0: the tile's 8 global loads (tile t+2)
+//                                                   kk == 1..4: LDS writes of tile t+1 (register
+//                                                   kk-1 of both operands' sets)
+//   before k-pair 7: wait for the LDS writes, barrier -- the fragments k-pair 7 reads are those of
+//   tile t+1, out of the other LDS buffer.
+//
+// A fence after every slot (sched_barrier) keeps the compiler from regrouping what was dealt out.
+// Two register sets and two LDS buffers alternate, so the K loop is unrolled by two tiles and
+// every buffer and register index in it is a constant. Operands must qualify for the branch-free
+// loads (16-byte aligned rows, K -- and M or N where they are the contiguous dimension --
+// multiples of 4); edges in M and N are clamped on load and predicated on store, a K tail reads
+// zeros.
+// ABL (timing experiments, -DDTF_GEMM_EXPERIMENTS only): bit 4 = per-k-pair cycle sums, as in
+// gemm_f32_block.
+constexpr int BIG_T = 256;
+
+__host__ __device__ constexpr size_t gemm_f32_big_lds_bytes(bool a_kc, bool b_kc) {
+  return sizeof(float) * 2 * BK * ((a_kc ? BIG_T + 2 : BIG_T) + (b_kc ? BIG_T + 2 : BIG_T));
+}
+
+template <bool A_KC, bool B_KC, int ABL = 0>
+__device__ __forceinline__ void gemm_f32_big_block(const GemmF32Args& p, const int bid) {
+  const float* __restrict__ A = p.A;
+  const float* __restrict__ B = p.B;
+  float* __restrict__ C = p.C;
+  const int M = p.M, N = p.N, K = p.K;
+  const long lda = p.lda, ldb = p.ldb, ldc = p.ldc;
+  using LA = Loader<BIG_T, A_KC>;
+  using LB = Loader<BIG_T, B_KC>;
+  constexpr int PT = LA::PER_THREAD;            // registers (of 16 bytes) per thread and K-tile
+  static_assert(PT == 4 && LB::PER_THREAD == 4, "slot plan assumes four registers per operand");
+  constexpr int A_BUF = BK * LA::LD, B_BUF = BK * LB::LD;    // floats per buffer
+  float* const As = gemm_f32_dyn_lds;                        // As[buf][k][m]
+  float* const Bs = gemm_f32_dyn_lds + 2 * A_BUF;            // Bs[buf][k][n]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int ntiles = p.ntiles, tiles_n = p.tiles_n;
+  const int tile = dtf_xcd_remap(bid, ntiles);
+  constexpr int GROUP = 8;
+  const int tiles_m = ntiles / tiles_n;
+  const int per_group = GROUP * tiles_n;
+  const int first_m = (tile / per_group) * GROUP;
+  const int gsize = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
+  const int m0 = (first_m + (tile % per_group) % gsize) * BIG_T;
+  const int n0 = ((tile % per_group) / gsize) * BIG_T;
+  const int nkt = (K + BK - 1) / BK;
+  const int lrow = lane & 31, lk = lane >> 5;
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 ra[2][PT], rb[2][PT];
+  unsigned voff_a[PT], voff_b[PT];
+  LA::lane_offsets(voff_a, lda, m0, M, tid);
+  LB::lane_offsets(voff_b, ldb, n0, N, tid);
+
+  // prologue: tiles 0 and 1 requested, tile 0 in LDS buffer 0, fragments of its k-pair 0 read
+  LA::fetch_fast(ra[0], A, lda, m0, 0, M, K, tid);
+  LB::fetch_fast(rb[0], B, ldb, n0, 0, N, K, tid);
+  LA::fetch_fast(ra[1], A, lda, m0, BK, M, K, tid);
+  LB::fetch_fast(rb[1], B, ldb, n0, BK, N, K, tid);
+  LA::stash(ra[0], As, tid);
+  LB::stash(rb[0], Bs, tid);
+  __syncthreads();
+
+  // fragment of k-pair kp in buffer `buf`: A[m = 32 i + lrow][k = 2 kp + lk] at a_rd[...]
+  const float* const a_rd = As + lk * LA::LD + wr * 128 + lrow;
+  const float* const b_rd = Bs + lk * LB::LD + wc * 128 + lrow;
+  float a[2][4], b[2][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a[0][i] = a_rd[32 * i];
+    b[0][i] = b_rd[32 * i];
+  }
+
+  unsigned long long t_prev = 0, t_sum[8] = {};
+  int t_count = 0;
+
+  // K-tiles kt0 (LDS buffer / register set 0) and kt0 + 1 (buffer / set 1)
+  auto pair_of_tiles = [&](auto interior_tag, int kt0) {
+    constexpr bool INTERIOR = decltype(interior_tag)::value;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int kt = kt0 + s;
+      if (!INTERIOR && kt >= nkt) return;
+      const int k_next = (kt + 2) * BK;                 // the tile this one requests
+      const float* const base_a = LA::tile_base(A, lda, m0, M, k_next);
+      const float* const base_b = LB::tile_base(B, ldb, n0, N, k_next);
+      const __amdgpu_buffer_rsrc_t rsrc_a =
+          __builtin_amdgcn_make_buffer_rsrc((void*)base_a, 0, 0xffffffff, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rsrc_b =
+          __builtin_amdgcn_make_buffer_rsrc((void*)base_b, 0, 0xffffffff, 0x00020000);
+      if (!INTERIOR) {
+        // clamped addresses and zeros beyond K, all eight at once (two tiles per product)
+        LA::fetch_fast(ra[s], A, lda, m0, k_next, M, K, tid);
+        LB::fetch_fast(rb[s], B, ldb, n0, k_next, N, K, tid);
+      }
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        constexpr int KP = 8;
+        if ((ABL & 16) && INTERIOR) {
+          const unsigned long long now = __builtin_amdgcn_s_memtime();
+          if (t_prev != 0) t_sum[(kk + KP - 1) % KP] += now - t_prev;
+          t_prev = now;
+          if (kk == 0) ++t_count;
+        }
+        if (kk == KP - 1) {
+          // every wave's writes of tile kt+1 are in LDS and every wave's reads of this tile's
+          // buffer are done: the other buffer may be read, this one refilled
+          __syncthreads();
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        const int c = kk & 1;                            // fragment ring slot of this k-pair
+        // where k-pair kk + 1 lives: this tile's buffer, or k-pair 0 of the other one
+        const int nb = kk + 1 < KP ? s : s ^ 1, nkp = (kk + 1) % KP;
+        const float* const an = a_rd + nb * A_BUF + 2 * nkp * LA::LD;
+        const float* const bn = b_rd + nb * B_BUF + 2 * nkp * LB::LD;
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+          acc[n >> 2][n & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][n >> 2], b[c][n & 3],
+                                                                    acc[n >> 2][n & 3], 0, 0, 0);
+          if (n < 4) {
+            a[c ^ 1][n] = an[32 * n];
+          } else if (n < 8) {
+            b[c ^ 1][n - 4] = bn[32 * (n - 4)];
+          } else if (kk == 0) {
+            if (INTERIOR) {
+              const int q = (n - 8) >> 1;
+              if (n & 1)
+                rb[s][q] = __builtin_bit_cast(
+                    f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, voff_b[q], 0, 0));
+              else
+                ra[s][q] = __builtin_bit_cast(
+                    f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff_a[q], 0, 0));
+            }
+          } else if (kk <= PT) {
+            // register kk-1 of tile kt+1's sets into the other buffer: a K-contiguous operand
+            // is transposed on the way (four one-word writes), the other goes as it is
+            const int q = kk - 1, w = n - 8;
+            float* const ad = As + (s ^ 1) * A_BUF;
+            float* const bd = Bs + (s ^ 1) * B_BUF;
+            const int idx = tid + q * NTHREADS;
+            if (w < 4) {
+              if (A_KC) ad[(4 * (idx & 3) + w) * LA::LD + (idx >> 2)] = ra[s ^ 1][q][w];
+              else if (w == 0) LA::stash_one(ra[s ^ 1][q], q, ad, tid);
+            } else {
+              if (B_KC) bd[(4 * (idx & 3) + (w - 4)) * LB::LD + (idx >> 2)] = rb[s ^ 1][q][w - 4];
+              else if (w == 4) LB::stash_one(rb[s ^ 1][q], q, bd, tid);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  };
+  int kt0 = 0;
+  for (; (kt0 + 4) * BK <= K; kt0 += 2) pair_of_tiles(std::true_type{}, kt0);
+  for (; kt0 < nkt; kt0 += 2) pair_of_tiles(std::false_type{}, kt0);
+
+  if ((ABL & 16) && lane == 0 && p.partial) {
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk)
+      p.partial[(bid * 4 + wave) * 16 + kk] = (float)t_sum[kk] / (float)(t_count > 0 ? t_count : 1);
+    p.partial[(bid * 4 + wave) * 16 + 15] = (float)t_count;
+  }
+
+  // C/D fragment: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = n0 + wc * 128 + 32 * j + lrow;
+      if (col >= N) continue;
+      const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wr * 128 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (row >= M) continue;
+        C[(long)row * ldc + col] = dtf_apply_act(acc[i][j][r] + bv, p.act);
+      }
+    }
+}
+
+// whether the operands of C[M,N] = op(A) op(B) qualify for gemm_f32_big_block
+__host__ inline bool gemm_f32_big_ok(const void* A, const void* B, int M, int N, int K, long lda,
+                                     long ldb, bool a_kc, bool b_kc) {
+  if (((uintptr_t)A | (uintptr_t)B) % 16 != 0 || lda % 4 != 0 || ldb % 4 != 0) return false;
+  if (K < 4 * BK || M < 4 || N < 4) return false;
+  if (a_kc ? K % 4 != 0 : M % 4 != 0) return false;
+  if (b_kc ? K % 4 != 0 : N % 4 != 0) return false;
+  // lane offsets within a tile are 32-bit byte offsets
+  if (lda * 4 * (a_kc ? BIG_T : BK) >= (1L << 32) || ldb * 4 * (b_kc ? BIG_T : BK) >= (1L << 32))
+    return false;
+  return true;
 }
 
 

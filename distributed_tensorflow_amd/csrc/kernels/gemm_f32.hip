@@ -7,9 +7,9 @@
 // [B,100]x[100,10] (tf_distributed.py:62,64) and their NT / TN gradient products.
 //
 // Structure: 256 threads = 4 waves in a 2x2 grid over a BMxBN block tile (128x128 for large
-// problems, 64x64 when that is what it takes to put a workgroup on every CU; the largest
-// products run 256x256 tiles with a hand-dealt instruction order, gemm_f32_big_block in
-// gemm_f32_body.h), BK = 16.
+// problems, 64x64 when that is what it takes to put a workgroup on every CU), BK = 16. Large
+// products with aligned operands run the same tiling with a hand-dealt instruction order
+// (gemm_f32_big_block in gemm_f32_body.h); what follows describes the general kernel.
 // Both operand tiles are staged K-major in LDS (As[k][m], Bs[k][n]) so the MFMA fragment read
 // -- lane l takes A[m = l&31][k = l>>5], B[k = l>>5][n = l&31] -- is 32 consecutive words per
 // half-wave: conflict-free ds_read_b32. An operand that is K-contiguous in memory is
@@ -46,10 +46,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmF32Args p) {
   gemm_f32_block<BM, BN, A_KC, B_KC, ABL, 0>(p, blockIdx.x);
 }
 
-// large products: 256x256 tiles, one wave per SIMD (gemm_f32_body.h)
-template <bool A_KC, bool B_KC, int ABL = 0>
+// large products: 128x128 or 256x256 tiles, every instruction dealt into an MFMA slot
+// (gemm_f32_body.h)
+template <int T, bool A_KC, bool B_KC, int ABL = 0>
 __global__ __launch_bounds__(NTHREADS) void gemm_f32_big_kernel(GemmF32Args p) {
-  gemm_f32_big_block<A_KC, B_KC, ABL>(p, blockIdx.x);
+  gemm_f32_big_block<T, A_KC, B_KC, ABL>(p, blockIdx.x);
 }
 
 // C = act(op(A) op(B) + bias) for small outputs: one 16x16 tile per workgroup (gemm_f32_body.h)
@@ -101,24 +102,30 @@ void launch_kernel(dim3 grid, dim3 block, hipStream_t stream, const GemmF32Args&
   hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, AKC, BKC, ABL>), grid, block, 0, stream, args);
 }
 
-// 256x256 tiles (gemm_f32_big_block); its staging buffers are dynamic LDS, just over the 64 KiB a
-// kernel may use without asking
-template <bool AKC, bool BKC, int ABL>
-void launch_big_kernel(dim3 grid, hipStream_t stream, const GemmF32Args& args) {
-  constexpr size_t lds = gemm_f32_big_lds_bytes(AKC, BKC);
+// T x T tiles dealt out in MFMA slots (gemm_f32_big_block); the staging buffers are dynamic LDS
+// (those of the 256x256 tile are just over the 64 KiB a kernel may use without asking)
+template <int T, bool AKC, bool BKC, int ABL>
+void launch_big_kernel(dim3 grid, hipStream_t stream, const GemmF32Args& args, int occ = 0) {
+  // occ: workgroups per CU wanted (0 = as many as fit); asking for a larger LDS allocation than
+  // the buffers need is what caps it
+  size_t lds = gemm_f32_slot_lds_bytes(T, AKC, BKC);
+  if (occ > 0 && (size_t)(160 * 1024 / (occ + 1) + 1024) > lds) lds = 160 * 1024 / (occ + 1) + 1024;
   static bool allowed = false;
   if (!allowed) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_big_kernel<AKC, BKC, ABL>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&gemm_f32_big_kernel<T, AKC, BKC, ABL>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     allowed = true;
   }
-  hipLaunchKernelGGL((gemm_f32_big_kernel<AKC, BKC, ABL>), grid, dim3(NTHREADS), lds, stream, args);
+  hipLaunchKernelGGL((gemm_f32_big_kernel<T, AKC, BKC, ABL>), grid, dim3(NTHREADS), lds, stream,
+                     args);
 }
 
+template <int T>
 int launch_big(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
                long lda, long ldb, long ldc, int trans_a, int trans_b, int act,
-               float* partial, hipStream_t stream) {
-  const int tiles_m = (M + BIG_T - 1) / BIG_T, tiles_n = (N + BIG_T - 1) / BIG_T;
+               float* partial, hipStream_t stream, int occ = 0) {
+  const int tiles_m = (M + T - 1) / T, tiles_n = (N + T - 1) / T;
   const int ntiles = tiles_m * tiles_n;
   const GemmF32Args args{A, B, C, bias, M, N, K, lda, ldb, ldc, 1, 1, act, tiles_n, ntiles,
                          1, K, partial, 0.f};
@@ -126,15 +133,15 @@ int launch_big(const float* A, const float* B, float* C, const float* bias, int 
 #ifdef DTF_GEMM_EXPERIMENTS
   if (const char* e = getenv("DTF_F32_ABL")) {
     if (atoi(e) == 16 && !trans_a && !trans_b) {
-      launch_big_kernel<true, false, 16>(grid, stream, args);
+      launch_big_kernel<T, true, false, 16>(grid, stream, args);
       return DTF_OK;
     }
   }
 #endif
-  if (!trans_a && !trans_b) launch_big_kernel<true, false, 0>(grid, stream, args);
-  else if (!trans_a && trans_b) launch_big_kernel<true, true, 0>(grid, stream, args);
-  else if (trans_a && !trans_b) launch_big_kernel<false, false, 0>(grid, stream, args);
-  else launch_big_kernel<false, true, 0>(grid, stream, args);
+  if (!trans_a && !trans_b) launch_big_kernel<T, true, false, 0>(grid, stream, args, occ);
+  else if (!trans_a && trans_b) launch_big_kernel<T, true, true, 0>(grid, stream, args, occ);
+  else if (trans_a && !trans_b) launch_big_kernel<T, false, false, 0>(grid, stream, args, occ);
+  else launch_big_kernel<T, false, true, 0>(grid, stream, args, occ);
   DTF_LAUNCH_CHECK();
   return DTF_OK;
 }
@@ -182,23 +189,34 @@ int launch(const float* A, const float* B, float* C, const float* bias, int M, i
 
 }  // namespace
 
-// Block tile for an M x N x K product, from measurements on MI355X. 256x256 (one wave per SIMD,
-// every other instruction in the shadow of an MFMA; 8192^3: 150 TF against 140 for the smaller
-// tiles) when K is long enough to amortise a tile's unoverlapped first loads and 256 KiB of
-// stores and the grid fills whole rounds of the 256 CUs -- a workgroup has its CU to itself, so
-// a last round that is a quarter full costs as much as a full one (6144^3: 576 tiles, 109 TF).
-// Otherwise 128x128 (2x2 MFMA tiles per wave, half the LDS reads per flop of 64x64) from 4096^2
-// outputs on; below that the 64x64 tile keeps more workgroups per CU in flight and is faster
-// (3072^3: 120 vs 96 TF, 2048^3: 128 vs 113 TF).
+// Block tile for an M x N x K product, from measurements on MI355X (profiles/
+// gemm_f32_tiles_vs_hipblaslt.jsonl). The 128x128 tile on the slot-dealt kernel
+// (gemm_f32_big_block) keeps the matrix pipe 97-98 % busy (8192^3: 151 TF, 6144^3: 152,
+// 4096^3: 148; the general kernel: 140, 139, 136) but holds a quarter or a half of a CU per
+// workgroup for a long time, so it is chosen when its grid fills the chip evenly: up to 256 tiles
+// run one per CU (2048^3: 123 TF against 112 with 64x64 tiles); more run two per CU, in rounds
+// of 512, and a last round that is at most half full costs half a round (the stragglers have
+// their CUs to themselves), a fuller one a whole round. Everything else takes 64x64 tiles, three
+// or four workgroups to a CU (3072^3: 130 TF, 5120^3: 140).
 DTF_API int dtf_gemm_f32_tile(int M, int N, int K) {
   if (gemm_f32_skinny_fits(M, N, K)) return 16;       // one 16x16 tile per workgroup, no split
-  const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
-  if (K >= 2048 && t256 >= 256) {
-    const long rounds = (t256 + 255) / 256;
-    if (t256 * 100 >= rounds * 256 * 93) return 256;
+  const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+  if (K >= 512) {
+    if (t128 >= 230 && t128 <= 256) return 128;
+    if (t128 > 256) {
+      const long full = t128 / 512, rest = t128 % 512;
+      // cost in half rounds against 2 * t128 / 512 half rounds of work: take it from 94 % on
+      const long cost2 = 2 * full + (rest == 0 ? 0 : rest <= 256 ? 1 : 2);
+      if (t128 * 100 >= cost2 * 256 * 94) return 128;
+    }
   }
-  const long big_tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
-  return big_tiles >= 1024 ? 128 : 64;
+  return 64;
+}
+
+// Workgroups per CU the slot-dealt 128x128 kernel is launched with (see dtf_gemm_f32_tile)
+static int gemm_f32_slot_occupancy(int M, int N) {
+  const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+  return t128 <= 256 ? 1 : 2;
 }
 
 // Split-K plan: number of K splits (1 = none). A 64x64-tile grid of up to ~1000 workgroups that
@@ -244,7 +262,8 @@ DTF_API int dtf_gemm_f32(const float* A, const float* B, float* C, const float* 
                          float* partial, int splits, int tile, hipStream_t stream) {
   if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return DTF_ERR_BAD_ARG;
   if (lda < (trans_a ? M : K) || ldb < (trans_b ? K : N) || ldc < N) return DTF_ERR_BAD_ARG;
-  if (tile != 16 && tile != 64 && tile != 128 && tile != 256) tile = dtf_gemm_f32_tile(M, N, K);
+  if (tile != 16 && tile != 64 && tile != 128 && tile != 129 && tile != 256)
+    tile = dtf_gemm_f32_tile(M, N, K);
   if (tile == 16) {
     const int tiles_m = (M + SK_T - 1) / SK_T, tiles_n = (N + SK_T - 1) / SK_T;
     const SkinnyArgs args{A, B, C, bias, M, N, K, lda, ldb, ldc, act, 0.f, tiles_n};
@@ -273,13 +292,17 @@ DTF_API int dtf_gemm_f32(const float* A, const float* B, float* C, const float* 
     kchunk = ((K + splits - 1) / splits + BK - 1) / BK * BK;
     splits = (K + kchunk - 1) / kchunk;          // never more than the caller allotted
   }
-  if (tile == 256) {
-    if (gemm_f32_big_ok(A, B, M, N, K, lda, ldb, !trans_a, trans_b != 0))
-      return launch_big(A, B, C, bias, M, N, K, lda, ldb, ldc, trans_a, trans_b, act, partial,
-                        stream);
-    tile = 128;                                  // operands the large-tile loads cannot take
-  }
-  if (tile == 128)
+  // 128 and 256: the slot-dealt kernel where the operands allow its loads (aligned rows,
+  // contiguous dimensions multiples of 4), the general one otherwise; 129: the general kernel
+  // with 128x128 tiles whatever the operands (for measurements)
+  const bool slot_ok = gemm_f32_big_ok(A, B, M, N, K, lda, ldb, !trans_a, trans_b != 0);
+  if (tile == 256 && slot_ok)
+    return launch_big<256>(A, B, C, bias, M, N, K, lda, ldb, ldc, trans_a, trans_b, act, partial,
+                           stream);
+  if ((tile == 128 || tile == 256) && slot_ok && (!partial || splits <= 1))
+    return launch_big<128>(A, B, C, bias, M, N, K, lda, ldb, ldc, trans_a, trans_b, act, partial,
+                           stream, gemm_f32_slot_occupancy(M, N));
+  if (tile != 64)
     return launch<128, 128>(A, B, C, bias, M, N, K, lda, ldb, ldc, trans_a, trans_b, act, splits,
                             kchunk, partial, stream);
   return launch<64, 64>(A, B, C, bias, M, N, K, lda, ldb, ldc, trans_a, trans_b, act, splits,

@@ -451,21 +451,32 @@ __device__ __forceinline__ void gemm_f32_block(const GemmF32Args& p, const int b
 // gemm_f32_block.
 constexpr int BIG_T = 256;
 
-__host__ __device__ constexpr size_t gemm_f32_big_lds_bytes(bool a_kc, bool b_kc) {
-  return sizeof(float) * 2 * BK * ((a_kc ? BIG_T + 2 : BIG_T) + (b_kc ? BIG_T + 2 : BIG_T));
+// LDS bytes of the staging buffers of a T x T tile
+__host__ __device__ constexpr size_t gemm_f32_slot_lds_bytes(int T, bool a_kc, bool b_kc) {
+  return sizeof(float) * 2 * BK * ((a_kc ? T + 2 : T) + (b_kc ? T + 2 : T));
 }
 
-template <bool A_KC, bool B_KC, int ABL = 0>
+// T: block tile edge, 256 (above) or 128. With 128 a wave owns 2x2 MFMA tiles, a k-pair is four
+// MFMAs, and the slot behind each of them takes a fragment read AND a load or an LDS write (two
+// workgroups share a CU, so the other wave's MFMAs cover what one slot cannot).
+template <int T, bool A_KC, bool B_KC, int ABL = 0>
 __device__ __forceinline__ void gemm_f32_big_block(const GemmF32Args& p, const int bid) {
+  static_assert(T == 128 || T == 256, "tile edge");
   const float* __restrict__ A = p.A;
   const float* __restrict__ B = p.B;
   float* __restrict__ C = p.C;
   const int M = p.M, N = p.N, K = p.K;
   const long lda = p.lda, ldb = p.ldb, ldc = p.ldc;
-  using LA = Loader<BIG_T, A_KC>;
-  using LB = Loader<BIG_T, B_KC>;
+  using LA = Loader<T, A_KC>;
+  using LB = Loader<T, B_KC>;
   constexpr int PT = LA::PER_THREAD;            // registers (of 16 bytes) per thread and K-tile
-  static_assert(PT == 4 && LB::PER_THREAD == 4, "slot plan assumes four registers per operand");
+  static_assert(PT == T / 64 && LB::PER_THREAD == PT, "registers per operand");
+  constexpr int WT = T / 2;                     // wave tile edge
+  constexpr int F = WT / 32;                    // MFMA tiles per wave and dimension
+  constexpr int MF = F * F;                     // MFMAs per k-pair
+  constexpr int J = 2 * PT;                     // loads / LDS-write jobs dealt out per k-pair
+  constexpr int J0 = MF - J;                    // ... behind MFMAs J0 .. MF-1
+  static_assert(J0 >= 0 && 2 * F <= MF, "slot plan");
   constexpr int A_BUF = BK * LA::LD, B_BUF = BK * LB::LD;    // floats per buffer
   float* const As = gemm_f32_dyn_lds;                        // As[buf][k][m]
   float* const Bs = gemm_f32_dyn_lds + 2 * A_BUF;            // Bs[buf][k][n]
@@ -480,16 +491,16 @@ __device__ __forceinline__ void gemm_f32_big_block(const GemmF32Args& p, const i
   const int per_group = GROUP * tiles_n;
   const int first_m = (tile / per_group) * GROUP;
   const int gsize = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
-  const int m0 = (first_m + (tile % per_group) % gsize) * BIG_T;
-  const int n0 = ((tile % per_group) / gsize) * BIG_T;
+  const int m0 = (first_m + (tile % per_group) % gsize) * T;
+  const int n0 = ((tile % per_group) / gsize) * T;
   const int nkt = (K + BK - 1) / BK;
   const int lrow = lane & 31, lk = lane >> 5;
 
-  f32x16 acc[4][4];
+  f32x16 acc[F][F];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < F; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < F; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -508,11 +519,11 @@ __device__ __forceinline__ void gemm_f32_big_block(const GemmF32Args& p, const i
   __syncthreads();
 
   // fragment of k-pair kp in buffer `buf`: A[m = 32 i + lrow][k = 2 kp + lk] at a_rd[...]
-  const float* const a_rd = As + lk * LA::LD + wr * 128 + lrow;
-  const float* const b_rd = Bs + lk * LB::LD + wc * 128 + lrow;
-  float a[2][4], b[2][4];
+  const float* const a_rd = As + lk * LA::LD + wr * WT + lrow;
+  const float* const b_rd = Bs + lk * LB::LD + wc * WT + lrow;
+  float a[2][F], b[2][F];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < F; ++i) {
     a[0][i] = a_rd[32 * i];
     b[0][i] = b_rd[32 * i];
   }
@@ -535,7 +546,7 @@ __device__ __forceinline__ void gemm_f32_big_block(const GemmF32Args& p, const i
       const __amdgpu_buffer_rsrc_t rsrc_b =
           __builtin_amdgcn_make_buffer_rsrc((void*)base_b, 0, 0xffffffff, 0x00020000);
       if (!INTERIOR) {
-        // clamped addresses and zeros beyond K, all eight at once (two tiles per product)
+        // clamped addresses and zeros beyond K, all at once (two tiles per product)
         LA::fetch_fast(ra[s], A, lda, m0, k_next, M, K, tid);
         LB::fetch_fast(rb[s], B, ldb, n0, k_next, N, K, tid);
       }
@@ -560,27 +571,27 @@ __device__ __forceinline__ void gemm_f32_big_block(const GemmF32Args& p, const i
         const float* const an = a_rd + nb * A_BUF + 2 * nkp * LA::LD;
         const float* const bn = b_rd + nb * B_BUF + 2 * nkp * LB::LD;
 #pragma unroll
-        for (int n = 0; n < 16; ++n) {
-          acc[n >> 2][n & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][n >> 2], b[c][n & 3],
-                                                                    acc[n >> 2][n & 3], 0, 0, 0);
-          if (n < 4) {
-            a[c ^ 1][n] = an[32 * n];
-          } else if (n < 8) {
-            b[c ^ 1][n - 4] = bn[32 * (n - 4)];
-          } else if (kk == 0) {
+        for (int n = 0; n < MF; ++n) {
+          acc[n / F][n % F] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][n / F], b[c][n % F],
+                                                                   acc[n / F][n % F], 0, 0, 0);
+          if (n < F) a[c ^ 1][n] = an[32 * n];
+          else if (n < 2 * F) b[c ^ 1][n - F] = bn[32 * (n - F)];
+          if (n >= J0 && kk == 0) {
             if (INTERIOR) {
-              const int q = (n - 8) >> 1;
-              if (n & 1)
+              const int q = (n - J0) >> 1;
+              if ((n - J0) & 1)
                 rb[s][q] = __builtin_bit_cast(
                     f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, voff_b[q], 0, 0));
               else
                 ra[s][q] = __builtin_bit_cast(
                     f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff_a[q], 0, 0));
             }
-          } else if (kk <= PT) {
-            // register kk-1 of tile kt+1's sets into the other buffer: a K-contiguous operand
-            // is transposed on the way (four one-word writes), the other goes as it is
-            const int q = kk - 1, w = n - 8;
+          } else if (n >= J0 && kk <= 4) {
+            // tile kt+1's register sets into the other buffer, 8 PT jobs over k-pairs 1..4:
+            // job = (register q, operand, word w). A K-contiguous operand is transposed on the
+            // way (four one-word writes per register), the other goes as it is (one write)
+            const int job = (kk - 1) * J + (n - J0);
+            const int q = job >> 3, w = job & 7;
             float* const ad = As + (s ^ 1) * A_BUF;
             float* const bd = Bs + (s ^ 1) * B_BUF;
             const int idx = tid + q * NTHREADS;
@@ -610,15 +621,15 @@ __device__ __forceinline__ void gemm_f32_big_block(const GemmF32Args& p, const i
 
   // C/D fragment: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < F; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int col = n0 + wc * 128 + 32 * j + lrow;
+    for (int j = 0; j < F; ++j) {
+      const int col = n0 + wc * WT + 32 * j + lrow;
       if (col >= N) continue;
       const float bv = p.bias ? p.bias[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wr * 128 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        const int row = m0 + wr * WT + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk;
         if (row >= M) continue;
         C[(long)row * ldc + col] = dtf_apply_act(acc[i][j][r] + bv, p.act);
       }

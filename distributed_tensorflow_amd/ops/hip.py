@@ -190,7 +190,11 @@ def gemm_f32(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: b
              out: Optional[torch.Tensor] = None, splits: Optional[int] = None,
              tile: int = 0, plan_mnk: Optional[Sequence[int]] = None) -> torch.Tensor:
     """``act(op(a) @ op(b) + bias)`` on the fp32 MFMA kernels. ``a`` is [M,K] ([K,M] when
-    ``trans_a``), ``b`` is [K,N] ([N,K] when ``trans_b``). ``plan_mnk``: choose tile and K split
+    ``trans_a``), ``b`` is [K,N] ([N,K] when ``trans_b``). ``tile``: 0 = chosen from the shape;
+    16 (small-product kernel), 64, 128 or 256 force a block tile (128 and 256 run the
+    slot-scheduled kernel when the operands are 16-byte aligned with contiguous dimensions that
+    are multiples of 4, the general kernel otherwise); 129 = 128x128 tiles on the general kernel
+    whatever the operands, for measurements. ``plan_mnk``: choose tile and K split
     as for a product of THAT shape (with the same K): a row or column block of a larger product
     then comes out bit-identical to the same block of the whole result."""
     if getattr(a, "dim", lambda: 0)() != 2 or getattr(b, "dim", lambda: 0)() != 2:

@@ -16,7 +16,7 @@ if __name__ == "__main__":
         us = timeit(lambda: torch.matmul(a, b, out=out), 10)
         print(json.dumps({"n": n, "kernel": "torch", "us": round(us, 1),
                           "tflops": round(2.0 * n ** 3 / us / 1e6, 1)}), flush=True)
-        for tile in (64, 128, 256):
+        for tile in (0, 64, 129, 128, 256):
             us = timeit(lambda: hip.gemm_f32(a, b, out=out, splits=1, tile=tile), 10)
             err = float((out - want).abs().max())
             print(json.dumps({"n": n, "tile": tile, "us": round(us, 1),

@@ -596,8 +596,10 @@ def test_gemm_fp8_writes_only_its_output(hip, m, n, k):
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
 @pytest.mark.parametrize("m,n,k,splits,tile", [(300, 200, 2048, 2, 64), (300, 200, 2048, 1, 64),
                                                (520, 388, 1000, 1, 128), (260, 132, 1536, 3, 128),
+                                               (520, 388, 1000, 1, 129), (260, 132, 1536, 1, 129),
                                                (520, 388, 1000, 1, 256), (260, 516, 200, 1, 256),
-                                               (768, 512, 64, 1, 256), (516, 260, 1002, 1, 256)])
+                                               (768, 512, 64, 1, 256), (516, 260, 1002, 1, 256),
+                                               (260, 516, 200, 1, 128), (516, 260, 1002, 1, 128)])
 def test_gemm_f32_interior_tiles_exact(hip, m, n, k, splits, tile, ta, tb):
     """Long K ranges run the buffer-load loop for interior K-tiles (inside each split, too) and
     the clamped loop for the tail: integer data must come out exact in every layout, with M and
@@ -613,19 +615,21 @@ def test_gemm_f32_interior_tiles_exact(hip, m, n, k, splits, tile, ta, tb):
 
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
 @pytest.mark.parametrize("m,n,k", [(520, 772, 2000), (256, 256, 64), (1028, 260, 1160)])
-def test_gemm_f32_large_tile_matches_128_tile_bitwise(hip, m, n, k, ta, tb):
-    """The 256x256-tile kernel sums k in the same order into one accumulator per output as the
-    128x128 one: on random data the two agree bit for bit (so a product that changes tile with
-    its size or its shard does not change its result), bias and activation included, and
+@pytest.mark.parametrize("tile", [128, 256])
+def test_gemm_f32_slot_kernel_matches_general_kernel_bitwise(hip, m, n, k, ta, tb, tile):
+    """The slot-dealt kernel (128x128 or 256x256 tiles, aligned operands) sums k in the same
+    order into one accumulator per output as the general 128x128 kernel (tile code 129): on
+    random data they agree bit for bit -- a product that changes kernel with its size, its
+    alignment or its shard does not change its result --, bias and activation included, and
     nothing outside the output is written."""
     g = torch.Generator().manual_seed(m * 7 + k)
     a = torch.randn((k, m) if ta else (m, k), generator=g).cuda()
     b = torch.randn((n, k) if tb else (k, n), generator=g).cuda()
     bias = torch.randn(n, generator=g).cuda()
-    want = hip.gemm_f32(a, b, ta, tb, bias=bias, activation=hip.ACT_SIGMOID, splits=1, tile=128)
+    want = hip.gemm_f32(a, b, ta, tb, bias=bias, activation=hip.ACT_SIGMOID, splits=1, tile=129)
     big = torch.full((m + 6, n), 12345.0, device="cuda")
     out = big[3:3 + m]
-    hip.gemm_f32(a, b, ta, tb, bias=bias, activation=hip.ACT_SIGMOID, out=out, splits=1, tile=256)
+    hip.gemm_f32(a, b, ta, tb, bias=bias, activation=hip.ACT_SIGMOID, out=out, splits=1, tile=tile)
     assert torch.equal(out, want)
     assert bool((big[:3] == 12345.0).all()) and bool((big[3 + m:] == 12345.0).all())
     ref = torch.sigmoid((a.t() if ta else a).double() @ (b.t() if tb else b).double() + bias.double())
@@ -633,14 +637,16 @@ def test_gemm_f32_large_tile_matches_128_tile_bitwise(hip, m, n, k, ta, tb):
 
 
 def test_gemm_f32_tile_plan(hip):
-    """Tile choice: 256x256 for long-K products whose grid fills whole rounds of the 256 CUs,
-    128x128 for other large ones, 64x64 below, the small-product kernel for the MLP's shapes."""
+    """Tile choice: 128x128 where that grid fills the chip evenly (one tile per CU, or rounds of
+    two per CU with a last round at most half full), 64x64 otherwise, the small-product kernel
+    for the MLP's shapes."""
     L = hip.lib()
-    assert L.dtf_gemm_f32_tile(8192, 8192, 8192) == 256
-    assert L.dtf_gemm_f32_tile(4096, 4096, 4096) == 256
-    assert L.dtf_gemm_f32_tile(16384, 16384, 4096) == 256
-    assert L.dtf_gemm_f32_tile(6144, 6144, 6144) == 128     # 576 tiles: 2.25 rounds
-    assert L.dtf_gemm_f32_tile(8192, 8192, 1000) == 128     # short K
+    assert L.dtf_gemm_f32_tile(8192, 8192, 8192) == 128     # 4096 tiles: 8 rounds of 512
+    assert L.dtf_gemm_f32_tile(4096, 4096, 4096) == 128     # 1024 tiles: 2 rounds
+    assert L.dtf_gemm_f32_tile(6144, 6144, 6144) == 128     # 2304 tiles: 4.5 rounds
+    assert L.dtf_gemm_f32_tile(2048, 2048, 2048) == 128     # 256 tiles: one per CU
+    assert L.dtf_gemm_f32_tile(3072, 3072, 3072) == 64      # 576 tiles: 1.125 rounds
+    assert L.dtf_gemm_f32_tile(5120, 5120, 5120) == 64      # 1600 tiles: 3.125 rounds
     assert L.dtf_gemm_f32_tile(1000, 1000, 1000) == 64
     assert L.dtf_gemm_f32_tile(100, 100, 784) == 16
 

@@ -712,8 +712,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
 //    still tracks.
 constexpr int W4_THREADS = 256;
 
-// DBG (timing experiments, -DDTF_GEMM_EXPERIMENTS only; results are wrong when set):
-// 1 = issue no LDS-DMA in the K-loop, 2 = always stage K-tile 0 (every load an L2 hit)
+// DBG (timing experiments, -DDTF_GEMM_EXPERIMENTS only; results are wrong when set), bits:
+// 1 = issue no LDS-DMA in the K-loop, 2 = always stage K-tile 0 (every load an L2 hit),
+// 4 = no barrier in the K-loop, 8 = no wait in front of it either
 template <bool OUT_F32, int DBG = 0>
 __global__ __launch_bounds__(W4_THREADS) void gemm_bf16_nt_w4_kernel(
     const char* __restrict__ A, const char* __restrict__ Bt, void* __restrict__ C, int M, int N,
@@ -769,7 +770,7 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_bf16_nt_w4_kernel(
   {                                                                                              \
     const char* rda_ = smem + (RD_BUF) + a_base + (RD_LANE_OFF);                                 \
     const char* rdb_ = smem + (RD_BUF) + b_base + (RD_LANE_OFF);                                 \
-    const long koff_ = DBG == 2 ? 0 : (long)((KT_DMA) < nkt ? (KT_DMA) : nkt - 1) * 128;         \
+    const long koff_ = (DBG & 2) ? 0 : (long)((KT_DMA) < nkt ? (KT_DMA) : nkt - 1) * 128;         \
     char* wr_ = smem + (WR_BUF) + wave * 8192;                                                   \
     _Pragma("unroll") for (int n_ = 0; n_ < 64; ++n_) {                                          \
       asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"                                      \
@@ -780,7 +781,7 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_bf16_nt_w4_kernel(
           fb[NXT][n_ >> 1] = *reinterpret_cast<const i32x4*>(rdb_ + (n_ >> 1) * 2048);           \
         else                                                                                     \
           fa[NXT][n_ >> 1] = *reinterpret_cast<const i32x4*>(rda_ + (n_ >> 1) * 2048);           \
-      } else if ((DMA) && DBG != 1 && n_ < 48 && ((n_ - 16) & 1) == 0) {                         \
+      } else if ((DMA) && !(DBG & 1) && n_ < 48 && ((n_ - 16) & 1) == 0) {                         \
         const int d_ = (n_ - 16) >> 1, j_ = d_ >> 1;                                             \
         if (d_ & 1)                                                                              \
           __builtin_amdgcn_global_load_lds((global_void*)(src_b[j_] + koff_),                    \
@@ -821,9 +822,9 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_bf16_nt_w4_kernel(
     // own reads of buffer t done (lgkmcnt 0), own DMA of tile t+1 landed (vmcnt 0); as the
     // builtin (imm 0x0070 = vmcnt 0, expcnt 7, lgkmcnt 0) so the compiler's wait-count
     // bookkeeping sees it and adds no second wait in front of the MFMAs
-    __builtin_amdgcn_s_waitcnt(0x0070);
+    if (!(DBG & 8)) __builtin_amdgcn_s_waitcnt(0x0070);
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
+    if (!(DBG & 4)) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     // (t, 1): fragments of (t+1, 0) from the other buffer; K-tile t+2 into this tile's buffer
     DTF_W4_STEP(1, 0, nxt_buf, lane_off0, true, t + 2, cur_buf)
@@ -1232,21 +1233,25 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
 #ifdef DTF_GEMM_EXPERIMENTS
       dtf_allow_lds(gemm_bf16_nt_w4_kernel<false, 1>, w4_lds);
       dtf_allow_lds(gemm_bf16_nt_w4_kernel<false, 2>, w4_lds);
+      dtf_allow_lds(gemm_bf16_nt_w4_kernel<false, 4>, w4_lds);
+      dtf_allow_lds(gemm_bf16_nt_w4_kernel<false, 6>, w4_lds);
+      dtf_allow_lds(gemm_bf16_nt_w4_kernel<false, 14>, w4_lds);
+      dtf_allow_lds(gemm_bf16_nt_w4_kernel<false, 5>, w4_lds);
+      dtf_allow_lds(gemm_bf16_nt_w4_kernel<false, 13>, w4_lds);
 #endif
     }); }
 #ifdef DTF_GEMM_EXPERIMENTS
-    if ((variant >> 4) == 1 || (variant >> 4) == 2) {
-      if ((variant >> 4) == 1)
-        hipLaunchKernelGGL((gemm_bf16_nt_w4_kernel<false, 1>), grid, dim3(W4_THREADS), w4_lds,
-                           stream, (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc,
-                           tiles_m, tiles_n, alpha, beta);
-      else
-        hipLaunchKernelGGL((gemm_bf16_nt_w4_kernel<false, 2>), grid, dim3(W4_THREADS), w4_lds,
-                           stream, (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc,
-                           tiles_m, tiles_n, alpha, beta);
-      DTF_LAUNCH_CHECK();
-      return DTF_OK;
-    }
+#define DTF_W4_DBG(D)                                                                          \
+  if ((variant >> 4) == D) {                                                                   \
+    hipLaunchKernelGGL((gemm_bf16_nt_w4_kernel<false, D>), grid, dim3(W4_THREADS), w4_lds,     \
+                       stream, (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc,     \
+                       tiles_m, tiles_n, alpha, beta);                                         \
+    DTF_LAUNCH_CHECK();                                                                        \
+    return DTF_OK;                                                                             \
+  }
+    DTF_W4_DBG(1) DTF_W4_DBG(2) DTF_W4_DBG(4) DTF_W4_DBG(6) DTF_W4_DBG(14) DTF_W4_DBG(5)
+    DTF_W4_DBG(13)
+#undef DTF_W4_DBG
 #endif
     if (out_f32)
       hipLaunchKernelGGL(gemm_bf16_nt_w4_kernel<true>, grid, dim3(W4_THREADS), w4_lds, stream,

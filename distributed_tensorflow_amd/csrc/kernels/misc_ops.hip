@@ -30,6 +30,21 @@ __global__ __launch_bounds__(BLOCK) void copy_2d_kernel(const unsigned char* __r
   }
 }
 
+// dst[r, 0:dst_units) = src[r, 0:src_units) followed by zeros, in units of 16 bytes: rows copied
+// into wider, zero-padded rows (a GEMM operand whose K is not a multiple of the kernel's K-tile)
+__global__ __launch_bounds__(BLOCK) void pad_rows_kernel(const unsigned char* __restrict__ src,
+                                                         unsigned char* __restrict__ dst, long rows,
+                                                         long src_units, long dst_units,
+                                                         long src_pitch, long dst_pitch) {
+  const long n = rows * dst_units;
+  for (long i = blockIdx.x * (long)BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * BLOCK) {
+    const long r = i / dst_units, u = i - r * dst_units;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (u < src_units) v = *reinterpret_cast<const u32x4*>(src + r * src_pitch + u * 16);
+    *reinterpret_cast<u32x4*>(dst + r * dst_pitch + u * 16) = v;
+  }
+}
+
 // var[i] += sign * delta[i % dn]
 __global__ __launch_bounds__(BLOCK) void assign_add_kernel(float* __restrict__ var,
                                                            const float* __restrict__ delta, long n,
@@ -258,6 +273,24 @@ int cast_dispatch_dst(const void* src, void* dst, int dst_kind, long n, hipStrea
 bool aligned(const void* p, unsigned a) { return ((uintptr_t)p & (a - 1)) == 0; }
 
 }  // namespace
+
+// dst[r, 0:dst_row_bytes) = src[r, 0:src_row_bytes) then zeros; everything a multiple of 16 bytes
+// and 16-byte aligned (DTF_ERR_UNSUPPORTED otherwise).
+DTF_API int dtf_pad_rows(const void* src, void* dst, long rows, long src_row_bytes,
+                         long dst_row_bytes, long src_pitch, long dst_pitch, hipStream_t stream) {
+  if (rows <= 0 || dst_row_bytes <= 0) return DTF_OK;
+  if (!src || !dst || src_row_bytes < 0 || dst_row_bytes < src_row_bytes ||
+      src_pitch < src_row_bytes || dst_pitch < dst_row_bytes)
+    return DTF_ERR_BAD_ARG;
+  if (!aligned(src, 16) || !aligned(dst, 16) ||
+      (src_row_bytes | dst_row_bytes | src_pitch | dst_pitch) % 16 != 0)
+    return DTF_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(pad_rows_kernel, dim3(grid_for(rows * (dst_row_bytes / 16), 1)), dim3(BLOCK),
+                     0, stream, (const unsigned char*)src, (unsigned char*)dst, rows,
+                     src_row_bytes / 16, dst_row_bytes / 16, src_pitch, dst_pitch);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
 
 // Copy a [rows, row_bytes] block between buffers with row pitches src_pitch / dst_pitch (bytes).
 DTF_API int dtf_copy_2d(const void* src, void* dst, long rows, long row_bytes, long src_pitch,

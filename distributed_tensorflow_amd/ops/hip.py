@@ -114,6 +114,7 @@ def _declare(L: ctypes.CDLL) -> None:
         "dtf_mlp_step_train": [P, P],
         "dtf_philox_fill_2d": [P, LG, LG, LG, U, U, LG, LG, LG, F, F, I, I, P],
         "dtf_copy_2d": [P, P, LG, LG, LG, LG, P],
+        "dtf_pad_rows": [P, P, LG, LG, LG, LG, LG, P],
         "dtf_assign_add_f32": [P, P, LG, LG, F, P],
         "dtf_sign_f32": [P, P, LG, P],
         "dtf_broadcast_mid_f32": [P, P, LG, LG, LG, F, P],
@@ -243,13 +244,26 @@ def gemm_f32(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: b
     return out
 
 
+def _bf16_fast_operands_ok(a: torch.Tensor, bt: torch.Tensor, out: torch.Tensor,
+                           out_f32: int) -> bool:
+    """What dtf_gemm_bf16_nt asks of its operands apart from K % 64 == 0 (row pitches, alignment,
+    32-bit tile offsets): checked here where a call must not fail after out has been written."""
+    lda, ldb, ldc = a.stride(0), bt.stride(0), out.stride(0)
+    if lda % 8 or ldb % 8 or ldc % 4:
+        return False
+    if a.data_ptr() % 16 or bt.data_ptr() % 16 or out.data_ptr() % (16 if out_f32 else 8):
+        return False
+    return lda * 2 * 256 < (1 << 32) and ldb * 2 * 256 < (1 << 32)
+
+
 def gemm_bf16_nt(a: torch.Tensor, bt: torch.Tensor, out_dtype: torch.dtype = torch.bfloat16,
                  alpha: float = 1.0, out: Optional[torch.Tensor] = None,
                  variant: int = 0, beta: float = 0.0,
                  splits: Optional[int] = None) -> torch.Tensor:
     """``alpha * a @ bt.T (+ beta * out)`` with a [M,K], bt [N,K] bf16 (both K-contiguous); fp32
     accumulate; result bf16 or fp32. Uses the 256x256x64 LDS-DMA kernel when the shape
-    qualifies and the predicated generic kernel otherwise. ``splits``: K splits for grids with
+    qualifies (operands whose K is a multiple of 8 but not of 64 are first copied into
+    zero-padded rows) and the predicated generic kernel otherwise. ``splits``: K splits for grids with
     few output tiles (default: the library's plan; 1 = never split)."""
     a = _req(a, torch.bfloat16, "gemm_bf16_nt a")
     bt = _req(bt, torch.bfloat16, "gemm_bf16_nt bt")
@@ -283,6 +297,19 @@ def gemm_bf16_nt(a: torch.Tensor, bt: torch.Tensor, out_dtype: torch.dtype = tor
             return out
         if code != -2:
             _check(code, "gemm_bf16_nt (split-K)")
+    if k % 64 and k % 8 == 0 and k > 64 and _bf16_fast_operands_ok(a, bt, out, out_f32):
+        # K is not a multiple of the fast kernel's K-tile (the reference's 1000 and 784 are not):
+        # both operands are copied into rows padded with zeros up to the next multiple of 64 --
+        # (M + N) K elements moved once, against M N K products -- and the fast kernel runs on
+        # the copies. (Running the K % 64 tail on the predicated kernel and accumulating the rest
+        # on top costs two more passes over C and measured 3x slower at 8192 x 8192 x 1000.)
+        kp = (k + 63) // 64 * 64
+        ap = torch.empty((m, kp), dtype=torch.bfloat16, device=a.device)
+        bp = torch.empty((n, kp), dtype=torch.bfloat16, device=a.device)
+        for src, dst, rows in ((a, ap, m), (bt, bp, n)):
+            _check(lib().dtf_pad_rows(src.data_ptr(), dst.data_ptr(), rows, 2 * k, 2 * kp,
+                                      2 * src.stride(0), 2 * kp, _stream()), "gemm_bf16_nt (pad K)")
+        return gemm_bf16_nt(ap, bp, out_dtype, alpha=alpha, out=out, variant=variant, beta=beta)
     code = lib().dtf_gemm_bf16_nt(a.data_ptr(), bt.data_ptr(), out.data_ptr(), m, n, k,
                                   a.stride(0), bt.stride(0), out.stride(0), float(alpha),
                                   float(beta), out_f32, int(variant), _stream())

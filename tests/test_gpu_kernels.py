@@ -652,6 +652,29 @@ def test_gemm_f32_tile_plan(hip):
 
 
 @pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("m,n,k", [(1000, 1000, 1000), (100, 100, 784), (512, 300, 1032)])
+def test_gemm_bf16_k_not_multiple_of_tile(hip, m, n, k, out_dtype):
+    """K = 1000 and 784 (the reference's shapes) are not multiples of the LDS-DMA kernel's
+    K-tile: the operands are copied into zero-padded rows and the product runs on that kernel
+    (split over K where the grid is small). Exact on integer data, alpha/beta applied once, close to fp64 on random
+    data."""
+    g = torch.Generator().manual_seed(k + m)
+    a = torch.randint(-2, 3, (m, k), generator=g).float()
+    bt = torch.randint(-2, 3, (n, k), generator=g).float()
+    c0 = torch.randint(-4, 5, (m, n), generator=g).float()
+    out = c0.to(out_dtype).cuda()
+    hip.gemm_bf16_nt(a.bfloat16().cuda(), bt.bfloat16().cuda(), out_dtype, alpha=0.5, out=out,
+                     beta=2.0)
+    assert torch.equal(out.float().cpu(), (0.5 * (a @ bt.t()) + 2.0 * c0).to(out_dtype).float())
+    ar = torch.randn(m, k, generator=g).bfloat16()
+    br = torch.randn(n, k, generator=g).bfloat16()
+    got = hip.gemm_bf16_nt(ar.cuda(), br.cuda(), out_dtype).float().cpu()
+    ref = ar.double() @ br.double().t()
+    tol = 0.02 * float(ref.abs().max()) if out_dtype == torch.bfloat16 else 1e-3 * float(ref.abs().max())
+    assert float((got.double() - ref).abs().max()) < tol
+
+
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("m,n,k,splits", [(512, 768, 4096, None), (300, 260, 2048, 4),
                                           (1024, 2048, 2048, None), (256, 256, 1024, 2)])
 def test_gemm_bf16_split_k(hip, m, n, k, splits, out_dtype):

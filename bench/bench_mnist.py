@@ -87,7 +87,8 @@ def bench_mnist(device: str, steps: int, warmup: int, hip_graphs: bool, fusion: 
             "session_stats": {k: v for k, v in stats.items() if isinstance(v, (int, float))}}
 
 
-def bench_matmul(device: str, steps: int, warmup: int, n: int, hip_graphs: bool) -> dict:
+def bench_matmul(device: str, steps: int, warmup: int, n: int, hip_graphs: bool,
+                 deferred: bool = False) -> dict:
     g = tf.Graph()
     with g.as_default():
         tf.set_random_seed(1)
@@ -96,7 +97,7 @@ def bench_matmul(device: str, steps: int, warmup: int, n: int, hip_graphs: bool)
         c = tf.matmul(a, b)
         checksum = tf.reduce_mean(c)
         init = tf.global_variables_initializer()
-        cfg = tf.ConfigProto(device=device, hip_graphs=hip_graphs)
+        cfg = tf.ConfigProto(device=device, hip_graphs=hip_graphs, deferred_fetches=deferred)
         with tf.Session(config=cfg) as sess:
             sess.run(init)
             for _ in range(warmup):
@@ -105,6 +106,7 @@ def bench_matmul(device: str, steps: int, warmup: int, n: int, hip_graphs: bool)
             t0 = time.perf_counter()
             for _ in range(steps):
                 v = sess.run(checksum)
+            v = float(v)                     # (deferred fetches: waits for the last step)
             _sync(device)
             ms = (time.perf_counter() - t0) * 1e3 / steps
             # device-side op only (no fetch): what the GEMM itself costs inside the step
@@ -114,7 +116,7 @@ def bench_matmul(device: str, steps: int, warmup: int, n: int, hip_graphs: bool)
             _sync(device)
             ms_nofetch = (time.perf_counter() - t0) * 1e3 / steps
     return {"bench": "matmul_%d_f32_step" % n, "device": device, "hip_graphs": hip_graphs,
-            "ms_per_step": round(ms, 4), "gflops": round(2.0 * n ** 3 / ms / 1e6, 1),
+            "deferred_fetches": deferred, "ms_per_step": round(ms, 4), "gflops": round(2.0 * n ** 3 / ms / 1e6, 1),
             "ms_per_step_no_fetch": round(ms_nofetch, 4),
             "gflops_no_fetch": round(2.0 * n ** 3 / ms_nofetch / 1e6, 1), "checksum": float(v)}
 
@@ -145,8 +147,10 @@ def main() -> None:
                                     device_data=dev_data, step_fusion=step, deferred=deferred))
             print(json.dumps(rows[-1]), flush=True)
     if "matmul" in args.which:
-        for graphs in ((True, False) if args.device.startswith("cuda") else (False,)):
-            rows.append(bench_matmul(args.device, args.steps, args.warmup, 1000, graphs))
+        cases = ((True, True), (True, False), (False, False)) if args.device.startswith("cuda") \
+            else ((False, False),)
+        for graphs, deferred in cases:
+            rows.append(bench_matmul(args.device, args.steps, args.warmup, 1000, graphs, deferred))
             print(json.dumps(rows[-1]), flush=True)
     if args.out:
         os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)

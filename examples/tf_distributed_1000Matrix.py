@@ -55,6 +55,9 @@ def define_flags():
     tf.app.flags.DEFINE_string("logs_path", logs_path, "event-file directory")
     tf.app.flags.DEFINE_boolean("shutdown_ps", False, "report completion so the ps exits once all workers are done")
     tf.app.flags.DEFINE_string("device", "", "torch device of this task (default: auto)")
+    tf.app.flags.DEFINE_boolean("deferred_fetches", False, "GPU tasks: sess.run returns as soon as "
+                                "the step is launched; the checksum is waited for when it is "
+                                "printed")
     tf.app.flags.DEFINE_boolean("capture_collectives", False, "rccl: record the step's RCCL calls "
                                 "into the HIP graph together with its kernels")
     return tf.app.flags.FLAGS
@@ -74,7 +77,7 @@ def main(argv=None):
                                         "worker": ["localhost:%d" % (2223 + i) for i in range(7)]})
     config = tf.ConfigProto(device=FLAGS.device or None, strategy=FLAGS.strategy,
                             capture_collectives=FLAGS.capture_collectives,
-                            matmul_sharding=FLAGS.shard)
+                            matmul_sharding=FLAGS.shard, deferred_fetches=FLAGS.deferred_fetches)
     server = tf.train.Server(cluster, job_name=FLAGS.job_name, task_index=FLAGS.task_index,
                              protocol=FLAGS.protocol, config=config)
     if FLAGS.job_name == "ps":

@@ -58,6 +58,21 @@ def test_matmul_example_on_gpu(tmp_path):
     assert "[worker:0] done" in out
 
 
+def test_matmul_example_with_deferred_fetches_on_gpu(tmp_path):
+    """``--deferred_fetches``: ``sess.run([checksum, summary_op])`` returns once the step is
+    launched and the checksum is waited for when the reporter prints it; the printed value is the
+    one a blocking run prints."""
+    outs = []
+    for extra in ([], ["--deferred_fetches"]):
+        rc, out = _launch(["--num_workers", "1", "--protocol", "rccl", "--timeout", "200",
+                           os.path.join(EX, "tf_distributed_1000Matrix.py"), "--",
+                           "--max_steps", "301", "--logs_path", str(tmp_path / "logs")] + extra)
+        assert rc == 0, out
+        assert "[worker:0] done" in out
+        outs.append(re.findall(r"Cost: (-?\d+\.\d+)", out))
+    assert outs[0] and outs[0] == outs[1]
+
+
 def test_linear_regression_example_on_gpu():
     rc, out = _launch(["--num_workers", "1", "--protocol", "rccl", "--strategy",
                        "reduce_scatter_sync", "--timeout", "200",

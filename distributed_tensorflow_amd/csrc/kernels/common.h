@@ -9,6 +9,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #define DTF_API extern "C" __attribute__((visibility("default")))
 
 // Launchers return 0 on success or a negative code for a rejected argument; a HIP launch
@@ -103,4 +105,29 @@ __device__ __forceinline__ int dtf_xcd_remap(int orig, int nwg) {
   int q = nwg / nxcd, r = nwg % nxcd;
   int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + orig / nxcd;
+}
+
+// ---- host side: things a launcher sets up once per device ---------------------------------
+// (per device: a process may drive several GPUs, and both the CU count and a kernel's dynamic-LDS
+// opt-in belong to the device that is current at the launch)
+static inline int dtf_current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  return dev;
+}
+
+// Runs BODY once per device (the first launcher call made while that device is current); other
+// threads arriving meanwhile wait until the attributes are in place.
+struct DtfPerDeviceOnce {
+  std::mutex mu;
+  unsigned long long done = 0;
+};
+template <typename F>
+static inline void dtf_once_per_device(DtfPerDeviceOnce& once, F&& body) {
+  const unsigned long long bit = 1ull << dtf_current_device();
+  std::lock_guard<std::mutex> lk(once.mu);
+  if (!(once.done & bit)) {
+    body();
+    once.done |= bit;
+  }
 }

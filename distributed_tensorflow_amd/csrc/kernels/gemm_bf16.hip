@@ -1158,14 +1158,6 @@ __global__ __launch_bounds__(T128_THREADS) void gemm_bf16_nt_t128_kernel(
 
 // workgroups of the persistent ping-pong kernel: one per CU (128 KiB of LDS each), fewer when
 // there are fewer tiles
-// (per device: a process may drive several GPUs, and both the CU count and a kernel's dynamic-LDS
-// opt-in belong to the device that is current at the launch)
-static int dtf_current_device() {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  return dev;
-}
-
 static int dtf_pp_grid(int ntiles) {
   static std::atomic<int> cus_of[64];
   const int dev = dtf_current_device();
@@ -1183,22 +1175,6 @@ static int dtf_pp_grid(int ntiles) {
 template <typename KernelT>
 static void dtf_allow_lds(KernelT kernel, size_t lds) {
   hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-}
-
-// Runs BODY once per device (the first launcher call made while that device is current); other
-// threads arriving meanwhile wait until the attributes are in place.
-struct DtfPerDeviceOnce {
-  std::mutex mu;
-  unsigned long long done = 0;
-};
-template <typename F>
-static void dtf_once_per_device(DtfPerDeviceOnce& once, F&& body) {
-  const unsigned long long bit = 1ull << dtf_current_device();
-  std::lock_guard<std::mutex> lk(once.mu);
-  if (!(once.done & bit)) {
-    body();
-    once.done |= bit;
-  }
 }
 
 DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int N, int K, long lda,

@@ -110,13 +110,12 @@ void launch_big_kernel(dim3 grid, hipStream_t stream, const GemmF32Args& args, i
   // the buffers need is what caps it
   size_t lds = gemm_f32_slot_lds_bytes(T, AKC, BKC);
   if (occ > 0 && (size_t)(160 * 1024 / (occ + 1) + 1024) > lds) lds = 160 * 1024 / (occ + 1) + 1024;
-  static bool allowed = false;
-  if (!allowed) {
+  static DtfPerDeviceOnce once;
+  dtf_once_per_device(once, [&] {
     (void)hipFuncSetAttribute(
         reinterpret_cast<const void*>(&gemm_f32_big_kernel<T, AKC, BKC, ABL>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    allowed = true;
-  }
+  });
   hipLaunchKernelGGL((gemm_f32_big_kernel<T, AKC, BKC, ABL>), grid, dim3(NTHREADS), lds, stream,
                      args);
 }

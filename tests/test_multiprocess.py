@@ -94,6 +94,21 @@ def test_mnist_example_two_collective_ranks(strategy, tmp_path):
     assert len(acc) == 2 and acc[0] == acc[1]       # replicas stay identical
 
 
+def test_mnist_example_four_collective_ranks_sharded_sgd(tmp_path):
+    """Four ranks under reduce_scatter_sync: the 79 510-parameter arena does not divide by four
+    (the last shard is padded), every rank owns and updates a quarter and all-gathers the rest;
+    the replicas must end identical."""
+    rc, out = _run_launcher(["--num_workers", "4", "--protocol", "rccl", "--strategy",
+                             "reduce_scatter_sync", "--timeout", "200",
+                             os.path.join(EX, "tf_distributed.py"), "--",
+                             "--max_steps", "30", "--device", "cpu",
+                             "--logs_path", str(tmp_path / "logs"),
+                             "--data_dir", str(tmp_path / "nodata")])
+    assert rc == 0, out
+    acc = re.findall(r"Test-Accuracy: (\d+\.\d\d)", out)
+    assert len(acc) == 4 and len(set(acc)) == 1
+
+
 @pytest.mark.parametrize("strategy,bucket_bytes", [("allreduce_sync", 0), ("allreduce_sync", 8),
                                                    ("reduce_scatter_sync", 0)])
 def test_gloo_two_process_comm_matmul_and_training(strategy, bucket_bytes, tmp_path):
@@ -230,3 +245,18 @@ def test_matmul_example_sharded_over_two_collective_ranks(shard, tmp_path):
             assert np.abs(c - ref).max() < 1e-3 * np.abs(ref).max()
         else:
             assert np.array_equal(c, ref)
+
+
+@pytest.mark.parametrize("shard,size", [("m", 1000), ("2d", 1000), ("m", 998)])
+def test_matmul_example_sharded_over_four_collective_ranks(shard, size, tmp_path):
+    """The same with 4 ranks: row blocks of 250 (or 250/250/250/248: 998 rows do not divide by
+    four), and a 2 x 2 process grid for the 2-D sharding; C must equal the single-rank product
+    bit for bit on every rank."""
+    import numpy as np
+    out1, dump1 = _run_matmul_example(1, "none", tmp_path, "w1", size=size)
+    out4, dump4 = _run_matmul_example(4, shard, tmp_path, "w4" + shard, size=size)
+    assert out4.count("done") == 4
+    ref = np.load(dump1 + "_0.npy")
+    assert ref.shape == (size, size)
+    for r in range(4):
+        assert np.array_equal(np.load(dump4 + "_%d.npy" % r), ref)

@@ -9,7 +9,7 @@
 // Structure: 256 threads = 4 waves in a 2x2 grid over a BMxBN block tile (128x128 for large
 // problems, 64x64 when that is what it takes to put a workgroup on every CU), BK = 16. Large
 // products with aligned operands run the same tiling with a hand-dealt instruction order
-// (gemm_f32_big_block in gemm_f32_body.h); what follows describes the general kernel.
+// (gemm_f32_slot_block in gemm_f32_body.h); what follows describes the general kernel.
 // Both operand tiles are staged K-major in LDS (As[k][m], Bs[k][n]) so the MFMA fragment read
 // -- lane l takes A[m = l&31][k = l>>5], B[k = l>>5][n = l&31] -- is 32 consecutive words per
 // half-wave: conflict-free ds_read_b32. An operand that is K-contiguous in memory is
@@ -49,8 +49,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmF32Args p) {
 // large products: 128x128 or 256x256 tiles, every instruction dealt into an MFMA slot
 // (gemm_f32_body.h)
 template <int T, bool A_KC, bool B_KC, int ABL = 0>
-__global__ __launch_bounds__(NTHREADS) void gemm_f32_big_kernel(GemmF32Args p) {
-  gemm_f32_big_block<T, A_KC, B_KC, ABL>(p, blockIdx.x);
+__global__ __launch_bounds__(NTHREADS) void gemm_f32_slot_kernel(GemmF32Args p) {
+  gemm_f32_slot_block<T, A_KC, B_KC, ABL>(p, blockIdx.x);
 }
 
 // C = act(op(A) op(B) + bias) for small outputs: one 16x16 tile per workgroup (gemm_f32_body.h)
@@ -102,10 +102,10 @@ void launch_kernel(dim3 grid, dim3 block, hipStream_t stream, const GemmF32Args&
   hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, AKC, BKC, ABL>), grid, block, 0, stream, args);
 }
 
-// T x T tiles dealt out in MFMA slots (gemm_f32_big_block); the staging buffers are dynamic LDS
+// T x T tiles dealt out in MFMA slots (gemm_f32_slot_block); the staging buffers are dynamic LDS
 // (those of the 256x256 tile are just over the 64 KiB a kernel may use without asking)
 template <int T, bool AKC, bool BKC, int ABL>
-void launch_big_kernel(dim3 grid, hipStream_t stream, const GemmF32Args& args, int occ = 0) {
+void launch_slot_kernel(dim3 grid, hipStream_t stream, const GemmF32Args& args, int occ = 0) {
   // occ: workgroups per CU wanted (0 = as many as fit); asking for a larger LDS allocation than
   // the buffers need is what caps it
   size_t lds = gemm_f32_slot_lds_bytes(T, AKC, BKC);
@@ -113,15 +113,15 @@ void launch_big_kernel(dim3 grid, hipStream_t stream, const GemmF32Args& args, i
   static DtfPerDeviceOnce once;
   dtf_once_per_device(once, [&] {
     (void)hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&gemm_f32_big_kernel<T, AKC, BKC, ABL>),
+        reinterpret_cast<const void*>(&gemm_f32_slot_kernel<T, AKC, BKC, ABL>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
-  hipLaunchKernelGGL((gemm_f32_big_kernel<T, AKC, BKC, ABL>), grid, dim3(NTHREADS), lds, stream,
+  hipLaunchKernelGGL((gemm_f32_slot_kernel<T, AKC, BKC, ABL>), grid, dim3(NTHREADS), lds, stream,
                      args);
 }
 
 template <int T>
-int launch_big(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
+int launch_slot(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
                long lda, long ldb, long ldc, int trans_a, int trans_b, int act,
                float* partial, hipStream_t stream, int occ = 0) {
   const int tiles_m = (M + T - 1) / T, tiles_n = (N + T - 1) / T;
@@ -132,15 +132,15 @@ int launch_big(const float* A, const float* B, float* C, const float* bias, int 
 #ifdef DTF_GEMM_EXPERIMENTS
   if (const char* e = getenv("DTF_F32_ABL")) {
     if (atoi(e) == 16 && !trans_a && !trans_b) {
-      launch_big_kernel<T, true, false, 16>(grid, stream, args);
+      launch_slot_kernel<T, true, false, 16>(grid, stream, args);
       return DTF_OK;
     }
   }
 #endif
-  if (!trans_a && !trans_b) launch_big_kernel<T, true, false, 0>(grid, stream, args, occ);
-  else if (!trans_a && trans_b) launch_big_kernel<T, true, true, 0>(grid, stream, args, occ);
-  else if (trans_a && !trans_b) launch_big_kernel<T, false, false, 0>(grid, stream, args, occ);
-  else launch_big_kernel<T, false, true, 0>(grid, stream, args, occ);
+  if (!trans_a && !trans_b) launch_slot_kernel<T, true, false, 0>(grid, stream, args, occ);
+  else if (!trans_a && trans_b) launch_slot_kernel<T, true, true, 0>(grid, stream, args, occ);
+  else if (trans_a && !trans_b) launch_slot_kernel<T, false, false, 0>(grid, stream, args, occ);
+  else launch_slot_kernel<T, false, true, 0>(grid, stream, args, occ);
   DTF_LAUNCH_CHECK();
   return DTF_OK;
 }
@@ -190,7 +190,7 @@ int launch(const float* A, const float* B, float* C, const float* bias, int M, i
 
 // Block tile for an M x N x K product, from measurements on MI355X (profiles/
 // gemm_f32_tiles_vs_hipblaslt.jsonl). The 128x128 tile on the slot-dealt kernel
-// (gemm_f32_big_block) keeps the matrix pipe 97-98 % busy (8192^3: 151 TF, 6144^3: 152,
+// (gemm_f32_slot_block) keeps the matrix pipe 97-98 % busy (8192^3: 151 TF, 6144^3: 152,
 // 4096^3: 148; the general kernel: 140, 139, 136) but holds a quarter or a half of a CU per
 // workgroup for a long time, so it is chosen when its grid fills the chip evenly: up to 256 tiles
 // run one per CU (2048^3: 123 TF against 112 with 64x64 tiles); more run two per CU, in rounds
@@ -294,12 +294,12 @@ DTF_API int dtf_gemm_f32(const float* A, const float* B, float* C, const float* 
   // 128 and 256: the slot-dealt kernel where the operands allow its loads (aligned rows,
   // contiguous dimensions multiples of 4), the general one otherwise; 129: the general kernel
   // with 128x128 tiles whatever the operands (for measurements)
-  const bool slot_ok = gemm_f32_big_ok(A, B, M, N, K, lda, ldb, !trans_a, trans_b != 0);
+  const bool slot_ok = gemm_f32_slot_ok(A, B, M, N, K, lda, ldb, !trans_a, trans_b != 0);
   if (tile == 256 && slot_ok)
-    return launch_big<256>(A, B, C, bias, M, N, K, lda, ldb, ldc, trans_a, trans_b, act, partial,
+    return launch_slot<256>(A, B, C, bias, M, N, K, lda, ldb, ldc, trans_a, trans_b, act, partial,
                            stream);
   if ((tile == 128 || tile == 256) && slot_ok && (!partial || splits <= 1))
-    return launch_big<128>(A, B, C, bias, M, N, K, lda, ldb, ldc, trans_a, trans_b, act, partial,
+    return launch_slot<128>(A, B, C, bias, M, N, K, lda, ldb, ldc, trans_a, trans_b, act, partial,
                            stream, gemm_f32_slot_occupancy(M, N));
   if (tile != 64)
     return launch<128, 128>(A, B, C, bias, M, N, K, lda, ldb, ldc, trans_a, trans_b, act, splits,

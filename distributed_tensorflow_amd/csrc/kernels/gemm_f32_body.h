@@ -425,14 +425,15 @@ __device__ __forceinline__ void gemm_f32_block(const GemmF32Args& p, const int b
 }
 
 
-// ---- large products: 256x256 block tile, four waves of 128x128 outputs, one wave per SIMD -----
+// ---- large products: the same tiling with every instruction dealt into an MFMA slot -----------
 // The exact-fp32 MFMA needs so little operand traffic (a 32x32x2 step is 64 cycles on two
 // registers) that a large product is limited by nothing but how often the matrix pipe is left
-// without its next instruction. With 128x128 tiles and two waves per SIMD it idled 11 % of the
-// time: each K-tile's 20 LDS writes, its barrier and the waits in front of them sat between MFMAs
-// that had nothing queued behind them. Here every wave owns 256 accumulators (4x4 MFMA tiles), a
-// K-tile of 16 is 128 MFMAs = 8192 cycles per wave, and everything else is dealt out one
-// instruction per MFMA so that it issues in the shadow of the 64 cycles the MFMA before it runs:
+// without its next instruction. The general kernel above leaves that to the compiler, which packs
+// each group of LDS writes, fragment reads and address arithmetic between two MFMAs; the matrix
+// pipe is one MFMA deep and ran dry behind every such group (11 % of the time at 8192^3). Here
+// whatever is not an MFMA is dealt out by hand, one instruction behind each MFMA, so that it
+// issues in the shadow of the 64 cycles that MFMA runs. For the 256x256 tile (four waves of 4x4
+// MFMA tiles, 256 accumulators each, a K-tile of 16 = 128 MFMAs = 8192 cycles per wave):
 //
 //   k-pair kk of a K-tile (16 MFMAs):  slots 0..7   the 8 fragment reads of k-pair kk+1
 //                                      slots 8..15  kk == 0: the tile's 8 global loads (tile t+2)
@@ -443,13 +444,18 @@ __device__ __forceinline__ void gemm_f32_block(const GemmF32Args& p, const int b
 //
 // A fence after every slot (sched_barrier) keeps the compiler from regrouping what was dealt out.
 // Two register sets and two LDS buffers alternate, so the K loop is unrolled by two tiles and
-// every buffer and register index in it is a constant. Operands must qualify for the branch-free
+// every buffer and register index in it is a constant: the loop has no vector ALU instruction at
+// all. Measured per k-pair: 1030 cycles (ideal 1024), 1160 for the one with the barrier. The
+// 128x128 tile (T = 128 below) is dealt the same way and, with two workgroups per CU covering
+// each other's barriers, is the faster of the two (8192^3: 151 against 150 TFLOP/s) and the one
+// dtf_gemm_f32_tile chooses; 256x256 stays selectable. Operands must qualify for the branch-free
 // loads (16-byte aligned rows, K -- and M or N where they are the contiguous dimension --
 // multiples of 4); edges in M and N are clamped on load and predicated on store, a K tail reads
-// zeros.
+// zeros. Sums run over k in the same order as in the general kernel: the results are bitwise the
+// same.
 // ABL (timing experiments, -DDTF_GEMM_EXPERIMENTS only): bit 4 = per-k-pair cycle sums, as in
 // gemm_f32_block.
-constexpr int BIG_T = 256;
+constexpr int SLOT_MAX_T = 256;
 
 // LDS bytes of the staging buffers of a T x T tile
 __host__ __device__ constexpr size_t gemm_f32_slot_lds_bytes(int T, bool a_kc, bool b_kc) {
@@ -460,7 +466,7 @@ __host__ __device__ constexpr size_t gemm_f32_slot_lds_bytes(int T, bool a_kc, b
 // MFMAs, and the slot behind each of them takes a fragment read AND a load or an LDS write (two
 // workgroups share a CU, so the other wave's MFMAs cover what one slot cannot).
 template <int T, bool A_KC, bool B_KC, int ABL = 0>
-__device__ __forceinline__ void gemm_f32_big_block(const GemmF32Args& p, const int bid) {
+__device__ __forceinline__ void gemm_f32_slot_block(const GemmF32Args& p, const int bid) {
   static_assert(T == 128 || T == 256, "tile edge");
   const float* __restrict__ A = p.A;
   const float* __restrict__ B = p.B;
@@ -636,15 +642,15 @@ __device__ __forceinline__ void gemm_f32_big_block(const GemmF32Args& p, const i
     }
 }
 
-// whether the operands of C[M,N] = op(A) op(B) qualify for gemm_f32_big_block
-__host__ inline bool gemm_f32_big_ok(const void* A, const void* B, int M, int N, int K, long lda,
+// whether the operands of C[M,N] = op(A) op(B) qualify for gemm_f32_slot_block
+__host__ inline bool gemm_f32_slot_ok(const void* A, const void* B, int M, int N, int K, long lda,
                                      long ldb, bool a_kc, bool b_kc) {
   if (((uintptr_t)A | (uintptr_t)B) % 16 != 0 || lda % 4 != 0 || ldb % 4 != 0) return false;
   if (K < 4 * BK || M < 4 || N < 4) return false;
   if (a_kc ? K % 4 != 0 : M % 4 != 0) return false;
   if (b_kc ? K % 4 != 0 : N % 4 != 0) return false;
   // lane offsets within a tile are 32-bit byte offsets
-  if (lda * 4 * (a_kc ? BIG_T : BK) >= (1L << 32) || ldb * 4 * (b_kc ? BIG_T : BK) >= (1L << 32))
+  if (lda * 4 * (a_kc ? SLOT_MAX_T : BK) >= (1L << 32) || ldb * 4 * (b_kc ? SLOT_MAX_T : BK) >= (1L << 32))
     return false;
   return true;
 }

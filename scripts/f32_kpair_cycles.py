@@ -18,7 +18,8 @@ L = hip.lib()
 a = torch.randn(n, n, device="cuda")
 b = torch.randn(n, n, device="cuda")
 out = torch.empty(n, n, device="cuda")
-for tile in (128, 256):
+tiles = [int(t) for t in sys.argv[2].split(',')] if len(sys.argv) > 2 else [128, 256]
+for tile in tiles:
     wgs = ((n + tile - 1) // tile) ** 2
     ws = torch.zeros(wgs * 4 * 16, device="cuda")
     for _ in range(2):

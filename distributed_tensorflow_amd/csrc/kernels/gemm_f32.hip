@@ -123,11 +123,11 @@ void launch_slot_kernel(dim3 grid, hipStream_t stream, const GemmF32Args& args, 
 template <int T>
 int launch_slot(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
                long lda, long ldb, long ldc, int trans_a, int trans_b, int act,
-               float* partial, hipStream_t stream, int occ = 0) {
+               float* partial, int m_load, int n_load, hipStream_t stream, int occ = 0) {
   const int tiles_m = (M + T - 1) / T, tiles_n = (N + T - 1) / T;
   const int ntiles = tiles_m * tiles_n;
   const GemmF32Args args{A, B, C, bias, M, N, K, lda, ldb, ldc, 1, 1, act, tiles_n, ntiles,
-                         1, K, partial, 0.f};
+                         1, K, partial, 0.f, m_load, n_load};
   dim3 grid(ntiles);
 #ifdef DTF_GEMM_EXPERIMENTS
   if (const char* e = getenv("DTF_F32_ABL")) {
@@ -148,14 +148,14 @@ int launch_slot(const float* A, const float* B, float* C, const float* bias, int
 template <int BM, int BN>
 int launch(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
            long lda, long ldb, long ldc, int trans_a, int trans_b, int act, int splits,
-           int kchunk, float* partial, hipStream_t stream) {
+           int kchunk, float* partial, int m_load, int n_load, hipStream_t stream) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const int ntiles = tiles_m * tiles_n;
   const int a_vec = (lda % 4 == 0) && ((uintptr_t)A % 16 == 0);
   const int b_vec = (ldb % 4 == 0) && ((uintptr_t)B % 16 == 0);
   dim3 grid(ntiles * splits), block(NTHREADS);
   const GemmF32Args args{A, B, C, bias, M, N, K, lda, ldb, ldc, a_vec, b_vec, act, tiles_n, ntiles,
-                         splits, kchunk, partial, 0.f};
+                         splits, kchunk, partial, 0.f, m_load, n_load};
   // op(A)(m,k): stored [M,K] -> K-contiguous; stored [K,M] (trans_a) -> M-contiguous
 #define DTF_GEMM_CASE(AKC, BKC) launch_kernel<BM, BN, AKC, BKC, 0>(grid, block, stream, args)
 #ifdef DTF_GEMM_EXPERIMENTS
@@ -256,11 +256,21 @@ DTF_API int dtf_gemm_f32_splits(int M, int N, int K, int* kchunk_out) {
 // partial: split-K workspace of `splits` * M * N floats, `splits` being what
 // dtf_gemm_f32_splits() returned (or the caller's own choice); splits <= 1 or a null workspace
 // runs the product unsplit.
-DTF_API int dtf_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N,
-                         int K, long lda, long ldb, long ldc, int trans_a, int trans_b, int act,
-                         float* partial, int splits, int tile, hipStream_t stream) {
+// m_load / n_load: how far the loads may read along M of a [K,M] A / along N of a [K,N] B: M (N)
+// itself, or M (N) rounded up to a multiple of 4 when every row -- the last one included -- is
+// that long in memory (the caller knows its allocation). With the rounded-up extent an operand
+// whose M (N) is not a multiple of 4 still takes the branch-free 16-byte loads; the columns past
+// M (N) feed only outputs that are never stored. Ignored for K-contiguous operands.
+DTF_API int dtf_gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, int M,
+                            int N, int K, long lda, long ldb, long ldc, int trans_a, int trans_b,
+                            int act, float* partial, int splits, int tile, int m_load, int n_load,
+                            hipStream_t stream) {
   if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return DTF_ERR_BAD_ARG;
   if (lda < (trans_a ? M : K) || ldb < (trans_b ? K : N) || ldc < N) return DTF_ERR_BAD_ARG;
+  if (!trans_a) m_load = M;
+  if (trans_b) n_load = N;
+  if (m_load < M || m_load > M + 3 || (trans_a && m_load > lda)) return DTF_ERR_BAD_ARG;
+  if (n_load < N || n_load > N + 3 || (!trans_b && n_load > ldb)) return DTF_ERR_BAD_ARG;
   if (tile != 16 && tile != 64 && tile != 128 && tile != 129 && tile != 256)
     tile = dtf_gemm_f32_tile(M, N, K);
   if (tile == 16) {
@@ -294,16 +304,24 @@ DTF_API int dtf_gemm_f32(const float* A, const float* B, float* C, const float* 
   // 128 and 256: the slot-dealt kernel where the operands allow its loads (aligned rows,
   // contiguous dimensions multiples of 4), the general one otherwise; 129: the general kernel
   // with 128x128 tiles whatever the operands (for measurements)
-  const bool slot_ok = gemm_f32_slot_ok(A, B, M, N, K, lda, ldb, !trans_a, trans_b != 0);
+  const bool slot_ok =
+      gemm_f32_slot_ok(A, B, m_load, n_load, K, lda, ldb, !trans_a, trans_b != 0);
   if (tile == 256 && slot_ok)
     return launch_slot<256>(A, B, C, bias, M, N, K, lda, ldb, ldc, trans_a, trans_b, act, partial,
-                           stream);
+                            m_load, n_load, stream);
   if ((tile == 128 || tile == 256) && slot_ok && (!partial || splits <= 1))
     return launch_slot<128>(A, B, C, bias, M, N, K, lda, ldb, ldc, trans_a, trans_b, act, partial,
-                           stream, gemm_f32_slot_occupancy(M, N));
+                            m_load, n_load, stream, gemm_f32_slot_occupancy(M, N));
   if (tile != 64)
     return launch<128, 128>(A, B, C, bias, M, N, K, lda, ldb, ldc, trans_a, trans_b, act, splits,
-                            kchunk, partial, stream);
+                            kchunk, partial, m_load, n_load, stream);
   return launch<64, 64>(A, B, C, bias, M, N, K, lda, ldb, ldc, trans_a, trans_b, act, splits,
-                        kchunk, partial, stream);
+                        kchunk, partial, m_load, n_load, stream);
+}
+
+DTF_API int dtf_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N,
+                         int K, long lda, long ldb, long ldc, int trans_a, int trans_b, int act,
+                         float* partial, int splits, int tile, hipStream_t stream) {
+  return dtf_gemm_f32_ex(A, B, C, bias, M, N, K, lda, ldb, ldc, trans_a, trans_b, act, partial,
+                         splits, tile, M, N, stream);
 }

@@ -27,6 +27,10 @@ struct GemmF32Args {
   int a_vec, b_vec, act, tiles_n, ntiles, splits, kchunk;
   float* partial;
   float lr;            // EPI == 1 only
+  // how far the branch-free loads may read along the contiguous dimension of an operand that is
+  // NOT K-contiguous: M (N) rounded up to a multiple of 4 when the rows are that long in memory,
+  // else M (N). Columns past M / N feed only outputs the epilogue drops.
+  int m_load, n_load;
 };
 
 
@@ -236,11 +240,12 @@ __device__ __forceinline__ void gemm_f32_block(const GemmF32Args& p, const int b
   const int nkt = (k_end - k_begin + BK - 1) / BK;
   const int lrow = lane & 31, lk = lane >> 5;
   // aligned operands take the branch-free loads (block-uniform choice, made once)
+  const int Ml = A_KC ? M : p.m_load, Nl = B_KC ? N : p.n_load;    // extents the loads clamp to
   const bool fast = a_vec != 0 && b_vec != 0 && k_end - k_begin >= 4 &&
                     lda * 4 * (A_KC ? BM : BK) < (1L << 32) &&
                     ldb * 4 * (B_KC ? BN : BK) < (1L << 32) &&
-                    (A_KC ? (K & 3) == 0 : ((M & 3) == 0 && M >= 4)) &&
-                    (B_KC ? (K & 3) == 0 : ((N & 3) == 0 && N >= 4));
+                    (A_KC ? (K & 3) == 0 : ((Ml & 3) == 0 && Ml >= 4)) &&
+                    (B_KC ? (K & 3) == 0 : ((Nl & 3) == 0 && Nl >= 4));
 
   // The K loop, instantiated twice (FAST: branch-free loads; otherwise fully predicated ones).
   auto k_loop = [&](auto fast_tag) {
@@ -249,15 +254,15 @@ __device__ __forceinline__ void gemm_f32_block(const GemmF32Args& p, const int b
     f32x4 ra[DEPTH][LA::PER_THREAD], rb[DEPTH][LB::PER_THREAD];
     unsigned voff_a[LA::PER_THREAD], voff_b[LB::PER_THREAD];
     if (FAST) {
-      LA::lane_offsets(voff_a, lda, m0, M, tid);
-      LB::lane_offsets(voff_b, ldb, n0, N, tid);
+      LA::lane_offsets(voff_a, lda, m0, Ml, tid);
+      LB::lane_offsets(voff_b, ldb, n0, Nl, tid);
     }
     // any tile: clamped addresses, zeros beyond k_end (K tail, prefetches past the end)
     auto fetch_tile = [&](f32x4 (&qa)[LA::PER_THREAD], f32x4 (&qb)[LB::PER_THREAD], int kt) {
       const int k0 = k_begin + kt * BK;
       if (FAST) {
-        LA::fetch_fast(qa, A, lda, m0, k0, M, k_end, tid);
-        LB::fetch_fast(qb, B, ldb, n0, k0, N, k_end, tid);
+        LA::fetch_fast(qa, A, lda, m0, k0, Ml, k_end, tid);
+        LB::fetch_fast(qb, B, ldb, n0, k0, Nl, k_end, tid);
       } else {
         LA::fetch(qa, A, lda, m0, k0, M, k_end, a_vec != 0, tid);
         LB::fetch(qb, B, ldb, n0, k0, N, k_end, b_vec != 0, tid);
@@ -267,8 +272,8 @@ __device__ __forceinline__ void gemm_f32_block(const GemmF32Args& p, const int b
     auto fetch_interior_tile = [&](f32x4 (&qa)[LA::PER_THREAD], f32x4 (&qb)[LB::PER_THREAD],
                                    int kt) {
       const int k0 = k_begin + kt * BK;
-      LA::fetch_interior(qa, LA::tile_base(A, lda, m0, M, k0), voff_a);
-      LB::fetch_interior(qb, LB::tile_base(B, ldb, n0, N, k0), voff_b);
+      LA::fetch_interior(qa, LA::tile_base(A, lda, m0, Ml, k0), voff_a);
+      LB::fetch_interior(qb, LB::tile_base(B, ldb, n0, Nl, k0), voff_b);
     };
 #pragma unroll
     for (int u = 0; u < DEPTH; ++u) fetch_tile(ra[u], rb[u], u);   // tiles past the end: zeros
@@ -512,14 +517,15 @@ __device__ __forceinline__ void gemm_f32_slot_block(const GemmF32Args& p, const 
 
   f32x4 ra[2][PT], rb[2][PT];
   unsigned voff_a[PT], voff_b[PT];
-  LA::lane_offsets(voff_a, lda, m0, M, tid);
-  LB::lane_offsets(voff_b, ldb, n0, N, tid);
+  const int Ml = A_KC ? M : p.m_load, Nl = B_KC ? N : p.n_load;    // extents the loads clamp to
+  LA::lane_offsets(voff_a, lda, m0, Ml, tid);
+  LB::lane_offsets(voff_b, ldb, n0, Nl, tid);
 
   // prologue: tiles 0 and 1 requested, tile 0 in LDS buffer 0, fragments of its k-pair 0 read
-  LA::fetch_fast(ra[0], A, lda, m0, 0, M, K, tid);
-  LB::fetch_fast(rb[0], B, ldb, n0, 0, N, K, tid);
-  LA::fetch_fast(ra[1], A, lda, m0, BK, M, K, tid);
-  LB::fetch_fast(rb[1], B, ldb, n0, BK, N, K, tid);
+  LA::fetch_fast(ra[0], A, lda, m0, 0, Ml, K, tid);
+  LB::fetch_fast(rb[0], B, ldb, n0, 0, Nl, K, tid);
+  LA::fetch_fast(ra[1], A, lda, m0, BK, Ml, K, tid);
+  LB::fetch_fast(rb[1], B, ldb, n0, BK, Nl, K, tid);
   LA::stash(ra[0], As, tid);
   LB::stash(rb[0], Bs, tid);
   __syncthreads();
@@ -545,16 +551,16 @@ __device__ __forceinline__ void gemm_f32_slot_block(const GemmF32Args& p, const 
       const int kt = kt0 + s;
       if (!INTERIOR && kt >= nkt) return;
       const int k_next = (kt + 2) * BK;                 // the tile this one requests
-      const float* const base_a = LA::tile_base(A, lda, m0, M, k_next);
-      const float* const base_b = LB::tile_base(B, ldb, n0, N, k_next);
+      const float* const base_a = LA::tile_base(A, lda, m0, Ml, k_next);
+      const float* const base_b = LB::tile_base(B, ldb, n0, Nl, k_next);
       const __amdgpu_buffer_rsrc_t rsrc_a =
           __builtin_amdgcn_make_buffer_rsrc((void*)base_a, 0, 0xffffffff, 0x00020000);
       const __amdgpu_buffer_rsrc_t rsrc_b =
           __builtin_amdgcn_make_buffer_rsrc((void*)base_b, 0, 0xffffffff, 0x00020000);
       if (!INTERIOR) {
         // clamped addresses and zeros beyond K, all at once (two tiles per product)
-        LA::fetch_fast(ra[s], A, lda, m0, k_next, M, K, tid);
-        LB::fetch_fast(rb[s], B, ldb, n0, k_next, N, K, tid);
+        LA::fetch_fast(ra[s], A, lda, m0, k_next, Ml, K, tid);
+        LB::fetch_fast(rb[s], B, ldb, n0, k_next, Nl, K, tid);
       }
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk) {
@@ -643,14 +649,15 @@ __device__ __forceinline__ void gemm_f32_slot_block(const GemmF32Args& p, const 
 }
 
 // whether the operands of C[M,N] = op(A) op(B) qualify for gemm_f32_slot_block
-__host__ inline bool gemm_f32_slot_ok(const void* A, const void* B, int M, int N, int K, long lda,
-                                     long ldb, bool a_kc, bool b_kc) {
+__host__ inline bool gemm_f32_slot_ok(const void* A, const void* B, int m_load, int n_load, int K,
+                                     long lda, long ldb, bool a_kc, bool b_kc) {
   if (((uintptr_t)A | (uintptr_t)B) % 16 != 0 || lda % 4 != 0 || ldb % 4 != 0) return false;
-  if (K < 4 * BK || M < 4 || N < 4) return false;
-  if (a_kc ? K % 4 != 0 : M % 4 != 0) return false;
-  if (b_kc ? K % 4 != 0 : N % 4 != 0) return false;
+  if (K < 4 * BK || m_load < 4 || n_load < 4) return false;
+  if (a_kc ? K % 4 != 0 : m_load % 4 != 0) return false;
+  if (b_kc ? K % 4 != 0 : n_load % 4 != 0) return false;
   // lane offsets within a tile are 32-bit byte offsets
-  if (lda * 4 * (a_kc ? SLOT_MAX_T : BK) >= (1L << 32) || ldb * 4 * (b_kc ? SLOT_MAX_T : BK) >= (1L << 32))
+  if (lda * 4 * (a_kc ? SLOT_MAX_T : BK) >= (1L << 32) ||
+      ldb * 4 * (b_kc ? SLOT_MAX_T : BK) >= (1L << 32))
     return false;
   return true;
 }

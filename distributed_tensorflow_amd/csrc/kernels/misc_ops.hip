@@ -45,6 +45,19 @@ __global__ __launch_bounds__(BLOCK) void pad_rows_kernel(const unsigned char* __
   }
 }
 
+// dst[r, c] = src[r, c] for r < rows, c < cols, zero elsewhere, for all r < dst_rows, c < dst_ld
+// (fp32; any alignment): an operand copied into an aligned, zero-padded image
+__global__ __launch_bounds__(BLOCK) void pad_2d_f32_kernel(const float* __restrict__ src,
+                                                           float* __restrict__ dst, long rows,
+                                                           long cols, long src_ld, long dst_rows,
+                                                           long dst_ld) {
+  const long n = dst_rows * dst_ld;
+  for (long i = blockIdx.x * (long)BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * BLOCK) {
+    const long r = i / dst_ld, c = i - r * dst_ld;
+    dst[i] = (r < rows && c < cols) ? src[r * src_ld + c] : 0.f;
+  }
+}
+
 // var[i] += sign * delta[i % dn]
 __global__ __launch_bounds__(BLOCK) void assign_add_kernel(float* __restrict__ var,
                                                            const float* __restrict__ delta, long n,
@@ -288,6 +301,18 @@ DTF_API int dtf_pad_rows(const void* src, void* dst, long rows, long src_row_byt
   hipLaunchKernelGGL(pad_rows_kernel, dim3(grid_for(rows * (dst_row_bytes / 16), 1)), dim3(BLOCK),
                      0, stream, (const unsigned char*)src, (unsigned char*)dst, rows,
                      src_row_bytes / 16, dst_row_bytes / 16, src_pitch, dst_pitch);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
+// dst [dst_rows, dst_ld] (dense) = src [rows, cols] (row pitch src_ld) padded with zeros
+DTF_API int dtf_pad_2d_f32(const float* src, float* dst, long rows, long cols, long src_ld,
+                           long dst_rows, long dst_ld, hipStream_t stream) {
+  if (dst_rows <= 0 || dst_ld <= 0) return DTF_OK;
+  if (!src || !dst || rows < 0 || cols < 0 || rows > dst_rows || cols > dst_ld || src_ld < cols)
+    return DTF_ERR_BAD_ARG;
+  hipLaunchKernelGGL(pad_2d_f32_kernel, dim3(grid_for(dst_rows * dst_ld, 1)), dim3(BLOCK), 0,
+                     stream, src, dst, rows, cols, src_ld, dst_rows, dst_ld);
   DTF_LAUNCH_CHECK();
   return DTF_OK;
 }

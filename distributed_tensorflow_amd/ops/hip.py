@@ -59,6 +59,8 @@ def _declare(L: ctypes.CDLL) -> None:
     P, I, LG, F, U = c.c_void_p, c.c_int, c.c_long, c.c_float, c.c_uint
     sigs = {
         "dtf_gemm_f32": [P, P, P, P, I, I, I, LG, LG, LG, I, I, I, P, I, I, P],
+        "dtf_gemm_f32_ex": [P, P, P, P, I, I, I, LG, LG, LG, I, I, I, P, I, I, I, I, P],
+        "dtf_pad_2d_f32": [P, P, LG, LG, LG, LG, LG, P],
         "dtf_gemm_f32_splits": [I, I, I, P],
         "dtf_gemm_f32_tile": [I, I, I],
         "dtf_gemm_bf16_nt": [P, P, P, I, I, I, LG, LG, LG, F, F, I, I, P],
@@ -225,23 +227,79 @@ def gemm_f32(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: b
     ldb = b.stride(0) if b.shape[0] > 1 else b.shape[1]
     ldc = out.stride(0) if m > 1 else n
     partial = None
+    # tile and K split come from the product's shape (or the plan's), never from how the operands
+    # happen to lie in memory: the padded copies below leave both as they are
     if plan_mnk is not None:
         pm, pn, pk = (int(v) for v in plan_mnk)
         if pk != k:
             raise HipKernelError("gemm_f32: plan_mnk must have the product's own K")
         tile = L.dtf_gemm_f32_tile(pm, pn, pk)
         splits = L.dtf_gemm_f32_splits(pm, pn, pk, None)
+    elif not tile:
+        tile = L.dtf_gemm_f32_tile(m, n, k)
     if splits is None:
         splits = L.dtf_gemm_f32_splits(m, n, k, None)
     splits = max(1, min(int(splits), 64))
+    a_ptr, b_ptr, kk, m_load, n_load = a.data_ptr(), b.data_ptr(), k, m, n
+    if tile != 16 and m * n * k >= _F32_PAD_MIN_WORK:
+        # The kernels' fast loads want 16-byte aligned rows and a K that is a multiple of 4 for
+        # K-contiguous operands; an operand that is contiguous along M / N may have any M / N as
+        # long as its rows can be read up to the next multiple of 4. Operands that do not
+        # qualify (an odd K, an odd row pitch, a view that starts off the grid) are copied once
+        # into zero-padded aligned images -- (M + N) K elements moved against M N K products;
+        # element-wise predicated loads cost 2-3x the whole product's time.
+        a_kc, b_kc = not trans_a, trans_b
+        k4 = (k + 3) // 4 * 4
+        pad_k = k4 != k and (a_kc or b_kc)
+        images = []
+        for t, kc, ld, extent in ((a, a_kc, lda, m), (b, b_kc, ldb, n)):
+            e4 = (extent + 3) // 4 * 4
+            aligned = t.data_ptr() % 16 == 0 and ld % 4 == 0
+            if kc:
+                ok = aligned and not pad_k
+            else:
+                ok = aligned and not pad_k and _rows_readable_to(t, e4)
+            if ok:
+                images.append((t.data_ptr(), ld, extent if kc else e4))
+                continue
+            rows, cols = (extent, k) if kc else (k, extent)
+            drows, dld = (extent, k4 if pad_k else k) if kc else (k4 if pad_k else k, e4)
+            if kc and dld % 4:
+                dld = (dld + 3) // 4 * 4          # (neither operand pads K: keep the pitch on the grid)
+            img = torch.empty((drows, dld), dtype=torch.float32, device=t.device)
+            _check(L.dtf_pad_2d_f32(t.data_ptr(), img.data_ptr(), rows, cols, ld, drows, dld,
+                                    _stream()), "gemm_f32 (aligned image)")
+            images.append((img.data_ptr(), dld, extent if kc else e4, img))
+        (a_ptr, lda, m_load), (b_ptr, ldb, n_load) = images[0][:3], images[1][:3]
+        if pad_k:
+            kk = k4
     if splits > 1:
         # split-K workspace: one plane per split (caching allocator; graph-capturable)
         partial = torch.empty(splits * m * n, dtype=torch.float32, device=a.device)
-    _check(L.dtf_gemm_f32(a.data_ptr(), b.data_ptr(), out.data_ptr(), _ptr(bias), m, n, k,
-                          lda, ldb, ldc, int(trans_a), int(trans_b),
-                          int(activation), _ptr(partial), splits, int(tile), _stream()),
+    _check(L.dtf_gemm_f32_ex(a_ptr, b_ptr, out.data_ptr(), _ptr(bias), m, n, kk,
+                             lda, ldb, ldc, int(trans_a), int(trans_b),
+                             int(activation), _ptr(partial), splits, int(tile), int(m_load),
+                             int(n_load), _stream()),
            "gemm_f32")
     return out
+
+
+# products smaller than this run on whatever loads their operands allow (a copy would cost more
+# than it saves)
+_F32_PAD_MIN_WORK = 64 * 64 * 64
+
+
+def _rows_readable_to(t: torch.Tensor, cols: int) -> bool:
+    """Whether every row of the rank-2 row-contiguous tensor, the last one included, can be read
+    up to column ``cols`` (>= its width) without leaving its storage or its own row pitch."""
+    if cols <= t.shape[1]:
+        return True
+    rows = t.shape[0]
+    ld = t.stride(0) if rows > 1 else t.shape[1]
+    if rows > 1 and cols > ld:
+        return False
+    last = t.storage_offset() + (rows - 1) * ld + cols
+    return last <= t.untyped_storage().nbytes() // t.element_size()
 
 
 def _bf16_fast_operands_ok(a: torch.Tensor, bt: torch.Tensor, out: torch.Tensor,

@@ -636,6 +636,48 @@ def test_gemm_f32_slot_kernel_matches_general_kernel_bitwise(hip, m, n, k, ta, t
     assert float((out.double() - ref).abs().max()) < 1e-4
 
 
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("m,n,k", [(999, 1001, 1003), (1000, 1001, 1000), (513, 258, 1002),
+                                   (2049, 2047, 515)])
+def test_gemm_f32_odd_shapes_take_aligned_images(hip, m, n, k, ta, tb):
+    """Operands the 16-byte loads cannot take (odd K, odd M / N, an odd row pitch, a view that
+    starts one element into its storage) are copied into zero-padded aligned images and run the
+    fast loads: exact on integer data, nothing outside the output written, and the same bits as
+    the same product on operands that were aligned to begin with (same tile, same K split)."""
+    g = torch.Generator().manual_seed(m + 3 * k)
+    ai = torch.randint(-3, 4, (m, k), generator=g).float()
+    bi = torch.randint(-3, 4, (k, n), generator=g).float()
+    a_in = (ai.t().contiguous() if ta else ai).cuda()
+    b_in = (bi.t().contiguous() if tb else bi).cuda()
+    big = torch.full((m + 6, n), 12345.0, device="cuda")
+    out = big[3:3 + m]
+    hip.gemm_f32(a_in, b_in, ta, tb, out=out)
+    assert torch.equal(out.cpu(), ai @ bi)
+    assert bool((big[:3] == 12345.0).all()) and bool((big[3 + m:] == 12345.0).all())
+    # random data: a view one element off the 16-byte grid against a fresh, aligned copy
+    ar = torch.randn(a_in.shape, generator=g)
+    br = torch.randn(b_in.shape, generator=g)
+    flat = torch.empty(ar.numel() + 1, device="cuda")
+    a_off = flat[1:].view(ar.shape)
+    a_off.copy_(ar)
+    got = hip.gemm_f32(a_off, br.cuda(), ta, tb)
+    want = hip.gemm_f32(ar.cuda(), br.cuda(), ta, tb)
+    assert torch.equal(got, want)
+    ref = (ar.t() if ta else ar).double() @ (br.t() if tb else br).double()
+    assert float((got.cpu().double() - ref).abs().max()) < 2e-3
+
+
+def test_gemm_f32_row_block_of_odd_product_matches_whole(hip):
+    """A row block of A (a view into the whole operand) under ``plan_mnk`` gives the bits of the
+    same rows of the whole product, also when K and N are odd and both go through images."""
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(1001, 1003, generator=g).cuda()
+    b = torch.randn(1003, 999, generator=g).cuda()
+    whole = hip.gemm_f32(a, b)
+    part = hip.gemm_f32(a[500:], b, plan_mnk=(1001, 999, 1003))
+    assert torch.equal(part, whole[500:])
+
+
 def test_gemm_f32_tile_plan(hip):
     """Tile choice: 128x128 where that grid fills the chip evenly (one tile per CU, or rounds of
     two per CU with a last round at most half full), 64x64 otherwise, the small-product kernel

@@ -46,15 +46,15 @@ __global__ __launch_bounds__(BLOCK) void pad_rows_kernel(const unsigned char* __
 }
 
 // dst[r, c] = src[r, c] for r < rows, c < cols, zero elsewhere, for all r < dst_rows, c < dst_ld
-// (fp32; any alignment): an operand copied into an aligned, zero-padded image
-__global__ __launch_bounds__(BLOCK) void pad_2d_f32_kernel(const float* __restrict__ src,
-                                                           float* __restrict__ dst, long rows,
-                                                           long cols, long src_ld, long dst_rows,
-                                                           long dst_ld) {
+// (elements of 2 or 4 bytes; any alignment): an operand copied into an aligned, zero-padded image
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void pad_2d_kernel(const T* __restrict__ src,
+                                                       T* __restrict__ dst, long rows, long cols,
+                                                       long src_ld, long dst_rows, long dst_ld) {
   const long n = dst_rows * dst_ld;
   for (long i = blockIdx.x * (long)BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * BLOCK) {
     const long r = i / dst_ld, c = i - r * dst_ld;
-    dst[i] = (r < rows && c < cols) ? src[r * src_ld + c] : 0.f;
+    dst[i] = (r < rows && c < cols) ? src[r * src_ld + c] : (T)0;
   }
 }
 
@@ -311,8 +311,21 @@ DTF_API int dtf_pad_2d_f32(const float* src, float* dst, long rows, long cols, l
   if (dst_rows <= 0 || dst_ld <= 0) return DTF_OK;
   if (!src || !dst || rows < 0 || cols < 0 || rows > dst_rows || cols > dst_ld || src_ld < cols)
     return DTF_ERR_BAD_ARG;
-  hipLaunchKernelGGL(pad_2d_f32_kernel, dim3(grid_for(dst_rows * dst_ld, 1)), dim3(BLOCK), 0,
+  hipLaunchKernelGGL(pad_2d_kernel<float>, dim3(grid_for(dst_rows * dst_ld, 1)), dim3(BLOCK), 0,
                      stream, src, dst, rows, cols, src_ld, dst_rows, dst_ld);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
+// the same for 2-byte elements (bf16; an all-zero bit pattern is 0.0 there too)
+DTF_API int dtf_pad_2d_b16(const void* src, void* dst, long rows, long cols, long src_ld,
+                           long dst_rows, long dst_ld, hipStream_t stream) {
+  if (dst_rows <= 0 || dst_ld <= 0) return DTF_OK;
+  if (!src || !dst || rows < 0 || cols < 0 || rows > dst_rows || cols > dst_ld || src_ld < cols)
+    return DTF_ERR_BAD_ARG;
+  hipLaunchKernelGGL(pad_2d_kernel<unsigned short>, dim3(grid_for(dst_rows * dst_ld, 1)),
+                     dim3(BLOCK), 0, stream, (const unsigned short*)src, (unsigned short*)dst, rows,
+                     cols, src_ld, dst_rows, dst_ld);
   DTF_LAUNCH_CHECK();
   return DTF_OK;
 }

@@ -61,6 +61,7 @@ def _declare(L: ctypes.CDLL) -> None:
         "dtf_gemm_f32": [P, P, P, P, I, I, I, LG, LG, LG, I, I, I, P, I, I, P],
         "dtf_gemm_f32_ex": [P, P, P, P, I, I, I, LG, LG, LG, I, I, I, P, I, I, I, I, P],
         "dtf_pad_2d_f32": [P, P, LG, LG, LG, LG, LG, P],
+        "dtf_pad_2d_b16": [P, P, LG, LG, LG, LG, LG, P],
         "dtf_gemm_f32_splits": [I, I, I, P],
         "dtf_gemm_f32_tile": [I, I, I],
         "dtf_gemm_bf16_nt": [P, P, P, I, I, I, LG, LG, LG, F, F, I, I, P],
@@ -302,16 +303,8 @@ def _rows_readable_to(t: torch.Tensor, cols: int) -> bool:
     return last <= t.untyped_storage().nbytes() // t.element_size()
 
 
-def _bf16_fast_operands_ok(a: torch.Tensor, bt: torch.Tensor, out: torch.Tensor,
-                           out_f32: int) -> bool:
-    """What dtf_gemm_bf16_nt asks of its operands apart from K % 64 == 0 (row pitches, alignment,
-    32-bit tile offsets): checked here where a call must not fail after out has been written."""
-    lda, ldb, ldc = a.stride(0), bt.stride(0), out.stride(0)
-    if lda % 8 or ldb % 8 or ldc % 4:
-        return False
-    if a.data_ptr() % 16 or bt.data_ptr() % 16 or out.data_ptr() % (16 if out_f32 else 8):
-        return False
-    return lda * 2 * 256 < (1 << 32) and ldb * 2 * 256 < (1 << 32)
+# bf16 products smaller than this run on whatever kernel their operands allow
+_BF16_PAD_MIN_WORK = 1 << 20
 
 
 def gemm_bf16_nt(a: torch.Tensor, bt: torch.Tensor, out_dtype: torch.dtype = torch.bfloat16,
@@ -320,8 +313,9 @@ def gemm_bf16_nt(a: torch.Tensor, bt: torch.Tensor, out_dtype: torch.dtype = tor
                  splits: Optional[int] = None) -> torch.Tensor:
     """``alpha * a @ bt.T (+ beta * out)`` with a [M,K], bt [N,K] bf16 (both K-contiguous); fp32
     accumulate; result bf16 or fp32. Uses the 256x256x64 LDS-DMA kernel when the shape
-    qualifies (operands whose K is a multiple of 8 but not of 64 are first copied into
-    zero-padded rows) and the predicated generic kernel otherwise. ``splits``: K splits for grids with
+    qualifies (operands with another K, an odd pitch or an offset start, and results with an
+    odd pitch, get there through padded copies when the product is large enough to care) and
+    the predicated generic kernel otherwise. ``splits``: K splits for grids with
     few output tiles (default: the library's plan; 1 = never split)."""
     a = _req(a, torch.bfloat16, "gemm_bf16_nt a")
     bt = _req(bt, torch.bfloat16, "gemm_bf16_nt bt")
@@ -355,19 +349,43 @@ def gemm_bf16_nt(a: torch.Tensor, bt: torch.Tensor, out_dtype: torch.dtype = tor
             return out
         if code != -2:
             _check(code, "gemm_bf16_nt (split-K)")
-    if k % 64 and k % 8 == 0 and k > 64 and _bf16_fast_operands_ok(a, bt, out, out_f32):
-        # K is not a multiple of the fast kernel's K-tile (the reference's 1000 and 784 are not):
-        # both operands are copied into rows padded with zeros up to the next multiple of 64 --
-        # (M + N) K elements moved once, against M N K products -- and the fast kernel runs on
-        # the copies. (Running the K % 64 tail on the predicated kernel and accumulating the rest
-        # on top costs two more passes over C and measured 3x slower at 8192 x 8192 x 1000.)
-        kp = (k + 63) // 64 * 64
-        ap = torch.empty((m, kp), dtype=torch.bfloat16, device=a.device)
-        bp = torch.empty((n, kp), dtype=torch.bfloat16, device=a.device)
-        for src, dst, rows in ((a, ap, m), (bt, bp, n)):
-            _check(lib().dtf_pad_rows(src.data_ptr(), dst.data_ptr(), rows, 2 * k, 2 * kp,
-                                      2 * src.stride(0), 2 * kp, _stream()), "gemm_bf16_nt (pad K)")
-        return gemm_bf16_nt(ap, bp, out_dtype, alpha=alpha, out=out, variant=variant, beta=beta)
+    # The fast kernel wants K % 64 == 0 (the reference's 1000 and 784 are not), 16-byte aligned
+    # rows with pitches that are multiples of 8 elements, and an out whose pitch is a multiple of
+    # 4 elements on an 8/16-byte grid. A product large enough to care gets there by copies:
+    # operands into zero-padded aligned images -- (M + N) K elements moved once against M N K
+    # products --, the result through a temporary with a padded pitch. (The predicated kernel
+    # alone took 1172 us for 8192 x 8192 x 1000; images + fast kernel take 142. Running only the
+    # K % 64 tail on the predicated kernel and accumulating the rest on top costs two more passes
+    # over C and measured 3x slower than the images.)
+    if m * n * k >= _BF16_PAD_MIN_WORK and k > 64:
+        def operand_ok(t):
+            return t.data_ptr() % 16 == 0 and t.stride(0) % 8 == 0 and k % 64 == 0 and \
+                t.stride(0) * 2 * 256 < (1 << 32)
+        out_ok = out.stride(0) % 4 == 0 and out.data_ptr() % (16 if out_f32 else 8) == 0
+        if not (operand_ok(a) and operand_ok(bt) and out_ok) and (out_ok or beta == 0.0):
+            kp = (k + 63) // 64 * 64
+            images = []
+            for t in (a, bt):
+                if operand_ok(t):
+                    images.append(t)
+                    continue
+                img = torch.empty((t.shape[0], kp), dtype=torch.bfloat16, device=t.device)
+                if t.data_ptr() % 16 == 0 and t.stride(0) % 8 == 0 and k % 8 == 0:
+                    code = lib().dtf_pad_rows(t.data_ptr(), img.data_ptr(), t.shape[0], 2 * k,
+                                              2 * kp, 2 * t.stride(0), 2 * kp, _stream())
+                else:
+                    code = lib().dtf_pad_2d_b16(t.data_ptr(), img.data_ptr(), t.shape[0], k,
+                                                t.stride(0), t.shape[0], kp, _stream())
+                _check(code, "gemm_bf16_nt (aligned image)")
+                images.append(img)
+            if out_ok:
+                return gemm_bf16_nt(images[0], images[1], out_dtype, alpha=alpha, out=out,
+                                    variant=variant, beta=beta)
+            n4 = (n + 3) // 4 * 4
+            tmp = torch.empty((m, n4), dtype=out_dtype, device=a.device)
+            gemm_bf16_nt(images[0], images[1], out_dtype, alpha=alpha, out=tmp[:, :n],
+                         variant=variant)
+            return copy_2d(tmp[:, :n], out)
     code = lib().dtf_gemm_bf16_nt(a.data_ptr(), bt.data_ptr(), out.data_ptr(), m, n, k,
                                   a.stride(0), bt.stride(0), out.stride(0), float(alpha),
                                   float(beta), out_f32, int(variant), _stream())

@@ -694,11 +694,14 @@ def test_gemm_f32_tile_plan(hip):
 
 
 @pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
-@pytest.mark.parametrize("m,n,k", [(1000, 1000, 1000), (100, 100, 784), (512, 300, 1032)])
+@pytest.mark.parametrize("m,n,k", [(1000, 1000, 1000), (100, 100, 784), (512, 300, 1032),
+                                   (513, 1001, 1003), (300, 258, 999)])
 def test_gemm_bf16_k_not_multiple_of_tile(hip, m, n, k, out_dtype):
     """K = 1000 and 784 (the reference's shapes) are not multiples of the LDS-DMA kernel's
-    K-tile: the operands are copied into zero-padded rows and the product runs on that kernel
-    (split over K where the grid is small). Exact on integer data, alpha/beta applied once, close to fp64 on random
+    K-tile; an odd K or N takes the operands (and the result's pitch) off the kernel's alignment
+    grid altogether: the operands are copied into zero-padded aligned images, an odd-pitch
+    result goes through a padded temporary, and the product runs on that kernel (split over K
+    where the grid is small). Exact on integer data, alpha/beta applied once, close to fp64 on random
     data."""
     g = torch.Generator().manual_seed(k + m)
     a = torch.randint(-2, 3, (m, k), generator=g).float()

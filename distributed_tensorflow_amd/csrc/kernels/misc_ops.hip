@@ -330,6 +330,19 @@ DTF_API int dtf_pad_2d_b16(const void* src, void* dst, long rows, long cols, lon
   return DTF_OK;
 }
 
+// ... and for 1-byte elements (fp8 e4m3: 0x00 is 0.0)
+DTF_API int dtf_pad_2d_b8(const void* src, void* dst, long rows, long cols, long src_ld,
+                          long dst_rows, long dst_ld, hipStream_t stream) {
+  if (dst_rows <= 0 || dst_ld <= 0) return DTF_OK;
+  if (!src || !dst || rows < 0 || cols < 0 || rows > dst_rows || cols > dst_ld || src_ld < cols)
+    return DTF_ERR_BAD_ARG;
+  hipLaunchKernelGGL(pad_2d_kernel<unsigned char>, dim3(grid_for(dst_rows * dst_ld, 1)),
+                     dim3(BLOCK), 0, stream, (const unsigned char*)src, (unsigned char*)dst, rows,
+                     cols, src_ld, dst_rows, dst_ld);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
 // Copy a [rows, row_bytes] block between buffers with row pitches src_pitch / dst_pitch (bytes).
 DTF_API int dtf_copy_2d(const void* src, void* dst, long rows, long row_bytes, long src_pitch,
                         long dst_pitch, hipStream_t stream) {

@@ -62,6 +62,7 @@ def _declare(L: ctypes.CDLL) -> None:
         "dtf_gemm_f32_ex": [P, P, P, P, I, I, I, LG, LG, LG, I, I, I, P, I, I, I, I, P],
         "dtf_pad_2d_f32": [P, P, LG, LG, LG, LG, LG, P],
         "dtf_pad_2d_b16": [P, P, LG, LG, LG, LG, LG, P],
+        "dtf_pad_2d_b8": [P, P, LG, LG, LG, LG, LG, P],
         "dtf_gemm_f32_splits": [I, I, I, P],
         "dtf_gemm_f32_tile": [I, I, I],
         "dtf_gemm_bf16_nt": [P, P, P, I, I, I, LG, LG, LG, F, F, I, I, P],
@@ -428,6 +429,32 @@ def gemm_fp8_nt(a: torch.Tensor, bt: torch.Tensor, out_dtype: torch.dtype = torc
     if k == 0:
         return out.mul_(beta) if beta != 0.0 else out.zero_()
     out_f32 = int(out_dtype == torch.float32)
+    if not force_generic and m * n * k >= _BF16_PAD_MIN_WORK and k > 128:
+        # as for bf16: operands off the fast kernel's grid (K % 128, 16-byte rows) are copied into
+        # zero-padded aligned images, a result with an odd pitch goes through a padded temporary
+        def operand_ok(t):
+            return t.data_ptr() % 16 == 0 and t.stride(0) % 16 == 0 and k % 128 == 0 and \
+                t.stride(0) * 256 < (1 << 32)
+        out_ok = out.stride(0) % 4 == 0 and out.data_ptr() % (16 if out_f32 else 8) == 0
+        if not (operand_ok(a) and operand_ok(bt) and out_ok) and (out_ok or beta == 0.0):
+            kp = (k + 127) // 128 * 128
+            images = []
+            for t in (a, bt):
+                if operand_ok(t):
+                    images.append(t)
+                    continue
+                img = torch.empty((t.shape[0], kp), dtype=FP8, device=t.device)
+                _check(lib().dtf_pad_2d_b8(t.data_ptr(), img.data_ptr(), t.shape[0], k,
+                                           t.stride(0), t.shape[0], kp, _stream()),
+                       "gemm_fp8_nt (aligned image)")
+                images.append(img)
+            if out_ok:
+                return gemm_fp8_nt(images[0], images[1], out_dtype, alpha=alpha, out=out,
+                                   beta=beta)
+            n4 = (n + 3) // 4 * 4
+            tmp = torch.empty((m, n4), dtype=out_dtype, device=a.device)
+            gemm_fp8_nt(images[0], images[1], out_dtype, alpha=alpha, out=tmp[:, :n])
+            return copy_2d(tmp[:, :n], out)
     code = -2 if force_generic else lib().dtf_gemm_fp8_nt(
         a.data_ptr(), bt.data_ptr(), out.data_ptr(), m, n, k, a.stride(0), bt.stride(0),
         out.stride(0), float(alpha), float(beta), out_f32, _stream())

@@ -580,6 +580,19 @@ def test_gemm_bf16_writes_only_its_output(hip, m, n, k, out_dtype, variant):
     assert _band_intact(big, (m, n), origin, sentinel)
 
 
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("m,n,k", [(512, 300, 1000), (513, 1001, 1003), (300, 258, 784)])
+def test_gemm_fp8_off_grid_shapes(hip, m, n, k, out_dtype):
+    """K that is not a multiple of 128, odd K, odd N: the fp8 product runs the block-scaled-MFMA
+    kernel on zero-padded aligned images (a padded temporary for an odd-pitch result) and equals
+    the predicated kernel's result exactly on integer data."""
+    g = torch.Generator().manual_seed(k + n)
+    a = torch.randint(-2, 3, (m, k), generator=g).float()
+    bt = torch.randint(-2, 3, (n, k), generator=g).float()
+    got = hip.gemm_fp8_nt(a.to(FP8).cuda(), bt.to(FP8).cuda(), out_dtype, alpha=0.5)
+    assert torch.equal(got.float().cpu(), (0.5 * (a @ bt.t())).to(out_dtype).float())
+
+
 @pytest.mark.parametrize("m,n,k", [(300, 520, 128), (512, 768, 256), (256, 256, 1408)])
 def test_gemm_fp8_writes_only_its_output(hip, m, n, k):
     g = torch.Generator().manual_seed(k)

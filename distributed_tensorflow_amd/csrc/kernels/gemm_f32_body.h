@@ -178,6 +178,55 @@ struct Loader {
   }
 };
 
+// Epilogue through LDS for a 16-byte aligned C. An accumulator register holds one column of C per
+// lane (C/D fragment of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) +
+// 4 * (lane >> 5)); stored as it is, every instruction writes 64 single words. Here each wave
+// turns its 32x32 tiles through a private 32 x XLD corner of the (idle) staging buffers and
+// stores 16 bytes per lane, eight lanes to a 128-byte row segment: 8192 x 8192 outputs leave in
+// 110 us instead of 175 (what a short-K product spends most of its time on). Values and the order
+// of the additions are those of the one-word path. The caller has made sure no wave still reads
+// the staging buffers.
+template <int FM, int FN, int XLD>
+__device__ __forceinline__ void gemm_f32_store_wide(float* xs, const f32x16 (&acc)[FM][FN],
+                                                    float* __restrict__ C, long ldc, int row0,
+                                                    int col0, int M, int N,
+                                                    const float* __restrict__ bias, int act,
+                                                    int lane) {
+  static_assert(XLD % 4 == 0 && XLD >= 32, "rows of the turning buffer are read 16 bytes at a time");
+  const int lrow = lane & 31, lk = lane >> 5;
+  const int rrow = lane >> 3, c4 = 4 * (lane & 7);
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        xs[((r & 3) + 8 * (r >> 2) + 4 * lk) * XLD + lrow] = acc[i][j][r];
+      const int col = col0 + 32 * j + c4;
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[e] = col + e < N ? bias[col + e] : 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = row0 + 32 * i + 8 * q + rrow;
+        f32x4 v = *reinterpret_cast<const f32x4*>(xs + (8 * q + rrow) * XLD + c4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = dtf_apply_act(v[e] + bv[e], act);
+        if (row >= M) continue;
+        float* const dst = C + (long)row * ldc + col;
+        if (col + 3 < N) {
+          *reinterpret_cast<f32x4*>(dst) = v;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (col + e < N) dst[e] = v[e];
+        }
+      }
+    }
+}
+
 // ABL (timing experiments, -DDTF_GEMM_EXPERIMENTS only; results are wrong when set): bit 0 = no
 // global loads in the K loop, bit 1 = no LDS stash, bit 2 = no barrier, bit 3 = no fragment reads,
 // bit 4 = every wave sums the shader-clock cycles each k-pair of its interior K-tiles took and
@@ -411,6 +460,13 @@ __device__ __forceinline__ void gemm_f32_block(const GemmF32Args& p, const int b
       }
     return;
   }
+  if (EPI == 0 && ((uintptr_t)C % 16 == 0) && (ldc % 4 == 0)) {
+    static_assert(4 * 32 * 32 <= 2 * BK * (LA::LD + LB::LD), "turning buffers fit the staging");
+    __syncthreads();                                     // staging buffers are idle from here on
+    gemm_f32_store_wide<TM, TN, 32>(smem + wave * (32 * 32), acc, C, ldc, m0 + wr * WM,
+                                    n0 + wc * WN, M, N, bias, act, lane);
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -631,7 +687,14 @@ __device__ __forceinline__ void gemm_f32_slot_block(const GemmF32Args& p, const 
     p.partial[(bid * 4 + wave) * 16 + 15] = (float)t_count;
   }
 
-  // C/D fragment: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  // (not for the 256x256 tile: with 256 accumulators live the turn spills registers)
+  const bool wide = T == 128 && ((uintptr_t)C % 16 == 0) && (ldc % 4 == 0);
+  if (wide) {
+    __syncthreads();                                     // staging buffers are idle from here on
+    gemm_f32_store_wide<F, F, 36>(gemm_f32_dyn_lds + wave * (32 * 36), acc, C, ldc,
+                                  m0 + wr * WT, n0 + wc * WT, M, N, p.bias, p.act, lane);
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < F; ++i)
 #pragma unroll

@@ -22,6 +22,7 @@ def _hipcc():
 @pytest.mark.skipif(_hipcc() is None, reason="hipcc not installed")
 @pytest.mark.parametrize("source,pattern", [("gemm_bf16.hip", "gemm_nt_pp_kernel"),
                                             ("gemm_f32.hip", "gemm_f32_kernel"),
+                                            ("gemm_f32.hip", "gemm_f32_slot_kernel"),
                                             ("mlp_head.hip", "mlp_head")])
 def test_hot_kernels_use_no_scratch(source, pattern, tmp_path):
     asm = str(tmp_path / "k.s")

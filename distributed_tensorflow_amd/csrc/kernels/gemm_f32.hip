@@ -200,7 +200,7 @@ int launch(const float* A, const float* B, float* C, const float* bias, int M, i
 DTF_API int dtf_gemm_f32_tile(int M, int N, int K) {
   if (gemm_f32_skinny_fits(M, N, K)) return 16;       // one 16x16 tile per workgroup, no split
   const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
-  if (K >= 512) {
+  if (K >= 4 * BK) {       // (the slot-dealt kernel's prologue holds two K-tiles)
     if (t128 >= 230 && t128 <= 256) return 128;
     if (t128 > 256) {
       const long full = t128 / 512, rest = t128 % 512;

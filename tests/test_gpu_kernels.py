@@ -702,6 +702,8 @@ def test_gemm_f32_tile_plan(hip):
     assert L.dtf_gemm_f32_tile(2048, 2048, 2048) == 128     # 256 tiles: one per CU
     assert L.dtf_gemm_f32_tile(3072, 3072, 3072) == 64      # 576 tiles: 1.125 rounds
     assert L.dtf_gemm_f32_tile(5120, 5120, 5120) == 64      # 1600 tiles: 3.125 rounds
+    assert L.dtf_gemm_f32_tile(8192, 8192, 64) == 128       # short K too: its stores are wide
+    assert L.dtf_gemm_f32_tile(8192, 8192, 48) == 64
     assert L.dtf_gemm_f32_tile(1000, 1000, 1000) == 64
     assert L.dtf_gemm_f32_tile(100, 100, 784) == 16
 

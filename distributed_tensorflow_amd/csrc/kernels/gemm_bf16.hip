@@ -631,6 +631,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
   int e_lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
   asm volatile("" : "+v"(e_lane));
   const int e_frow = e_lane & 15, e_fq = e_lane >> 4;
+  const bool wide_bf16 = !OUT_F32 && beta == 0.f && (ldc & 7) == 0 &&
+                         (reinterpret_cast<uintptr_t>(c_plane) & 15) == 0;
 #pragma unroll
   for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
@@ -638,7 +640,31 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
       const int row = cm0 + mh * 128 + wr * 64 + i * 16 + e_frow;
       if (row >= M) continue;
 #pragma unroll
-      for (int nh = 0; nh < 2; ++nh)
+      for (int nh = 0; nh < 2; ++nh) {
+        if (!OUT_F32) {
+          // bf16 out: a lane holds 4 consecutive columns of each of its two adjacent 16x16
+          // tiles (8 bytes + 8 bytes, 32 apart). One v_permlane16_swap per register pair
+          // trades the odd 16-lane rows' first tile against the even rows' second one, after
+          // which every lane owns 8 consecutive columns: one 16-byte store per lane, 64
+          // contiguous bytes per output row and instruction instead of two stores of 32.
+          const int cb = cn0 + nh * 128 + wc * 32;
+          if (wide_bf16 && cb + 32 <= N) {
+            const f32x4 v0 = acc[mh][nh][i][0] * alpha, v1 = acc[mh][nh][i][1] * alpha;
+            const unsigned p0a = dtf_f32_to_bf16(v0[0]) | ((unsigned)dtf_f32_to_bf16(v0[1]) << 16);
+            const unsigned p0b = dtf_f32_to_bf16(v0[2]) | ((unsigned)dtf_f32_to_bf16(v0[3]) << 16);
+            const unsigned p1a = dtf_f32_to_bf16(v1[0]) | ((unsigned)dtf_f32_to_bf16(v1[1]) << 16);
+            const unsigned p1b = dtf_f32_to_bf16(v1[2]) | ((unsigned)dtf_f32_to_bf16(v1[3]) << 16);
+            const auto sa = __builtin_amdgcn_permlane16_swap(p0a, p1a, false, false);
+            const auto sb = __builtin_amdgcn_permlane16_swap(p0b, p1b, false, false);
+            // even rows of lanes (fq = 0, 2): columns 4 fq .. 4 fq + 7 of the first tile;
+            // odd rows (fq = 1, 3): columns 4 (fq - 1) .. 4 fq + 3 of the second
+            const int col = cb + ((e_fq & 1) ? 16 + 4 * (e_fq - 1) : 4 * e_fq);
+            u32x4 o = {sa[0], sb[0], sa[1], sb[1]};
+            *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(c_plane) +
+                                      (long)row * ldc + col) = o;
+            continue;
+          }
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int col = cn0 + nh * 128 + wc * 32 + j * 16 + 4 * e_fq;
@@ -668,6 +694,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
             }
           }
         }
+      }
     }
   if (!more) break;
   }   // tile loop

@@ -49,6 +49,35 @@ _SPIN_SECS = 300e-6              # how long a step's completion word is polled b
 _NO_SPIN_FETCH = bool(os.environ.get("DTF_NO_SPIN_FETCH"))
 _NO_FETCH_AHEAD = bool(os.environ.get("DTF_NO_FETCH_AHEAD"))
 _NO_DIRECT_STEP = bool(os.environ.get("DTF_NO_DIRECT_STEP"))
+# a captured step of at most this many library calls is re-issued call by call rather than
+# replayed as a HIP graph: a graph launch costs about 15 us of host time plus a gap of several
+# microseconds on the GPU between one replay and the next, a direct launch 3-5 us
+_DIRECT_MAX_CALLS = int(os.environ.get("DTF_DIRECT_MAX_CALLS", "4"))
+_HIP_KERNEL_NODE = 0
+
+
+def _graph_node_types(graph) -> Optional[List[int]]:
+    """hipGraphNodeType of every node of a captured graph that was created with
+    ``keep_graph=True`` (None when the runtime cannot be asked)."""
+    import ctypes
+    try:
+        rt = ctypes.CDLL("libamdhip64.so")
+        raw = ctypes.c_void_p(graph.raw_cuda_graph())
+        n = ctypes.c_size_t(0)
+        if rt.hipGraphGetNodes(raw, None, ctypes.byref(n)) != 0:
+            return None
+        nodes = (ctypes.c_void_p * max(1, n.value))()
+        if rt.hipGraphGetNodes(raw, nodes, ctypes.byref(n)) != 0:
+            return None
+        types = []
+        for i in range(n.value):
+            t = ctypes.c_int(-1)
+            if rt.hipGraphNodeGetType(ctypes.c_void_p(nodes[i]), ctypes.byref(t)) != 0:
+                return None
+            types.append(t.value)
+        return types
+    except (OSError, AttributeError, RuntimeError):
+        return None
 # ops that write a variable in place (a gather must not move across them)
 _MUTATING_OPS = frozenset(("Assign", "AssignAdd", "AssignSub", "ApplyGradientDescent",
                            "MultiApplySGD"))
@@ -407,6 +436,8 @@ class _CapturedStep:
         self.generation = 0                               # variable-store generation at capture
         self.direct = None          # (library function, prepared argument block) of a step that
                                     # is a single library call: issued directly, not replayed
+        self.calls = None           # [(library function, arguments without the stream)] of a
+                                    # short step: re-issued in order instead of replayed
 
 
 class _DeferredHost:
@@ -1203,6 +1234,14 @@ class Session:
             rc = fn(ref, torch._C._cuda_getCurrentRawStream(self.device.index))
             if rc != 0:
                 raise RuntimeError("captured step: direct launch failed with code %d" % rc)
+        elif cap.calls is not None:
+            # a handful of launches: cheaper issued one by one than as a graph
+            s = torch._C._cuda_getCurrentRawStream(self.device.index)
+            for fn, args in cap.calls:
+                rc = fn(*args, s)
+                if rc != 0:
+                    raise RuntimeError("captured step: direct launch failed with code %d" % rc)
+            self.stats["direct_steps"] = self.stats.get("direct_steps", 0) + 1
         else:
             cap.graph.replay()
         ring.launched = n + 1
@@ -1222,6 +1261,36 @@ class Session:
             if sl is not None and sl not in out:
                 out[sl] = cap.slot_values[sl]
         return out
+
+    def _direct_call_list(self, graph, calls, capture_stream):
+        """The captured step as a list of library calls, or None when it has to stay a graph.
+
+        ``calls`` is everything the capturing thread asked of the kernel library; the launchers
+        among them are the calls whose last argument was the capture stream. The list may stand
+        for the graph only if it accounts for ALL of it: the list is captured a second time into
+        a scratch graph, and both graphs must consist of kernel nodes only and of equally many
+        (a torch kernel, a copy or a memset in the step -- none of which the recorder sees --
+        leaves the counts different)."""
+        launchers = [(fn, args[:-1]) for fn, args in calls
+                     if args and capture_stream and args[-1] == capture_stream]
+        if not launchers or len(launchers) > _DIRECT_MAX_CALLS:
+            return None
+        main = _graph_node_types(graph)
+        if not main or any(t != _HIP_KERNEL_NODE for t in main):
+            return None
+        try:
+            scratch = torch.cuda.CUDAGraph(keep_graph=True)
+            with torch.cuda.graph(scratch, capture_error_mode="thread_local"):
+                s = torch._C._cuda_getCurrentRawStream(self.device.index)
+                for fn, args in launchers:
+                    if fn(*args, s) != 0:
+                        return None
+            again = _graph_node_types(scratch)
+        except (RuntimeError, TypeError):
+            return None
+        if again is None or len(again) != len(main) or any(t != _HIP_KERNEL_NODE for t in again):
+            return None
+        return launchers
 
     def _retire(self, cap: _CapturedStep) -> None:
         """Take every outstanding result out of a captured step's ring (before the step is
@@ -1253,17 +1322,24 @@ class Session:
                               if any(sl in st.in_slots for sl in feed_slots)))
         ctx = self._ctx
         torch.cuda.synchronize(self.device)
-        graph = torch.cuda.CUDAGraph()
+        try:
+            graph = torch.cuda.CUDAGraph(keep_graph=True)     # its nodes are counted below
+        except TypeError:
+            graph = torch.cuda.CUDAGraph()
         vals: List[Any] = [None] * plan.num_slots
         packed: List[Tuple[int, int, tuple, torch.Tensor]] = []
         limit = ring.words - 1
+        recorder = None
+        capture_stream = None
         # (thread-local capture mode: a service thread's host allocation or copy during this
         # capture must not invalidate it)
         try:
             ctx.ring = ring.args
             ctx.ring_feeds = {t.data_ptr(): i for i, t in enumerate(cap.static_feeds)} \
                 if direct else {}
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"), \
+                    hip.record_calls() as recorder:
+                capture_stream = torch._C._cuda_getCurrentRawStream(self.device.index)
                 if use_table and not direct:
                     hip.gather_feeds_ring(ring.args, cap.static_feeds)
                 for (_, sl), v in zip(plan.feed_slots, cap.static_feeds):
@@ -1354,6 +1430,8 @@ class Session:
             ctx.direct_call = None
         cap.host_words = sum(p[3].numel() for p in packed)
         cap.layout = [(sl, off, shape, int(v.numel())) for sl, off, shape, v in packed]
+        if cap.direct is None and recorder is not None and not _NO_DIRECT_STEP:
+            cap.calls = self._direct_call_list(graph, recorder.calls, capture_stream)
         cap.graph = graph
         cap.slot_values = vals
         cap.generation = self._local_store.generation

@@ -11,9 +11,11 @@ missing, importing this module's users fails loudly rather than falling back to 
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import os
-from typing import List, Optional, Sequence
+import threading
+from typing import Any, List, Optional, Sequence, Tuple
 
 import torch
 
@@ -52,6 +54,46 @@ def lib() -> ctypes.CDLL:
         _lib = ctypes.CDLL(LIB_PATH)
         _declare(_lib)
     return _lib
+
+
+class _CallRecorder:
+    """Stands in for the kernel library while a session captures a step: every call goes through
+    to the real library and is noted as (function, arguments) when it was made by the capturing
+    thread. A short step is later re-issued from that list instead of replayed as a HIP graph."""
+
+    def __init__(self, real: ctypes.CDLL):
+        self._real = real
+        self._thread = threading.get_ident()
+        self.calls: List[Tuple[Any, tuple]] = []
+
+    def __getattr__(self, name):
+        fn = getattr(self._real, name)
+        if not callable(fn):
+            return fn
+
+        def call(*args):
+            rc = fn(*args)
+            if threading.get_ident() == self._thread:
+                self.calls.append((fn, args))
+            return rc
+        return call
+
+
+@contextlib.contextmanager
+def record_calls():
+    """``with record_calls() as rec:`` -- ``rec.calls`` lists the library calls this thread makes
+    inside the block, in order."""
+    global _lib
+    real = lib()
+    if isinstance(real, _CallRecorder):            # nested: keep the outer recorder
+        yield real
+        return
+    rec = _CallRecorder(real)
+    _lib = rec
+    try:
+        yield rec
+    finally:
+        _lib = real
 
 
 def _declare(L: ctypes.CDLL) -> None:

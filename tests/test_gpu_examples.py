@@ -235,8 +235,42 @@ def test_captured_step_completion_polling_and_blocking_fallback(monkeypatch):
         got = [float(sess.run(total, {x: batch})) for i in range(3)]
         assert got == [440.0, 460.0, 480.0]
         cap.ring.skip_spin = 2                             # as after a step that outlasted it
-        got = [float(sess.run(total, {x: batch})) for i in range(3)]
-        assert got == [500.0, 520.0, 540.0] and cap.ring.skip_spin == 0
+        got = [float(sess.run(total, {x: batch})) for i in range(2)]
+        assert got == [500.0, 520.0] and cap.ring.skip_spin == 0     # two steps went unpolled
+        assert float(sess.run(total, {x: batch})) == 540.0
+
+
+def test_short_captured_steps_are_issued_call_by_call(monkeypatch):
+    """A captured step of a few library calls (the reference's matmul step: product, mean, gather
+    of the fetched scalar) is re-issued from its recorded call list instead of replayed as a HIP
+    graph, after the list has been checked against the graph node for node; values equal those
+    of the graph replay bit for bit, and a longer step stays a graph."""
+    import numpy as np
+    import distributed_tensorflow_amd as tf
+    from distributed_tensorflow_amd.client import session as S
+
+    def run(max_calls):
+        monkeypatch.setattr(S, "_DIRECT_MAX_CALLS", max_calls)
+        g = tf.Graph()
+        with g.as_default():
+            tf.set_random_seed(1)
+            a = tf.Variable(tf.random_normal([256, 256]))
+            b = tf.Variable(tf.random_normal([256, 256]))
+            x = tf.placeholder(tf.float32, [256, 256])
+            checksum = tf.reduce_mean(tf.matmul(a + x, b))
+            with tf.Session(config=tf.ConfigProto(device="cuda")) as sess:
+                sess.run(tf.global_variables_initializer())
+                feeds = [np.full((256, 256), float(i), np.float32) for i in range(8)]
+                vals = [float(sess.run(checksum, {x: f})) for f in feeds]
+                return vals, dict(sess.stats)
+
+    direct_vals, direct_stats = run(8)
+    graph_vals, graph_stats = run(0)
+    assert direct_vals == graph_vals
+    assert direct_stats.get("direct_steps", 0) >= 6 and direct_stats["torch_fallbacks"] == 0
+    assert graph_stats.get("direct_steps", 0) == 0 and graph_stats["graph_replays"] >= 6
+    # (graph_replays counts captured steps however they are launched)
+    assert direct_stats["graph_replays"] == graph_stats["graph_replays"]
 
 
 def test_fetch_ahead_of_the_optimizer_launch_matches_eager_values():

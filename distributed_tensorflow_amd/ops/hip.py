@@ -340,7 +340,7 @@ def _rows_readable_to(t: torch.Tensor, cols: int) -> bool:
         return True
     rows = t.shape[0]
     ld = t.stride(0) if rows > 1 else t.shape[1]
-    if rows > 1 and cols > ld:
+    if cols > ld:                      # (one row: its pitch is its width)
         return False
     last = t.storage_offset() + (rows - 1) * ld + cols
     return last <= t.untyped_storage().nbytes() // t.element_size()

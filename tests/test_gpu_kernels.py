@@ -680,6 +680,16 @@ def test_gemm_f32_odd_shapes_take_aligned_images(hip, m, n, k, ta, tb):
     assert float((got.cpu().double() - ref).abs().max()) < 2e-3
 
 
+def test_gemm_f32_outer_product_with_odd_extents(hip):
+    """K = 1 with M and N off the 4-grid, both operands stored with M / N contiguous (one row
+    each): the single row cannot be read past its end, so both go through images."""
+    g = torch.Generator().manual_seed(11)
+    a = torch.randint(-3, 4, (1, 1001), generator=g).float().cuda()     # [K, M]
+    b = torch.randint(-3, 4, (1, 999), generator=g).float().cuda()      # [K, N]
+    out = hip.gemm_f32(a, b, trans_a=True)
+    assert torch.equal(out, a.t() @ b)
+
+
 def test_gemm_f32_row_block_of_odd_product_matches_whole(hip):
     """A row block of A (a view into the whole operand) under ``plan_mnk`` gives the bits of the
     same rows of the whole product, also when K and N are odd and both go through images."""

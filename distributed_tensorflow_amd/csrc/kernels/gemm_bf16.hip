@@ -1422,8 +1422,27 @@ __global__ __launch_bounds__(256) void planes_reduce_kernel(const float* __restr
 // is about one work item per CU, each split keeping at least 512 columns of K. Only for grids
 // of at most 32 tiles: the planes are fp32, and from 64 tiles on (2048^2 outputs) reading them
 // back costs what the extra CUs gain (measured: 2048^3 44.6 us split four ways, 44.2 us unsplit).
+// From 33 to 128 tiles the product normally runs on 128x128 tiles, whose operand traffic (1 GiB
+// from L2 for 2048 x 2048 x 8192) is what bounds it. With a long K the 256x256 tiles split so
+// that tiles x splits is about one work item per CU move half of that and win in spite of the
+// planes (2048 x 2048 x 8192: 74 us split four ways, 89 us on 128x128 tiles, torch.matmul 74;
+// 2048 x 4096 x 8192: 120 / 140 / 137; 2048 x 2048 x 16384: 119 / 160 / 126). Below K = 6144
+// (four ways) or 8192 (two ways) the planes cost more than the traffic saved
+// (`profiles/gemm_bf16_splitk_scan.jsonl`).
 DTF_API int dtf_gemm_bf16_splits(int M, int N, int K) {
   const long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  if (tiles > 32 && tiles <= 128) {
+    if (N % 4 != 0) return 1;
+    // the most splits that still leave at most one work item per CU and divide K into whole
+    // K-tiles; worth it from 144 work items on (1280 x 2048 x 8192, 40 tiles: 54 us split four
+    // ways, 79 us unsplit)
+    for (int s = (int)(256 / tiles); s >= 2; --s) {
+      if (K % (s * BK) != 0) continue;
+      if (tiles * s >= 144 && K >= (s >= 3 ? 6144 : 8192)) return s;
+      break;
+    }
+    return 1;
+  }
   if (tiles > 32 || K < 1024) return 1;
   int splits = 1;
   while (splits < 8 && tiles * splits * 2 <= 256 && K % (splits * 2 * BK) == 0 &&

@@ -266,7 +266,11 @@ def main() -> None:
                             panels=args.panels, seed=1, device=device,
                             distribution=args.distribution, pipelined=not args.no_pipeline,
                             recompute_rows=recompute_rows, peer_transport=args.peer_transport,
-                            scaling=args.fp8_scaling)
+                            scaling=args.fp8_scaling,
+                            # candidates are compared bit for bit: every product sums K in one
+                            # sequential order whatever its shape (none of the 16384-wide panels
+                            # of the default plan would be split anyway)
+                            k_splits=1 if world > 1 else None)
         eng.init_operands()
         return eng
 

@@ -29,7 +29,7 @@ backward chains be replaced without pattern-matching their internals.
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional, Sequence, Set, Tuple
+from typing import Any, Dict, List, Optional, Sequence, Set, Tuple
 
 from ..framework import dtypes
 from ..framework.graph import Graph, Operation, Tensor
@@ -494,4 +494,49 @@ def build_rewrite(graph: Graph, ops: Sequence[Operation], fed: Set[Tensor],
         if step_fusion and not shard_plan and not stored_layouts:
             rw.step_candidate = _match_mlp_step(graph, alive, fed, fetched, rw, heads, node,
                                                 applies)
+
+    # -- optimizer rules with slots: one multi-tensor launch per (rule, constants) ------------
+    groups: Dict[Any, List[Any]] = {}
+    for op in ops:
+        if op.type == "ApplyOptimizer" and not consumers.get(op.outputs[0]) \
+                and op.outputs[0] not in fetched:
+            groups.setdefault((op.attrs["rule"], op.attrs["hyper"]), []).append(op)
+    for (rule, hyper), members in groups.items():
+        n_slots = 2 if rule in ("rmsprop", "adam") else 1
+        refs = [[t.op for t in a.inputs[:a.attrs["num_refs"]]] for a in members]
+        power_ops = refs[0][1 + n_slots:]
+        if any(r[1 + n_slots:] != power_ops for r in refs):
+            continue                          # (two Adam instances: leave their ops alone)
+        node = FusedNode(graph, "MultiApplyOptimizer", "fused_" + rule,
+                         [a.inputs[a.attrs["num_refs"]] for a in members], [],
+                         {"var_ops": [r[0] for r in refs],
+                          "slot_ops": [r[1:1 + n_slots] for r in refs],
+                          "power_ops": power_ops, "rule": rule, "hyper": hyper,
+                          "scalar_updates": []},
+                         control_inputs=[c for a in members for c in a.control_inputs],
+                         device=members[0].device)
+        for a in members:
+            rw.op_map[a] = node
+        if len(groups) > 1 or applies:
+            continue
+        # a single rule updates the whole step: the scalars that advance behind it (running
+        # powers, the step counter) ride on the node's second, one-wave launch
+        member_set = set(members)
+        tails = [op for op in ops if op.type == "AffineUpdateVariable" and op.control_inputs
+                 and set(op.control_inputs) <= member_set
+                 and not consumers.get(op.outputs[0]) and op.outputs[0] not in fetched]
+        for op in tails:
+            node.attrs["scalar_updates"].append(
+                (op.inputs[0].op, float(op.attrs["factor"]), float(op.attrs["increment"])))
+            rw.op_map[op] = node
+        done = member_set | set(tails)
+        for op in ops:
+            if (op.type == "AssignAdd" and op.inputs[1].op.type in ("Const", "Fill")
+                    and op.control_inputs and set(op.control_inputs) <= done
+                    and not consumers.get(op.outputs[0]) and op.outputs[0] not in fed
+                    and op.outputs[0] not in fetched
+                    and op.inputs[0].op.outputs[0].dtype.name == "float32"):
+                node.attrs["scalar_updates"].append(
+                    (op.inputs[0].op, 1.0, float(op.inputs[1].op.attrs["value"])))
+                rw.op_map[op] = node
     return rw

@@ -80,7 +80,8 @@ def _graph_node_types(graph) -> Optional[List[int]]:
         return None
 # ops that write a variable in place (a gather must not move across them)
 _MUTATING_OPS = frozenset(("Assign", "AssignAdd", "AssignSub", "ApplyGradientDescent",
-                           "MultiApplySGD"))
+                           "MultiApplySGD", "ApplyOptimizer", "MultiApplyOptimizer",
+                           "AffineUpdateVariable"))
 _PACK_WORDS = 256     # fp32 words of pinned staging per captured step for small fetches
 
 
@@ -743,10 +744,10 @@ class Session:
                     readers[sl] = readers.get(sl, 0) + 1
         fetched = {sl for sl in plan.fetch_slots if sl is not None} | set(plan.host_input_slots)
         for st in plan.steps:
-            if st.node.type == "MultiApplySGD":
+            if st.node.type in ("MultiApplySGD", "MultiApplyOptimizer"):
                 pairs = [(v.name, sl) for v, sl in zip(st.node.attrs["var_ops"], st.in_slots)]
-            elif st.node.type == "ApplyGradientDescent":
-                pairs = [(st.node.inputs[0].op.name, st.in_slots[1])]
+            elif st.node.type in ("ApplyGradientDescent", "ApplyOptimizer"):
+                pairs = [(st.node.inputs[0].op.name, st.in_slots[-1])]
             else:
                 continue
             for name, sl in pairs:
@@ -826,10 +827,10 @@ class Session:
         limit = int(self.config.grad_bucket_bytes or rt.bucket_bytes)
         grad_slots: List[int] = []
         for s in plan.steps:
-            if s.node.type == "MultiApplySGD":
+            if s.node.type in ("MultiApplySGD", "MultiApplyOptimizer"):
                 grad_slots.extend(sl for sl in s.in_slots if sl >= 0)
-            elif s.node.type == "ApplyGradientDescent":
-                grad_slots.append(s.in_slots[1])
+            elif s.node.type in ("ApplyGradientDescent", "ApplyOptimizer"):
+                grad_slots.append(s.in_slots[-1])
         producer = {sl: i for i, s in enumerate(plan.steps) for sl in s.out_slots}
         sized = []
         for sl in grad_slots:

@@ -148,7 +148,8 @@ DeviceLike = Union[None, str, Callable[[Operation], Optional[str]]]
 # op types that take a variable's storage as their first input and therefore run wherever
 # the variable lives (so that the SGD update executes on the parameter owner)
 REF_CONSUMER_TYPES = frozenset(
-    ["Assign", "AssignAdd", "AssignSub", "ApplyGradientDescent", "IsVariableInitialized"])
+    ["Assign", "AssignAdd", "AssignSub", "ApplyGradientDescent", "IsVariableInitialized",
+     "ApplyOptimizer", "AffineUpdateVariable"])
 # op types all of whose inputs are variable references (never evaluated as values)
 ALL_REF_INPUT_TYPES = frozenset(["ReportUninitializedVariables"])
 
@@ -159,6 +160,9 @@ def value_inputs(node):
     can run before the variable holds anything)."""
     if node.type in ALL_REF_INPUT_TYPES:
         return []
+    if node.type == "ApplyOptimizer":
+        # [variable, its slots, (running powers), gradient]: only the gradient is a value
+        return list(enumerate(node.inputs))[node.attrs["num_refs"]:]
     if node.type in REF_CONSUMER_TYPES:
         return list(enumerate(node.inputs))[1:]
     return list(enumerate(node.inputs))

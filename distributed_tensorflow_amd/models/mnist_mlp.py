@@ -28,9 +28,11 @@ NUM_PARAMS = INPUT_DIM * HIDDEN_DIM + HIDDEN_DIM + HIDDEN_DIM * NUM_CLASSES + NU
 
 
 def build_model(learning_rate: float = LEARNING_RATE, seed: Optional[int] = 1,
-                hidden: int = HIDDEN_DIM, with_summaries: bool = True) -> SimpleNamespace:
+                hidden: int = HIDDEN_DIM, with_summaries: bool = True,
+                optimizer=None) -> SimpleNamespace:
     """Build the model into the default graph (inside whatever device scope is active) and
-    return its handles."""
+    return its handles. ``optimizer``: a ``tf.train.Optimizer`` to train with instead of the
+    reference's ``GradientDescentOptimizer(learning_rate)``."""
     global_step = get_variable("global_step", [], initializer=constant_initializer(0),
                                trainable=False)
     with name_scope("input"):
@@ -51,7 +53,8 @@ def build_model(learning_rate: float = LEARNING_RATE, seed: Optional[int] = 1,
     with name_scope("cross_entropy"):
         loss = F.reduce_mean(-F.reduce_sum(y_ * F.log(y), axis=[1]))
     with name_scope("train"):
-        optimizer = GradientDescentOptimizer(learning_rate)
+        if optimizer is None:
+            optimizer = GradientDescentOptimizer(learning_rate)
         train_op = optimizer.minimize(loss, global_step=global_step)
     with name_scope("Accuracy"):
         correct = F.equal(F.argmax(y, 1), F.argmax(y_, 1))

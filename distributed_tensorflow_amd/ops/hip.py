@@ -148,6 +148,8 @@ def _declare(L: ctypes.CDLL) -> None:
         "dtf_softmax_xent_f32": [P, P, P, P, P, P, LG, LG, P],
         "dtf_softmax_grad_f32": [P, P, P, LG, LG, P],
         "dtf_multi_sgd_f32": [I, P, P, P, P, I, P, P, P],
+        "dtf_multi_optim_f32": [I, I, P, P, P, P, P, P, I, P, P, P],
+        "dtf_affine_scalars_f32": [I, P, P, P, P],
         "dtf_philox_normal": [P, LG, U, U, LG, F, F, I, P],
         "dtf_philox_uniform": [P, LG, U, U, LG, F, F, I, P],
         "dtf_reduce_partials": [I, P, P, LG, F, I, P],
@@ -1059,6 +1061,75 @@ def multi_sgd(params: Sequence[torch.Tensor], grads: Sequence[torch.Tensor],
         _check(lib().dtf_multi_sgd_f32(n, w_arr, g_arr, n_arr, lr_arr, nc, c_arr, d_arr,
                                        _stream()), "multi_sgd")
         first = False
+
+
+OPTIM_RULES = {"momentum": 0, "nesterov": 1, "adagrad": 2, "rmsprop": 3, "adam": 4}
+
+
+def multi_optim(rule: str, params: Sequence[torch.Tensor], grads: Sequence[torch.Tensor],
+                slots0: Sequence[torch.Tensor], slots1: Sequence[torch.Tensor] = (),
+                hyper: Sequence[float] = (), powers: Sequence[torch.Tensor] = ()) -> None:
+    """In-place update of every ``params[i]`` (and its state ``slots0[i]`` / ``slots1[i]``) from
+    ``grads[i]`` by one of the slot-carrying rules -- one launch per 16 tensors. ``hyper``:
+    momentum / nesterov (lr, mu); adagrad (lr,); rmsprop (lr, rho, mu, eps); adam (lr, b1, b2,
+    eps) with ``powers`` = the device scalars holding b1^t and b2^t (read, not advanced: see
+    ``affine_scalars``)."""
+    code = OPTIM_RULES.get(rule)
+    if code is None:
+        raise HipKernelError("multi_optim: unknown rule %r" % (rule,))
+    two = rule in ("rmsprop", "adam")
+    if len(params) != len(grads) or len(params) != len(slots0) or \
+            (two and len(slots1) != len(params)):
+        raise HipKernelError("multi_optim: argument lists differ in length")
+    if rule == "adam" and len(powers) != 2:
+        raise HipKernelError("multi_optim: adam needs the two power scalars")
+    want = {"momentum": 2, "nesterov": 2, "adagrad": 1, "rmsprop": 4, "adam": 4}[rule]
+    if len(hyper) != want:
+        raise HipKernelError("multi_optim: %s takes %d constants" % (rule, want))
+    grads = [g if g.is_contiguous() else g.contiguous() for g in grads]
+    for group in zip(params, grads, slots0, *([slots1] if two else [])):
+        p = group[0]
+        for t in group:
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != p.numel() \
+                    or t.device.type != "cuda":
+                raise HipKernelError("multi_optim: params, grads and slots must be matching "
+                                     "contiguous fp32 GPU tensors")
+    for t in powers:
+        if t.dtype != torch.float32 or t.numel() != 1 or t.device.type != "cuda":
+            raise HipKernelError("multi_optim: powers must be fp32 GPU scalars")
+    c = ctypes
+    h_arr = (c.c_float * max(len(hyper), 1))(*[float(x) for x in hyper])
+    pw = [t.data_ptr() for t in powers] + [None, None]
+    for start in range(0, len(params), 16):
+        sl = slice(start, start + 16)
+        ps, gs, a0 = params[sl], grads[sl], slots0[sl]
+        n = len(ps)
+        w_arr = (c.c_void_p * n)(*[t.data_ptr() for t in ps])
+        g_arr = (c.c_void_p * n)(*[t.data_ptr() for t in gs])
+        a_arr = (c.c_void_p * n)(*[t.data_ptr() for t in a0])
+        b_arr = (c.c_void_p * n)(*[t.data_ptr() for t in slots1[sl]]) if two else None
+        n_arr = (c.c_long * n)(*[t.numel() for t in ps])
+        _check(lib().dtf_multi_optim_f32(code, n, w_arr, g_arr, a_arr, b_arr, n_arr, h_arr,
+                                         len(hyper), pw[0], pw[1], _stream()), "multi_optim")
+
+
+def affine_scalars(scalars: Sequence[torch.Tensor], factors: Sequence[float],
+                   increments: Sequence[float]) -> None:
+    """``scalars[i] = scalars[i] * factors[i] + increments[i]`` for up to 8 distinct fp32 device
+    scalars in one one-wave launch (Adam's running powers, step counters)."""
+    if len(scalars) != len(factors) or len(scalars) != len(increments) or len(scalars) > 8:
+        raise HipKernelError("affine_scalars: up to 8 scalars with one factor and increment each")
+    for t in scalars:
+        if t.dtype != torch.float32 or t.numel() != 1 or t.device.type != "cuda":
+            raise HipKernelError("affine_scalars: fp32 GPU scalars")
+    if not scalars:
+        return
+    c = ctypes
+    p_arr = (c.c_void_p * len(scalars))(*[t.data_ptr() for t in scalars])
+    f_arr = (c.c_float * len(scalars))(*[float(f) for f in factors])
+    d_arr = (c.c_float * len(scalars))(*[float(d) for d in increments])
+    _check(lib().dtf_affine_scalars_f32(len(scalars), p_arr, f_arr, d_arr, _stream()),
+           "affine_scalars")
 
 
 def philox_normal(shape: Sequence[int], seed: int, op_seed: int, mean: float = 0.0,

@@ -576,6 +576,85 @@ def _multi_apply_sgd(op, inputs, ctx):
     return []
 
 
+def _optim_launch(ctx, rule, hyper, var_ops, slot_ops_list, power_ops, grads) -> list:
+    """Update every variable whose storage, slots and powers are local fp32 GPU tensors with the
+    multi-tensor kernel; returns the (var_op, slot_ops, grad) triples it could not take."""
+    powers = [_local_f32(ctx, p) for p in power_ops]
+    rest, ps, gs, s0, s1 = [], [], [], [], []
+    for var_op, slot_ops, g in zip(var_ops, slot_ops_list, grads):
+        p = _local_f32(ctx, var_op)
+        slots = [_local_f32(ctx, s) for s in slot_ops]
+        if p is None or any(t is None for t in slots + powers) or not _is_f32(g) \
+                or not g.is_cuda or g.numel() != p.numel():
+            rest.append((var_op, slot_ops, g))
+            continue
+        ps.append(p)
+        gs.append(g)
+        s0.append(slots[0])
+        if len(slots) > 1:
+            s1.append(slots[1])
+        ctx.session._store_for(var_op).update_count += 1
+    if ps:
+        hip.multi_optim(rule, ps, gs, s0, s1, hyper, powers)
+    return rest
+
+
+def _affine_launch(ctx, updates) -> None:
+    """``var = var * factor + increment`` for scalar variables: local fp32 GPU scalars in one
+    launch, anything else through its store."""
+    from .ref_kernels import affine_through_store
+    local, rest = [], []
+    for var_op, factor, increment in updates:
+        p = _local_f32(ctx, var_op)
+        if p is not None and p.numel() == 1 and len(local) < 8 \
+                and all(p.data_ptr() != q.data_ptr() for q, _, _ in local):
+            local.append((p, factor, increment))
+        else:
+            rest.append((var_op, factor, increment))
+    if local:
+        hip.affine_scalars([p for p, _, _ in local], [f for _, f, _ in local],
+                           [d for _, _, d in local])
+    for var_op, factor, increment in rest:
+        affine_through_store(ctx, var_op, factor, increment)
+
+
+@hip_kernel("ApplyOptimizer")
+def _apply_optimizer(op, inputs, ctx):
+    from .ref_kernels import _optimizer_refs, apply_rule_through_stores
+    var_op, slot_ops, power_ops = _optimizer_refs(op)
+    grad = ctx.reduce_gradients([inputs[op.attrs["num_refs"]]], [var_op])[0]
+    rest = _optim_launch(ctx, op.attrs["rule"], op.attrs["hyper"], [var_op], [slot_ops],
+                         power_ops, [grad])
+    for v, s_ops, g in rest:       # state in another process (parameter server)
+        return [apply_rule_through_stores(ctx, op.attrs["rule"], op.attrs["hyper"], v, s_ops,
+                                          power_ops, g)]
+    return [_local_f32(ctx, var_op)]
+
+
+@hip_kernel("MultiApplyOptimizer")
+def _multi_apply_optimizer(op, inputs, ctx):
+    """Every variable of the step in one launch, then one one-wave launch for the scalars that
+    advance with the step (Adam's running powers, step counters)."""
+    from .ref_kernels import apply_rule_through_stores
+    var_ops = op.attrs["var_ops"]
+    grads = ctx.reduce_gradients(list(inputs), var_ops)       # no-op without a sync runtime
+    rest = _optim_launch(ctx, op.attrs["rule"], op.attrs["hyper"], var_ops, op.attrs["slot_ops"],
+                         op.attrs["power_ops"], grads)
+    for v, s_ops, g in rest:
+        apply_rule_through_stores(ctx, op.attrs["rule"], op.attrs["hyper"], v, s_ops,
+                                  op.attrs["power_ops"], g)
+    _affine_launch(ctx, op.attrs.get("scalar_updates", []))
+    return []
+
+
+@hip_kernel("AffineUpdateVariable")
+def _affine_update_variable(op, inputs, ctx):
+    var_op = op.inputs[0].op
+    _affine_launch(ctx, [(var_op, op.attrs["factor"], op.attrs["increment"])])
+    p = _local_f32(ctx, var_op)
+    return [p if p is not None else ctx.var_read(var_op)]
+
+
 def _spans_overlap(a: torch.Tensor, b: torch.Tensor) -> bool:
     a0, b0 = a.data_ptr(), b.data_ptr()
     return a0 < b0 + b.numel() * b.element_size() and b0 < a0 + a.numel() * a.element_size()

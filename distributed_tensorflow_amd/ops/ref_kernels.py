@@ -128,6 +128,100 @@ def _apply_sgd(op, inputs, ctx):
     return [ctx.var_apply_sgd(op.inputs[0].op, op.attrs["learning_rate"], grad)]
 
 
+def optimizer_rule_step(rule: str, hyper, w, g, s0, s1=None, powers=None):
+    """One step of a slot-carrying update rule on plain tensors, in fp32 (or the variable's
+    dtype): returns ``(new w, new s0, new s1)``. The formulas are TensorFlow's
+    (``ApplyMomentum``, ``ApplyAdagrad``, ``ApplyRMSProp``, ``ApplyAdam``); the gfx950 kernel
+    (``csrc/kernels/optim.hip``) computes the same expressions with fused multiply-adds."""
+    g = g.to(w.device, w.dtype)
+    if rule in ("momentum", "nesterov"):
+        lr, mu = hyper
+        s0 = mu * s0 + g
+        w = w - lr * (g + mu * s0) if rule == "nesterov" else w - lr * s0
+    elif rule == "adagrad":
+        (lr,) = hyper
+        s0 = s0 + g * g
+        w = w - lr * g / torch.sqrt(s0)
+    elif rule == "rmsprop":
+        lr, rho, mu, eps = hyper
+        s0 = s0 + (1.0 - rho) * (g * g - s0)
+        s1 = mu * s1 + lr * g / torch.sqrt(s0 + eps)
+        w = w - s1
+    elif rule == "adam":
+        lr, b1, b2, eps = hyper
+        p1, p2 = (float(p) for p in powers)
+        lr_t = lr * math.sqrt(1.0 - p2) / (1.0 - p1)
+        s0 = s0 + (1.0 - b1) * (g - s0)
+        s1 = s1 + (1.0 - b2) * (g * g - s1)
+        w = w - lr_t * s0 / (torch.sqrt(s1) + eps)
+    else:
+        raise ValueError("unknown optimizer rule %r" % (rule,))
+    return w, s0, s1
+
+
+def apply_rule_through_stores(ctx, rule, hyper, var_op, slot_ops, power_ops, grad):
+    """The update of one variable through the variable-store interface (any store: local CPU
+    storage, a parameter-server task). State that lives in this process is assigned; state on a
+    parameter server receives the *difference* (queued with the step's other updates and added
+    on arrival), so concurrent workers' updates compose the way their plain-SGD updates do."""
+    w = ctx.var_read(var_op)
+    slots = [ctx.var_read(s) for s in slot_ops]
+    powers = [ctx.var_read(p) for p in power_ops] if power_ops else None
+    new_w, new_s0, new_s1 = optimizer_rule_step(
+        rule, hyper, w, grad, slots[0], slots[1] if len(slots) > 1 else None, powers)
+    for s_op, old, new in zip(slot_ops, slots, (new_s0, new_s1)):
+        store = ctx.session._store_for(s_op)
+        if getattr(store, "local_tensor", lambda n: None)(s_op.name) is not None:
+            ctx.var_assign(s_op, new)
+        else:
+            ctx.var_assign_add(s_op, new - old)
+    return ctx.var_apply_sgd(var_op, 1.0, w - new_w)
+
+
+def _optimizer_refs(op):
+    """(variable op, slot ops, power ops) of an ``ApplyOptimizer`` op."""
+    refs = [t.op for t in op.inputs[:op.attrs["num_refs"]]]
+    n_slots = 2 if op.attrs["rule"] in ("rmsprop", "adam") else 1
+    return refs[0], refs[1:1 + n_slots], refs[1 + n_slots:]
+
+
+@ref_kernel("ApplyOptimizer", stateful=True)
+def _apply_optimizer(op, inputs, ctx):
+    var_op, slot_ops, power_ops = _optimizer_refs(op)
+    grad = ctx.reduce_gradients([inputs[op.attrs["num_refs"]]], [var_op])[0]
+    return [apply_rule_through_stores(ctx, op.attrs["rule"], op.attrs["hyper"], var_op,
+                                      slot_ops, power_ops, grad)]
+
+
+def affine_through_store(ctx, var_op, factor: float, increment: float):
+    """``var = var * factor + increment`` through the store interface (assigned locally, shipped
+    as a difference to a parameter server)."""
+    cur = ctx.var_read(var_op)
+    new = cur * factor + increment
+    store = ctx.session._store_for(var_op)
+    if getattr(store, "local_tensor", lambda n: None)(var_op.name) is not None:
+        return ctx.var_assign(var_op, new)
+    return ctx.var_assign_add(var_op, new - cur)
+
+
+@ref_kernel("AffineUpdateVariable", stateful=True)
+def _affine_update_variable(op, inputs, ctx):
+    return [affine_through_store(ctx, op.inputs[0].op, op.attrs["factor"],
+                                 op.attrs["increment"])]
+
+
+@ref_kernel("MultiApplyOptimizer", stateful=True)
+def _multi_apply_optimizer(op, inputs, ctx):
+    var_ops = op.attrs["var_ops"]
+    grads = ctx.reduce_gradients(list(inputs), var_ops)
+    for var_op, slot_ops, g in zip(var_ops, op.attrs["slot_ops"], grads):
+        apply_rule_through_stores(ctx, op.attrs["rule"], op.attrs["hyper"], var_op, slot_ops,
+                                  op.attrs["power_ops"], g)
+    for var_op, factor, increment in op.attrs.get("scalar_updates", []):
+        affine_through_store(ctx, var_op, factor, increment)
+    return []
+
+
 @ref_kernel("IsVariableInitialized", stateful=True)
 def _is_var_init(op, inputs, ctx):
     return [torch.tensor(ctx.var_is_initialized(op.inputs[0].op))]

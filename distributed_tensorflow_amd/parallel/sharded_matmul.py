@@ -117,7 +117,8 @@ class ShardedMatmul:
                  device: Optional[torch.device] = None,
                  reduce_dtype: Optional[torch.dtype] = None, distribution: str = "uniform",
                  pipelined: bool = False, recompute_rows: int = 0,
-                 peer_transport: str = "copy", scaling: str = "tensor"):
+                 peer_transport: str = "copy", scaling: str = "tensor",
+                 k_splits: Optional[int] = None):
         if strategy not in STRATEGIES:
             raise ValueError("unknown strategy %r (choose from %s)" % (strategy, STRATEGIES))
         self.m, self.n, self.k = int(m), int(n), int(k)
@@ -125,6 +126,11 @@ class ShardedMatmul:
         self.rank, self.world = self.comm.rank, self.comm.world_size
         self.device = torch.device(device) if device is not None else self.comm.device
         self.dtype = dtype
+        # K splits of the local products: None = the kernel library's plan for each shape (small
+        # tile grids are cut along K and their fp32 partial planes summed, which changes the
+        # summation order with the shape); 1 = every product sums K in one sequential order, so
+        # a row of C has the same bits whichever panel, head block or world size computed it
+        self.k_splits = k_splits
         # fp8 operands: "tensor" = unit scales (the generated operands fit e4m3 as they are),
         # "mx" = block-scaled (one E8M0 scale per 32 k of a row, applied by the matrix
         # instruction): operands are generated in bf16 and quantised by the MX kernel
@@ -317,14 +323,15 @@ class ShardedMatmul:
             if self.scaling == "mx":
                 self._hip.gemm_fp8_mx_nt(a, bt, out.dtype, out=out, beta=beta)
             elif a.dtype == torch.bfloat16:
-                self._hip.gemm_bf16_nt(a, bt, out.dtype, out=out, beta=beta)
+                self._hip.gemm_bf16_nt(a, bt, out.dtype, out=out, beta=beta,
+                                       splits=self.k_splits)
             elif a.dtype == torch.float8_e4m3fn:
                 self._hip.gemm_fp8_nt(a, bt, out.dtype, out=out, beta=beta)
             elif a.dtype == torch.float32:
                 if accumulate:
-                    out.add_(self._hip.gemm_f32(a, bt, trans_b=True))
+                    out.add_(self._hip.gemm_f32(a, bt, trans_b=True, splits=self.k_splits))
                 else:
-                    self._hip.gemm_f32(a, bt, trans_b=True, out=out)
+                    self._hip.gemm_f32(a, bt, trans_b=True, out=out, splits=self.k_splits)
             else:
                 raise TypeError("unsupported GEMM dtype %s" % a.dtype)
         else:

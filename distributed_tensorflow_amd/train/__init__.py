@@ -4,7 +4,8 @@ checkpointing -- the ``tf.train.*`` symbols the reference scripts use
 from .cluster import ClusterDef, ClusterSpec, task_from_env  # noqa: F401
 from .device_setter import (GreedyLoadBalancingStrategy, byte_size_load_fn,  # noqa: F401
                             replica_device_setter)
-from .optimizer import GradientDescentOptimizer, Optimizer  # noqa: F401
+from .optimizer import (AdagradOptimizer, AdamOptimizer, GradientDescentOptimizer,  # noqa: F401
+                        MomentumOptimizer, Optimizer, RMSPropOptimizer)
 from .saver import (Saver, checkpoint_exists, get_checkpoint_state,  # noqa: F401
                     latest_checkpoint)
 from .server import Server, ServerDef  # noqa: F401

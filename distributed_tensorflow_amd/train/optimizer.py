@@ -1,4 +1,6 @@
-"""Optimizers: ``GradientDescentOptimizer(lr).minimize(loss, global_step=...)``.
+"""Optimizers: ``GradientDescentOptimizer(lr).minimize(loss, global_step=...)`` and the
+slot-carrying rules of the same family (``MomentumOptimizer``, ``AdagradOptimizer``,
+``RMSPropOptimizer``, ``AdamOptimizer``).
 
 Reference usage: ``tf_distributed.py:75-76``. ``minimize`` = ``compute_gradients``
 (reverse-mode autodiff) + ``apply_gradients`` (one ``ApplyGradientDescent`` per variable,
@@ -9,6 +11,13 @@ How the gradient reaches the variable depends on the session's strategy: applied
 the owner as it arrives (asynchronous parameter server -- the reference's semantics), or
 summed across workers by an RCCL all-reduce / reduce-scatter first (synchronous). The graph
 built here is the same in every case.
+
+Rules with per-variable state keep it in *slot variables* (non-trainable, colocated with their
+variable, named ``<variable>/<optimizer name>`` -- so they are placed on the parameter owner,
+initialised by ``global_variables_initializer`` and saved by ``Saver`` like any variable). One
+``ApplyOptimizer`` op per variable takes ``[variable, slots..., (running powers), gradient]``;
+the session fuses the ops of a step into one multi-tensor launch
+(``csrc/kernels/optim.hip``).
 """
 from __future__ import annotations
 
@@ -44,8 +53,10 @@ class Optimizer:
         if not grads_and_vars:
             raise ValueError("No gradients provided for any variable.")
         g = get_default_graph()
+        self._create_slots([v for _, v in grads_and_vars])
         with g.name_scope(name or self._name) as scope:
             updates = [self._apply_dense(grad, var) for grad, var in grads_and_vars]
+            updates = updates + self._finish(updates)
             if global_step is None:
                 train_op = F.group(*updates, name="update")
             else:
@@ -70,6 +81,48 @@ class Optimizer:
     def _apply_dense(self, grad: Tensor, var: Variable) -> Operation:
         raise NotImplementedError
 
+    # -- per-variable state ------------------------------------------------------------------
+    def _create_slots(self, var_list: Sequence[Variable]) -> None:
+        """Create the rule's state variables (called once per ``apply_gradients``, before the
+        update ops are built)."""
+
+    def _finish(self, updates: List[Operation]) -> List[Operation]:
+        """Ops that run after every variable's update (e.g. advancing Adam's running powers)."""
+        return []
+
+    def _slot_dict(self):
+        if not hasattr(self, "_slots"):
+            self._slots = {}
+        return self._slots
+
+    def _zeros_slot(self, var: Variable, slot_name: str, op_name: str,
+                    value: float = 0.0) -> Variable:
+        slots = self._slot_dict().setdefault(slot_name, {})
+        if var not in slots:
+            g = var.graph
+            # (named after the variable from the root scope, wherever minimize() is called)
+            with g.colocate_with(var), g.name_scope(None):
+                slots[var] = Variable(
+                    F.fill(tuple(var.shape), value, dtype=var.dtype), trainable=False,
+                    name=var.op.name + "/" + op_name)
+        return slots[var]
+
+    def get_slot(self, var: Variable, name: str) -> Optional[Variable]:
+        return self._slot_dict().get(name, {}).get(var)
+
+    def get_slot_names(self) -> List[str]:
+        return sorted(self._slot_dict())
+
+    def _apply_rule(self, rule: str, hyper: Sequence[float], var: Variable,
+                    refs: Sequence[Variable], grad: Tensor) -> Operation:
+        g = var.graph
+        ref_tensors = [var._variable] + [r._variable for r in refs]
+        return g.create_op("ApplyOptimizer", ref_tensors + [grad], [(var.dtype, var.shape)],
+                           name="update_" + var.op.name.split("/")[-1],
+                           attrs={"rule": rule, "hyper": tuple(float(h) for h in hyper),
+                                  "num_refs": len(ref_tensors),
+                                  "use_locking": self._use_locking})
+
 
 class GradientDescentOptimizer(Optimizer):
     def __init__(self, learning_rate: float, use_locking: bool = False,
@@ -83,3 +136,111 @@ class GradientDescentOptimizer(Optimizer):
                            [(var.dtype, var.shape)], name="update_" + var.op.name.split("/")[-1],
                            attrs={"learning_rate": self._learning_rate,
                                   "use_locking": self._use_locking})
+
+
+class MomentumOptimizer(Optimizer):
+    """``accum = momentum * accum + grad; var -= lr * accum`` (``use_nesterov``:
+    ``var -= lr * (grad + momentum * accum)``)."""
+
+    def __init__(self, learning_rate: float, momentum: float, use_locking: bool = False,
+                 name: str = "Momentum", use_nesterov: bool = False):
+        super().__init__(use_locking, name)
+        self._learning_rate, self._momentum = float(learning_rate), float(momentum)
+        self._use_nesterov = bool(use_nesterov)
+
+    def _create_slots(self, var_list):
+        for v in var_list:
+            self._zeros_slot(v, "momentum", self._name)
+
+    def _apply_dense(self, grad, var):
+        return self._apply_rule("nesterov" if self._use_nesterov else "momentum",
+                                (self._learning_rate, self._momentum), var,
+                                [self.get_slot(var, "momentum")], grad)
+
+
+class AdagradOptimizer(Optimizer):
+    """``accum += grad**2; var -= lr * grad / sqrt(accum)``."""
+
+    def __init__(self, learning_rate: float, initial_accumulator_value: float = 0.1,
+                 use_locking: bool = False, name: str = "Adagrad"):
+        if initial_accumulator_value <= 0.0:
+            raise ValueError("initial_accumulator_value must be positive: %s"
+                             % initial_accumulator_value)
+        super().__init__(use_locking, name)
+        self._learning_rate = float(learning_rate)
+        self._initial_accumulator_value = float(initial_accumulator_value)
+
+    def _create_slots(self, var_list):
+        for v in var_list:
+            self._zeros_slot(v, "accumulator", self._name, self._initial_accumulator_value)
+
+    def _apply_dense(self, grad, var):
+        return self._apply_rule("adagrad", (self._learning_rate,), var,
+                                [self.get_slot(var, "accumulator")], grad)
+
+
+class RMSPropOptimizer(Optimizer):
+    """``ms = decay * ms + (1 - decay) * grad**2; mom = momentum * mom + lr * grad /
+    sqrt(ms + epsilon); var -= mom`` (``ms`` starts at one, as in TensorFlow)."""
+
+    def __init__(self, learning_rate: float, decay: float = 0.9, momentum: float = 0.0,
+                 epsilon: float = 1e-10, use_locking: bool = False, centered: bool = False,
+                 name: str = "RMSProp"):
+        if centered:
+            raise NotImplementedError("centered RMSProp is not provided")
+        super().__init__(use_locking, name)
+        self._learning_rate, self._decay = float(learning_rate), float(decay)
+        self._momentum, self._epsilon = float(momentum), float(epsilon)
+
+    def _create_slots(self, var_list):
+        for v in var_list:
+            self._zeros_slot(v, "rms", self._name, 1.0)
+            self._zeros_slot(v, "momentum", self._name + "_1")
+
+    def _apply_dense(self, grad, var):
+        return self._apply_rule(
+            "rmsprop", (self._learning_rate, self._decay, self._momentum, self._epsilon), var,
+            [self.get_slot(var, "rms"), self.get_slot(var, "momentum")], grad)
+
+
+class AdamOptimizer(Optimizer):
+    """``m += (1 - beta1) * (grad - m); v += (1 - beta2) * (grad**2 - v);
+    var -= lr * sqrt(1 - beta2**t) / (1 - beta1**t) * m / (sqrt(v) + epsilon)``. ``beta1**t``
+    and ``beta2**t`` are two scalar variables (``beta1_power``, ``beta2_power``) colocated with
+    the first variable and advanced once per step after every update."""
+
+    def __init__(self, learning_rate: float = 0.001, beta1: float = 0.9, beta2: float = 0.999,
+                 epsilon: float = 1e-8, use_locking: bool = False, name: str = "Adam"):
+        super().__init__(use_locking, name)
+        self._learning_rate, self._epsilon = float(learning_rate), float(epsilon)
+        self._beta1, self._beta2 = float(beta1), float(beta2)
+        self._powers: Optional[Tuple[Variable, Variable]] = None
+
+    def _create_slots(self, var_list):
+        if self._powers is None:
+            first = min(var_list, key=lambda v: v.name)
+            with first.graph.colocate_with(first), first.graph.name_scope(None):
+                self._powers = (
+                    Variable(F.fill((), self._beta1, dtype=first.dtype), trainable=False,
+                             name="beta1_power"),
+                    Variable(F.fill((), self._beta2, dtype=first.dtype), trainable=False,
+                             name="beta2_power"))
+        for v in var_list:
+            self._zeros_slot(v, "m", self._name)
+            self._zeros_slot(v, "v", self._name + "_1")
+
+    def _apply_dense(self, grad, var):
+        return self._apply_rule(
+            "adam", (self._learning_rate, self._beta1, self._beta2, self._epsilon), var,
+            [self.get_slot(var, "m"), self.get_slot(var, "v"), *self._powers], grad)
+
+    def _finish(self, updates):
+        g = get_default_graph()
+        out = []
+        with g.control_dependencies(updates):
+            for power, beta in zip(self._powers, (self._beta1, self._beta2)):
+                out.append(g.create_op(
+                    "AffineUpdateVariable", [power._variable], [(power.dtype, power.shape)],
+                    name="advance_" + power.op.name.split("/")[-1],
+                    attrs={"factor": beta, "increment": 0.0}))
+        return out

@@ -1094,3 +1094,19 @@ def test_mx_fp8_is_more_accurate_than_per_tensor_fp8_when_blocks_differ_in_magni
     # and the whole product is no worse
     e_mx, e_pt, _ = errors(a)
     assert float(e_mx) <= float(e_pt) * 1.05
+
+
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
+def test_gemm_bf16_unsplit_rows_have_shape_independent_bits(hip, out_dtype):
+    """With ``splits=1`` a row of the product has the same bits whichever tile plan its shape
+    selects (256x256 persistent kernel for >128 tiles and for <=32 tiles, 128x128 tiles in
+    between): what the recompute candidates of the sharded product rely on when their rows are
+    compared with the rows an owner computed as part of a larger block."""
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(4096, 2048, generator=g).cuda().bfloat16()
+    bt = torch.randn(4096, 2048, generator=g).cuda().bfloat16()
+    full = hip.gemm_bf16_nt(a, bt, out_dtype, splits=1)                  # 256 tiles
+    mid = hip.gemm_bf16_nt(a[1024:2048], bt, out_dtype, splits=1)        # 64 tiles of 256x256
+    small = hip.gemm_bf16_nt(a[:512], bt, out_dtype, splits=1)           # 32 tiles
+    assert torch.equal(full[1024:2048], mid)
+    assert torch.equal(full[:512], small)

@@ -1,0 +1,353 @@
+"""Slot-carrying optimizers (momentum, Adagrad, RMSProp, Adam): update rules against
+``torch.optim`` / a NumPy transcription of TensorFlow's formulas, slot placement and naming,
+checkpointing of the state, fused vs per-variable execution, parameter-server and collective
+jobs. The reference itself only uses plain SGD (``tf_distributed.py:75``); these are the other
+members of the ``tf.train`` optimizer family a user of that API reaches for next."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+import distributed_tensorflow_amd as tf
+from distributed_tensorflow_amd.models import mnist_mlp
+from distributed_tensorflow_amd.parallel.comm import LoopbackComm
+
+STEPS = 6
+
+
+def _problem():
+    rng = np.random.RandomState(0)
+    return rng.randn(16, 8).astype(np.float32), rng.randn(16, 3).astype(np.float32)
+
+
+def _train(make_opt, device="cpu", fusion=True, steps=STEPS):
+    bx, by = _problem()
+    g = tf.Graph()
+    with g.as_default():
+        tf.set_random_seed(1)
+        x = tf.placeholder(tf.float32, [None, 8])
+        y = tf.placeholder(tf.float32, [None, 3])
+        w = tf.Variable(tf.random_normal([8, 3]), name="W")
+        b = tf.Variable(tf.zeros([3]), name="b")
+        loss = tf.reduce_mean(tf.reduce_sum(tf.square(tf.subtract(tf.add(tf.matmul(x, w), b), y)), 1))
+        gs = tf.train.get_or_create_global_step()
+        opt = make_opt()
+        train = opt.minimize(loss, global_step=gs)
+        init = tf.global_variables_initializer()
+        with tf.Session(config=tf.ConfigProto(device=device, graph_fusion=fusion)) as sess:
+            sess.run(init)
+            w0, b0 = sess.run([w, b])
+            losses = [float(sess.run([train, loss], {x: bx, y: by})[1]) for _ in range(steps)]
+            types = {s.node.type for p in sess._plans.values() for s in p.steps}
+            out = dict(w0=w0, b0=b0, w=sess.run(w), b=sess.run(b), losses=losses,
+                       step=float(sess.run(gs)), types=types,
+                       names=sorted(v.op.name for v in tf.global_variables()),
+                       slots={n: sess.run(opt.get_slot(w, n)) for n in opt.get_slot_names()})
+    return out
+
+
+def _numpy_rule(rule, hyper, w, b, steps=STEPS):
+    """TensorFlow's update formulas in float64 on the quadratic problem of ``_train``."""
+    bx, by = _problem()
+    params = [w.astype(np.float64), b.astype(np.float64)]
+    s0 = [np.full_like(p, {"adagrad": 0.1, "rmsprop": 1.0}.get(rule, 0.0)) for p in params]
+    s1 = [np.zeros_like(p) for p in params]
+    for t in range(1, steps + 1):
+        z = bx @ params[0] + params[1]
+        dz = 2.0 * (z - by) / bx.shape[0]
+        grads = [bx.T @ dz, dz.sum(0)]
+        for i, g in enumerate(grads):
+            if rule in ("momentum", "nesterov"):
+                lr, mu = hyper
+                s0[i] = mu * s0[i] + g
+                params[i] -= lr * (g + mu * s0[i]) if rule == "nesterov" else lr * s0[i]
+            elif rule == "adagrad":
+                s0[i] += g * g
+                params[i] -= hyper[0] * g / np.sqrt(s0[i])
+            elif rule == "rmsprop":
+                lr, rho, mu, eps = hyper
+                s0[i] = rho * s0[i] + (1 - rho) * g * g
+                s1[i] = mu * s1[i] + lr * g / np.sqrt(s0[i] + eps)
+                params[i] -= s1[i]
+            else:
+                lr, b1, b2, eps = hyper
+                s0[i] = b1 * s0[i] + (1 - b1) * g
+                s1[i] = b2 * s1[i] + (1 - b2) * g * g
+                params[i] -= lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t) * s0[i] / (np.sqrt(s1[i]) + eps)
+    return params
+
+
+CASES = [
+    ("momentum", (0.01, 0.9), lambda: tf.train.MomentumOptimizer(0.01, 0.9)),
+    ("nesterov", (0.01, 0.9), lambda: tf.train.MomentumOptimizer(0.01, 0.9, use_nesterov=True)),
+    ("adagrad", (0.1,), lambda: tf.train.AdagradOptimizer(0.1)),
+    ("rmsprop", (0.01, 0.9, 0.5, 1e-10), lambda: tf.train.RMSPropOptimizer(0.01, momentum=0.5)),
+    ("adam", (0.01, 0.9, 0.999, 1e-8), lambda: tf.train.AdamOptimizer(0.01)),
+]
+
+
+@pytest.mark.parametrize("rule,hyper,make", CASES, ids=[c[0] for c in CASES])
+def test_rules_match_the_published_formulas_fused_and_unfused(rule, hyper, make):
+    fused = _train(make)
+    plain = _train(make, fusion=False)
+    assert "MultiApplyOptimizer" in fused["types"] and "ApplyOptimizer" not in fused["types"]
+    assert "ApplyOptimizer" in plain["types"]
+    ref_w, ref_b = _numpy_rule(rule, hyper, fused["w0"], fused["b0"])
+    for run in (fused, plain):
+        assert np.allclose(run["w"], ref_w, rtol=2e-5, atol=2e-6)
+        assert np.allclose(run["b"], ref_b, rtol=2e-5, atol=2e-6)
+        assert run["step"] == STEPS
+        assert run["losses"][-1] < run["losses"][0]
+    assert np.allclose(fused["w"], plain["w"], rtol=1e-6, atol=1e-7)
+
+
+def test_adam_and_momentum_agree_with_torch_optim():
+    for make, make_torch in (
+            (lambda: tf.train.AdamOptimizer(0.01), lambda p: torch.optim.Adam(p, lr=0.01)),
+            (lambda: tf.train.MomentumOptimizer(0.01, 0.9),
+             lambda p: torch.optim.SGD(p, lr=0.01, momentum=0.9))):
+        run = _train(make)
+        bx, by = (torch.tensor(a) for a in _problem())
+        w = torch.tensor(run["w0"], requires_grad=True)
+        b = torch.tensor(run["b0"], requires_grad=True)
+        opt = make_torch([w, b])
+        for _ in range(STEPS):
+            opt.zero_grad()
+            ((bx @ w + b - by) ** 2).sum(1).mean().backward()
+            opt.step()
+        assert np.allclose(run["w"], w.detach().numpy(), rtol=1e-5, atol=2e-6)
+        assert np.allclose(run["b"], b.detach().numpy(), rtol=1e-5, atol=2e-6)
+
+
+def test_slots_are_named_after_and_placed_with_their_variable():
+    cluster = tf.train.ClusterSpec({"ps": ["h:1", "h:2"], "worker": ["h:3"]})
+    g = tf.Graph()
+    with g.as_default():
+        with tf.device(tf.train.replica_device_setter(worker_device="/job:worker/task:0",
+                                                      cluster=cluster)):
+            with tf.name_scope("model"):
+                w = tf.Variable(tf.zeros([4, 2]), name="W")
+                b = tf.Variable(tf.zeros([2]), name="b")
+            x = tf.placeholder(tf.float32, [None, 4])
+            loss = tf.reduce_mean(tf.square(tf.add(tf.matmul(x, w), b)))
+            with tf.name_scope("train"):
+                opt = tf.train.AdamOptimizer()
+                train = opt.minimize(loss)
+        assert {w.device, b.device} == {"/job:ps/task:0", "/job:ps/task:1"}
+        for v in (w, b):
+            for slot in ("m", "v"):
+                s = opt.get_slot(v, slot)
+                assert s.device == v.device and not s.trainable
+                assert s.op.name.startswith(v.op.name + "/Adam")
+        assert opt.get_slot_names() == ["m", "v"]
+        names = {v.op.name for v in tf.global_variables()}
+        assert {"beta1_power", "beta2_power", "model/W/Adam", "model/W/Adam_1"} <= names
+        assert tf.trainable_variables() == [w, b]
+        # every update runs where its variable lives (the parameter owner)
+        for op in g.get_operations():
+            if op.type == "ApplyOptimizer":
+                assert op.device == op.inputs[0].op.device
+        assert train.type in ("NoOp", "Group") or train.control_inputs or True
+
+
+def test_optimizer_state_is_checkpointed(tmp_path):
+    def build():
+        tf.set_random_seed(3)
+        w = tf.Variable(tf.random_normal([4, 2]), name="W")
+        x = tf.placeholder(tf.float32, [None, 4])
+        loss = tf.reduce_mean(tf.square(tf.matmul(x, w)))
+        opt = tf.train.AdamOptimizer(0.05)
+        return w, x, loss, opt, opt.minimize(loss), tf.train.Saver()
+
+    bx = np.random.RandomState(1).randn(8, 4).astype(np.float32)
+    with tf.Graph().as_default():
+        w, x, loss, opt, train, saver = build()
+        with tf.Session(config=tf.ConfigProto(device="cpu")) as sess:
+            sess.run(tf.global_variables_initializer())
+            for _ in range(3):
+                sess.run(train, {x: bx})
+            path = saver.save(sess, str(tmp_path / "model"))
+            for _ in range(2):
+                sess.run(train, {x: bx})
+            want = sess.run(w)
+    with tf.Graph().as_default():
+        w, x, loss, opt, train, saver = build()
+        with tf.Session(config=tf.ConfigProto(device="cpu")) as sess:
+            saver.restore(sess, path)
+            assert np.isclose(float(sess.run(opt._powers[0])), 0.9 ** 4)   # three steps taken
+            assert np.abs(sess.run(opt.get_slot(w, "m"))).max() > 0
+            for _ in range(2):
+                sess.run(train, {x: bx})
+            assert np.allclose(sess.run(w), want, rtol=1e-6, atol=1e-7)
+
+
+def _mlp_job(cluster, task, steps, results, make_opt, protocol="grpc", comm=None, strategy=None):
+    g = tf.Graph()
+    with g.as_default():
+        config = tf.ConfigProto(device="cpu", strategy=strategy)
+        server = tf.train.Server(cluster, job_name="worker", task_index=task, protocol=protocol,
+                                 config=config, comm=comm)
+        with tf.device(tf.train.replica_device_setter(
+                worker_device="/job:worker/task:%d" % task, cluster=cluster)):
+            m = mnist_mlp.build_model(seed=1, optimizer=make_opt(), with_summaries=False)
+        sv = tf.train.Supervisor(is_chief=(task == 0), global_step=m.global_step,
+                                 init_op=m.init_op, logdir=None, recovery_wait_secs=0.05,
+                                 summary_op=None)
+        from distributed_tensorflow_amd.data.mnist import synthetic_mnist
+        images, labels = synthetic_mnist(400, seed=task)
+        onehot = np.eye(10, dtype=np.float32)[labels]
+        rng = np.random.RandomState(7 + task)
+        costs = []
+        with sv.prepare_or_wait_for_session(server.target, config=config) as sess:
+            for _ in range(steps):
+                idx = rng.randint(0, 400, 50)
+                costs.append(float(sess.run([m.train_op, m.loss],
+                                            {m.x: images[idx], m.y_: onehot[idx]})[1]))
+            slot = m.optimizer.get_slot(m.w1, m.optimizer.get_slot_names()[0])
+            final = {"w1": sess.run(m.w1), "m": sess.run(slot),
+                     "step": float(sess.run(m.global_step))}
+            if hasattr(m.optimizer, "_powers"):
+                final["p1"] = float(sess.run(m.optimizer._powers[0]))
+        sv.stop()
+        results[task] = dict(costs=costs, final=final, runtime=server.runtime,
+                             slot_device=slot.device)
+        server.stop()
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _cluster(workers):
+    return tf.train.ClusterSpec({"ps": ["127.0.0.1:%d" % _free_port()],
+                                 "worker": ["127.0.0.1:%d" % _free_port() for _ in range(workers)]})
+
+
+@pytest.mark.parametrize("strategy", ["allreduce_sync", "reduce_scatter_sync"])
+def test_adam_under_the_collective_strategies_keeps_replicas_identical(strategy):
+    world, steps = 2, 12
+    cluster = _cluster(world)
+    comms = LoopbackComm.create_world(world, timeout_s=30)
+    results = {}
+    threads = [threading.Thread(target=_mlp_job, args=(cluster, t, steps, results,
+                                                       lambda: tf.train.AdamOptimizer(0.01)),
+                                kwargs=dict(protocol="rccl", comm=comms[t], strategy=strategy))
+               for t in range(world)]
+    [t.start() for t in threads]
+    [t.join(120) for t in threads]
+    assert set(results) == {0, 1}
+    a, b = results[0]["final"], results[1]["final"]
+    assert np.array_equal(a["w1"], b["w1"]) and np.array_equal(a["m"], b["m"])      # bitwise
+    assert a["step"] == b["step"] == steps
+    assert np.isclose(a["p1"], 0.9 ** (steps + 1))
+    assert results[0]["costs"] != results[1]["costs"]
+    assert np.mean(results[0]["costs"][-3:]) < np.mean(results[0]["costs"][:3])
+    assert results[0]["runtime"].bytes_reduced > 0
+
+
+def test_momentum_on_a_parameter_server_keeps_its_state_on_the_ps():
+    cluster = _cluster(2)
+    ps = tf.train.Server(cluster, job_name="ps", task_index=0)
+    results = {}
+    threads = [threading.Thread(target=_mlp_job, args=(
+        cluster, t, 15, results, lambda: tf.train.MomentumOptimizer(0.001, 0.9)))
+        for t in (1, 0)]
+    [t.start() for t in threads]
+    [t.join(120) for t in threads]
+    assert set(results) == {0, 1}
+    store = ps.runtime.local_store
+    assert "weights/Variable/Momentum" in store.names()
+    assert results[0]["slot_device"] == "/job:ps/task:0"
+    assert store.read("global_step").item() == 30.0
+    assert float(store.read("weights/Variable/Momentum").abs().max()) > 0
+    assert results[0]["runtime"].local_store.names() == []
+    for t in (0, 1):
+        assert np.mean(results[t]["costs"][-3:]) < np.mean(results[t]["costs"][:3])
+    ps.stop()
+
+
+# -- gfx950 kernels (run on the MI355X box) -------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("rule,hyper", [(c[0], c[1]) for c in CASES], ids=[c[0] for c in CASES])
+def test_multi_optim_kernel_against_fp64(rule, hyper):
+    from distributed_tensorflow_amd.ops import hip
+    from distributed_tensorflow_amd.ops.ref_kernels import optimizer_rule_step
+    g = torch.Generator().manual_seed(3)
+    sizes = [78400, 100, 1000, 10, 1, 4099]           # the reference MLP's tensors + odd sizes
+    two = rule in ("rmsprop", "adam")
+    backing = [torch.randn(n + 3, generator=g).cuda() for n in sizes]
+    params = [t[(i % 2):(i % 2) + n] for i, (t, n) in enumerate(zip(backing, sizes))]   # odd starts
+    grads = [torch.randn(n, generator=g).cuda() for n in sizes]
+    s0 = [torch.rand(n, generator=g).cuda() + 0.1 for n in sizes]
+    s1 = [torch.rand(n, generator=g).cuda() for n in sizes] if two else []
+    powers = [torch.tensor(0.9 ** 3).cuda(), torch.tensor(0.999 ** 3).cuda()] \
+        if rule == "adam" else []
+    want = [optimizer_rule_step(rule, hyper, p.double(), gr.double(), a.double(),
+                                s1[i].double() if two else None,
+                                [pw.double() for pw in powers] or None)
+            for i, (p, gr, a) in enumerate(zip(params, grads, s0))]
+    guard = [t.clone() for t in backing]
+    hip.multi_optim(rule, params, grads, s0, s1, hyper, powers)
+    torch.cuda.synchronize()
+    for i, (p, a) in enumerate(zip(params, s0)):
+        w_ref, a_ref, b_ref = want[i]
+        assert torch.allclose(p.double(), w_ref, rtol=2e-6, atol=2e-6), (rule, i)
+        assert torch.allclose(a.double(), a_ref, rtol=2e-6, atol=1e-7), (rule, i)
+        if two:
+            assert torch.allclose(s1[i].double(), b_ref, rtol=2e-6, atol=1e-7), (rule, i)
+        # nothing outside the tensor's span was written
+        off, n = i % 2, sizes[i]
+        assert torch.equal(backing[i][:off], guard[i][:off])
+        assert torch.equal(backing[i][off + n:], guard[i][off + n:])
+    if powers:
+        assert float(powers[0]) == pytest.approx(0.9 ** 3)              # read, not advanced
+    # more than 16 tensors: several launches
+    many = [torch.ones(5).cuda() for _ in range(19)]
+    hip.multi_optim("momentum", many, [torch.ones(5).cuda() for _ in many],
+                    [torch.zeros(5).cuda() for _ in many], (), (0.5, 0.0))
+    assert all(torch.equal(t, torch.full((5,), 0.5).cuda()) for t in many)
+
+
+@pytest.mark.gpu
+def test_affine_scalars_kernel():
+    from distributed_tensorflow_amd.ops import hip
+    a, b, c = (torch.tensor(v).cuda() for v in (0.9, 0.999, 41.0))
+    hip.affine_scalars([a, b, c], [0.9, 0.999, 1.0], [0.0, 0.0, 1.0])
+    assert float(a) == pytest.approx(0.81) and float(b) == pytest.approx(0.998001)
+    assert float(c) == 42.0
+    with pytest.raises(hip.HipKernelError):
+        hip.affine_scalars([a, a], [1.0, 1.0], [0.0, 0.0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rule,hyper,make", CASES, ids=[c[0] for c in CASES])
+def test_gpu_session_runs_the_rules_natively_and_captured(rule, hyper, make):
+    run = _train(make, device="cuda:0", steps=STEPS)
+    ref_w, ref_b = _numpy_rule(rule, hyper, run["w0"], run["b0"])
+    assert np.allclose(run["w"], ref_w, rtol=5e-5, atol=5e-6)
+    assert np.allclose(run["b"], ref_b, rtol=5e-5, atol=5e-6)
+    assert run["step"] == STEPS and "MultiApplyOptimizer" in run["types"]
+
+
+@pytest.mark.gpu
+def test_gpu_mnist_with_adam_is_captured_without_torch_kernels():
+    g = tf.Graph()
+    with g.as_default():
+        m = mnist_mlp.build_model(seed=1, optimizer=tf.train.AdamOptimizer(0.01),
+                                  with_summaries=False)
+        rng = np.random.RandomState(0)
+        bx = rng.rand(100, 784).astype(np.float32)
+        by = np.eye(10, dtype=np.float32)[rng.randint(0, 10, 100)]
+        with tf.Session(config=tf.ConfigProto(device="cuda:0")) as sess:
+            sess.run(m.init_op)
+            costs = [float(sess.run([m.train_op, m.loss], {m.x: bx, m.y_: by})[1])
+                     for _ in range(30)]
+            assert costs[-1] < 0.5 * costs[0], costs
+            assert sess.stats["graph_replays"] >= 20
+            assert sess.stats["torch_fallbacks"] == 0 and not sess.fallback_log
+            assert float(sess.run(m.global_step)) == 30.0
+            assert float(sess.run(m.optimizer._powers[0])) == pytest.approx(0.9 ** 31, rel=1e-4)

@@ -39,8 +39,9 @@ struct OptArgs {
   int num_tensors;
 };
 
-// One element. h: momentum {lr, mu}; adagrad {lr}; rmsprop {lr, rho, mu, eps};
-// adam {lr_t (bias-corrected), b1, b2, eps}.
+// One element. h: momentum {lr, mu}; adagrad {lr}; rmsprop {lr, rho, mu, eps, 1 - rho};
+// adam {lr_t (bias-corrected), b1, b2, eps, 1 - b1, 1 - b2}. The complements arrive from the host,
+// rounded once from double (1.f - 0.999f is off by 5e-5 of its value).
 template <int RULE>
 __device__ __forceinline__ void update(float& w, float g, float& s0, float& s1, const float* h) {
   if (RULE == MOMENTUM || RULE == NESTEROV) {
@@ -51,12 +52,12 @@ __device__ __forceinline__ void update(float& w, float g, float& s0, float& s1, 
     s0 = __builtin_fmaf(g, g, s0);
     w = __builtin_fmaf(-h[0], g / __builtin_sqrtf(s0), w);
   } else if (RULE == RMSPROP) {
-    s0 = __builtin_fmaf(1.f - h[1], __builtin_fmaf(g, g, -s0), s0);
+    s0 = __builtin_fmaf(h[4], __builtin_fmaf(g, g, -s0), s0);
     s1 = __builtin_fmaf(h[2], s1, h[0] * g / __builtin_sqrtf(s0 + h[3]));
     w -= s1;
   } else {
-    s0 = __builtin_fmaf(1.f - h[1], g - s0, s0);
-    s1 = __builtin_fmaf(1.f - h[2], __builtin_fmaf(g, g, -s1), s1);
+    s0 = __builtin_fmaf(h[4], g - s0, s0);
+    s1 = __builtin_fmaf(h[5], __builtin_fmaf(g, g, -s1), s1);
     w = __builtin_fmaf(-h[0], s0 / (__builtin_sqrtf(s1) + h[3]), w);
   }
 }
@@ -66,7 +67,7 @@ template <int RULE>
 __global__ __launch_bounds__(BLOCK) void multi_optim_kernel(OptArgs args) {
   const OptTensor t = args.t[blockIdx.y];
   constexpr bool TWO = RULE == RMSPROP || RULE == ADAM;
-  float h[4] = {args.h[0], args.h[1], args.h[2], args.h[3]};
+  float h[6] = {args.h[0], args.h[1], args.h[2], args.h[3], args.h[4], args.h[5]};
   if (RULE == ADAM) {
     // bias correction from the running powers (read only: the launch behind this one advances them)
     const float p1 = args.pw0[0], p2 = args.pw1[0];
@@ -131,7 +132,8 @@ int grid_x(long n) {
 
 // In-place update of `count` (<= 16) fp32 tensors by `rule` (0 momentum, 1 Nesterov momentum,
 // 2 Adagrad, 3 RMSProp, 4 Adam). s0 / s1: the rule's per-element state (s1 only for RMSProp and
-// Adam); hyper: the rule's constants in the order documented at update(); pw0 / pw1: device
+// Adam); hyper: the rule's constants in the order documented at update() (complements
+// included); pw0 / pw1: device
 // scalars holding b1^t and b2^t (Adam only; not modified here).
 DTF_API int dtf_multi_optim_f32(int rule, int count, float* const* w, const float* const* g,
                                 float* const* s0, float* const* s1, const long* n,

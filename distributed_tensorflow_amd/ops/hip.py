@@ -1098,7 +1098,12 @@ def multi_optim(rule: str, params: Sequence[torch.Tensor], grads: Sequence[torch
         if t.dtype != torch.float32 or t.numel() != 1 or t.device.type != "cuda":
             raise HipKernelError("multi_optim: powers must be fp32 GPU scalars")
     c = ctypes
-    h_arr = (c.c_float * max(len(hyper), 1))(*[float(x) for x in hyper])
+    hyper = [float(x) for x in hyper]
+    if rule == "rmsprop":
+        hyper.append(1.0 - hyper[1])              # complements rounded once, from double
+    elif rule == "adam":
+        hyper += [1.0 - hyper[1], 1.0 - hyper[2]]
+    h_arr = (c.c_float * max(len(hyper), 1))(*hyper)
     pw = [t.data_ptr() for t in powers] + [None, None]
     for start in range(0, len(params), 16):
         sl = slice(start, start + 16)

@@ -34,10 +34,12 @@ def _sync(device: str) -> None:
 
 def bench_mnist(device: str, steps: int, warmup: int, hip_graphs: bool, fusion: bool,
                 batch: int = 100, device_data: bool = False, step_fusion: bool = True,
-                deferred: bool = False) -> dict:
+                deferred: bool = False, optimizer: str = "sgd") -> dict:
     g = tf.Graph()
     with g.as_default():
-        model = mnist_mlp.build_model(seed=1)
+        opt = {"sgd": None, "momentum": lambda: tf.train.MomentumOptimizer(0.0005, 0.9),
+               "adam": lambda: tf.train.AdamOptimizer(0.001)}[optimizer]
+        model = mnist_mlp.build_model(seed=1, optimizer=opt() if opt else None)
         rng = np.random.RandomState(0)
         batches = [(rng.rand(batch, 784).astype(np.float32),
                     np.eye(10, dtype=np.float32)[rng.randint(0, 10, batch)]) for _ in range(16)]
@@ -80,7 +82,7 @@ def bench_mnist(device: str, steps: int, warmup: int, hip_graphs: bool, fusion: 
     return {"bench": "mnist_mlp_train_step", "device": device, "batch": batch,
             "hip_graphs": hip_graphs, "fusion": fusion, "device_data": device_data,
             "step_fusion": bool(step_fusion and fusion and device.startswith("cuda")),
-            "deferred_fetches": deferred,
+            "deferred_fetches": deferred, "optimizer": optimizer,
             "ms_per_step": round(train_ms, 4),
             "steps_per_s": round(1e3 / train_ms, 1), "eval_10k_ms": round(eval_ms, 3),
             "final_cost": final_cost, "global_step": float(out[3]), "accuracy": float(acc),
@@ -128,6 +130,9 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--which", default="mnist,matmul")
     ap.add_argument("--out", default="")
+    ap.add_argument("--optimizers", default="sgd",
+                    help="comma-separated: sgd (the reference's), momentum, adam -- the rules "
+                         "with slots run on the captured rows (HIP graphs + device data) only")
     ap.add_argument("--rows", default="", help="comma-separated indices of the mnist "
                     "configurations to run (default: all)")
     args = ap.parse_args()
@@ -143,9 +148,13 @@ def main() -> None:
                 continue
             if only and idx not in only:
                 continue
-            rows.append(bench_mnist(args.device, args.steps, args.warmup, graphs, fusion,
-                                    device_data=dev_data, step_fusion=step, deferred=deferred))
-            print(json.dumps(rows[-1]), flush=True)
+            for opt in args.optimizers.split(","):
+                if opt != "sgd" and not (graphs and dev_data and step):
+                    continue
+                rows.append(bench_mnist(args.device, args.steps, args.warmup, graphs, fusion,
+                                        device_data=dev_data, step_fusion=step,
+                                        deferred=deferred, optimizer=opt))
+                print(json.dumps(rows[-1]), flush=True)
     if "matmul" in args.which:
         cases = ((True, True), (True, False), (False, False)) if args.device.startswith("cuda") \
             else ((False, False),)

@@ -51,6 +51,22 @@ learning_rate = 0.0005
 logs_path = "/tmp/mnist/1"
 
 
+def make_optimizer(name: str, lr: float):
+    """The optimizer named on the command line; ``None`` = the reference's
+    ``GradientDescentOptimizer(learning_rate)`` (built by the model itself)."""
+    if name == "sgd":
+        return None
+    if name in ("momentum", "nesterov"):
+        return tf.train.MomentumOptimizer(lr, 0.9, use_nesterov=(name == "nesterov"))
+    if name == "adagrad":
+        return tf.train.AdagradOptimizer(lr * 20)
+    if name == "rmsprop":
+        return tf.train.RMSPropOptimizer(lr)
+    if name == "adam":
+        return tf.train.AdamOptimizer(lr * 2)
+    raise ValueError("unknown --optimizer %r" % name)
+
+
 def define_flags(default_job=DEFAULT_JOB, default_epochs=DEFAULT_EPOCHS):
     tf.app.flags.define_cluster_flags(default_job)
     tf.app.flags.DEFINE_string("protocol", "grpc", "grpc (async parameter server) | rccl")
@@ -64,6 +80,8 @@ def define_flags(default_job=DEFAULT_JOB, default_epochs=DEFAULT_EPOCHS):
     tf.app.flags.DEFINE_string("checkpoint_dir", "", "Supervisor logdir (enables checkpoints)")
     tf.app.flags.DEFINE_boolean("shutdown_ps", False, "report completion so the ps exits once all workers are done")
     tf.app.flags.DEFINE_string("device", "", "torch device of this task (default: auto)")
+    tf.app.flags.DEFINE_string("optimizer", "sgd", "sgd (the reference's plain gradient descent) | "
+                               "momentum | nesterov | adagrad | rmsprop | adam")
     tf.app.flags.DEFINE_boolean("capture_collectives", False, "rccl: record the step's RCCL calls "
                                 "into the HIP graph together with its kernels")
     tf.app.flags.DEFINE_boolean("device_data", True, "keep the data set resident in GPU memory "
@@ -110,7 +128,8 @@ def main(argv=None, default_num_workers=DEFAULT_NUM_WORKERS):
     # Between-graph replication
     with tf.device(tf.train.replica_device_setter(
             worker_device="/job:worker/task:%d" % FLAGS.task_index, cluster=cluster)):
-        model = mnist_mlp.build_model(learning_rate=learning_rate, seed=1)
+        model = mnist_mlp.build_model(learning_rate=learning_rate, seed=1,
+                                      optimizer=make_optimizer(FLAGS.optimizer, learning_rate))
         print("Variables initialized ...")
 
     sv = tf.train.Supervisor(is_chief=(FLAGS.task_index == 0), global_step=model.global_step,

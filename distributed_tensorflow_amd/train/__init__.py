@@ -5,10 +5,17 @@ from .cluster import ClusterDef, ClusterSpec, task_from_env  # noqa: F401
 from .device_setter import (GreedyLoadBalancingStrategy, byte_size_load_fn,  # noqa: F401
                             replica_device_setter)
 from .optimizer import (AdagradOptimizer, AdamOptimizer, GradientDescentOptimizer,  # noqa: F401
-                        MomentumOptimizer, Optimizer, RMSPropOptimizer)
+                        MomentumOptimizer, Optimizer, RMSPropOptimizer,
+                        SyncReplicasOptimizer)
 from .saver import (Saver, checkpoint_exists, get_checkpoint_state,  # noqa: F401
                     latest_checkpoint)
 from .server import Server, ServerDef  # noqa: F401
 from .supervisor import Coordinator, SessionManager, Supervisor  # noqa: F401
 from .training_util import (create_global_step, get_global_step,  # noqa: F401
                             get_or_create_global_step)
+from .monitored_session import (CheckpointSaverHook, ChiefSessionCreator, FinalOpsHook,  # noqa: F401,E402
+                                LoggingTensorHook, MonitoredSession, MonitoredTrainingSession,
+                                NanLossDuringTrainingError, NanTensorHook, Scaffold,
+                                SessionRunArgs, SessionRunContext, SessionRunHook,
+                                SessionRunValues, StepCounterHook, StopAtStepHook,
+                                SummarySaverHook, WorkerSessionCreator)

@@ -244,3 +244,74 @@ class AdamOptimizer(Optimizer):
                     name="advance_" + power.op.name.split("/")[-1],
                     attrs={"factor": beta, "increment": 0.0}))
         return out
+
+
+class SyncReplicasOptimizer(Optimizer):
+    """Synchronous between-graph training: every step applies the MEAN of the replicas'
+    gradients once, and ``global_step`` advances by one per step.
+
+    TensorFlow implements this on top of the asynchronous parameter server with gradient
+    accumulators and a token queue. Here the synchronous strategies (``allreduce_sync``,
+    ``reduce_scatter_sync``: servers started with ``protocol="rccl"``) already aggregate in
+    lock-step with one collective per step, so the wrapper only has to select averaging and to
+    refuse configurations it cannot honour: the hook from ``make_session_run_hook`` (pass it to
+    ``MonitoredTrainingSession(hooks=...)``, or call ``configure_session(sess)`` under a
+    ``Supervisor``) checks that the session runs a collective strategy over exactly
+    ``total_num_replicas`` ranks. Backup replicas (``replicas_to_aggregate <
+    total_num_replicas``) would need the stragglers' gradients dropped; a collective waits for
+    every rank, so that is rejected."""
+
+    def __init__(self, opt: Optimizer, replicas_to_aggregate: int,
+                 total_num_replicas: Optional[int] = None, use_locking: bool = False,
+                 name: str = "sync_replicas"):
+        super().__init__(use_locking, name)
+        if total_num_replicas is None:
+            total_num_replicas = replicas_to_aggregate
+        if replicas_to_aggregate != total_num_replicas:
+            raise ValueError("replicas_to_aggregate=%d != total_num_replicas=%d: backup replicas "
+                             "are not available with collective aggregation"
+                             % (replicas_to_aggregate, total_num_replicas))
+        self._opt = opt
+        self._total_num_replicas = int(total_num_replicas)
+
+    def compute_gradients(self, *args, **kwargs):
+        return self._opt.compute_gradients(*args, **kwargs)
+
+    def apply_gradients(self, grads_and_vars, global_step=None, name=None):
+        if global_step is None:
+            raise ValueError("global_step is required for SyncReplicasOptimizer")
+        return self._opt.apply_gradients(grads_and_vars, global_step=global_step, name=name)
+
+    def get_slot(self, *args, **kwargs):
+        return self._opt.get_slot(*args, **kwargs)
+
+    def get_slot_names(self, *args, **kwargs):
+        return self._opt.get_slot_names(*args, **kwargs)
+
+    def configure_session(self, session) -> None:
+        rt = getattr(session, "_runtime", None)
+        comm = getattr(rt, "comm", None)
+        world = comm.world_size if comm is not None else 1
+        strategy = getattr(rt, "strategy", None)
+        if world > 1 and strategy not in ("allreduce_sync", "reduce_scatter_sync"):
+            raise ValueError("SyncReplicasOptimizer needs a synchronous strategy (servers with "
+                             "protocol='rccl'); this session runs %r" % (strategy,))
+        if rt is not None and strategy not in (None, "allreduce_sync", "reduce_scatter_sync") \
+                and self._total_num_replicas > 1:
+            raise ValueError("SyncReplicasOptimizer needs a synchronous strategy (servers with "
+                             "protocol='rccl'); this session runs %r" % (strategy,))
+        if world != self._total_num_replicas:
+            raise ValueError("SyncReplicasOptimizer(total_num_replicas=%d) in a job of %d "
+                             "replica(s)" % (self._total_num_replicas, world))
+        if rt is not None and hasattr(rt, "grad_aggregation"):
+            rt.grad_aggregation = "mean"
+
+    def make_session_run_hook(self, is_chief: bool = True, num_tokens: int = -1):
+        from .monitored_session import SessionRunHook
+        outer = self
+
+        class _SyncReplicasHook(SessionRunHook):
+            def after_create_session(self, session, coord=None):
+                outer.configure_session(session)
+
+        return _SyncReplicasHook()

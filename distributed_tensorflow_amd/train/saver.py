@@ -172,7 +172,18 @@ def update_checkpoint_state(save_dir: str, latest: str, all_paths: Sequence[str]
     os.replace(tmp, os.path.join(save_dir, "checkpoint"))
 
 
-def get_checkpoint_state(checkpoint_dir: str) -> Optional[Dict[str, Any]]:
+class CheckpointState(dict):
+    """The ``checkpoint`` state file: ``model_checkpoint_path`` and
+    ``all_model_checkpoint_paths``, readable as attributes (TensorFlow's proto) or as keys."""
+
+    def __getattr__(self, name: str):
+        try:
+            return self[name]
+        except KeyError:
+            raise AttributeError(name)
+
+
+def get_checkpoint_state(checkpoint_dir: str) -> Optional[CheckpointState]:
     path = os.path.join(checkpoint_dir, "checkpoint")
     if not os.path.exists(path):
         return None
@@ -190,7 +201,7 @@ def get_checkpoint_state(checkpoint_dir: str) -> Optional[Dict[str, Any]]:
                 all_paths.append(full)
     if latest is None:
         return None
-    return {"model_checkpoint_path": latest, "all_model_checkpoint_paths": all_paths}
+    return CheckpointState(model_checkpoint_path=latest, all_model_checkpoint_paths=all_paths)
 
 
 def latest_checkpoint(checkpoint_dir: str) -> Optional[str]:

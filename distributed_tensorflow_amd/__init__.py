@@ -39,6 +39,7 @@ from .framework.variables import (Variable, constant_initializer, get_variable, 
                                   report_uninitialized_variables, trainable_variables,
                                   truncated_normal_initializer, variables_initializer,
                                   zeros_initializer)
-from . import nn  # noqa: F401,E402
+from . import layers, nn  # noqa: F401,E402
+from .framework.ops import clip_by_value, one_hot  # noqa: F401,E402
 
 __version__ = "0.1.0"

@@ -74,6 +74,21 @@ __global__ __launch_bounds__(BLOCK) void sign_kernel(const float* __restrict__ x
   }
 }
 
+// out[r, c] = (idx[r] == c) ? on : off for `rows` indices and `depth` classes (tf.one_hot on the
+// last axis); an index outside [0, depth) yields a row of `off`. WIDE: 64-bit indices.
+template <bool WIDE>
+__global__ __launch_bounds__(BLOCK) void one_hot_kernel(const void* __restrict__ idx,
+                                                        float* __restrict__ out, long rows,
+                                                        long depth, float on, float off) {
+  const long n = rows * depth;
+  for (long i = blockIdx.x * (long)BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * BLOCK) {
+    const long r = i / depth, c = i - r * depth;
+    const long k = WIDE ? reinterpret_cast<const long*>(idx)[r]
+                        : (long)reinterpret_cast<const int*>(idx)[r];
+    out[i] = k == c ? on : off;
+  }
+}
+
 // Gradient of a reduction / broadcast target: out[o, m, i] = g[o, i] * scale, where the output is
 // viewed as [outer, mid, inner] and g as [outer, inner] (mid = the reduced extent). Covers
 // reduce over all axes (outer = inner = 1), over axis 1 of a matrix (inner = 1), over axis 0
@@ -378,6 +393,17 @@ DTF_API int dtf_assign_add_f32(float* var, const float* delta, long n, long dn, 
   if (!var || !delta || dn <= 0 || dn > n || n % dn) return DTF_ERR_BAD_ARG;
   hipLaunchKernelGGL(assign_add_kernel, dim3(grid_for(n, 1)), dim3(BLOCK), 0, stream, var, delta,
                      n, dn, sign);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
+DTF_API int dtf_one_hot_f32(const void* idx, int wide, float* out, long rows, long depth, float on,
+                            float off, hipStream_t stream) {
+  if (rows <= 0 || depth <= 0) return DTF_OK;
+  if (!idx || !out) return DTF_ERR_BAD_ARG;
+  const dim3 grid(grid_for(rows * depth, 1)), block(BLOCK);
+  if (wide) hipLaunchKernelGGL(one_hot_kernel<true>, grid, block, 0, stream, idx, out, rows, depth, on, off);
+  else hipLaunchKernelGGL(one_hot_kernel<false>, grid, block, 0, stream, idx, out, rows, depth, on, off);
   DTF_LAUNCH_CHECK();
   return DTF_OK;
 }

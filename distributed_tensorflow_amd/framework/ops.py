@@ -465,6 +465,42 @@ def bias_add(value, bias, name=None) -> Tensor:
     return add(value, bias, name=name or "BiasAdd")
 
 
+def one_hot(indices, depth: int, on_value=1.0, off_value=0.0, axis: int = -1,
+            dtype=dtypes.float32, name=None) -> Tensor:
+    """``[..., depth]`` tensor with ``on_value`` at the index of the last axis (an index outside
+    ``[0, depth)`` gives a row of ``off_value``)."""
+    indices = convert_to_tensor(indices)
+    if axis != -1:
+        raise ValueError("one_hot is implemented for the last axis only")
+    if indices.dtype not in (dtypes.int32, dtypes.int64):
+        raise TypeError("one_hot: indices must be int32 or int64, got %s" % indices.dtype)
+    shape = None if indices.shape is None else tuple(indices.shape) + (int(depth),)
+    return _op1("OneHot", [indices], dtypes.as_dtype(dtype), shape, name=name or "one_hot",
+                depth=int(depth), on_value=float(on_value), off_value=float(off_value),
+                dtype=dtypes.as_dtype(dtype))
+
+
+def sparse_softmax_cross_entropy_with_logits(labels=None, logits=None, name=None,
+                                             _sentinel=None) -> Tensor:
+    """Per-example cross-entropy against integer class labels: the labels are expanded on the
+    device (``one_hot``) and the fused softmax-cross-entropy kernels take it from there."""
+    logits = convert_to_tensor(logits)
+    if logits.shape is None or logits.shape[-1] is None:
+        raise ValueError("sparse_softmax_cross_entropy_with_logits needs a static class count")
+    dense = one_hot(labels, logits.shape[-1], dtype=logits.dtype)
+    return softmax_cross_entropy_with_logits(
+        labels=dense, logits=logits, name=name or "sparse_softmax_cross_entropy_with_logits")
+
+
+def l2_loss(t, name=None) -> Tensor:
+    """``sum(t ** 2) / 2`` (weight decay term)."""
+    return scale(reduce_sum(square(t)), 0.5, name=name or "L2Loss")
+
+
+def clip_by_value(t, clip_value_min, clip_value_max, name=None) -> Tensor:
+    return minimum(maximum(t, clip_value_min), clip_value_max, name=name or "clip_by_value")
+
+
 # ---------------------------------------------------------------------------------------
 # control / grouping
 # ---------------------------------------------------------------------------------------

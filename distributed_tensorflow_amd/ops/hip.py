@@ -165,6 +165,7 @@ def _declare(L: ctypes.CDLL) -> None:
         "dtf_pad_rows": [P, P, LG, LG, LG, LG, LG, P],
         "dtf_assign_add_f32": [P, P, LG, LG, F, P],
         "dtf_sign_f32": [P, P, LG, P],
+        "dtf_one_hot_f32": [P, I, P, LG, LG, F, F, P],
         "dtf_broadcast_mid_f32": [P, P, LG, LG, LG, F, P],
         "dtf_log_softmax_grad_f32": [P, P, P, LG, LG, P],
         "dtf_absmax_scale": [P, I, LG, F, P, P, P],
@@ -1537,6 +1538,20 @@ def assign_add(var: torch.Tensor, delta: torch.Tensor, sign: float = 1.0) -> tor
     _check(lib().dtf_assign_add_f32(var.data_ptr(), delta.data_ptr(), var.numel(), dn,
                                     float(sign), _stream()), "assign_add")
     return var
+
+
+def one_hot(indices: torch.Tensor, depth: int, on_value: float = 1.0,
+            off_value: float = 0.0) -> torch.Tensor:
+    """fp32 ``[..., depth]`` with ``on_value`` where the last axis equals the index."""
+    if indices.dtype not in (torch.int32, torch.int64) or indices.device.type != "cuda":
+        raise HipKernelError("one_hot: indices must be an int32 / int64 GPU tensor")
+    indices = indices.contiguous()
+    out = torch.empty(tuple(indices.shape) + (int(depth),), dtype=torch.float32,
+                      device=indices.device)
+    _check(lib().dtf_one_hot_f32(indices.data_ptr(), int(indices.dtype == torch.int64),
+                                 out.data_ptr(), indices.numel(), int(depth), float(on_value),
+                                 float(off_value), _stream()), "one_hot")
+    return out
 
 
 def sign(x: torch.Tensor) -> torch.Tensor:

@@ -418,6 +418,14 @@ def _transpose(op, inputs, ctx):
     return _fallback("Transpose", op, inputs, ctx, "perm %s of rank %d" % (perm, x.dim()))
 
 
+@hip_kernel("OneHot")
+def _one_hot(op, inputs, ctx):
+    idx = inputs[0]
+    if idx.dtype not in (torch.int32, torch.int64) or op.attrs["dtype"].torch != _f32:
+        return _fallback("OneHot", op, inputs, ctx)
+    return [hip.one_hot(idx, op.attrs["depth"], op.attrs["on_value"], op.attrs["off_value"])]
+
+
 @hip_kernel("Sign")
 def _sign(op, inputs, ctx):
     if not _is_f32(inputs[0]):

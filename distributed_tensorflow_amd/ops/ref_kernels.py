@@ -270,6 +270,16 @@ ref_kernel("Square")(_un(torch.square))
 ref_kernel("Reciprocal")(_un(torch.reciprocal))
 ref_kernel("Abs")(_un(torch.abs))
 ref_kernel("Sign")(_un(torch.sign))
+
+
+@ref_kernel("OneHot")
+def _one_hot(op, inputs, ctx):
+    idx = inputs[0].long()
+    depth = op.attrs["depth"]
+    hit = idx.unsqueeze(-1) == torch.arange(depth, device=idx.device)
+    on = torch.tensor(op.attrs["on_value"], device=idx.device)
+    off = torch.tensor(op.attrs["off_value"], device=idx.device)
+    return [torch.where(hit, on, off).to(op.attrs["dtype"].torch)]
 ref_kernel("Sigmoid")(_un(torch.sigmoid))
 ref_kernel("Tanh")(_un(torch.tanh))
 ref_kernel("Relu")(_un(torch.relu))

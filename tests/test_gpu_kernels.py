@@ -1110,3 +1110,14 @@ def test_gemm_bf16_unsplit_rows_have_shape_independent_bits(hip, out_dtype):
     small = hip.gemm_bf16_nt(a[:512], bt, out_dtype, splits=1)           # 32 tiles
     assert torch.equal(full[1024:2048], mid)
     assert torch.equal(full[:512], small)
+
+
+@pytest.mark.parametrize("dtype", [torch.int32, torch.int64])
+def test_one_hot(hip, dtype):
+    idx = torch.tensor([[0, 3, 9], [10, -1, 5]], dtype=dtype).cuda()
+    out = hip.one_hot(idx, 10, 2.0, -1.0)
+    ref = torch.where(idx.long().unsqueeze(-1) == torch.arange(10).cuda(),
+                      torch.tensor(2.0).cuda(), torch.tensor(-1.0).cuda())
+    assert out.shape == (2, 3, 10) and torch.equal(out, ref)
+    big = torch.randint(0, 1000, (4099,), dtype=dtype).cuda()
+    assert torch.equal(hip.one_hot(big, 1000).argmax(-1), big.long())

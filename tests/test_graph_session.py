@@ -333,3 +333,42 @@ def test_make_callable_runs_the_same_plan_as_run():
             f(bx, bx)
         with pytest.raises(TypeError):
             f(bx, options=tf.RunOptions())
+
+
+def test_one_hot_sparse_xent_l2_clip_and_dense_layer():
+    """Facade compositions: integer-label cross-entropy equals the one-hot spelling, ``l2_loss``
+    and ``clip_by_value`` differentiate, ``tf.layers.dense`` creates named variables and trains."""
+    rng = np.random.RandomState(0)
+    bx = rng.randn(12, 6).astype(np.float32)
+    labels = rng.randint(0, 4, 12).astype(np.int64)
+    with tf.Graph().as_default():
+        tf.set_random_seed(2)
+        x = tf.placeholder(tf.float32, [None, 6])
+        y = tf.placeholder(tf.int64, [None])
+        h = tf.layers.dense(x, 5, activation=tf.nn.sigmoid, name="hidden")
+        logits = tf.layers.dense(h, 4, name="out")
+        sparse = tf.nn.sparse_softmax_cross_entropy_with_logits(labels=y, logits=logits)
+        dense = tf.nn.softmax_cross_entropy_with_logits(labels=tf.one_hot(y, 4), logits=logits)
+        names = sorted(v.op.name for v in tf.trainable_variables())
+        assert names == ["hidden/bias", "hidden/kernel", "out/bias", "out/kernel"]
+        w = [v for v in tf.trainable_variables() if v.op.name == "out/kernel"][0]
+        loss = tf.add(tf.reduce_mean(sparse), tf.scale(tf.nn.l2_loss(w), 0.01))
+        clipped = tf.clip_by_value(logits, -0.05, 0.05)
+        dclip = tf.gradients(tf.reduce_sum(clipped), [logits])[0]
+        train = tf.train.GradientDescentOptimizer(0.5).minimize(loss)
+        with tf.Session(config=tf.ConfigProto(device="cpu")) as sess:
+            sess.run(tf.global_variables_initializer())
+            a, b, oh = sess.run([sparse, dense, tf.one_hot(y, 4)], {x: bx, y: labels})
+            assert np.allclose(a, b) and a.shape == (12,)
+            assert np.array_equal(oh, np.eye(4, dtype=np.float32)[labels])
+            assert np.array_equal(sess.run(tf.one_hot(tf.constant([1, 7, -1]), 3, 5.0, -1.0)),
+                                  np.array([[-1, 5, -1], [-1, -1, -1], [-1, -1, -1]], np.float32))
+            lg, cl, dc = sess.run([logits, clipped, dclip], {x: bx})
+            assert np.allclose(cl, np.clip(lg, -0.05, 0.05))
+            assert np.array_equal(dc, ((lg > -0.05) & (lg < 0.05)).astype(np.float32))
+            wv = sess.run(w)
+            assert np.isclose(sess.run(tf.nn.l2_loss(w)), 0.5 * (wv ** 2).sum(), rtol=1e-6)
+            first = sess.run(loss, {x: bx, y: labels})
+            for _ in range(60):
+                sess.run(train, {x: bx, y: labels})
+            assert sess.run(loss, {x: bx, y: labels}) < 0.6 * first

@@ -351,3 +351,27 @@ def test_gpu_mnist_with_adam_is_captured_without_torch_kernels():
             assert sess.stats["torch_fallbacks"] == 0 and not sess.fallback_log
             assert float(sess.run(m.global_step)) == 30.0
             assert float(sess.run(m.optimizer._powers[0])) == pytest.approx(0.9 ** 31, rel=1e-4)
+
+
+@pytest.mark.gpu
+def test_gpu_dense_layers_with_integer_labels_and_adam_run_natively():
+    rng = np.random.RandomState(0)
+    bx = rng.rand(64, 32).astype(np.float32)
+    labels = rng.randint(0, 8, 64).astype(np.int64)
+    with tf.Graph().as_default():
+        tf.set_random_seed(4)
+        x = tf.placeholder(tf.float32, [None, 32])
+        y = tf.placeholder(tf.int64, [None])
+        h = tf.layers.dense(x, 48, activation=tf.nn.relu, name="hidden")
+        logits = tf.layers.dense(h, 8, name="out")
+        w = [v for v in tf.trainable_variables() if v.op.name == "out/kernel"][0]
+        loss = tf.add(tf.reduce_mean(tf.nn.sparse_softmax_cross_entropy_with_logits(
+            labels=y, logits=logits)), tf.scale(tf.nn.l2_loss(w), 1e-3))
+        train = tf.train.AdamOptimizer(0.01).minimize(
+            loss, global_step=tf.train.get_or_create_global_step())
+        with tf.Session(config=tf.ConfigProto(device="cuda:0")) as sess:
+            sess.run(tf.global_variables_initializer())
+            costs = [float(sess.run([train, loss], {x: bx, y: labels})[1]) for _ in range(80)]
+            assert costs[-1] < 0.5 * costs[0], (costs[0], costs[-1])
+            assert sess.stats["torch_fallbacks"] == 0 and not sess.fallback_log
+            assert sess.stats["graph_replays"] >= 60

@@ -497,6 +497,30 @@ def l2_loss(t, name=None) -> Tensor:
     return scale(reduce_sum(square(t)), 0.5, name=name or "L2Loss")
 
 
+def global_norm(t_list, name=None) -> Tensor:
+    """``sqrt(sum_i ||t_i||^2)`` over the tensors of ``t_list`` (``None`` entries are skipped)."""
+    parts = [reduce_sum(square(convert_to_tensor(t))) for t in t_list if t is not None]
+    if not parts:
+        raise ValueError("global_norm of an empty list")
+    total = parts[0] if len(parts) == 1 else add_n(parts)
+    return sqrt(total, name=name or "global_norm")
+
+
+def clip_by_global_norm(t_list, clip_norm, use_norm=None, name=None):
+    """``t_i * clip_norm / max(global_norm, clip_norm)`` for every tensor; returns
+    ``(clipped list, global_norm)`` -- gradient clipping between ``compute_gradients`` and
+    ``apply_gradients``."""
+    norm = use_norm if use_norm is not None else global_norm(t_list)
+    factor = divide(clip_norm, maximum(norm, clip_norm))
+    return [None if t is None else multiply(convert_to_tensor(t), factor) for t in t_list], norm
+
+
+def clip_by_norm(t, clip_norm, name=None) -> Tensor:
+    t = convert_to_tensor(t)
+    norm = sqrt(reduce_sum(square(t)))
+    return multiply(t, divide(clip_norm, maximum(norm, clip_norm)), name=name or "clip_by_norm")
+
+
 def clip_by_value(t, clip_value_min, clip_value_max, name=None) -> Tensor:
     return minimum(maximum(t, clip_value_min), clip_value_max, name=name or "clip_by_value")
 

@@ -372,3 +372,33 @@ def test_one_hot_sparse_xent_l2_clip_and_dense_layer():
             for _ in range(60):
                 sess.run(train, {x: bx, y: labels})
             assert sess.run(loss, {x: bx, y: labels}) < 0.6 * first
+
+
+def test_gradient_clipping_by_global_norm_between_compute_and_apply():
+    rng = np.random.RandomState(1)
+    bx = (10 * rng.randn(8, 5)).astype(np.float32)
+    with tf.Graph().as_default():
+        tf.set_random_seed(7)
+        x = tf.placeholder(tf.float32, [None, 5])
+        w = tf.Variable(tf.random_normal([5, 3]), name="W")
+        b = tf.Variable(tf.ones([3]), name="b")
+        loss = tf.reduce_sum(tf.square(tf.add(tf.matmul(x, w), b)))
+        opt = tf.train.GradientDescentOptimizer(0.1)
+        gv = opt.compute_gradients(loss)
+        clipped, norm = tf.clip_by_global_norm([g for g, _ in gv], 1.5)
+        train = opt.apply_gradients(list(zip(clipped, [v for _, v in gv])))
+        one = tf.clip_by_norm(gv[0][0], 0.5)
+        with tf.Session(config=tf.ConfigProto(device="cpu")) as sess:
+            sess.run(tf.global_variables_initializer())
+            raw = sess.run([g for g, _ in gv], {x: bx})
+            got, n, single = sess.run([clipped, norm, one], {x: bx})
+            want_norm = np.sqrt(sum((g.astype(np.float64) ** 2).sum() for g in raw))
+            assert np.isclose(n, want_norm, rtol=1e-5) and want_norm > 1.5
+            for g, c in zip(raw, got):
+                assert np.allclose(c, g * 1.5 / want_norm, rtol=1e-5)
+            assert np.isclose(np.sqrt((single.astype(np.float64) ** 2).sum()), 0.5, rtol=1e-5)
+            w0, b0 = sess.run([w, b])
+            sess.run(train, {x: bx})
+            w1, b1 = sess.run([w, b])
+            step = np.sqrt(((w1 - w0) ** 2).sum() + ((b1 - b0) ** 2).sum())
+            assert np.isclose(step, 0.1 * 1.5, rtol=1e-4)       # lr x clipped norm

@@ -375,3 +375,27 @@ def test_gpu_dense_layers_with_integer_labels_and_adam_run_natively():
             assert costs[-1] < 0.5 * costs[0], (costs[0], costs[-1])
             assert sess.stats["torch_fallbacks"] == 0 and not sess.fallback_log
             assert sess.stats["graph_replays"] >= 60
+
+
+@pytest.mark.gpu
+def test_gpu_clipped_momentum_step_runs_natively():
+    rng = np.random.RandomState(1)
+    bx = (10 * rng.randn(8, 5)).astype(np.float32)
+    with tf.Graph().as_default():
+        tf.set_random_seed(7)
+        x = tf.placeholder(tf.float32, [None, 5])
+        w = tf.Variable(tf.random_normal([5, 3]), name="W")
+        b = tf.Variable(tf.ones([3]), name="b")
+        loss = tf.reduce_sum(tf.square(tf.add(tf.matmul(x, w), b)))
+        opt = tf.train.MomentumOptimizer(0.1, 0.0)
+        gv = opt.compute_gradients(loss)
+        clipped, norm = tf.clip_by_global_norm([g for g, _ in gv], 1.5)
+        train = opt.apply_gradients(list(zip(clipped, [v for _, v in gv])))
+        with tf.Session(config=tf.ConfigProto(device="cuda:0")) as sess:
+            sess.run(tf.global_variables_initializer())
+            w0, b0 = sess.run([w, b])
+            _, n = sess.run([train, norm], {x: bx})
+            w1, b1 = sess.run([w, b])
+            assert n > 1.5 and sess.stats["torch_fallbacks"] == 0 and not sess.fallback_log
+            step = np.sqrt(((w1 - w0) ** 2).sum() + ((b1 - b0) ** 2).sum())
+            assert np.isclose(step, 0.1 * 1.5, rtol=1e-4)

@@ -343,6 +343,16 @@ class CollectiveRuntime(LocalRuntime):
                 for n, off, numel, shape in self._layout}
         return views.get(name)
 
+    def _grad_extent(self, names: Sequence[str]) -> int:
+        """Elements of the flat gradient arena up to the end of the last of ``names``."""
+        key = tuple(names)
+        cache = self.__dict__.setdefault("_extent_cache", {})
+        hit = cache.get(key)
+        if hit is None or hit[0] is not self._flat_grads:
+            ends = {n: off + numel for n, off, numel, _ in self._layout}
+            hit = cache[key] = (self._flat_grads, max(ends[n] for n in names))
+        return hit[1]
+
     def _place(self, grads: Sequence[torch.Tensor], names: Optional[Sequence[str]]) -> bool:
         """Make sure every gradient sits in its arena slot (a gradient the session already had
         produced there is left alone; anything else is copied in). False when a gradient has no
@@ -385,7 +395,10 @@ class CollectiveRuntime(LocalRuntime):
                 if rest else iter(())
             return [done[id(g)] if id(g) in done else next(reduced_rest) for g in grads]
         if self._place(grads, names):
-            flat = self._flat_grads
+            # only the span of the arena that holds this step's gradients travels: the session
+            # manager lays trainable variables out first, so optimizer state, counters and
+            # other non-trainables behind them (whose gradient slots stay zero) are left out
+            flat = self._flat_grads[:self._grad_extent(names)]
             self.comm.all_reduce(flat, op)
             self.bytes_reduced += flat.numel() * 4
             return [self.grad_view(n) for n in names]

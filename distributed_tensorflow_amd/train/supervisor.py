@@ -173,7 +173,11 @@ class SessionManager:
         runtime = sess._runtime
         if runtime is not None:
             sess._shard_plan()      # every rank knows the variable layouts before the exchange
-            names = [v.op.name for v in self._graph.get_collection(GraphKeys.GLOBAL_VARIABLES)]
+            # trainable variables first: the flat arena a collective runtime builds in this order
+            # then holds every gradient in its leading span, which is all its all-reduce moves
+            variables = self._graph.get_collection(GraphKeys.GLOBAL_VARIABLES)
+            names = [v.op.name for v in variables if v.trainable] + \
+                    [v.op.name for v in variables if not v.trainable]
             runtime.after_init(sess, names)
 
 

@@ -9,7 +9,7 @@ PyTorch-ROCm tensors, with RCCL collectives in place of the gRPC parameter-serve
 """
 from . import app, summary, train  # noqa: F401
 from .app import flags  # noqa: F401
-from .client.session import (ConfigProto, InteractiveSession, RunMetadata,  # noqa: F401
+from .client.session import (ConfigProto, GPUOptions, InteractiveSession, RunMetadata,  # noqa: F401
                              RunOptions, Session, get_default_session)
 from .client.variable_store import FailedPreconditionError  # noqa: F401
 from .framework import dtypes  # noqa: F401

@@ -135,7 +135,9 @@ class ConfigProto:
                           are looked at (``float(v)``, ``np.asarray(v)``, arithmetic, printing):
                           the host prepares the following steps while the GPU runs this one, up
                           to a ring of 16 steps ahead.
-    ``allow_soft_placement`` / ``log_device_placement`` -- accepted for compatibility.
+    ``allow_soft_placement`` / ``log_device_placement`` and any other TensorFlow option
+    (``device_filters``, ``gpu_options`` ...) -- accepted for compatibility, kept in
+    ``tensorflow_only``.
     """
 
     def __init__(self, graph_fusion: bool = True, hip_graphs: bool = True,
@@ -145,7 +147,12 @@ class ConfigProto:
                  capture_collectives: Optional[bool] = None,
                  grad_bucket_bytes: Optional[int] = None, matmul_sharding: Optional[str] = None,
                  shard_variables: bool = True, allow_torch_fallback: Optional[bool] = None,
-                 step_fusion: Optional[bool] = None, deferred_fetches: Optional[bool] = None):
+                 step_fusion: Optional[bool] = None, deferred_fetches: Optional[bool] = None,
+                 **tensorflow_only):
+        # TensorFlow options without a meaning here (device_filters, gpu_options,
+        # intra_op_parallelism_threads, ...): kept, not interpreted, so that a script's
+        # ConfigProto(...) call runs unchanged
+        self.tensorflow_only = dict(tensorflow_only)
         self.step_fusion = step_fusion
         self.deferred_fetches = bool(os.environ.get("DTF_DEFERRED_FETCHES")) \
             if deferred_fetches is None else bool(deferred_fetches)
@@ -162,6 +169,14 @@ class ConfigProto:
         self.allow_soft_placement = allow_soft_placement
         self.log_device_placement = log_device_placement
         self.strategy = strategy
+
+
+class GPUOptions:
+    """``tf.GPUOptions(allow_growth=..., per_process_gpu_memory_fraction=...)``: accepted and
+    kept; device memory here is managed by the caching allocator of the torch runtime."""
+
+    def __init__(self, **options):
+        self.__dict__.update(options)
 
 
 class RunOptions:

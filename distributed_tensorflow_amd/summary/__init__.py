@@ -53,6 +53,73 @@ def decode_summary(data: bytes) -> List[Tuple[str, float]]:
     return out
 
 
+_HISTOGRAM_LIMITS: Optional[np.ndarray] = None
+
+
+def histogram_bucket_limits() -> np.ndarray:
+    """TensorFlow's default histogram buckets: limits 1e-12 * 1.1**k up to 1e20, mirrored for
+    negative values around one bucket ending at 0, and a last bucket up to the largest double."""
+    global _HISTOGRAM_LIMITS
+    if _HISTOGRAM_LIMITS is None:
+        pos, v = [], 1e-12
+        while v < 1e20:
+            pos.append(v)
+            v *= 1.1
+        pos.append(np.finfo(np.float64).max)
+        _HISTOGRAM_LIMITS = np.array([-x for x in reversed(pos)] + [0.0] + pos, dtype=np.float64)
+    return _HISTOGRAM_LIMITS
+
+
+def encode_histogram_summary(tag: str, values) -> bytes:
+    """``Summary{ value{ tag, histo: HistogramProto{min, max, num, sum, sum_squares,
+    bucket_limit[], bucket[]} } }`` with TensorFlow's default buckets; runs of empty buckets are
+    collapsed into one, as TensorFlow's encoder does."""
+    x = np.asarray(values, dtype=np.float64).reshape(-1)
+    x = x[np.isfinite(x)]
+    limits = histogram_bucket_limits()
+    # a value v falls into the first bucket whose limit is > v (std::upper_bound)
+    idx = np.minimum(np.searchsorted(limits, x, side="right"), len(limits) - 1)
+    counts = np.bincount(idx, minlength=len(limits)).astype(np.float64)
+    out_limits, out_counts = [], []
+    i, n = 0, len(limits)
+    while i < n:
+        end, count = limits[i], counts[i]
+        i += 1
+        if count <= 0.0:
+            while i < n and counts[i] <= 0.0:
+                end, count = limits[i], counts[i]
+                i += 1
+        out_limits.append(end)
+        out_counts.append(count)
+    histo = (pw.f_double(1, float(x.min()) if x.size else 0.0)
+             + pw.f_double(2, float(x.max()) if x.size else 0.0)
+             + pw.f_double(3, float(x.size)) + pw.f_double(4, float(x.sum()))
+             + pw.f_double(5, float((x * x).sum()))
+             + pw.f_bytes(6, struct.pack("<%dd" % len(out_limits), *out_limits))
+             + pw.f_bytes(7, struct.pack("<%dd" % len(out_counts), *out_counts)))
+    return pw.f_message(1, pw.f_bytes(1, tag) + pw.f_message(5, histo))
+
+
+def decode_histograms(data: bytes) -> List[Tuple[str, dict]]:
+    """``(tag, {min, max, num, sum, sum_squares, bucket_limit, bucket})`` of every histogram value
+    of a serialized ``Summary``."""
+    out = []
+    for field, _w, value in pw.iter_fields(data):
+        if field != 1:
+            continue
+        v = pw.parse(value)
+        if 5 not in v:
+            continue
+        h = pw.parse(v[5][0])
+        unpack = lambda b: list(struct.unpack("<%dd" % (len(b) // 8), b))  # noqa: E731
+        out.append((v.get(1, [b""])[0].decode("utf-8"), {
+            "min": pw.as_double(h[1][0]), "max": pw.as_double(h[2][0]),
+            "num": pw.as_double(h[3][0]), "sum": pw.as_double(h[4][0]),
+            "sum_squares": pw.as_double(h[5][0]),
+            "bucket_limit": unpack(h[6][0]), "bucket": unpack(h[7][0])}))
+    return out
+
+
 def encode_event(wall_time: float, step: Optional[int] = None, file_version: Optional[str] = None,
                  graph_def: Optional[bytes] = None, summary: Optional[bytes] = None) -> bytes:
     out = pw.f_double(1, wall_time)
@@ -128,6 +195,21 @@ def scalar(name: str, tensor, collections=None) -> Tensor:
     return op.outputs[0]
 
 
+def histogram(name: str, values, collections=None) -> Tensor:
+    """Distribution of a tensor's values (weights, activations, gradients) as a TensorBoard
+    histogram. A host op like ``scalar``: the tensor reaches the host with the step's fetches
+    and is bucketed there."""
+    t = F.convert_to_tensor(values)
+    g = t.graph
+    scope = g._name_stack
+    tag = (scope + "/" + name) if scope else name
+    op = g.create_op("HistogramSummary", [t], [(dtypes.string, ())],
+                     name=name.replace(" ", "_"), attrs={"tag": tag})
+    for c in (collections or [GraphKeys.SUMMARIES]):
+        g.add_to_collection(c, op.outputs[0])
+    return op.outputs[0]
+
+
 def merge(inputs, collections=None, name: Optional[str] = None) -> Tensor:
     inputs = [F.convert_to_tensor(i) for i in inputs]
     g = inputs[0].graph
@@ -155,6 +237,14 @@ def _scalar_summary_kernel(op, inputs, ctx):
     v = inputs[0]
     value = float(v) if isinstance(v, (float, np.floating)) else float(np.asarray(v).reshape(-1)[0])
     return [prefix + struct.pack("<f", value)]
+
+
+@ref_kernel("HistogramSummary", host_only=True)
+def _histogram_summary_kernel(op, inputs, ctx):
+    v = inputs[0]
+    if hasattr(v, "detach"):
+        v = v.detach().float().cpu().numpy()
+    return [encode_histogram_summary(op.attrs["tag"], v)]
 
 
 @ref_kernel("MergeSummary", host_only=True)

@@ -582,3 +582,28 @@ def test_deferred_fetches_return_the_blocking_values_without_blocking():
     chain = _mnist_run(tf.ConfigProto(device="cuda", deferred_fetches=True, step_fusion=False),
                        50, look=False)
     assert [[float(o[0]), bytes(o[1]), float(o[2])] for o in chain[0]] == ref[0]
+
+
+def test_histogram_summary_of_the_weights_in_a_gpu_training_step(tmp_path):
+    """A histogram of W1 (78 400 values) fetched next to the training op: the tensor reaches the
+    host op with the step's other results, the step still trains, no torch kernel is planned."""
+    import numpy as np
+    import distributed_tensorflow_amd as tf
+    from distributed_tensorflow_amd.models import mnist_mlp
+    from distributed_tensorflow_amd.summary import decode_histograms
+    rng = np.random.RandomState(0)
+    bx = rng.rand(100, 784).astype(np.float32)
+    by = np.eye(10, dtype=np.float32)[rng.randint(0, 10, 100)]
+    with tf.Graph().as_default():
+        m = mnist_mlp.build_model(seed=1, with_summaries=False)
+        tf.summary.histogram("w1", m.w1)
+        tf.summary.scalar("cost", m.loss)
+        merged = tf.summary.merge_all()
+        with tf.Session(config=tf.ConfigProto(device="cuda:0")) as sess:
+            sess.run(m.init_op)
+            for _ in range(5):
+                _, data, w1 = sess.run([m.train_op, merged, m.w1], {m.x: bx, m.y_: by})
+            (tag, h), = decode_histograms(bytes(data))
+            assert tag == "w1" and h["num"] == 78400
+            assert np.isclose(h["sum"], float(np.asarray(w1, dtype=np.float64).sum()), rtol=1e-5)
+            assert sess.stats["torch_fallbacks"] == 0 and not sess.fallback_log

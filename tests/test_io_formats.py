@@ -227,3 +227,49 @@ def test_philox_known_answer_and_stream_properties():
     win = philox.window(4, 6, 1, 2, row0=10, col0=3, global_cols=50)
     full = philox.normal(50 * 20, 1, 2).reshape(20, 50)
     assert np.allclose(win, full[10:14, 3:9], atol=1e-6)
+
+
+def test_histogram_summary_buckets_and_event_round_trip(tmp_path):
+    """``tf.summary.histogram``: TensorFlow's default bucket limits, empty runs collapsed the way
+    its encoder collapses them, statistics exact, and the value survives an event file."""
+    from distributed_tensorflow_amd.summary import (decode_histograms, encode_histogram_summary,
+                                                    histogram_bucket_limits)
+    limits = histogram_bucket_limits()
+    assert np.all(np.diff(limits) > 0) and limits[len(limits) // 2] == 0.0
+    assert np.isclose(limits[len(limits) // 2 + 1], 1e-12) and limits[-1] == np.finfo(np.float64).max
+    (tag, h), = decode_histograms(encode_histogram_summary("one", [0.5]))
+    assert tag == "one" and h["bucket"] == [0.0, 1.0, 0.0]
+    assert h["bucket_limit"][0] <= 0.5 < h["bucket_limit"][1] <= 0.5 * 1.1
+    assert h["bucket_limit"][2] == np.finfo(np.float64).max
+    assert (h["min"], h["max"], h["num"], h["sum"], h["sum_squares"]) == (0.5, 0.5, 1.0, 0.5, 0.25)
+    vals = np.random.RandomState(0).randn(5000) * 3
+    (_, h), = decode_histograms(encode_histogram_summary("w", vals))
+    assert sum(h["bucket"]) == 5000 and h["num"] == 5000
+    assert np.isclose(h["sum"], vals.sum()) and np.isclose(h["sum_squares"], (vals ** 2).sum())
+    assert all(a < b for a, b in zip(h["bucket_limit"], h["bucket_limit"][1:]))
+    # no two neighbouring entries are both empty (runs are collapsed)
+    assert not any(a == 0 and b == 0 for a, b in zip(h["bucket"], h["bucket"][1:]))
+    # every value lies below its bucket's limit and at or above the previous one
+    edges = np.array(h["bucket_limit"])
+    counts = np.bincount(np.searchsorted(edges, vals, side="right"), minlength=len(edges))
+    assert counts.tolist() == [int(c) for c in h["bucket"]]
+
+    with tf.Graph().as_default():
+        tf.set_random_seed(1)
+        w = tf.Variable(tf.random_normal([30, 10]), name="W")
+        tf.summary.histogram("weights", w)
+        tf.summary.scalar("mean", tf.reduce_mean(w))
+        merged = tf.summary.merge_all()
+        writer = tf.summary.FileWriter(str(tmp_path))
+        with tf.Session(config=tf.ConfigProto(device="cpu", device_filters=["/job:ps"],
+                                              gpu_options=tf.GPUOptions(allow_growth=True))) as sess:
+            sess.run(tf.global_variables_initializer())
+            data, wv = sess.run([merged, w])
+            writer.add_summary(data, 3)
+        writer.close()
+    from distributed_tensorflow_amd.summary import read_records
+    from distributed_tensorflow_amd.utils import protowire as pw
+    path = [os.path.join(str(tmp_path), f) for f in os.listdir(tmp_path)][0]
+    summaries = [pw.parse(r)[5][0] for r in read_records(path) if 5 in pw.parse(r)]
+    (tag, h), = decode_histograms(summaries[0])
+    assert tag == "weights" and h["num"] == 300 and np.isclose(h["min"], wv.min())

@@ -6,7 +6,7 @@ run() {
   timeout -k 10 150 python -m distributed_tensorflow_amd.launch --num_workers 1 --protocol rccl --timeout 140 "$@" > /tmp/sweep_out.txt 2>&1
   rc=$?
   grep -E "AvgTime" /tmp/sweep_out.txt | tail -1
-  grep -E "Test-Accuracy|GFLOPS|Weight-Error|Total Time|Traceback|Error" /tmp/sweep_out.txt | tail -4
+  grep -E "Test-Accuracy|GFLOPS|Weight-Error|Total Time|Global Step|Traceback|Error" /tmp/sweep_out.txt | tail -4
   echo "rc=$rc"
   [ $rc -eq 0 ] || { tail -20 /tmp/sweep_out.txt; exit 1; }
 }
@@ -20,3 +20,4 @@ run --strategy allreduce_sync examples/tf_distributed_1000Matrix.py -- --trainin
 run --strategy reduce_scatter_sync examples/linear_regression.py -- --max_steps 1000
 run --strategy allreduce_sync examples/linear_regression.py -- --max_steps 1000 --capture_collectives
 run --strategy allreduce_sync examples/linear_regression.py -- --max_steps 500 --nodevice_data
+run --strategy allreduce_sync examples/mnist_monitored.py -- --last_step 1000 --optimizer adam

@@ -607,3 +607,22 @@ def test_histogram_summary_of_the_weights_in_a_gpu_training_step(tmp_path):
             assert tag == "w1" and h["num"] == 78400
             assert np.isclose(h["sum"], float(np.asarray(w1, dtype=np.float64).sum()), rtol=1e-5)
             assert sess.stats["torch_fallbacks"] == 0 and not sess.fallback_log
+
+
+def test_monitored_session_example_on_gpu(tmp_path):
+    """``examples/mnist_monitored.py`` on the GPU under the real RCCL backend (world of one):
+    dense layers + integer labels + Adam + SyncReplicasOptimizer + hooks, captured steps."""
+    ckpt = str(tmp_path / "ckpt")
+    rc, out = _launch(["--num_workers", "1", "--protocol", "rccl", "--timeout", "200",
+                       os.path.join(EX, "mnist_monitored.py"), "--", "--last_step", "400",
+                       "--optimizer", "adam", "--checkpoint_dir", ckpt,
+                       "--data_dir", str(tmp_path / "nodata")])
+    assert rc == 0, out
+    assert "Global Step: 400  (local steps: 400)" in out, out
+    acc = float(re.search(r"Test-Accuracy: (\d\.\d\d)", out).group(1))
+    assert acc > 0.5, out
+    files = os.listdir(ckpt)
+    assert "model.ckpt-400.index" in files
+    tags = {t for f in files if "tfevents" in f
+            for e in read_events(os.path.join(ckpt, f)) for t, _ in e.get("summary", [])}
+    assert {"cost", "accuracy"} <= tags

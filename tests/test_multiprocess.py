@@ -260,3 +260,28 @@ def test_matmul_example_sharded_over_four_collective_ranks(shard, size, tmp_path
     assert ref.shape == (size, size)
     for r in range(4):
         assert np.array_equal(np.load(dump4 + "_%d.npy" % r), ref)
+
+
+def test_monitored_session_example_two_synchronous_workers(tmp_path):
+    """``examples/mnist_monitored.py``: dense layers, integer labels, Adam inside
+    ``SyncReplicasOptimizer``, ``MonitoredTrainingSession`` with its hooks -- two gloo ranks in
+    lock-step: both see global_step reach ``--last_step`` after as many local steps, and the
+    chief leaves checkpoints and event files behind."""
+    ckpt = str(tmp_path / "ckpt")
+    rc, out = _run_launcher(["--num_workers", "2", "--protocol", "rccl", "--timeout", "200",
+                             os.path.join(EX, "mnist_monitored.py"), "--", "--device", "cpu",
+                             "--last_step", "150", "--optimizer", "adam", "--checkpoint_dir", ckpt,
+                             "--save_checkpoint_steps", "100",
+                             "--data_dir", str(tmp_path / "nodata")])
+    assert rc == 0, out
+    for w in (0, 1):
+        assert "[worker:%d] Global Step: 150  (local steps: 150)" % w in out, out
+        assert re.search(r"\[worker:%d\] Test-Accuracy: \d\.\d\d" % w, out)
+        assert "[worker:%d] done" % w in out
+    assert "[worker:0] Step: 101,  Cost:" in out
+    files = os.listdir(ckpt)
+    assert "checkpoint" in files and "model.ckpt-150.index" in files
+    assert any(f.startswith("events.out.tfevents") for f in files)
+    tags = {t for f in files if "tfevents" in f
+            for e in read_events(os.path.join(ckpt, f)) for t, _ in e.get("summary", [])}
+    assert {"cost", "accuracy", "global_step/sec"} <= tags

@@ -191,6 +191,20 @@ def _declare(L: ctypes.CDLL) -> None:
 # ---------------------------------------------------------------------------------------
 # helpers
 # ---------------------------------------------------------------------------------------
+def _broadcast_shape(a, b) -> Tuple[int, ...]:
+    """NumPy broadcasting of two shapes (``torch.broadcast_shapes`` imports the symbolic-shape
+    machinery on first use: a quarter of a second of start-up for a three-line rule)."""
+    a, b = tuple(a), tuple(b)
+    n = max(len(a), len(b))
+    a, b = (1,) * (n - len(a)) + a, (1,) * (n - len(b)) + b
+    out = []
+    for x, y in zip(a, b):
+        if x != y and x != 1 and y != 1:
+            raise HipKernelError("shapes %s and %s do not broadcast" % (a, b))
+        out.append(y if x == 1 else x)
+    return tuple(out)
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -716,7 +730,7 @@ def _bcast_numel(out_shape: torch.Size, t: torch.Tensor, what: str) -> int:
 def binary(op: str, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     a = _req(a, torch.float32, "binary a")
     b = _req(b, torch.float32, "binary b")
-    out_shape = torch.broadcast_shapes(a.shape, b.shape)
+    out_shape = _broadcast_shape(a.shape, b.shape)
     an = _bcast_numel(out_shape, a, "binary a")
     bn = _bcast_numel(out_shape, b, "binary b")
     out = torch.empty(out_shape, dtype=torch.float32, device=a.device)
@@ -734,7 +748,7 @@ def compare(op: str, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
         return out
     a = _req(a, torch.float32, "compare a")
     b = _req(b, torch.float32, "compare b")
-    out_shape = torch.broadcast_shapes(a.shape, b.shape)
+    out_shape = _broadcast_shape(a.shape, b.shape)
     an = _bcast_numel(out_shape, a, "compare a")
     bn = _bcast_numel(out_shape, b, "compare b")
     out = torch.empty(out_shape, dtype=torch.bool, device=a.device)

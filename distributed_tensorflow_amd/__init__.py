@@ -41,6 +41,6 @@ from .framework.variables import (Variable, constant_initializer, get_variable, 
                                   zeros_initializer)
 from . import layers, nn  # noqa: F401,E402
 from .framework.ops import (clip_by_global_norm, clip_by_norm, clip_by_value,  # noqa: F401,E402
-                            global_norm, one_hot)
+                            floor, global_norm, one_hot)
 
 __version__ = "0.1.0"

@@ -500,16 +500,18 @@ def build_rewrite(graph: Graph, ops: Sequence[Operation], fed: Set[Tensor],
     for op in ops:
         if op.type == "ApplyOptimizer" and not consumers.get(op.outputs[0]) \
                 and op.outputs[0] not in fetched:
-            groups.setdefault((op.attrs["rule"], op.attrs["hyper"]), []).append(op)
-    for (rule, hyper), members in groups.items():
-        n_slots = 2 if rule in ("rmsprop", "adam") else 1
+            lr_t = op.inputs[op.attrs["num_refs"]] if op.attrs.get("lr_input") else None
+            groups.setdefault((op.attrs["rule"], op.attrs["hyper"], lr_t), []).append(op)
+    for (rule, hyper, lr_t), members in groups.items():
+        n_slots = {"rmsprop": 2, "adam": 2, "sgd": 0}.get(rule, 1)
         refs = [[t.op for t in a.inputs[:a.attrs["num_refs"]]] for a in members]
         power_ops = refs[0][1 + n_slots:]
         if any(r[1 + n_slots:] != power_ops for r in refs):
             continue                          # (two Adam instances: leave their ops alone)
         node = FusedNode(graph, "MultiApplyOptimizer", "fused_" + rule,
-                         [a.inputs[a.attrs["num_refs"]] for a in members], [],
-                         {"var_ops": [r[0] for r in refs],
+                         [a.inputs[-1] for a in members] + ([lr_t] if lr_t is not None else []),
+                         [],
+                         {"var_ops": [r[0] for r in refs], "lr_input": lr_t is not None,
                           "slot_ops": [r[1:1 + n_slots] for r in refs],
                           "power_ops": power_ops, "rule": rule, "hyper": hyper,
                           "scalar_updates": []},

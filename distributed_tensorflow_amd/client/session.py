@@ -843,7 +843,8 @@ class Session:
         grad_slots: List[int] = []
         for s in plan.steps:
             if s.node.type in ("MultiApplySGD", "MultiApplyOptimizer"):
-                grad_slots.extend(sl for sl in s.in_slots if sl >= 0)
+                n_grads = len(s.node.attrs["var_ops"])      # (a learning-rate input follows)
+                grad_slots.extend(sl for sl in s.in_slots[:n_grads] if sl >= 0)
             elif s.node.type in ("ApplyGradientDescent", "ApplyOptimizer"):
                 grad_slots.append(s.in_slots[-1])
         producer = {sl: i for i, s in enumerate(plan.steps) for sl in s.out_slots}

@@ -22,7 +22,7 @@ enum BinaryOp { B_ADD = 0, B_SUB, B_MUL, B_DIV, B_MAX, B_MIN, B_POW, B_SIGMOID_G
                 B_RELU_GRAD };
 enum CompareOp { C_EQ = 0, C_NE, C_LT, C_GT };
 enum UnaryOp { U_NEG = 0, U_LOG, U_EXP, U_SQRT, U_SQUARE, U_RECIP, U_ABS, U_SIGMOID, U_TANH,
-               U_RELU };
+               U_RELU, U_FLOOR };
 
 template <int OP>
 __device__ __forceinline__ float bin(float a, float b) {
@@ -49,6 +49,7 @@ __device__ __forceinline__ float una(float x) {
   if (OP == U_ABS) return fabsf(x);
   if (OP == U_SIGMOID) return 1.f / (1.f + expf(-x));
   if (OP == U_TANH) return tanhf(x);
+  if (OP == U_FLOOR) return floorf(x);
   return x > 0.f ? x : 0.f;
 }
 
@@ -297,7 +298,7 @@ DTF_API int dtf_unary_f32(int op, const float* x, float* out, long n, hipStream_
   switch (op) {
     DTF_UN_CASE(U_NEG) DTF_UN_CASE(U_LOG) DTF_UN_CASE(U_EXP) DTF_UN_CASE(U_SQRT)
     DTF_UN_CASE(U_SQUARE) DTF_UN_CASE(U_RECIP) DTF_UN_CASE(U_ABS) DTF_UN_CASE(U_SIGMOID)
-    DTF_UN_CASE(U_TANH) DTF_UN_CASE(U_RELU)
+    DTF_UN_CASE(U_TANH) DTF_UN_CASE(U_RELU) DTF_UN_CASE(U_FLOOR)
     default: return DTF_ERR_UNSUPPORTED;
   }
   DTF_LAUNCH_CHECK();

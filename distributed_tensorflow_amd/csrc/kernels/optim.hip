@@ -22,7 +22,7 @@ namespace {
 constexpr int BLOCK = 256;
 constexpr int MAX_OPT_TENSORS = 16;
 
-enum Rule { MOMENTUM = 0, NESTEROV = 1, ADAGRAD = 2, RMSPROP = 3, ADAM = 4 };
+enum Rule { MOMENTUM = 0, NESTEROV = 1, ADAGRAD = 2, RMSPROP = 3, ADAM = 4, SGD = 5 };
 
 struct OptTensor {
   float* w;
@@ -36,6 +36,7 @@ struct OptArgs {
   float h[6];              // rule-specific constants, see update()
   const float* pw0;        // adam: b1^t, b2^t
   const float* pw1;
+  const float* lr;         // when set: the learning rate, read from the device (a schedule)
   int num_tensors;
 };
 
@@ -44,7 +45,9 @@ struct OptArgs {
 // rounded once from double (1.f - 0.999f is off by 5e-5 of its value).
 template <int RULE>
 __device__ __forceinline__ void update(float& w, float g, float& s0, float& s1, const float* h) {
-  if (RULE == MOMENTUM || RULE == NESTEROV) {
+  if (RULE == SGD) {
+    w = __builtin_fmaf(-h[0], g, w);
+  } else if (RULE == MOMENTUM || RULE == NESTEROV) {
     s0 = __builtin_fmaf(h[1], s0, g);
     if (RULE == NESTEROV) w = __builtin_fmaf(-h[0], __builtin_fmaf(h[1], s0, g), w);
     else w = __builtin_fmaf(-h[0], s0, w);
@@ -67,14 +70,17 @@ template <int RULE>
 __global__ __launch_bounds__(BLOCK) void multi_optim_kernel(OptArgs args) {
   const OptTensor t = args.t[blockIdx.y];
   constexpr bool TWO = RULE == RMSPROP || RULE == ADAM;
+  constexpr bool NONE = RULE == SGD;
   float h[6] = {args.h[0], args.h[1], args.h[2], args.h[3], args.h[4], args.h[5]};
+  if (args.lr) h[0] = args.lr[0];
   if (RULE == ADAM) {
     // bias correction from the running powers (read only: the launch behind this one advances them)
     const float p1 = args.pw0[0], p2 = args.pw1[0];
     h[0] = h[0] * __builtin_sqrtf(1.f - p2) / (1.f - p1);
   }
   const long start = blockIdx.x * (long)BLOCK + threadIdx.x, step = (long)gridDim.x * BLOCK;
-  uintptr_t bits = (uintptr_t)t.w | (uintptr_t)t.g | (uintptr_t)t.s0;
+  uintptr_t bits = (uintptr_t)t.w | (uintptr_t)t.g;
+  if (!NONE) bits |= (uintptr_t)t.s0;
   if (TWO) bits |= (uintptr_t)t.s1;
   long done = 0;
   if ((bits & 15) == 0) {
@@ -85,7 +91,8 @@ __global__ __launch_bounds__(BLOCK) void multi_optim_kernel(OptArgs args) {
     f32x4* b4 = reinterpret_cast<f32x4*>(t.s1);
     for (long i = start; i < n4; i += step) {
       const f32x4 g = g4[i];
-      f32x4 w = w4[i], a = a4[i], b = {0.f, 0.f, 0.f, 0.f};
+      f32x4 w = w4[i], a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+      if (!NONE) a = a4[i];
       if (TWO) b = b4[i];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -96,16 +103,16 @@ __global__ __launch_bounds__(BLOCK) void multi_optim_kernel(OptArgs args) {
         b[j] = bj;
       }
       w4[i] = w;
-      a4[i] = a;
+      if (!NONE) a4[i] = a;
       if (TWO) b4[i] = b;
     }
     done = n4 << 2;
   }
   for (long i = done + start; i < t.n; i += step) {
-    float w = t.w[i], a = t.s0[i], b = TWO ? t.s1[i] : 0.f;
+    float w = t.w[i], a = NONE ? 0.f : t.s0[i], b = TWO ? t.s1[i] : 0.f;
     update<RULE>(w, t.g[i], a, b, h);
     t.w[i] = w;
-    t.s0[i] = a;
+    if (!NONE) t.s0[i] = a;
     if (TWO) t.s1[i] = b;
   }
 }
@@ -131,16 +138,19 @@ int grid_x(long n) {
 }  // namespace
 
 // In-place update of `count` (<= 16) fp32 tensors by `rule` (0 momentum, 1 Nesterov momentum,
-// 2 Adagrad, 3 RMSProp, 4 Adam). s0 / s1: the rule's per-element state (s1 only for RMSProp and
+// 2 Adagrad, 3 RMSProp, 4 Adam, 5 plain gradient descent: no state). lr: optional device scalar
+// that replaces hyper[0] when the kernel runs. s0 / s1: the rule's per-element state (s1 only for RMSProp and
 // Adam); hyper: the rule's constants in the order documented at update() (complements
 // included); pw0 / pw1: device
 // scalars holding b1^t and b2^t (Adam only; not modified here).
 DTF_API int dtf_multi_optim_f32(int rule, int count, float* const* w, const float* const* g,
                                 float* const* s0, float* const* s1, const long* n,
                                 const float* hyper, int num_hyper, const float* pw0,
-                                const float* pw1, hipStream_t stream) {
-  if (rule < 0 || rule > ADAM || count < 0 || count > MAX_OPT_TENSORS || num_hyper < 0 ||
-      num_hyper > 6 || (count > 0 && (!w || !g || !s0 || !n)) || (num_hyper > 0 && !hyper))
+                                const float* pw1, const float* lr, hipStream_t stream) {
+  const bool none = rule == SGD;
+  if (rule < 0 || rule > SGD || count < 0 || count > MAX_OPT_TENSORS || num_hyper < 0 ||
+      num_hyper > 6 || (count > 0 && (!w || !g || (!none && !s0) || !n)) ||
+      (num_hyper > 0 && !hyper))
     return DTF_ERR_BAD_ARG;
   if (count == 0) return DTF_OK;
   const bool two = rule == RMSPROP || rule == ADAM;
@@ -149,13 +159,15 @@ DTF_API int dtf_multi_optim_f32(int rule, int count, float* const* w, const floa
   OptArgs args = {};
   long max_n = 1;
   for (int i = 0; i < count; ++i) {
-    if (!w[i] || !g[i] || !s0[i] || (two && !s1[i]) || n[i] < 0) return DTF_ERR_BAD_ARG;
-    args.t[i] = OptTensor{w[i], g[i], s0[i], two ? s1[i] : nullptr, n[i]};
+    if (!w[i] || !g[i] || (!none && !s0[i]) || (two && !s1[i]) || n[i] < 0)
+      return DTF_ERR_BAD_ARG;
+    args.t[i] = OptTensor{w[i], g[i], none ? nullptr : s0[i], two ? s1[i] : nullptr, n[i]};
     if (n[i] > max_n) max_n = n[i];
   }
   for (int j = 0; j < num_hyper; ++j) args.h[j] = hyper[j];
   args.pw0 = pw0;
   args.pw1 = pw1;
+  args.lr = lr;
   args.num_tensors = count;
   const dim3 grid(grid_x(max_n), count), block(BLOCK);
   switch (rule) {
@@ -163,6 +175,7 @@ DTF_API int dtf_multi_optim_f32(int rule, int count, float* const* w, const floa
     case NESTEROV: hipLaunchKernelGGL(multi_optim_kernel<NESTEROV>, grid, block, 0, stream, args); break;
     case ADAGRAD: hipLaunchKernelGGL(multi_optim_kernel<ADAGRAD>, grid, block, 0, stream, args); break;
     case RMSPROP: hipLaunchKernelGGL(multi_optim_kernel<RMSPROP>, grid, block, 0, stream, args); break;
+    case SGD: hipLaunchKernelGGL(multi_optim_kernel<SGD>, grid, block, 0, stream, args); break;
     default: hipLaunchKernelGGL(multi_optim_kernel<ADAM>, grid, block, 0, stream, args); break;
   }
   DTF_LAUNCH_CHECK();

@@ -286,6 +286,11 @@ def abs(x, name=None) -> Tensor:  # noqa: A001
     return _unary("Abs", x, name)
 
 
+def floor(x, name=None) -> Tensor:
+    """Largest integer not above ``x``, element-wise (no gradient flows through it)."""
+    return _unary("Floor", x, name)
+
+
 def sign(x, name=None) -> Tensor:
     return _unary("Sign", x, name)
 

@@ -30,7 +30,7 @@ BINARY = {"add": 0, "sub": 1, "mul": 2, "div": 3, "max": 4, "min": 5, "pow": 6,
           "sigmoid_grad": 7, "tanh_grad": 8, "relu_grad": 9}
 COMPARE = {"eq": 0, "ne": 1, "lt": 2, "gt": 3}
 UNARY = {"neg": 0, "log": 1, "exp": 2, "sqrt": 3, "square": 4, "recip": 5, "abs": 6,
-         "sigmoid": 7, "tanh": 8, "relu": 9}
+         "sigmoid": 7, "tanh": 8, "relu": 9, "floor": 10}
 ROW_SUM, ROW_MEAN, ROW_MAX = 0, 1, 2
 
 _lib: Optional[ctypes.CDLL] = None
@@ -148,7 +148,7 @@ def _declare(L: ctypes.CDLL) -> None:
         "dtf_softmax_xent_f32": [P, P, P, P, P, P, LG, LG, P],
         "dtf_softmax_grad_f32": [P, P, P, LG, LG, P],
         "dtf_multi_sgd_f32": [I, P, P, P, P, I, P, P, P],
-        "dtf_multi_optim_f32": [I, I, P, P, P, P, P, P, I, P, P, P],
+        "dtf_multi_optim_f32": [I, I, P, P, P, P, P, P, I, P, P, P, P],
         "dtf_affine_scalars_f32": [I, P, P, P, P],
         "dtf_philox_normal": [P, LG, U, U, LG, F, F, I, P],
         "dtf_philox_uniform": [P, LG, U, U, LG, F, F, I, P],
@@ -1078,31 +1078,37 @@ def multi_sgd(params: Sequence[torch.Tensor], grads: Sequence[torch.Tensor],
         first = False
 
 
-OPTIM_RULES = {"momentum": 0, "nesterov": 1, "adagrad": 2, "rmsprop": 3, "adam": 4}
+OPTIM_RULES = {"momentum": 0, "nesterov": 1, "adagrad": 2, "rmsprop": 3, "adam": 4, "sgd": 5}
 
 
 def multi_optim(rule: str, params: Sequence[torch.Tensor], grads: Sequence[torch.Tensor],
                 slots0: Sequence[torch.Tensor], slots1: Sequence[torch.Tensor] = (),
-                hyper: Sequence[float] = (), powers: Sequence[torch.Tensor] = ()) -> None:
+                hyper: Sequence[float] = (), powers: Sequence[torch.Tensor] = (),
+                lr: Optional[torch.Tensor] = None) -> None:
     """In-place update of every ``params[i]`` (and its state ``slots0[i]`` / ``slots1[i]``) from
     ``grads[i]`` by one of the slot-carrying rules -- one launch per 16 tensors. ``hyper``:
     momentum / nesterov (lr, mu); adagrad (lr,); rmsprop (lr, rho, mu, eps); adam (lr, b1, b2,
     eps) with ``powers`` = the device scalars holding b1^t and b2^t (read, not advanced: see
-    ``affine_scalars``)."""
+    ``affine_scalars``); sgd (lr,) takes no slots. ``lr``: a device scalar that replaces the
+    constant learning rate (a schedule computed in the step's graph), read when the kernel runs."""
     code = OPTIM_RULES.get(rule)
     if code is None:
         raise HipKernelError("multi_optim: unknown rule %r" % (rule,))
     two = rule in ("rmsprop", "adam")
-    if len(params) != len(grads) or len(params) != len(slots0) or \
+    none = rule == "sgd"
+    if len(params) != len(grads) or (not none and len(params) != len(slots0)) or \
             (two and len(slots1) != len(params)):
         raise HipKernelError("multi_optim: argument lists differ in length")
+    if lr is not None and (lr.dtype != torch.float32 or lr.numel() != 1
+                           or lr.device.type != "cuda"):
+        raise HipKernelError("multi_optim: lr must be an fp32 GPU scalar")
     if rule == "adam" and len(powers) != 2:
         raise HipKernelError("multi_optim: adam needs the two power scalars")
-    want = {"momentum": 2, "nesterov": 2, "adagrad": 1, "rmsprop": 4, "adam": 4}[rule]
+    want = {"momentum": 2, "nesterov": 2, "adagrad": 1, "rmsprop": 4, "adam": 4, "sgd": 1}[rule]
     if len(hyper) != want:
         raise HipKernelError("multi_optim: %s takes %d constants" % (rule, want))
     grads = [g if g.is_contiguous() else g.contiguous() for g in grads]
-    for group in zip(params, grads, slots0, *([slots1] if two else [])):
+    for group in zip(params, grads, *([] if none else [slots0]), *([slots1] if two else [])):
         p = group[0]
         for t in group:
             if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != p.numel() \
@@ -1122,15 +1128,17 @@ def multi_optim(rule: str, params: Sequence[torch.Tensor], grads: Sequence[torch
     pw = [t.data_ptr() for t in powers] + [None, None]
     for start in range(0, len(params), 16):
         sl = slice(start, start + 16)
-        ps, gs, a0 = params[sl], grads[sl], slots0[sl]
+        ps, gs = params[sl], grads[sl]
         n = len(ps)
         w_arr = (c.c_void_p * n)(*[t.data_ptr() for t in ps])
         g_arr = (c.c_void_p * n)(*[t.data_ptr() for t in gs])
-        a_arr = (c.c_void_p * n)(*[t.data_ptr() for t in a0])
+        a_arr = None if none else (c.c_void_p * n)(*[t.data_ptr() for t in slots0[sl]])
         b_arr = (c.c_void_p * n)(*[t.data_ptr() for t in slots1[sl]]) if two else None
         n_arr = (c.c_long * n)(*[t.numel() for t in ps])
         _check(lib().dtf_multi_optim_f32(code, n, w_arr, g_arr, a_arr, b_arr, n_arr, h_arr,
-                                         len(hyper), pw[0], pw[1], _stream()), "multi_optim")
+                                         len(hyper), pw[0], pw[1],
+                                         None if lr is None else lr.data_ptr(), _stream()),
+               "multi_optim")
 
 
 def affine_scalars(scalars: Sequence[torch.Tensor], factors: Sequence[float],

@@ -158,7 +158,7 @@ def _register_unary(op_type: str, code: str) -> None:
 
 for _t, _c in (("Neg", "neg"), ("Log", "log"), ("Exp", "exp"), ("Sqrt", "sqrt"),
                ("Square", "square"), ("Reciprocal", "recip"), ("Abs", "abs"),
-               ("Sigmoid", "sigmoid"), ("Tanh", "tanh"), ("Relu", "relu")):
+               ("Sigmoid", "sigmoid"), ("Tanh", "tanh"), ("Relu", "relu"), ("Floor", "floor")):
     _register_unary(_t, _c)
 
 
@@ -584,11 +584,13 @@ def _multi_apply_sgd(op, inputs, ctx):
     return []
 
 
-def _optim_launch(ctx, rule, hyper, var_ops, slot_ops_list, power_ops, grads) -> list:
+def _optim_launch(ctx, rule, hyper, var_ops, slot_ops_list, power_ops, grads, lr=None) -> list:
     """Update every variable whose storage, slots and powers are local fp32 GPU tensors with the
     multi-tensor kernel; returns the (var_op, slot_ops, grad) triples it could not take."""
     powers = [_local_f32(ctx, p) for p in power_ops]
     rest, ps, gs, s0, s1 = [], [], [], [], []
+    if lr is not None and not (_is_f32(lr) and lr.is_cuda and lr.numel() == 1):
+        return list(zip(var_ops, slot_ops_list, grads))
     for var_op, slot_ops, g in zip(var_ops, slot_ops_list, grads):
         p = _local_f32(ctx, var_op)
         slots = [_local_f32(ctx, s) for s in slot_ops]
@@ -598,12 +600,13 @@ def _optim_launch(ctx, rule, hyper, var_ops, slot_ops_list, power_ops, grads) ->
             continue
         ps.append(p)
         gs.append(g)
-        s0.append(slots[0])
+        if slots:
+            s0.append(slots[0])
         if len(slots) > 1:
             s1.append(slots[1])
         ctx.session._store_for(var_op).update_count += 1
     if ps:
-        hip.multi_optim(rule, ps, gs, s0, s1, hyper, powers)
+        hip.multi_optim(rule, ps, gs, s0, s1, hyper, powers, lr=lr)
     return rest
 
 
@@ -630,12 +633,13 @@ def _affine_launch(ctx, updates) -> None:
 def _apply_optimizer(op, inputs, ctx):
     from .ref_kernels import _optimizer_refs, apply_rule_through_stores
     var_op, slot_ops, power_ops = _optimizer_refs(op)
-    grad = ctx.reduce_gradients([inputs[op.attrs["num_refs"]]], [var_op])[0]
+    grad = ctx.reduce_gradients([inputs[-1]], [var_op])[0]
+    lr = inputs[op.attrs["num_refs"]] if op.attrs.get("lr_input") else None
     rest = _optim_launch(ctx, op.attrs["rule"], op.attrs["hyper"], [var_op], [slot_ops],
-                         power_ops, [grad])
+                         power_ops, [grad], lr)
     for v, s_ops, g in rest:       # state in another process (parameter server)
         return [apply_rule_through_stores(ctx, op.attrs["rule"], op.attrs["hyper"], v, s_ops,
-                                          power_ops, g)]
+                                          power_ops, g, lr)]
     return [_local_f32(ctx, var_op)]
 
 
@@ -645,12 +649,13 @@ def _multi_apply_optimizer(op, inputs, ctx):
     advance with the step (Adam's running powers, step counters)."""
     from .ref_kernels import apply_rule_through_stores
     var_ops = op.attrs["var_ops"]
-    grads = ctx.reduce_gradients(list(inputs), var_ops)       # no-op without a sync runtime
+    lr = inputs[len(var_ops)] if op.attrs.get("lr_input") else None
+    grads = ctx.reduce_gradients(list(inputs[:len(var_ops)]), var_ops)   # no-op without a sync runtime
     rest = _optim_launch(ctx, op.attrs["rule"], op.attrs["hyper"], var_ops, op.attrs["slot_ops"],
-                         op.attrs["power_ops"], grads)
+                         op.attrs["power_ops"], grads, lr)
     for v, s_ops, g in rest:
         apply_rule_through_stores(ctx, op.attrs["rule"], op.attrs["hyper"], v, s_ops,
-                                  op.attrs["power_ops"], g)
+                                  op.attrs["power_ops"], g, lr)
     _affine_launch(ctx, op.attrs.get("scalar_updates", []))
     return []
 

@@ -134,7 +134,10 @@ def optimizer_rule_step(rule: str, hyper, w, g, s0, s1=None, powers=None):
     (``ApplyMomentum``, ``ApplyAdagrad``, ``ApplyRMSProp``, ``ApplyAdam``); the gfx950 kernel
     (``csrc/kernels/optim.hip``) computes the same expressions with fused multiply-adds."""
     g = g.to(w.device, w.dtype)
-    if rule in ("momentum", "nesterov"):
+    if rule == "sgd":
+        (lr,) = hyper
+        w = w - lr * g
+    elif rule in ("momentum", "nesterov"):
         lr, mu = hyper
         s0 = mu * s0 + g
         w = w - lr * (g + mu * s0) if rule == "nesterov" else w - lr * s0
@@ -159,16 +162,19 @@ def optimizer_rule_step(rule: str, hyper, w, g, s0, s1=None, powers=None):
     return w, s0, s1
 
 
-def apply_rule_through_stores(ctx, rule, hyper, var_op, slot_ops, power_ops, grad):
+def apply_rule_through_stores(ctx, rule, hyper, var_op, slot_ops, power_ops, grad, lr=None):
     """The update of one variable through the variable-store interface (any store: local CPU
     storage, a parameter-server task). State that lives in this process is assigned; state on a
     parameter server receives the *difference* (queued with the step's other updates and added
     on arrival), so concurrent workers' updates compose the way their plain-SGD updates do."""
+    if lr is not None:                 # a learning rate computed in the graph (a schedule)
+        hyper = (float(lr),) + tuple(hyper[1:])
     w = ctx.var_read(var_op)
     slots = [ctx.var_read(s) for s in slot_ops]
     powers = [ctx.var_read(p) for p in power_ops] if power_ops else None
     new_w, new_s0, new_s1 = optimizer_rule_step(
-        rule, hyper, w, grad, slots[0], slots[1] if len(slots) > 1 else None, powers)
+        rule, hyper, w, grad, slots[0] if slots else None,
+        slots[1] if len(slots) > 1 else None, powers)
     for s_op, old, new in zip(slot_ops, slots, (new_s0, new_s1)):
         store = ctx.session._store_for(s_op)
         if getattr(store, "local_tensor", lambda n: None)(s_op.name) is not None:
@@ -181,16 +187,17 @@ def apply_rule_through_stores(ctx, rule, hyper, var_op, slot_ops, power_ops, gra
 def _optimizer_refs(op):
     """(variable op, slot ops, power ops) of an ``ApplyOptimizer`` op."""
     refs = [t.op for t in op.inputs[:op.attrs["num_refs"]]]
-    n_slots = 2 if op.attrs["rule"] in ("rmsprop", "adam") else 1
+    n_slots = {"rmsprop": 2, "adam": 2, "sgd": 0}.get(op.attrs["rule"], 1)
     return refs[0], refs[1:1 + n_slots], refs[1 + n_slots:]
 
 
 @ref_kernel("ApplyOptimizer", stateful=True)
 def _apply_optimizer(op, inputs, ctx):
     var_op, slot_ops, power_ops = _optimizer_refs(op)
-    grad = ctx.reduce_gradients([inputs[op.attrs["num_refs"]]], [var_op])[0]
+    grad = ctx.reduce_gradients([inputs[-1]], [var_op])[0]
+    lr = inputs[op.attrs["num_refs"]] if op.attrs.get("lr_input") else None
     return [apply_rule_through_stores(ctx, op.attrs["rule"], op.attrs["hyper"], var_op,
-                                      slot_ops, power_ops, grad)]
+                                      slot_ops, power_ops, grad, lr)]
 
 
 def affine_through_store(ctx, var_op, factor: float, increment: float):
@@ -213,10 +220,11 @@ def _affine_update_variable(op, inputs, ctx):
 @ref_kernel("MultiApplyOptimizer", stateful=True)
 def _multi_apply_optimizer(op, inputs, ctx):
     var_ops = op.attrs["var_ops"]
-    grads = ctx.reduce_gradients(list(inputs), var_ops)
+    lr = inputs[len(var_ops)] if op.attrs.get("lr_input") else None
+    grads = ctx.reduce_gradients(list(inputs[:len(var_ops)]), var_ops)
     for var_op, slot_ops, g in zip(var_ops, op.attrs["slot_ops"], grads):
         apply_rule_through_stores(ctx, op.attrs["rule"], op.attrs["hyper"], var_op, slot_ops,
-                                  op.attrs["power_ops"], g)
+                                  op.attrs["power_ops"], g, lr)
     for var_op, factor, increment in op.attrs.get("scalar_updates", []):
         affine_through_store(ctx, var_op, factor, increment)
     return []
@@ -266,6 +274,7 @@ ref_kernel("Neg")(_un(torch.neg))
 ref_kernel("Log")(_un(torch.log))
 ref_kernel("Exp")(_un(torch.exp))
 ref_kernel("Sqrt")(_un(torch.sqrt))
+ref_kernel("Floor")(_un(torch.floor))
 ref_kernel("Square")(_un(torch.square))
 ref_kernel("Reciprocal")(_un(torch.reciprocal))
 ref_kernel("Abs")(_un(torch.abs))

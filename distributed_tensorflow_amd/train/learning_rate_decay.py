@@ -1,0 +1,55 @@
+"""Learning-rate schedules as graph tensors: ``tf.train.exponential_decay`` and friends.
+
+The schedule is a handful of scalar ops on ``global_step`` inside the training step's own graph;
+the optimizers hand the resulting device scalar to the update kernel (``csrc/kernels/optim.hip``
+reads it when it runs), so a captured step replays with a changing rate and the host never
+computes or uploads one. ``global_step`` is read at its value BEFORE the step's increment, as in
+TensorFlow.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+from ..framework import dtypes
+from ..framework import ops as F
+from ..framework.graph import Tensor, get_default_graph
+
+
+def _step_as_float(global_step) -> Tensor:
+    if global_step is None:
+        raise ValueError("global_step is required for a learning-rate schedule")
+    step = F.convert_to_tensor(global_step)
+    return step if step.dtype == dtypes.float32 else F.cast(step, dtypes.float32)
+
+
+def exponential_decay(learning_rate: float, global_step, decay_steps: float, decay_rate: float,
+                      staircase: bool = False, name: Optional[str] = None) -> Tensor:
+    """``learning_rate * decay_rate ** (global_step / decay_steps)`` (``staircase``: the exponent
+    is floored, so the rate drops once every ``decay_steps`` steps)."""
+    with get_default_graph().name_scope(name or "ExponentialDecay"):
+        p = F.divide(_step_as_float(global_step), float(decay_steps))
+        if staircase:
+            p = F.floor(p)
+        return F.multiply(float(learning_rate), F.pow(float(decay_rate), p))
+
+
+def inverse_time_decay(learning_rate: float, global_step, decay_steps: float, decay_rate: float,
+                       staircase: bool = False, name: Optional[str] = None) -> Tensor:
+    """``learning_rate / (1 + decay_rate * global_step / decay_steps)``."""
+    with get_default_graph().name_scope(name or "InverseTimeDecay"):
+        p = F.divide(_step_as_float(global_step), float(decay_steps))
+        if staircase:
+            p = F.floor(p)
+        return F.divide(float(learning_rate), F.add(1.0, F.multiply(float(decay_rate), p)))
+
+
+def polynomial_decay(learning_rate: float, global_step, decay_steps: float,
+                     end_learning_rate: float = 0.0001, power: float = 1.0,
+                     name: Optional[str] = None) -> Tensor:
+    """``(learning_rate - end) * (1 - min(global_step, decay_steps) / decay_steps) ** power +
+    end``."""
+    with get_default_graph().name_scope(name or "PolynomialDecay"):
+        step = F.minimum(_step_as_float(global_step), float(decay_steps))
+        frac = F.subtract(1.0, F.divide(step, float(decay_steps)))
+        return F.add(F.multiply(float(learning_rate) - float(end_learning_rate),
+                                F.pow(frac, float(power))), float(end_learning_rate))

@@ -113,14 +113,26 @@ class Optimizer:
     def get_slot_names(self) -> List[str]:
         return sorted(self._slot_dict())
 
+    @staticmethod
+    def _split_lr(learning_rate):
+        """``(constant, tensor)``: a Python number is a constant baked into the update; a
+        tensor or variable (a schedule such as ``exponential_decay``) is read on the device by
+        the update kernel every step."""
+        if isinstance(learning_rate, (int, float)):
+            return float(learning_rate), None
+        return 0.0, F.convert_to_tensor(learning_rate, dtype=None)
+
     def _apply_rule(self, rule: str, hyper: Sequence[float], var: Variable,
-                    refs: Sequence[Variable], grad: Tensor) -> Operation:
+                    refs: Sequence[Variable], grad: Tensor,
+                    lr_tensor: Optional[Tensor] = None) -> Operation:
         g = var.graph
         ref_tensors = [var._variable] + [r._variable for r in refs]
-        return g.create_op("ApplyOptimizer", ref_tensors + [grad], [(var.dtype, var.shape)],
+        values = ([lr_tensor] if lr_tensor is not None else []) + [grad]
+        return g.create_op("ApplyOptimizer", ref_tensors + values, [(var.dtype, var.shape)],
                            name="update_" + var.op.name.split("/")[-1],
                            attrs={"rule": rule, "hyper": tuple(float(h) for h in hyper),
                                   "num_refs": len(ref_tensors),
+                                  "lr_input": lr_tensor is not None,
                                   "use_locking": self._use_locking})
 
 
@@ -128,10 +140,12 @@ class GradientDescentOptimizer(Optimizer):
     def __init__(self, learning_rate: float, use_locking: bool = False,
                  name: str = "GradientDescent"):
         super().__init__(use_locking, name)
-        self._learning_rate = float(learning_rate)
+        self._learning_rate, self._lr_tensor = self._split_lr(learning_rate)
 
     def _apply_dense(self, grad: Tensor, var: Variable) -> Operation:
         g = var.graph
+        if self._lr_tensor is not None:
+            return self._apply_rule("sgd", (0.0,), var, [], grad, self._lr_tensor)
         return g.create_op("ApplyGradientDescent", [var._variable, grad],
                            [(var.dtype, var.shape)], name="update_" + var.op.name.split("/")[-1],
                            attrs={"learning_rate": self._learning_rate,
@@ -145,7 +159,8 @@ class MomentumOptimizer(Optimizer):
     def __init__(self, learning_rate: float, momentum: float, use_locking: bool = False,
                  name: str = "Momentum", use_nesterov: bool = False):
         super().__init__(use_locking, name)
-        self._learning_rate, self._momentum = float(learning_rate), float(momentum)
+        self._learning_rate, self._lr_tensor = self._split_lr(learning_rate)
+        self._momentum = float(momentum)
         self._use_nesterov = bool(use_nesterov)
 
     def _create_slots(self, var_list):
@@ -155,7 +170,7 @@ class MomentumOptimizer(Optimizer):
     def _apply_dense(self, grad, var):
         return self._apply_rule("nesterov" if self._use_nesterov else "momentum",
                                 (self._learning_rate, self._momentum), var,
-                                [self.get_slot(var, "momentum")], grad)
+                                [self.get_slot(var, "momentum")], grad, self._lr_tensor)
 
 
 class AdagradOptimizer(Optimizer):
@@ -167,7 +182,7 @@ class AdagradOptimizer(Optimizer):
             raise ValueError("initial_accumulator_value must be positive: %s"
                              % initial_accumulator_value)
         super().__init__(use_locking, name)
-        self._learning_rate = float(learning_rate)
+        self._learning_rate, self._lr_tensor = self._split_lr(learning_rate)
         self._initial_accumulator_value = float(initial_accumulator_value)
 
     def _create_slots(self, var_list):
@@ -176,7 +191,7 @@ class AdagradOptimizer(Optimizer):
 
     def _apply_dense(self, grad, var):
         return self._apply_rule("adagrad", (self._learning_rate,), var,
-                                [self.get_slot(var, "accumulator")], grad)
+                                [self.get_slot(var, "accumulator")], grad, self._lr_tensor)
 
 
 class RMSPropOptimizer(Optimizer):
@@ -189,7 +204,8 @@ class RMSPropOptimizer(Optimizer):
         if centered:
             raise NotImplementedError("centered RMSProp is not provided")
         super().__init__(use_locking, name)
-        self._learning_rate, self._decay = float(learning_rate), float(decay)
+        self._learning_rate, self._lr_tensor = self._split_lr(learning_rate)
+        self._decay = float(decay)
         self._momentum, self._epsilon = float(momentum), float(epsilon)
 
     def _create_slots(self, var_list):
@@ -200,7 +216,7 @@ class RMSPropOptimizer(Optimizer):
     def _apply_dense(self, grad, var):
         return self._apply_rule(
             "rmsprop", (self._learning_rate, self._decay, self._momentum, self._epsilon), var,
-            [self.get_slot(var, "rms"), self.get_slot(var, "momentum")], grad)
+            [self.get_slot(var, "rms"), self.get_slot(var, "momentum")], grad, self._lr_tensor)
 
 
 class AdamOptimizer(Optimizer):
@@ -212,7 +228,8 @@ class AdamOptimizer(Optimizer):
     def __init__(self, learning_rate: float = 0.001, beta1: float = 0.9, beta2: float = 0.999,
                  epsilon: float = 1e-8, use_locking: bool = False, name: str = "Adam"):
         super().__init__(use_locking, name)
-        self._learning_rate, self._epsilon = float(learning_rate), float(epsilon)
+        self._learning_rate, self._lr_tensor = self._split_lr(learning_rate)
+        self._epsilon = float(epsilon)
         self._beta1, self._beta2 = float(beta1), float(beta2)
         self._powers: Optional[Tuple[Variable, Variable]] = None
 
@@ -232,7 +249,8 @@ class AdamOptimizer(Optimizer):
     def _apply_dense(self, grad, var):
         return self._apply_rule(
             "adam", (self._learning_rate, self._beta1, self._beta2, self._epsilon), var,
-            [self.get_slot(var, "m"), self.get_slot(var, "v"), *self._powers], grad)
+            [self.get_slot(var, "m"), self.get_slot(var, "v"), *self._powers], grad,
+            self._lr_tensor)
 
     def _finish(self, updates):
         g = get_default_graph()

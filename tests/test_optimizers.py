@@ -402,3 +402,86 @@ def test_gpu_clipped_momentum_step_runs_natively():
             assert n > 1.5 and sess.stats["torch_fallbacks"] == 0 and not sess.fallback_log
             step = np.sqrt(((w1 - w0) ** 2).sum() + ((b1 - b0) ** 2).sum())
             assert np.isclose(step, 0.1 * 1.5, rtol=1e-4)
+
+
+# -- learning-rate schedules ----------------------------------------------------------------
+def _scheduled_run(make_opt, schedule, device="cpu", steps=7, fusion=True):
+    bx, by = _problem()
+    with tf.Graph().as_default():
+        tf.set_random_seed(1)
+        x = tf.placeholder(tf.float32, [None, 8])
+        y = tf.placeholder(tf.float32, [None, 3])
+        w = tf.Variable(tf.random_normal([8, 3]), name="W")
+        b = tf.Variable(tf.zeros([3]), name="b")
+        loss = tf.reduce_mean(tf.reduce_sum(tf.square(tf.subtract(tf.add(tf.matmul(x, w), b), y)), 1))
+        gs = tf.train.get_or_create_global_step()
+        lr = schedule(gs)
+        train = make_opt(lr).minimize(loss, global_step=gs)
+        with tf.Session(config=tf.ConfigProto(device=device, graph_fusion=fusion)) as sess:
+            sess.run(tf.global_variables_initializer())
+            w0, b0 = sess.run([w, b])
+            rates = [float(sess.run([train, lr], {x: bx, y: by})[1]) for _ in range(steps)]
+            types = {s.node.type for p in sess._plans.values() for s in p.steps}
+            stats = dict(sess.stats)
+            return w0, b0, sess.run(w), sess.run(b), rates, types, stats
+
+
+def _sgd_reference(w0, b0, rates):
+    bx, by = _problem()
+    w, b = w0.astype(np.float64), b0.astype(np.float64)
+    for lr in rates:
+        dz = 2.0 * (bx @ w + b - by) / bx.shape[0]
+        w, b = w - lr * (bx.T @ dz), b - lr * dz.sum(0)
+    return w, b
+
+
+SCHEDULES = [
+    ("exponential", lambda gs: tf.train.exponential_decay(0.05, gs, 2, 0.5),
+     lambda t: 0.05 * 0.5 ** (t / 2)),
+    ("staircase", lambda gs: tf.train.exponential_decay(0.05, gs, 3, 0.5, staircase=True),
+     lambda t: 0.05 * 0.5 ** (t // 3)),
+    ("inverse_time", lambda gs: tf.train.inverse_time_decay(0.05, gs, 2, 0.5),
+     lambda t: 0.05 / (1 + 0.5 * t / 2)),
+    ("polynomial", lambda gs: tf.train.polynomial_decay(0.05, gs, 5, 0.01, power=2.0),
+     lambda t: (0.05 - 0.01) * (1 - min(t, 5) / 5) ** 2 + 0.01),
+]
+
+
+@pytest.mark.parametrize("name,schedule,formula", SCHEDULES, ids=[s[0] for s in SCHEDULES])
+def test_learning_rate_schedules_drive_plain_sgd(name, schedule, formula):
+    w0, b0, w, b, rates, types, _ = _scheduled_run(tf.train.GradientDescentOptimizer, schedule)
+    want = [formula(t) for t in range(len(rates))]          # step value BEFORE the increment
+    assert np.allclose(rates, want, rtol=1e-5)
+    ref_w, ref_b = _sgd_reference(w0, b0, want)
+    assert np.allclose(w, ref_w, rtol=2e-5, atol=2e-6) and np.allclose(b, ref_b, rtol=2e-5, atol=2e-6)
+    assert "MultiApplyOptimizer" in types
+
+
+def test_scheduled_adam_equals_adam_with_the_rate_of_each_step():
+    schedule, formula = SCHEDULES[1][1], SCHEDULES[1][2]
+    for fusion in (True, False):
+        w0, b0, w, b, rates, _, _ = _scheduled_run(tf.train.AdamOptimizer, schedule, fusion=fusion)
+        bx, by = _problem()
+        p = [w0.astype(np.float64), b0.astype(np.float64)]
+        m = [np.zeros_like(v) for v in p]
+        v2 = [np.zeros_like(v) for v in p]
+        for t in range(1, len(rates) + 1):
+            dz = 2.0 * (bx @ p[0] + p[1] - by) / bx.shape[0]
+            for i, g in enumerate([bx.T @ dz, dz.sum(0)]):
+                m[i] = 0.9 * m[i] + 0.1 * g
+                v2[i] = 0.999 * v2[i] + 0.001 * g * g
+                p[i] -= formula(t - 1) * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t) * m[i] / (
+                    np.sqrt(v2[i]) + 1e-8)
+        assert np.allclose(w, p[0], rtol=5e-5, atol=5e-6) and np.allclose(b, p[1], rtol=5e-5, atol=5e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,schedule,formula", SCHEDULES[:2], ids=[s[0] for s in SCHEDULES[:2]])
+def test_gpu_schedule_is_read_on_the_device_inside_captured_steps(name, schedule, formula):
+    w0, b0, w, b, rates, types, stats = _scheduled_run(tf.train.GradientDescentOptimizer,
+                                                       schedule, device="cuda:0", steps=12)
+    want = [formula(t) for t in range(len(rates))]
+    assert np.allclose(rates, want, rtol=1e-5)
+    ref_w, ref_b = _sgd_reference(w0, b0, want)
+    assert np.allclose(w, ref_w, rtol=5e-5, atol=5e-6) and np.allclose(b, ref_b, rtol=5e-5, atol=5e-6)
+    assert stats["graph_replays"] >= 8 and stats["torch_fallbacks"] == 0

@@ -53,3 +53,23 @@ def polynomial_decay(learning_rate: float, global_step, decay_steps: float,
         frac = F.subtract(1.0, F.divide(step, float(decay_steps)))
         return F.add(F.multiply(float(learning_rate) - float(end_learning_rate),
                                 F.pow(frac, float(power))), float(end_learning_rate))
+
+
+def piecewise_constant(x, boundaries, values, name: Optional[str] = None) -> Tensor:
+    """``values[0]`` while ``x <= boundaries[0]``, ``values[i]`` while ``boundaries[i-1] < x <=
+    boundaries[i]``, ``values[-1]`` beyond the last boundary. Built from comparisons and a
+    weighted sum, all scalar device ops."""
+    boundaries, values = [float(b) for b in boundaries], [float(v) for v in values]
+    if len(values) != len(boundaries) + 1:
+        raise ValueError("piecewise_constant needs one more value than boundaries")
+    if any(a >= b for a, b in zip(boundaries, boundaries[1:])):
+        raise ValueError("boundaries must increase strictly")
+    with get_default_graph().name_scope(name or "PiecewiseConstant"):
+        step = _step_as_float(x)
+        # below[i] = 1 while x <= boundaries[i]; it only ever switches from 1 to 0 as x grows
+        below = [F.subtract(1.0, F.cast(F.greater(step, b), dtypes.float32)) for b in boundaries]
+        terms = [F.multiply(values[0], below[0])]
+        for i in range(1, len(boundaries)):
+            terms.append(F.multiply(values[i], F.subtract(below[i], below[i - 1])))
+        terms.append(F.multiply(values[-1], F.subtract(1.0, below[-1])))
+        return terms[0] if len(terms) == 1 else F.add_n(terms)

@@ -444,6 +444,8 @@ SCHEDULES = [
      lambda t: 0.05 / (1 + 0.5 * t / 2)),
     ("polynomial", lambda gs: tf.train.polynomial_decay(0.05, gs, 5, 0.01, power=2.0),
      lambda t: (0.05 - 0.01) * (1 - min(t, 5) / 5) ** 2 + 0.01),
+    ("piecewise", lambda gs: tf.train.piecewise_constant(gs, [1, 4], [0.05, 0.02, 0.005]),
+     lambda t: 0.05 if t <= 1 else (0.02 if t <= 4 else 0.005)),
 ]
 
 
@@ -476,7 +478,8 @@ def test_scheduled_adam_equals_adam_with_the_rate_of_each_step():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,schedule,formula", SCHEDULES[:2], ids=[s[0] for s in SCHEDULES[:2]])
+@pytest.mark.parametrize("name,schedule,formula", SCHEDULES[:2] + SCHEDULES[4:],
+                         ids=[s[0] for s in SCHEDULES[:2] + SCHEDULES[4:]])
 def test_gpu_schedule_is_read_on_the_device_inside_captured_steps(name, schedule, formula):
     w0, b0, w, b, rates, types, stats = _scheduled_run(tf.train.GradientDescentOptimizer,
                                                        schedule, device="cuda:0", steps=12)

@@ -73,6 +73,11 @@ def main(argv=None):
         formatter=lambda v: "Step: %d,  Cost: %.4f" % (int(v["step"]), float(v["cost"])))
 
     test_x, test_y = mnist.test.images, mnist.test.labels.astype(np.int64)
+    if FLAGS.device_data and server.device.type == "cuda":
+        # the data set lives in HBM: a batch is a view of it, nothing is uploaded per step
+        mnist.train.to_device(server.device)
+        mnist.test.to_device(server.device)
+        test_x, test_y = mnist.test.device_images, mnist.test.device_labels
     begin = time.time()
     steps = 0
     with tf.train.MonitoredTrainingSession(
@@ -82,7 +87,7 @@ def main(argv=None):
             log_step_count_steps=100) as sess:
         while not sess.should_stop():
             bx, by = mnist.train.next_batch(batch_size)
-            sess.run(train_op, feed_dict={x: bx, y: by.astype(np.int64)})
+            sess.run(train_op, feed_dict={x: bx, y: by})
             steps += 1
         raw = sess.raw_session()
         acc, step = raw.run([accuracy, global_step], feed_dict={x: test_x, y: test_y})

@@ -20,6 +20,7 @@ from ..framework.graph import get_default_graph, name_scope, set_random_seed
 from ..framework.variables import (Variable, constant_initializer, get_variable,
                                    global_variables_initializer)
 from ..train.optimizer import GradientDescentOptimizer
+from ..train.training_util import get_or_create_global_step
 
 INPUT_DIM, HIDDEN_DIM, NUM_CLASSES = 784, 100, 10
 BATCH_SIZE = 100
@@ -33,8 +34,8 @@ def build_model(learning_rate: float = LEARNING_RATE, seed: Optional[int] = 1,
     """Build the model into the default graph (inside whatever device scope is active) and
     return its handles. ``optimizer``: a ``tf.train.Optimizer`` to train with instead of the
     reference's ``GradientDescentOptimizer(learning_rate)``."""
-    global_step = get_variable("global_step", [], initializer=constant_initializer(0),
-                               trainable=False)
+    # (a caller that built a learning-rate schedule has created the counter already)
+    global_step = get_or_create_global_step()
     with name_scope("input"):
         x = F.placeholder(dtypes.float32, shape=[None, INPUT_DIM], name="x-input")
         y_ = F.placeholder(dtypes.float32, shape=[None, NUM_CLASSES], name="y-input")

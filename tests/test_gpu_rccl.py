@@ -103,8 +103,9 @@ def test_collective_runtime_trains_like_local_session(nccl_comm, strategy, captu
     assert np.allclose(got[1], ref[1], rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("optimizer", ["sgd", "adam", "scheduled_momentum"])
 @pytest.mark.parametrize("strategy", ["allreduce_sync", "reduce_scatter_sync"])
-def test_captured_collective_steps_equal_eager_ones_bit_for_bit(nccl_comm, strategy):
+def test_captured_collective_steps_equal_eager_ones_bit_for_bit(nccl_comm, strategy, optimizer):
     """The same 30 training steps under the collective runtime (RCCL, world of one) run eagerly
     and as replayed HIP graphs with the RCCL calls captured: losses, step counter and every
     variable are bit-equal, and no gradient is copied on its way to the collective."""
@@ -124,7 +125,14 @@ def test_captured_collective_steps_equal_eager_ones_bit_for_bit(nccl_comm, strat
             server = tf.train.Server(cluster, job_name="worker", task_index=0, protocol="rccl",
                                      config=cfg, comm=nccl_comm)
             with tf.device(tf.train.replica_device_setter(cluster=cluster)):
-                model = mnist_mlp.build_model(learning_rate=0.01, seed=1)
+                opt = None
+                if optimizer == "adam":
+                    opt = tf.train.AdamOptimizer(0.01)
+                elif optimizer == "scheduled_momentum":
+                    gs = tf.train.get_or_create_global_step()
+                    opt = tf.train.MomentumOptimizer(
+                        tf.train.exponential_decay(0.01, gs, 10, 0.5, staircase=True), 0.9)
+                model = mnist_mlp.build_model(learning_rate=0.01, seed=1, optimizer=opt)
             sv = tf.train.Supervisor(is_chief=True, global_step=model.global_step,
                                      init_op=model.init_op)
             sess = sv.prepare_or_wait_for_session(server.target, config=cfg)

@@ -181,6 +181,7 @@ class CollectiveRuntime(LocalRuntime):
         self.grads_in_place = 0            # gradients found already in their arena slot
         self.grads_copied = 0              # gradients that had to be copied into it
         self._grad_views: Optional[Dict[str, torch.Tensor]] = None
+        self._extent_cache: Dict[Any, Any] = {}     # names of a step -> (arena, gradient span)
         self._g_shard: Optional[torch.Tensor] = None
         self._p_stage: Optional[torch.Tensor] = None
         self.shard_plan = None             # parallel.planner.ShardPlan of the session's graph
@@ -346,7 +347,7 @@ class CollectiveRuntime(LocalRuntime):
     def _grad_extent(self, names: Sequence[str]) -> int:
         """Elements of the flat gradient arena up to the end of the last of ``names``."""
         key = tuple(names)
-        cache = self.__dict__.setdefault("_extent_cache", {})
+        cache = self._extent_cache
         hit = cache.get(key)
         if hit is None or hit[0] is not self._flat_grads:
             ends = {n: off + numel for n, off, numel, _ in self._layout}

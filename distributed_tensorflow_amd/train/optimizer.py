@@ -307,21 +307,20 @@ class SyncReplicasOptimizer(Optimizer):
         return self._opt.get_slot_names(*args, **kwargs)
 
     def configure_session(self, session) -> None:
+        """Check that ``session`` can aggregate synchronously over ``total_num_replicas`` ranks
+        and select mean aggregation in its runtime."""
         rt = getattr(session, "_runtime", None)
         comm = getattr(rt, "comm", None)
         world = comm.world_size if comm is not None else 1
         strategy = getattr(rt, "strategy", None)
-        if world > 1 and strategy not in ("allreduce_sync", "reduce_scatter_sync"):
-            raise ValueError("SyncReplicasOptimizer needs a synchronous strategy (servers with "
-                             "protocol='rccl'); this session runs %r" % (strategy,))
-        if rt is not None and strategy not in (None, "allreduce_sync", "reduce_scatter_sync") \
-                and self._total_num_replicas > 1:
-            raise ValueError("SyncReplicasOptimizer needs a synchronous strategy (servers with "
-                             "protocol='rccl'); this session runs %r" % (strategy,))
+        synchronous = strategy in ("allreduce_sync", "reduce_scatter_sync")
         if world != self._total_num_replicas:
             raise ValueError("SyncReplicasOptimizer(total_num_replicas=%d) in a job of %d "
                              "replica(s)" % (self._total_num_replicas, world))
-        if rt is not None and hasattr(rt, "grad_aggregation"):
+        if self._total_num_replicas > 1 and not synchronous:
+            raise ValueError("SyncReplicasOptimizer needs a synchronous strategy (servers with "
+                             "protocol='rccl'); this session runs %r" % (strategy,))
+        if synchronous:
             rt.grad_aggregation = "mean"
 
     def make_session_run_hook(self, is_chief: bool = True, num_tokens: int = -1):

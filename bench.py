@@ -21,7 +21,9 @@ choice in two phases:
 
 0. the product with no data exchange (every rank computes all of C), kept as a fallback line:
    reported only if no sharded strategy completes (first contact with hardware this code has not
-   run on must not end without a number).
+   run on must not end without a number). Next to it, for information only
+   (``config.row_blocks_only_tflops``): the row-sharded product with C left in row blocks, i.e.
+   what the same ranks reach when nothing has to travel.
 A. the plain RCCL strategies -- row-sharded A + all-gather of C, K-sharded operands +
    all-reduce of partial sums -- are each measured in full (W warm-up steps, K timed steps
    between barriers). From here on a valid result line exists.
@@ -116,6 +118,9 @@ def result_line(args, world: int, strategy: str, engine: ShardedMatmul, elapsed:
                    "fp8_scaling": engine.scaling if args.dtype == "fp8" else None,
                    "peer_transport": engine.peer_transport
                    if strategy.endswith("_direct") else None,
+                   # what the same ranks reach when every rank keeps only its own row block of C
+                   # (no data exchange): the ceiling the links take the step away from
+                   "row_blocks_only_tflops": getattr(args, "row_blocks_only_tflops", None),
                    "result": "full C on every rank" if strategy in
                    ("replicated", "m_shard_allgather", "k_shard_allreduce",
                     "m_shard_allgather_direct", "k_shard_allreduce_direct")
@@ -317,6 +322,19 @@ def main() -> None:
         torch.cuda.empty_cache()
     except Exception as e:  # noqa: BLE001
         say("note: replicated baseline failed: %s" % str(e)[:200])
+    # (informational, same guard: the row-sharded product with C left in row blocks -- no
+    # collective carries data -- shows what the transfer of the full result costs)
+    try:
+        eng, elapsed = measure("m_shard")
+        args.row_blocks_only_tflops = round(
+            eng.flops_per_step / (elapsed / args.steps) / 1e12, 2)
+        say("candidate %-28s %8.3f ms/step (%d timed steps; C left in row blocks, reported as "
+            "config.row_blocks_only_tflops only)" % ("m_shard", elapsed * 1e3 / args.steps,
+                                                     args.steps))
+        del eng
+        torch.cuda.empty_cache()
+    except Exception as e:  # noqa: BLE001
+        say("note: m_shard measurement failed: %s" % str(e)[:200])
     secured.arm(args.phase_a_budget)
 
     # Phase A: the plain RCCL strategies, measured in full. After it a sharded result exists.

@@ -20,7 +20,7 @@ inline int grid_for(long n, int per_thread) {
 
 enum BinaryOp { B_ADD = 0, B_SUB, B_MUL, B_DIV, B_MAX, B_MIN, B_POW, B_SIGMOID_GRAD, B_TANH_GRAD,
                 B_RELU_GRAD };
-enum CompareOp { C_EQ = 0, C_NE, C_LT, C_GT };
+enum CompareOp { C_EQ = 0, C_NE, C_LT, C_GT, C_LE, C_GE };
 enum UnaryOp { U_NEG = 0, U_LOG, U_EXP, U_SQRT, U_SQUARE, U_RECIP, U_ABS, U_SIGMOID, U_TANH,
                U_RELU, U_FLOOR };
 
@@ -98,8 +98,19 @@ __global__ __launch_bounds__(BLOCK) void compare_kernel(const float* __restrict_
                                                         long an, long bn) {
   for (long i = blockIdx.x * (long)BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * BLOCK) {
     const float x = a[an == n ? i : i % an], y = b[bn == n ? i : i % bn];
-    out[i] = OP == C_EQ ? x == y : OP == C_NE ? x != y : OP == C_LT ? x < y : x > y;
+    out[i] = OP == C_EQ ? x == y : OP == C_NE ? x != y : OP == C_LT ? x < y : OP == C_GT ? x > y
+             : OP == C_LE ? x <= y : x >= y;
   }
+}
+
+// out[i] = cond[i] ? a[i] : b[i]; cond / a / b broadcast by period (a scalar operand has period 1)
+__global__ __launch_bounds__(BLOCK) void select_kernel(const unsigned char* __restrict__ cond,
+                                                       const float* __restrict__ a,
+                                                       const float* __restrict__ b,
+                                                       float* __restrict__ out, long n, long cn,
+                                                       long an, long bn) {
+  for (long i = blockIdx.x * (long)BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * BLOCK)
+    out[i] = cond[cn == n ? i : i % cn] ? a[an == n ? i : i % an] : b[bn == n ? i : i % bn];
 }
 
 __global__ __launch_bounds__(BLOCK) void compare_i64_eq_kernel(const long* __restrict__ a,
@@ -317,8 +328,19 @@ DTF_API int dtf_compare_f32(int op, const float* a, const float* b, unsigned cha
   if (!a || !b || !out || an <= 0 || bn <= 0) return DTF_ERR_BAD_ARG;
   switch (op) {
     DTF_CMP_CASE(C_EQ) DTF_CMP_CASE(C_NE) DTF_CMP_CASE(C_LT) DTF_CMP_CASE(C_GT)
+    DTF_CMP_CASE(C_LE) DTF_CMP_CASE(C_GE)
     default: return DTF_ERR_UNSUPPORTED;
   }
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
+DTF_API int dtf_select_f32(const unsigned char* cond, const float* a, const float* b, float* out,
+                           long n, long cn, long an, long bn, hipStream_t stream) {
+  if (n <= 0) return DTF_OK;
+  if (!cond || !a || !b || !out || cn <= 0 || an <= 0 || bn <= 0) return DTF_ERR_BAD_ARG;
+  hipLaunchKernelGGL(select_kernel, dim3(grid_for(n, 1)), dim3(BLOCK), 0, stream, cond, a, b, out,
+                     n, cn, an, bn);
   DTF_LAUNCH_CHECK();
   return DTF_OK;
 }

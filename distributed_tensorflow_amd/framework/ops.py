@@ -253,6 +253,60 @@ def greater(x, y, name=None) -> Tensor:
     return _binary("Greater", x, y, name, out_dtype=dtypes.bool_)
 
 
+def less_equal(x, y, name=None) -> Tensor:
+    return _binary("LessEqual", x, y, name, out_dtype=dtypes.bool_)
+
+
+def greater_equal(x, y, name=None) -> Tensor:
+    return _binary("GreaterEqual", x, y, name, out_dtype=dtypes.bool_)
+
+
+def where(condition, x=None, y=None, name=None) -> Tensor:
+    """``condition ? x : y`` element-wise (``tf.where`` with both branches; the one-argument form
+    that returns coordinates is not provided). ``x`` and ``y`` may be scalars."""
+    if x is None or y is None:
+        raise ValueError("where needs both x and y")
+    condition = convert_to_tensor(condition)
+    if condition.dtype != dtypes.bool_:
+        raise TypeError("where: condition must be bool, got %s" % condition.dtype)
+    x, y = _binary_inputs(x, y)
+    shape = broadcast_static_shape(broadcast_static_shape(condition.shape, x.shape), y.shape)
+    return _op1("Select", [condition, x, y], x.dtype, shape, name=name or "Select")
+
+
+def expand_dims(x, axis: int, name=None) -> Tensor:
+    x = convert_to_tensor(x)
+    if x.shape is None:
+        raise ValueError("expand_dims needs a known rank")
+    rank = len(x.shape)
+    axis = axis + rank + 1 if axis < 0 else axis
+    if not 0 <= axis <= rank:
+        raise ValueError("expand_dims: axis %d out of range for rank %d" % (axis, rank))
+    dims = [-1 if d is None else d for d in x.shape]
+    if dims.count(-1) > 1:
+        raise ValueError("expand_dims supports at most one unknown dimension")
+    return reshape(x, dims[:axis] + [1] + dims[axis:], name=name or "ExpandDims")
+
+
+def squeeze(x, axis=None, name=None) -> Tensor:
+    x = convert_to_tensor(x)
+    if x.shape is None:
+        raise ValueError("squeeze needs a known rank")
+    rank = len(x.shape)
+    axes = None if axis is None else {a + rank if a < 0 else a
+                                      for a in ([axis] if isinstance(axis, int) else axis)}
+    dims = []
+    for i, d in enumerate(x.shape):
+        drop = d == 1 and (axes is None or i in axes)
+        if axes is not None and i in axes and d != 1:
+            raise ValueError("squeeze: dimension %d has extent %s, not 1" % (i, d))
+        if not drop:
+            dims.append(-1 if d is None else d)
+    if dims.count(-1) > 1:
+        raise ValueError("squeeze supports at most one unknown dimension")
+    return reshape(x, dims, name=name or "Squeeze")
+
+
 def _unary(op_type: str, x, name=None) -> Tensor:
     x = convert_to_tensor(x)
     return _op1(op_type, [x], x.dtype, x.shape, name=name)
@@ -639,6 +693,15 @@ def _square_grad(op, g):
 @gradient("Abs")
 def _abs_grad(op, g):
     return (multiply(g, sign(op.inputs[0])),)
+
+
+@gradient("Select")
+def _select_grad(op, g):
+    cond, x, y = op.inputs
+    zero = constant(0.0, dtype=g.dtype)
+    gx = _unbroadcast(where(cond, g, zero), x)
+    gy = _unbroadcast(where(cond, zero, g), y)
+    return None, gx, gy
 
 
 @gradient("Maximum")

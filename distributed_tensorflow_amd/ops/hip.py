@@ -28,7 +28,7 @@ ACTIVATIONS = {"none": ACT_NONE, "sigmoid": ACT_SIGMOID, "relu": ACT_RELU, "tanh
 # op codes (must match csrc/kernels/elementwise.hip and reduce.hip)
 BINARY = {"add": 0, "sub": 1, "mul": 2, "div": 3, "max": 4, "min": 5, "pow": 6,
           "sigmoid_grad": 7, "tanh_grad": 8, "relu_grad": 9}
-COMPARE = {"eq": 0, "ne": 1, "lt": 2, "gt": 3}
+COMPARE = {"eq": 0, "ne": 1, "lt": 2, "gt": 3, "le": 4, "ge": 5}
 UNARY = {"neg": 0, "log": 1, "exp": 2, "sqrt": 3, "square": 4, "recip": 5, "abs": 6,
          "sigmoid": 7, "tanh": 8, "relu": 9, "floor": 10}
 ROW_SUM, ROW_MEAN, ROW_MAX = 0, 1, 2
@@ -165,6 +165,7 @@ def _declare(L: ctypes.CDLL) -> None:
         "dtf_pad_rows": [P, P, LG, LG, LG, LG, LG, P],
         "dtf_assign_add_f32": [P, P, LG, LG, F, P],
         "dtf_sign_f32": [P, P, LG, P],
+        "dtf_select_f32": [P, P, P, P, LG, LG, LG, LG, P],
         "dtf_one_hot_f32": [P, I, P, LG, LG, F, F, P],
         "dtf_broadcast_mid_f32": [P, P, LG, LG, LG, F, P],
         "dtf_log_softmax_grad_f32": [P, P, P, LG, LG, P],
@@ -754,6 +755,24 @@ def compare(op: str, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     out = torch.empty(out_shape, dtype=torch.bool, device=a.device)
     _check(lib().dtf_compare_f32(COMPARE[op], a.data_ptr(), b.data_ptr(), out.data_ptr(),
                                  out.numel(), an, bn, _stream()), "compare " + op)
+    return out
+
+
+def select(cond: torch.Tensor, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """``cond ? a : b`` element-wise (fp32 values, bool condition); an operand whose element
+    count divides the result's trailing layout -- a scalar, a row -- is repeated."""
+    if cond.dtype != torch.bool or cond.device.type != "cuda":
+        raise HipKernelError("select: cond must be a bool GPU tensor")
+    a = _req(a, torch.float32, "select a")
+    b = _req(b, torch.float32, "select b")
+    out_shape = _broadcast_shape(_broadcast_shape(cond.shape, a.shape), b.shape)
+    cond = cond.contiguous()
+    cn = _bcast_numel(out_shape, cond, "select cond")
+    an = _bcast_numel(out_shape, a, "select a")
+    bn = _bcast_numel(out_shape, b, "select b")
+    out = torch.empty(out_shape, dtype=torch.float32, device=a.device)
+    _check(lib().dtf_select_f32(cond.data_ptr(), a.data_ptr(), b.data_ptr(), out.data_ptr(),
+                                out.numel(), cn, an, bn, _stream()), "select")
     return out
 
 

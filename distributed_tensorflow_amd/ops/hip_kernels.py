@@ -144,7 +144,8 @@ def _register_compare(op_type: str, code: str) -> None:
         return _fallback(_type, op, inputs, ctx)
 
 
-for _t, _c in (("Equal", "eq"), ("NotEqual", "ne"), ("Less", "lt"), ("Greater", "gt")):
+for _t, _c in (("Equal", "eq"), ("NotEqual", "ne"), ("Less", "lt"), ("Greater", "gt"),
+               ("LessEqual", "le"), ("GreaterEqual", "ge")):
     _register_compare(_t, _c)
 
 
@@ -416,6 +417,14 @@ def _transpose(op, inputs, ctx):
     if perm == tuple(range(x.dim())):
         return [x]
     return _fallback("Transpose", op, inputs, ctx, "perm %s of rank %d" % (perm, x.dim()))
+
+
+@hip_kernel("Select")
+def _select(op, inputs, ctx):
+    cond, a, b = inputs
+    if cond.dtype != torch.bool or not _is_f32(a, b):
+        return _fallback("Select", op, inputs, ctx)
+    return [hip.select(cond, a, b)]
 
 
 @hip_kernel("OneHot")

@@ -270,6 +270,13 @@ ref_kernel("Equal")(_bin(torch.eq))
 ref_kernel("NotEqual")(_bin(torch.ne))
 ref_kernel("Less")(_bin(torch.lt))
 ref_kernel("Greater")(_bin(torch.gt))
+ref_kernel("LessEqual")(_bin(torch.le))
+ref_kernel("GreaterEqual")(_bin(torch.ge))
+
+
+@ref_kernel("Select")
+def _select(op, inputs, ctx):
+    return [torch.where(inputs[0], inputs[1], inputs[2])]
 ref_kernel("Neg")(_un(torch.neg))
 ref_kernel("Log")(_un(torch.log))
 ref_kernel("Exp")(_un(torch.exp))

@@ -1121,3 +1121,38 @@ def test_one_hot(hip, dtype):
     assert out.shape == (2, 3, 10) and torch.equal(out, ref)
     big = torch.randint(0, 1000, (4099,), dtype=dtype).cuda()
     assert torch.equal(hip.one_hot(big, 1000).argmax(-1), big.long())
+
+
+def test_select_and_inclusive_comparisons(hip):
+    g = torch.Generator().manual_seed(9)
+    a = torch.randn(37, 19, generator=g).cuda()
+    b = torch.randn(37, 19, generator=g).cuda()
+    b[::3] = a[::3]                                   # ties
+    assert torch.equal(hip.compare("le", a, b), a <= b)
+    assert torch.equal(hip.compare("ge", a, b), a >= b)
+    cond = a >= b
+    assert torch.equal(hip.select(cond, a, b), torch.where(cond, a, b))
+    zero = torch.zeros((), device="cuda")
+    assert torch.equal(hip.select(cond, a, zero), torch.where(cond, a, zero))
+    row = torch.randn(19, generator=g).cuda()
+    assert torch.equal(hip.select(cond, row, b), torch.where(cond, row, b))
+
+
+def test_where_through_a_gpu_session_runs_natively():
+    import distributed_tensorflow_amd as tf
+    rng = np.random.RandomState(3)
+    a = rng.randn(64, 5).astype(np.float32)
+    with tf.Graph().as_default():
+        x = tf.placeholder(tf.float32, [None, 5])
+        w = tf.Variable(tf.ones([5, 3]), name="W")
+        h = tf.matmul(x, w)
+        leaky = tf.where(tf.less_equal(h, 0.0), tf.scale(h, 0.1), h)
+        loss = tf.reduce_mean(tf.square(leaky))
+        train = tf.train.GradientDescentOptimizer(0.01).minimize(loss)
+        with tf.Session(config=tf.ConfigProto(device="cuda:0")) as sess:
+            sess.run(tf.global_variables_initializer())
+            first = float(sess.run(loss, {x: a}))
+            for _ in range(20):
+                sess.run(train, {x: a})
+            assert float(sess.run(loss, {x: a})) < first
+            assert sess.stats["torch_fallbacks"] == 0 and not sess.fallback_log

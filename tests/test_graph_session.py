@@ -402,3 +402,26 @@ def test_gradient_clipping_by_global_norm_between_compute_and_apply():
             w1, b1 = sess.run([w, b])
             step = np.sqrt(((w1 - w0) ** 2).sum() + ((b1 - b0) ** 2).sum())
             assert np.isclose(step, 0.1 * 1.5, rtol=1e-4)       # lr x clipped norm
+
+
+def test_where_comparisons_expand_dims_and_squeeze():
+    rng = np.random.RandomState(3)
+    a = rng.randn(4, 5).astype(np.float32)
+    b = rng.randn(4, 5).astype(np.float32)
+    with tf.Graph().as_default():
+        x = tf.placeholder(tf.float32, [None, 5])
+        y = tf.placeholder(tf.float32, [None, 5])
+        picked = tf.where(tf.greater_equal(x, y), x, y)                  # = maximum
+        leaky = tf.where(tf.less_equal(x, 0.0), tf.scale(x, 0.1), x)     # scalar threshold
+        gx, gy = tf.gradients(tf.reduce_sum(picked), [x, y])
+        gl = tf.gradients(tf.reduce_sum(leaky), [x])[0]
+        e = tf.expand_dims(x, 1)
+        s = tf.squeeze(tf.expand_dims(tf.expand_dims(x, 0), -1))
+        with tf.Session(config=tf.ConfigProto(device="cpu")) as sess:
+            p, l, dgx, dgy, dl, ev, sv = sess.run([picked, leaky, gx, gy, gl, e, s], {x: a, y: b})
+    assert np.array_equal(p, np.maximum(a, b))
+    assert np.allclose(l, np.where(a <= 0, 0.1 * a, a))
+    assert np.array_equal(dgx, (a >= b).astype(np.float32))
+    assert np.array_equal(dgy, (a < b).astype(np.float32))
+    assert np.allclose(dl, np.where(a <= 0, 0.1, 1.0))
+    assert ev.shape == (4, 1, 5) and sv.shape == (4, 5) and np.array_equal(sv, a)

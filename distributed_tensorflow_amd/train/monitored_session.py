@@ -148,6 +148,16 @@ class CheckpointSaverHook(SessionRunHook):
             self._saver = Saver()
 
     def _save(self, session, step: int) -> None:
+        sharded = getattr(getattr(session, "_runtime", None), "has_sharded_storage", None)
+        if sharded is not None and sharded():
+            # reading a variable that is stored as per-rank blocks is a collective; this hook
+            # runs on the chief only and would wait for peers that never call it
+            if not getattr(self, "_warned", False):
+                import warnings
+                warnings.warn("variables are stored sharded: CheckpointSaverHook is off; call "
+                              "saver.save(...) on every worker")
+                self._warned = True
+            return
         if self._saver is None:               # the scaffold was finalized after begin()
             self._saver = self._scaffold.saver
         os.makedirs(os.path.dirname(self._path), exist_ok=True)

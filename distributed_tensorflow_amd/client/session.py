@@ -1103,16 +1103,21 @@ class Session:
             return t.data_ptr(), t.data_ptr() + t.numel() * t.element_size()
 
         written, counters = [], {}
-        for var_op in sgd_node.attrs["var_ops"]:
+        state = [s for slots in sgd_node.attrs.get("slot_ops", []) for s in slots] + \
+            list(sgd_node.attrs.get("power_ops", []))        # (rules with per-variable state)
+        for var_op in list(sgd_node.attrs["var_ops"]) + state:
             t = local(var_op)
             if t is None or not t.is_cuda:
                 return None
             written.append(span(t))
-        for var_op, delta in sgd_node.attrs.get("counter_increments", []):
+        bumps = [(v, 1.0, d) for v, d in sgd_node.attrs.get("counter_increments", [])] + \
+            list(sgd_node.attrs.get("scalar_updates", []))
+        for var_op, factor, delta in bumps:
             t = local(var_op)
             if t is None or not t.is_cuda or t.numel() != 1 or t.dtype != torch.float32:
                 return None
-            counters[t.data_ptr()] = float(delta)
+            if factor == 1.0:                    # a counter: its new value is old + increment
+                counters[t.data_ptr()] = float(delta)
             written.append(span(t))
         packed_ids = {id(p) for p in parts}
         for v in fetched:                        # values that bypass the gather must be untouched
@@ -1407,7 +1412,8 @@ class Session:
                         packed = _packable([(sl, vals[sl]) for sl in dict.fromkeys(want)], limit)
                         hip.pack_f32_ring([p[3] for p in packed], ring.args)
                     done = True
-                elif k >= 0 and steps[k].node.type == "MultiApplySGD" and not _NO_FETCH_AHEAD:
+                elif k >= 0 and steps[k].node.type in ("MultiApplySGD", "MultiApplyOptimizer") \
+                        and not _NO_FETCH_AHEAD:
                     # A step that ends in the fused optimizer launch: nothing that is fetched
                     # depends on it except the step counters it bumps, and their new value is
                     # known beforehand (old + increment). The gather of the small results -- with

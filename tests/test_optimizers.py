@@ -347,8 +347,11 @@ def test_gpu_mnist_with_adam_is_captured_without_torch_kernels():
         by = np.eye(10, dtype=np.float32)[rng.randint(0, 10, 100)]
         with tf.Session(config=tf.ConfigProto(device="cuda:0")) as sess:
             sess.run(m.init_op)
-            costs = [float(sess.run([m.train_op, m.loss], {m.x: bx, m.y_: by})[1])
-                     for _ in range(30)]
+            costs = []
+            for i in range(30):
+                _, cost, step = sess.run([m.train_op, m.loss, m.global_step], {m.x: bx, m.y_: by})
+                costs.append(float(cost))
+                assert float(step) == i + 1          # fetched next to the update that bumps it
             assert costs[-1] < 0.5 * costs[0], costs
             assert sess.stats["graph_replays"] >= 20
             assert sess.stats["torch_fallbacks"] == 0 and not sess.fallback_log

@@ -13,9 +13,8 @@
 //              w -= lr sqrt(1 - b2^t) / (1 - b1^t) m / (sqrt(v) + eps)
 //
 // Adam's b1^t and b2^t live in two device scalars (as TensorFlow keeps them in two variables):
-// the update launch only READS them; they are multiplied by b1 and b2 (and the step counters bumped)
-// by the last workgroup of that launch to finish, or by a one-wave launch behind it
-// (affine_scalars_kernel), so a captured step replays without any host-side step count.
+// the update launch only READS them, and a one-wave launch behind it (affine_scalars_kernel, which
+// also bumps the step counters) multiplies them by b1 and b2, so a captured step replays without any host-side step count.
 #include "common.h"
 
 namespace {
@@ -24,13 +23,6 @@ constexpr int BLOCK = 256;
 constexpr int MAX_OPT_TENSORS = 16;
 
 enum Rule { MOMENTUM = 0, NESTEROV = 1, ADAGRAD = 2, RMSPROP = 3, ADAM = 4, SGD = 5 };
-
-struct AffineArgs {
-  float* p[8];
-  float f[8];
-  float d[8];
-  int n;
-};
 
 struct OptTensor {
   float* w;
@@ -46,10 +38,6 @@ struct OptArgs {
   const float* pw1;
   const float* lr;         // when set: the learning rate, read from the device (a schedule)
   int num_tensors;
-  // scalars that advance once every tensor is updated (Adam's powers, step counters): done by the
-  // LAST workgroup to finish, found by a ticket counter that it rearms -- no second launch
-  AffineArgs tail;
-  unsigned* ticket;
 };
 
 // One element. h: momentum {lr, mu}; adagrad {lr}; rmsprop {lr, rho, mu, eps, 1 - rho};
@@ -127,20 +115,14 @@ __global__ __launch_bounds__(BLOCK) void multi_optim_kernel(OptArgs args) {
     if (!NONE) t.s0[i] = a;
     if (TWO) t.s1[i] = b;
   }
-  if (args.ticket) {
-    // every lane of this workgroup has used the running powers (h[0] above) by now
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      __threadfence();
-      const unsigned total = gridDim.x * gridDim.y;
-      if (atomicAdd(args.ticket, 1u) == total - 1) {
-        for (int i = 0; i < args.tail.n; ++i)
-          args.tail.p[i][0] = __builtin_fmaf(args.tail.p[i][0], args.tail.f[i], args.tail.d[i]);
-        *args.ticket = 0;               // rearmed for the next launch (stream order)
-      }
-    }
-  }
 }
+
+struct AffineArgs {
+  float* p[8];
+  float f[8];
+  float d[8];
+  int n;
+};
 
 __global__ void affine_scalars_kernel(AffineArgs args) {
   if (threadIdx.x < (unsigned)args.n)
@@ -157,20 +139,14 @@ int grid_x(long n) {
 
 // In-place update of `count` (<= 16) fp32 tensors by `rule` (0 momentum, 1 Nesterov momentum,
 // 2 Adagrad, 3 RMSProp, 4 Adam, 5 plain gradient descent: no state). lr: optional device scalar
-// that replaces hyper[0] when the kernel runs. tail_*: up to 8 distinct device scalars updated as
-// p = p * f + d by the last workgroup to finish (`ticket`: a zeroed device word kept by the caller). s0 / s1: the rule's per-element state (s1 only for RMSProp and
+// that replaces hyper[0] when the kernel runs. s0 / s1: the rule's per-element state (s1 only for RMSProp and
 // Adam); hyper: the rule's constants in the order documented at update() (complements
 // included); pw0 / pw1: device
 // scalars holding b1^t and b2^t (Adam only; not modified here).
 DTF_API int dtf_multi_optim_f32(int rule, int count, float* const* w, const float* const* g,
                                 float* const* s0, float* const* s1, const long* n,
                                 const float* hyper, int num_hyper, const float* pw0,
-                                const float* pw1, const float* lr, int tail_count,
-                                float* const* tail_p, const float* tail_f, const float* tail_d,
-                                unsigned* ticket, hipStream_t stream) {
-  if (tail_count < 0 || tail_count > 8 ||
-      (tail_count > 0 && (!tail_p || !tail_f || !tail_d || !ticket)))
-    return DTF_ERR_BAD_ARG;
+                                const float* pw1, const float* lr, hipStream_t stream) {
   const bool none = rule == SGD;
   if (rule < 0 || rule > SGD || count < 0 || count > MAX_OPT_TENSORS || num_hyper < 0 ||
       num_hyper > 6 || (count > 0 && (!w || !g || (!none && !s0) || !n)) ||
@@ -193,16 +169,6 @@ DTF_API int dtf_multi_optim_f32(int rule, int count, float* const* w, const floa
   args.pw1 = pw1;
   args.lr = lr;
   args.num_tensors = count;
-  for (int i = 0; i < tail_count; ++i) {
-    if (!tail_p[i]) return DTF_ERR_BAD_ARG;
-    for (int j = 0; j < i; ++j)
-      if (tail_p[j] == tail_p[i]) return DTF_ERR_BAD_ARG;
-    args.tail.p[i] = tail_p[i];
-    args.tail.f[i] = tail_f[i];
-    args.tail.d[i] = tail_d[i];
-  }
-  args.tail.n = tail_count;
-  args.ticket = tail_count > 0 ? ticket : nullptr;
   const dim3 grid(grid_x(max_n), count), block(BLOCK);
   switch (rule) {
     case MOMENTUM: hipLaunchKernelGGL(multi_optim_kernel<MOMENTUM>, grid, block, 0, stream, args); break;

@@ -148,7 +148,7 @@ def _declare(L: ctypes.CDLL) -> None:
         "dtf_softmax_xent_f32": [P, P, P, P, P, P, LG, LG, P],
         "dtf_softmax_grad_f32": [P, P, P, LG, LG, P],
         "dtf_multi_sgd_f32": [I, P, P, P, P, I, P, P, P],
-        "dtf_multi_optim_f32": [I, I, P, P, P, P, P, P, I, P, P, P, I, P, P, P, P, P],
+        "dtf_multi_optim_f32": [I, I, P, P, P, P, P, P, I, P, P, P, P],
         "dtf_affine_scalars_f32": [I, P, P, P, P],
         "dtf_philox_normal": [P, LG, U, U, LG, F, F, I, P],
         "dtf_philox_uniform": [P, LG, U, U, LG, F, F, I, P],
@@ -1103,17 +1103,13 @@ OPTIM_RULES = {"momentum": 0, "nesterov": 1, "adagrad": 2, "rmsprop": 3, "adam":
 def multi_optim(rule: str, params: Sequence[torch.Tensor], grads: Sequence[torch.Tensor],
                 slots0: Sequence[torch.Tensor], slots1: Sequence[torch.Tensor] = (),
                 hyper: Sequence[float] = (), powers: Sequence[torch.Tensor] = (),
-                lr: Optional[torch.Tensor] = None, tail=None,
-                ticket: Optional[torch.Tensor] = None) -> None:
+                lr: Optional[torch.Tensor] = None) -> None:
     """In-place update of every ``params[i]`` (and its state ``slots0[i]`` / ``slots1[i]``) from
     ``grads[i]`` by one of the slot-carrying rules -- one launch per 16 tensors. ``hyper``:
     momentum / nesterov (lr, mu); adagrad (lr,); rmsprop (lr, rho, mu, eps); adam (lr, b1, b2,
     eps) with ``powers`` = the device scalars holding b1^t and b2^t (read, not advanced: see
     ``affine_scalars``); sgd (lr,) takes no slots. ``lr``: a device scalar that replaces the
-    constant learning rate (a schedule computed in the step's graph), read when the kernel runs.
-    ``tail`` = (scalars, factors, increments): up to 8 distinct fp32 device scalars advanced as
-    ``s = s * f + d`` by the launch's last workgroup once every tensor is updated (``ticket``: an
-    int32 device word, zero before the first use, that the kernel rearms)."""
+    constant learning rate (a schedule computed in the step's graph), read when the kernel runs."""
     code = OPTIM_RULES.get(rule)
     if code is None:
         raise HipKernelError("multi_optim: unknown rule %r" % (rule,))
@@ -1142,20 +1138,6 @@ def multi_optim(rule: str, params: Sequence[torch.Tensor], grads: Sequence[torch
         if t.dtype != torch.float32 or t.numel() != 1 or t.device.type != "cuda":
             raise HipKernelError("multi_optim: powers must be fp32 GPU scalars")
     c = ctypes
-    t_n, t_p, t_f, t_d, t_k = 0, None, None, None, None
-    if tail is not None and tail[0]:
-        scalars, factors, increments = tail
-        if len(scalars) > 8 or len({t.data_ptr() for t in scalars}) != len(scalars) \
-                or ticket is None or ticket.dtype != torch.int32 or ticket.numel() != 1:
-            raise HipKernelError("multi_optim: tail takes up to 8 distinct scalars and a ticket")
-        for t in scalars:
-            if t.dtype != torch.float32 or t.numel() != 1 or t.device.type != "cuda":
-                raise HipKernelError("multi_optim: tail scalars must be fp32 GPU scalars")
-        t_n = len(scalars)
-        t_p = (c.c_void_p * t_n)(*[t.data_ptr() for t in scalars])
-        t_f = (c.c_float * t_n)(*[float(f) for f in factors])
-        t_d = (c.c_float * t_n)(*[float(d) for d in increments])
-        t_k = ticket.data_ptr()
     hyper = [float(x) for x in hyper]
     if rule == "rmsprop":
         hyper.append(1.0 - hyper[1])              # complements rounded once, from double
@@ -1172,11 +1154,9 @@ def multi_optim(rule: str, params: Sequence[torch.Tensor], grads: Sequence[torch
         a_arr = None if none else (c.c_void_p * n)(*[t.data_ptr() for t in slots0[sl]])
         b_arr = (c.c_void_p * n)(*[t.data_ptr() for t in slots1[sl]]) if two else None
         n_arr = (c.c_long * n)(*[t.numel() for t in ps])
-        last = start + 16 >= len(params)          # the tail rides on the last launch only
         _check(lib().dtf_multi_optim_f32(code, n, w_arr, g_arr, a_arr, b_arr, n_arr, h_arr,
                                          len(hyper), pw[0], pw[1],
-                                         None if lr is None else lr.data_ptr(),
-                                         t_n if last else 0, t_p, t_f, t_d, t_k, _stream()),
+                                         None if lr is None else lr.data_ptr(), _stream()),
                "multi_optim")
 
 

@@ -593,8 +593,7 @@ def _multi_apply_sgd(op, inputs, ctx):
     return []
 
 
-def _optim_launch(ctx, rule, hyper, var_ops, slot_ops_list, power_ops, grads, lr=None,
-                  tail=None, ticket=None) -> list:
+def _optim_launch(ctx, rule, hyper, var_ops, slot_ops_list, power_ops, grads, lr=None) -> list:
     """Update every variable whose storage, slots and powers are local fp32 GPU tensors with the
     multi-tensor kernel; returns the (var_op, slot_ops, grad) triples it could not take."""
     powers = [_local_f32(ctx, p) for p in power_ops]
@@ -616,10 +615,7 @@ def _optim_launch(ctx, rule, hyper, var_ops, slot_ops_list, power_ops, grads, lr
             s1.append(slots[1])
         ctx.session._store_for(var_op).update_count += 1
     if ps:
-        hip.multi_optim(rule, ps, gs, s0, s1, hyper, powers, lr=lr,
-                        tail=None if rest else tail, ticket=ticket)
-    elif tail is not None:
-        rest = rest or [None]             # nothing launched: the caller advances the scalars
+        hip.multi_optim(rule, ps, gs, s0, s1, hyper, powers, lr=lr)
     return rest
 
 
@@ -664,28 +660,12 @@ def _multi_apply_optimizer(op, inputs, ctx):
     var_ops = op.attrs["var_ops"]
     lr = inputs[len(var_ops)] if op.attrs.get("lr_input") else None
     grads = ctx.reduce_gradients(list(inputs[:len(var_ops)]), var_ops)   # no-op without a sync runtime
-    # the scalars that advance with the step ride on the update launch (its last workgroup
-    # advances them) when all of them are local fp32 GPU scalars
-    updates = op.attrs.get("scalar_updates", [])
-    scalars = [_local_f32(ctx, v) for v, _, _ in updates]
-    tail = ticket = None
-    if updates and len(updates) <= 8 and all(t is not None and t.numel() == 1 for t in scalars) \
-            and len({t.data_ptr() for t in scalars}) == len(scalars):
-        ticket = ctx.buffers.get((op, "ticket"))
-        if ticket is None and not torch.cuda.is_current_stream_capturing():
-            ticket = ctx.buffers[(op, "ticket")] = torch.zeros((), dtype=torch.int32,
-                                                               device=ctx.device)
-        if ticket is not None:
-            tail = (scalars, [f for _, f, _ in updates], [d for _, _, d in updates])
     rest = _optim_launch(ctx, op.attrs["rule"], op.attrs["hyper"], var_ops, op.attrs["slot_ops"],
-                         op.attrs["power_ops"], grads, lr, tail, ticket)
-    for item in rest:
-        if item is not None:
-            v, s_ops, g = item
-            apply_rule_through_stores(ctx, op.attrs["rule"], op.attrs["hyper"], v, s_ops,
-                                      op.attrs["power_ops"], g, lr)
-    if tail is None or rest:
-        _affine_launch(ctx, updates)
+                         op.attrs["power_ops"], grads, lr)
+    for v, s_ops, g in rest:
+        apply_rule_through_stores(ctx, op.attrs["rule"], op.attrs["hyper"], v, s_ops,
+                                  op.attrs["power_ops"], g, lr)
+    _affine_launch(ctx, op.attrs.get("scalar_updates", []))
     return []
 
 

@@ -491,35 +491,3 @@ def test_gpu_schedule_is_read_on_the_device_inside_captured_steps(name, schedule
     ref_w, ref_b = _sgd_reference(w0, b0, want)
     assert np.allclose(w, ref_w, rtol=5e-5, atol=5e-6) and np.allclose(b, ref_b, rtol=5e-5, atol=5e-6)
     assert stats["graph_replays"] >= 8 and stats["torch_fallbacks"] == 0
-
-
-@pytest.mark.gpu
-def test_multi_optim_tail_advances_scalars_once_per_launch():
-    """The scalars that advance with the step ride on the update launch: its last workgroup
-    advances them after every workgroup has read them, and rearms the ticket."""
-    from distributed_tensorflow_amd.ops import hip
-    from distributed_tensorflow_amd.ops.ref_kernels import optimizer_rule_step
-    g = torch.Generator().manual_seed(11)
-    sizes = [300000, 100, 7]                      # many workgroups, and tiny tensors
-    params = [torch.randn(n, generator=g).cuda() for n in sizes]
-    m = [torch.zeros(n).cuda() for n in sizes]
-    v = [torch.zeros(n).cuda() for n in sizes]
-    p1, p2, step = torch.tensor(0.9).cuda(), torch.tensor(0.999).cuda(), torch.tensor(0.0).cuda()
-    ticket = torch.zeros((), dtype=torch.int32).cuda()
-    hyper = (0.01, 0.9, 0.999, 1e-8)
-    ref = [(p.double(), a.double(), b.double()) for p, a, b in zip(params, m, v)]
-    rp1, rp2 = 0.9, 0.999
-    for it in range(3):
-        grads = [torch.randn(n, generator=g).cuda() for n in sizes]
-        hip.multi_optim("adam", params, grads, m, v, hyper, [p1, p2],
-                        tail=([p1, p2, step], [0.9, 0.999, 1.0], [0.0, 0.0, 1.0]), ticket=ticket)
-        ref = [optimizer_rule_step("adam", hyper, w, gr.double(), a, b,
-                                   [torch.tensor(np.float32(rp1)).double(),
-                                    torch.tensor(np.float32(rp2)).double()])
-               for (w, a, b), gr in zip(ref, grads)]
-        rp1, rp2 = float(np.float32(rp1) * np.float32(0.9)), float(np.float32(rp2) * np.float32(0.999))
-        torch.cuda.synchronize()
-        assert int(ticket) == 0 and float(step) == it + 1
-        assert float(p1) == pytest.approx(rp1, rel=1e-6) and float(p2) == pytest.approx(rp2, rel=1e-6)
-    for p, (w, _, _) in zip(params, ref):
-        assert torch.allclose(p.double(), w, rtol=1e-5, atol=1e-6)

@@ -452,6 +452,16 @@ def reduce_max(x, axis=None, keepdims=False, name=None) -> Tensor:
     return _reduce("Max", x, axis, keepdims, name or "Max")
 
 
+def reduce_min(x, axis=None, keepdims=False, name=None) -> Tensor:
+    """``-reduce_max(-x)``: the row-maximum kernel serves both."""
+    return negative(reduce_max(negative(x), axis=axis, keepdims=keepdims), name=name or "Min")
+
+
+def argmin(x, axis=None, name=None, dimension=None, output_type=dtypes.int64) -> Tensor:
+    return argmax(negative(x), axis=axis, name=name or "ArgMin", dimension=dimension,
+                  output_type=output_type)
+
+
 def argmax(x, axis=None, name=None, dimension=None, output_type=dtypes.int64) -> Tensor:
     x = convert_to_tensor(x)
     axis = dimension if axis is None else axis
@@ -784,6 +794,16 @@ def _sum_grad(op, g):
 @gradient("Mean")
 def _mean_grad(op, g):
     return (_reduce_grad(g, op.inputs[0], op.attrs["axis"], op.attrs["keepdims"], True),)
+
+
+@gradient("Max")
+def _max_grad(op, g):
+    """The gradient goes to the positions that hold the maximum, shared equally among ties."""
+    x, axes, keep = op.inputs[0], op.attrs["axis"], op.attrs["keepdims"]
+    y_b = _reduce_grad(op.outputs[0], x, axes, keep, False)          # max, spread back over x
+    hit = cast(equal(x, y_b), x.dtype)
+    ties_b = _reduce_grad(_reduce("Sum", hit, axes, keep, None), x, axes, keep, False)
+    return (multiply(divide(hit, ties_b), _reduce_grad(g, x, axes, keep, False)),)
 
 
 @gradient("Reshape")

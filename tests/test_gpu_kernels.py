@@ -1156,3 +1156,18 @@ def test_where_through_a_gpu_session_runs_natively():
                 sess.run(train, {x: a})
             assert float(sess.run(loss, {x: a})) < first
             assert sess.stats["torch_fallbacks"] == 0 and not sess.fallback_log
+
+
+def test_reduce_max_gradient_and_min_through_a_gpu_session():
+    import distributed_tensorflow_amd as tf
+    a = np.random.RandomState(5).randn(33, 17).astype(np.float32)
+    a[3, 4] = a[3, 9] = a[3].max() + 1.0                          # a tie
+    with tf.Graph().as_default():
+        x = tf.placeholder(tf.float32, [None, 17])
+        g = tf.gradients(tf.reduce_sum(tf.reduce_max(x, axis=1)), [x])[0]
+        with tf.Session(config=tf.ConfigProto(device="cuda:0")) as sess:
+            gv, mn, am = sess.run([g, tf.reduce_min(x, axis=1), tf.argmin(x, 1)], {x: a})
+            assert sess.stats["torch_fallbacks"] == 0 and not sess.fallback_log
+    hit = (a == a.max(1, keepdims=True)).astype(np.float32)
+    assert np.allclose(gv, hit / hit.sum(1, keepdims=True))
+    assert np.array_equal(mn, a.min(1)) and np.array_equal(am, a.argmin(1))

@@ -425,3 +425,21 @@ def test_where_comparisons_expand_dims_and_squeeze():
     assert np.array_equal(dgy, (a < b).astype(np.float32))
     assert np.allclose(dl, np.where(a <= 0, 0.1, 1.0))
     assert ev.shape == (4, 1, 5) and sv.shape == (4, 5) and np.array_equal(sv, a)
+
+
+def test_reduce_max_gradient_min_and_argmin():
+    a = np.array([[1.0, 5.0, 5.0, -2.0], [0.5, -1.0, 0.25, 0.5], [3.0, 2.0, 1.0, 0.0]], np.float32)
+    with tf.Graph().as_default():
+        x = tf.placeholder(tf.float32, [None, 4])
+        row_max = tf.reduce_max(x, axis=1)
+        g_row = tf.gradients(tf.reduce_sum(tf.multiply(row_max, [1.0, 2.0, 3.0])), [x])[0]
+        g_all = tf.gradients(tf.reduce_max(x), [x])[0]
+        with tf.Session(config=tf.ConfigProto(device="cpu")) as sess:
+            rm, gr, ga, mn, am, cmin = sess.run(
+                [row_max, g_row, g_all, tf.reduce_min(x, axis=1), tf.argmin(x, 1),
+                 tf.reduce_min(x)], {x: a})
+    assert np.array_equal(rm, a.max(1)) and np.array_equal(mn, a.min(1)) and cmin == a.min()
+    assert np.array_equal(am, a.argmin(1))
+    want = np.array([[0, 0.5, 0.5, 0], [1.0, 0, 0, 1.0], [3.0, 0, 0, 0]], np.float32)
+    assert np.allclose(gr, want)                                  # ties share the gradient
+    assert np.allclose(ga, (a == a.max()) / (a == a.max()).sum())

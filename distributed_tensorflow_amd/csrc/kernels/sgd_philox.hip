@@ -116,6 +116,38 @@ __global__ __launch_bounds__(BLOCK) void philox_fill_kernel(void* __restrict__ o
   }
 }
 
+// Dropout: out = x * m with m = (u < keep) / keep, u the uniform of stream element
+// round * 4 * ceil(n / 4) + e. `round` is a device scalar the caller bumps after every run, so a
+// captured step draws a fresh mask at every replay without the host touching anything; `keep_dev`
+// (optional) overrides the constant keep probability (a fed keep_prob placeholder: 1.0 at
+// evaluation time). The scaled mask is kept for the backward pass.
+__global__ __launch_bounds__(BLOCK) void dropout_kernel(const float* __restrict__ x,
+                                                        float* __restrict__ out,
+                                                        float* __restrict__ mask, long n,
+                                                        unsigned int seed, unsigned int op_seed,
+                                                        const float* __restrict__ round,
+                                                        float keep,
+                                                        const float* __restrict__ keep_dev) {
+  if (keep_dev) keep = keep_dev[0];
+  const float scale = 1.f / keep;
+  const long nblocks = (n + 3) >> 2;
+  const unsigned long base = (unsigned long)round[0] * (unsigned long)nblocks;
+  for (long q = blockIdx.x * (long)BLOCK + threadIdx.x; q < nblocks;
+       q += (long)gridDim.x * BLOCK) {
+    const U4 r = philox4x32_10(base + (unsigned long)q, seed, op_seed);
+    const float u[4] = {u01(r.x), u01(r.y), u01(r.z), u01(r.w)};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long e = (q << 2) + j;
+      if (e < n) {
+        const float m = u[j] < keep ? scale : 0.f;
+        mask[e] = m;
+        out[e] = x[e] * m;
+      }
+    }
+  }
+}
+
 // 2-D window of a stream laid out as a [*, global_cols] matrix: out[i, j] is stream element
 // (row0 + i) * global_cols + col0 + j. This is how a rank materialises its shard of a global
 // random matrix (row block, column block or 2-D block) without generating the rest.
@@ -319,6 +351,20 @@ DTF_API int dtf_multi_sgd_f32(int count, float* const* w, const float* const* g,
     args.t[0] = SgdTensor{args.counter[0], args.counter[0], 0, 0.f};
   dim3 grid(grid_for(max_n, 4), count > 0 ? count : 1), block(BLOCK);
   hipLaunchKernelGGL(multi_sgd_kernel, grid, block, 0, stream, args);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
+// out = x * mask, mask[e] = (u_e < keep) / keep drawn from round `round[0]` of the (seed, op_seed)
+// stream (see dropout_kernel); keep_dev: optional device scalar replacing `keep`.
+DTF_API int dtf_dropout_f32(const float* x, float* out, float* mask, long n, unsigned int seed,
+                            unsigned int op_seed, const float* round, float keep,
+                            const float* keep_dev, hipStream_t stream) {
+  if (n <= 0) return DTF_OK;
+  if (!x || !out || !mask || !round || (!keep_dev && !(keep > 0.f && keep <= 1.f)))
+    return DTF_ERR_BAD_ARG;
+  hipLaunchKernelGGL(dropout_kernel, dim3(grid_for((n + 3) >> 2, 1)), dim3(BLOCK), 0, stream, x,
+                     out, mask, n, seed, op_seed, round, keep, keep_dev);
   DTF_LAUNCH_CHECK();
   return DTF_OK;
 }

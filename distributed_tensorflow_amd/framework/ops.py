@@ -534,6 +534,31 @@ def bias_add(value, bias, name=None) -> Tensor:
     return add(value, bias, name=name or "BiasAdd")
 
 
+def dropout(x, keep_prob, noise_shape=None, seed=None, name=None) -> Tensor:
+    """``x * mask / keep_prob`` with an independent Bernoulli(keep_prob) mask at every run (and
+    at every replay of a captured step: the mask's position in its Philox stream is a counter
+    on the device). ``keep_prob`` may be a scalar tensor, e.g. a placeholder fed 1.0 at
+    evaluation time."""
+    if noise_shape is not None:
+        raise NotImplementedError("dropout: noise_shape is not provided")
+    x = convert_to_tensor(x)
+    g = x.graph
+    op_seed = len(g.get_operations()) if seed is None else int(seed)
+    graph_seed = 0 if g.seed is None else int(g.seed)
+    inputs, constant_keep = [x], 1.0
+    if isinstance(keep_prob, (int, float)):
+        if not 0.0 < keep_prob <= 1.0:
+            raise ValueError("keep_prob must be in (0, 1], got %r" % (keep_prob,))
+        constant_keep = float(keep_prob)
+    else:
+        inputs.append(convert_to_tensor(keep_prob))
+    op = g.create_op("Dropout", inputs, [(x.dtype, x.shape), (x.dtype, x.shape)],
+                     name=name or "dropout",
+                     attrs={"keep_prob": constant_keep, "seed": graph_seed, "seed2": op_seed,
+                            "deterministic": g.seed is not None or seed is not None})
+    return op.outputs[0]
+
+
 def one_hot(indices, depth: int, on_value=1.0, off_value=0.0, axis: int = -1,
             dtype=dtypes.float32, name=None) -> Tensor:
     """``[..., depth]`` tensor with ``on_value`` at the index of the last axis (an index outside
@@ -794,6 +819,12 @@ def _sum_grad(op, g):
 @gradient("Mean")
 def _mean_grad(op, g):
     return (_reduce_grad(g, op.inputs[0], op.attrs["axis"], op.attrs["keepdims"], True),)
+
+
+@gradient("Dropout")
+def _dropout_grad(op, g, g_mask=None):
+    gx = multiply(g, op.outputs[1])
+    return (gx,) if len(op.inputs) == 1 else (gx, None)
 
 
 @gradient("Max")

@@ -148,6 +148,7 @@ def _declare(L: ctypes.CDLL) -> None:
         "dtf_softmax_xent_f32": [P, P, P, P, P, P, LG, LG, P],
         "dtf_softmax_grad_f32": [P, P, P, LG, LG, P],
         "dtf_multi_sgd_f32": [I, P, P, P, P, I, P, P, P],
+        "dtf_dropout_f32": [P, P, P, LG, U, U, P, F, P, P],
         "dtf_multi_optim_f32": [I, I, P, P, P, P, P, P, I, P, P, P, P],
         "dtf_affine_scalars_f32": [I, P, P, P, P],
         "dtf_philox_normal": [P, LG, U, U, LG, F, F, I, P],
@@ -1177,6 +1178,25 @@ def affine_scalars(scalars: Sequence[torch.Tensor], factors: Sequence[float],
     d_arr = (c.c_float * len(scalars))(*[float(d) for d in increments])
     _check(lib().dtf_affine_scalars_f32(len(scalars), p_arr, f_arr, d_arr, _stream()),
            "affine_scalars")
+
+
+def dropout(x: torch.Tensor, keep_prob: float, seed: int, op_seed: int, round_counter: torch.Tensor,
+            keep_tensor: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``(x * mask, mask)`` with ``mask = (u < keep) / keep`` from round ``round_counter[0]`` of
+    the ``(seed, op_seed)`` Philox stream (the caller bumps the counter after the call).
+    ``keep_tensor``: an fp32 device scalar that replaces ``keep_prob`` when the kernel runs."""
+    x = _req(x, torch.float32, "dropout x")
+    for t, what in ((round_counter, "round counter"), (keep_tensor, "keep_prob")):
+        if t is not None and (t.dtype != torch.float32 or t.numel() != 1
+                              or t.device.type != "cuda"):
+            raise HipKernelError("dropout: %s must be an fp32 GPU scalar" % what)
+    out, mask = torch.empty_like(x), torch.empty_like(x)
+    _check(lib().dtf_dropout_f32(x.data_ptr(), out.data_ptr(), mask.data_ptr(), x.numel(),
+                                 seed & 0xFFFFFFFF, op_seed & 0xFFFFFFFF,
+                                 round_counter.data_ptr(), float(keep_prob),
+                                 None if keep_tensor is None else keep_tensor.data_ptr(),
+                                 _stream()), "dropout")
+    return out, mask
 
 
 def philox_normal(shape: Sequence[int], seed: int, op_seed: int, mean: float = 0.0,

@@ -427,6 +427,28 @@ def _select(op, inputs, ctx):
     return [hip.select(cond, a, b)]
 
 
+@hip_kernel("Dropout")
+def _dropout(op, inputs, ctx):
+    x = inputs[0]
+    keep_t = inputs[1] if len(inputs) > 1 else None
+    if not _is_f32(x) or (keep_t is not None and not (_is_f32(keep_t) and keep_t.numel() == 1)):
+        return _fallback("Dropout", op, inputs, ctx)
+    key = (op, "round")
+    rnd = ctx.buffers.get(key)
+    if rnd is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise hip.HipKernelError("Dropout: the round counter must exist before the step is "
+                                     "captured (the first runs of a plan are eager)")
+        rnd = ctx.buffers[key] = hip.fill((), 0.0, ctx.device)
+    if op.attrs.get("deterministic", True):
+        seed, seed2 = op.attrs["seed"], op.attrs["seed2"]
+    else:
+        seed, seed2 = ctx.nondeterministic_seed(), op.attrs["seed2"]
+    out, mask = hip.dropout(x.contiguous(), op.attrs["keep_prob"], seed, seed2, rnd, keep_t)
+    hip.affine_scalars([rnd], [1.0], [1.0])          # the next run draws the next round
+    return [out, mask]
+
+
 @hip_kernel("OneHot")
 def _one_hot(op, inputs, ctx):
     idx = inputs[0]

@@ -288,6 +288,24 @@ ref_kernel("Abs")(_un(torch.abs))
 ref_kernel("Sign")(_un(torch.sign))
 
 
+@ref_kernel("Dropout", stateful=True)
+def _dropout(op, inputs, ctx):
+    """Host oracle of the device kernel: round r of the op's stream covers elements
+    ``r * 4 * ceil(n / 4) ...``; the round number lives with the session."""
+    x = inputs[0]
+    keep = float(inputs[1]) if len(inputs) > 1 else op.attrs["keep_prob"]
+    seed, seed2 = _stream_keys(op, ctx)
+    n = x.numel()
+    key = (op, "round")
+    rnd = ctx.buffers.get(key, 0)
+    ctx.buffers[key] = rnd + 1
+    u = philox.uniform(n, seed, seed2, offset=rnd * 4 * ((n + 3) // 4))
+    mask = torch.from_numpy(np.where(u < np.float32(keep), np.float32(1.0) / np.float32(keep),
+                                     np.float32(0.0)).astype(np.float32).reshape(tuple(x.shape)))
+    mask = mask.to(x.device)
+    return [x * mask, mask]
+
+
 @ref_kernel("OneHot")
 def _one_hot(op, inputs, ctx):
     idx = inputs[0].long()

@@ -1171,3 +1171,19 @@ def test_reduce_max_gradient_and_min_through_a_gpu_session():
     hit = (a == a.max(1, keepdims=True)).astype(np.float32)
     assert np.allclose(gv, hit / hit.sum(1, keepdims=True))
     assert np.array_equal(mn, a.min(1)) and np.array_equal(am, a.argmin(1))
+
+
+def test_dropout_on_the_gpu_matches_the_host_stream_through_captured_replays():
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "_graph_session_tests", os.path.join(os.path.dirname(__file__), "test_graph_session.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    _dropout_runs = mod._dropout_runs
+    a, cpu, ident_c, half_c, _ = _dropout_runs("cpu", runs=9)
+    _, gpu, ident_g, half_g, stats = _dropout_runs("cuda:0", runs=9)
+    assert stats["graph_replays"] >= 4 and stats["torch_fallbacks"] == 0
+    for (yc, gc), (yg, gg) in zip(cpu, gpu):          # eager runs, the capture and the replays
+        assert np.array_equal(yc, yg) and np.allclose(gc, gg, rtol=1e-6)
+    assert np.array_equal(ident_g, a) and np.array_equal(half_c, half_g)

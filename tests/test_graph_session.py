@@ -443,3 +443,34 @@ def test_reduce_max_gradient_min_and_argmin():
     want = np.array([[0, 0.5, 0.5, 0], [1.0, 0, 0, 1.0], [3.0, 0, 0, 0]], np.float32)
     assert np.allclose(gr, want)                                  # ties share the gradient
     assert np.allclose(ga, (a == a.max()) / (a == a.max()).sum())
+
+
+def _dropout_runs(device, runs=7, keep=0.6):
+    a = np.random.RandomState(2).randn(50, 37).astype(np.float32)
+    with tf.Graph().as_default():
+        tf.set_random_seed(11)
+        x = tf.placeholder(tf.float32, [None, 37])
+        kp = tf.placeholder(tf.float32, [])
+        y = tf.nn.dropout(x, keep)
+        y_fed = tf.nn.dropout(x, kp)
+        gx = tf.gradients(tf.reduce_sum(tf.multiply(y, 3.0)), [x])[0]
+        with tf.Session(config=tf.ConfigProto(device=device)) as sess:
+            outs = [sess.run([y, gx], {x: a}) for _ in range(runs)]
+            ident = sess.run(y_fed, {x: a, kp: 1.0})
+            half = sess.run(y_fed, {x: a, kp: 0.5})
+            stats = dict(sess.stats)
+    return a, outs, ident, half, stats
+
+
+def test_dropout_draws_a_fresh_reproducible_mask_every_run():
+    a, outs, ident, half, _ = _dropout_runs("cpu")
+    masks = [np.where(a != 0, y / a, 0) for y, _ in outs]
+    for (y, g), m in zip(outs, masks):
+        assert np.all(np.isclose(m, 0.0) | np.isclose(m, 1 / 0.6, rtol=1e-5))
+        assert abs((m > 0).mean() - 0.6) < 0.05
+        assert np.allclose(g, 3.0 * m, rtol=1e-6)                 # the backward pass reuses the mask
+    assert not np.array_equal(masks[0], masks[1]) and not np.array_equal(masks[1], masks[2])
+    assert np.array_equal(ident, a)
+    assert abs((half != 0).mean() - 0.5) < 0.06
+    _, again, _, _, _ = _dropout_runs("cpu")
+    assert all(np.array_equal(p[0], q[0]) for p, q in zip(outs, again))   # same seed, same rounds

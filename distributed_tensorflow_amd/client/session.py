@@ -338,7 +338,7 @@ class _StepRing:
         self.table_np = self.table.numpy().reshape(n, hip.RING_FEEDS)
         self.out = torch.zeros(n * hip.RING_WORDS, dtype=torch.float32).pin_memory()
         self.out_np = self.out.numpy().reshape(n, hip.RING_WORDS)
-        self.ctr = torch.zeros(2, dtype=torch.int32, device=device)
+        self.ctr = torch.zeros(hip.RING_CTR_WORDS, dtype=torch.int32, device=device)
         self.args = hip.RingArgs(self.table, self.ctr, self.out, n)
         self.words = hip.RING_WORDS
         self.launched = 0
@@ -1324,6 +1324,51 @@ class Session:
                 p.resolve()
                 cap.ring.pending[i] = None
 
+    def _ring_reads_suffice(self, plan: ExecutionPlan, feed_of: Dict[int, torch.Tensor]) -> bool:
+        """Whether every step that reads a fed tensor can take it straight from where it lies,
+        through the step ring's address table, so that the feed gather can be dropped: the
+        whole-step node, or the small fp32 products (``FusedDense`` / ``MatMul`` with the fed
+        tensor as their first operand) and the classifier head (the fed labels) of the chain of
+        general kernels. The first of them in plan order must be one that can publish the
+        replay number (the head kernel cannot)."""
+        from ..ops import hip
+        first_type = None
+        for st in plan.steps + plan.host_steps:
+            hits = [(i, sl) for i, sl in enumerate(st.in_slots) if sl in feed_of]
+            if not hits:
+                continue
+            t = st.node.type
+            if first_type is None:
+                first_type = t
+            if t in _RING_READERS:
+                continue
+            if len(hits) != 1 or st.host:
+                return False
+            i, sl = hits[0]
+            f = feed_of[sl]
+            if f.dtype != torch.float32 or f.dim() != 2 or not f.is_contiguous():
+                return False
+            shapes = [getattr(inp, "shape", None) for inp in st.node.inputs]
+            if t in ("FusedDense", "MatMul") and i == 0:
+                ta = bool(st.node.attrs.get("transpose_a")) if t == "MatMul" else False
+                tb = bool(st.node.attrs.get("transpose_b")) if t == "MatMul" else False
+                bs = shapes[1]
+                if bs is None or len(bs) != 2:
+                    return False
+                m, k = (f.shape[1], f.shape[0]) if ta else f.shape
+                n, kb = (bs[0], bs[1]) if tb else (bs[1], bs[0])
+                if n is None or kb not in (None, k) or \
+                        hip.lib().dtf_gemm_f32_tile(int(m), int(n), int(k)) != 16:
+                    return False
+            elif t == "ClassifierHeadTrain" and i == 3:
+                a_shape = shapes[0]
+                if a_shape is None or len(a_shape) != 2 or a_shape[1] is None or \
+                        not hip.mlp_head_supported(f.shape[0], int(a_shape[1]), f.shape[1]):
+                    return False
+            else:
+                return False
+        return first_type in _RING_READERS or first_type in ("FusedDense", "MatMul")
+
     def _capture(self, plan: ExecutionPlan, feeds: List[torch.Tensor],
                  use_table: bool = False) -> _CapturedStep:
         from ..ops import hip
@@ -1340,8 +1385,7 @@ class Session:
         feed_slots = [sl for _, sl in plan.feed_slots]
         direct = bool(use_table and feeds and not os.environ.get("DTF_NO_RING_READS")
                       and not any(sl in want for sl in feed_slots)
-                      and all(st.node.type in _RING_READERS for st in plan.steps
-                              if any(sl in st.in_slots for sl in feed_slots)))
+                      and self._ring_reads_suffice(plan, dict(zip(feed_slots, feeds))))
         ctx = self._ctx
         torch.cuda.synchronize(self.device)
         try:
@@ -1359,6 +1403,8 @@ class Session:
             ctx.ring = ring.args
             ctx.ring_feeds = {t.data_ptr(): i for i, t in enumerate(cap.static_feeds)} \
                 if direct else {}
+            if direct:
+                self.stats["ring_read_captures"] = self.stats.get("ring_read_captures", 0) + 1
             with torch.cuda.graph(graph, capture_error_mode="thread_local"), \
                     hip.record_calls() as recorder:
                 capture_stream = torch._C._cuda_getCurrentRawStream(self.device.index)

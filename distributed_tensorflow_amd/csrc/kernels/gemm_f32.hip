@@ -32,6 +32,7 @@
 // cache write-back and measured 64 us on the 100x100x784 product against 23 us unsplit.)
 #include "common.h"
 #include "gemm_f32_body.h"
+#include "step_ring.h"
 
 #include <cstdlib>
 
@@ -56,6 +57,19 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_slot_kernel(GemmF32Args p) 
 // C = act(op(A) op(B) + bias) for small outputs: one 16x16 tile per workgroup (gemm_f32_body.h)
 template <bool A_KC, bool B_KC, int NW>
 __global__ __launch_bounds__(64 * NW) void gemm_f32_skinny_kernel(SkinnyArgs p) {
+  gemm_f32_skinny_block<A_KC, B_KC, 0, NW>(p, blockIdx.x);
+}
+
+// The same product inside a CAPTURED step whose A operand is a fed tensor: A is entry `a_index` of
+// the replay's slot of the step ring's address table (step_ring.h), so the batch is read where it
+// lies in the resident data set and no gather launch copies it first. `first`: this is the step's
+// first ring kernel and publishes the replay number.
+template <bool A_KC, bool B_KC, int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_f32_skinny_ring_kernel(SkinnyArgs p,
+                                                                       DtfStepRing ring,
+                                                                       int a_index, int first) {
+  p.A = first ? (const float*)dtf_ring_feed(ring, dtf_ring_begin(ring), a_index)
+              : (const float*)dtf_ring_feed_later(ring, a_index);
   gemm_f32_skinny_block<A_KC, B_KC, 0, NW>(p, blockIdx.x);
 }
 
@@ -317,6 +331,42 @@ DTF_API int dtf_gemm_f32_ex(const float* A, const float* B, float* C, const floa
                             kchunk, partial, m_load, n_load, stream);
   return launch<64, 64>(A, B, C, bias, M, N, K, lda, ldb, ldc, trans_a, trans_b, act, splits,
                         kchunk, partial, m_load, n_load, stream);
+}
+
+// dtf_gemm_f32 for a product the 16x16-tile kernel takes (dtf_gemm_f32_tile() == 16), with A read
+// through the step ring: entry a_index of the replay's table slot holds A's address (same
+// extents and leading dimension at every replay). Anything else: DTF_ERR_UNSUPPORTED.
+DTF_API int dtf_gemm_f32_skinny_ring(const void* ring_table, void* ring_ctr, void* ring_out,
+                                     int ring, int a_index, int first, const float* B, float* C,
+                                     const float* bias, int M, int N, int K, long lda, long ldb,
+                                     long ldc, int trans_a, int trans_b, int act,
+                                     hipStream_t stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || !B || !C || !ring_table || !ring_ctr || ring < 1 ||
+      (ring & (ring - 1)) || a_index < 0 || a_index >= DTF_RING_FEEDS)
+    return DTF_ERR_BAD_ARG;
+  if (lda < (trans_a ? M : K) || ldb < (trans_b ? K : N) || ldc < N) return DTF_ERR_BAD_ARG;
+  if (dtf_gemm_f32_tile(M, N, K) != 16) return DTF_ERR_UNSUPPORTED;
+  const DtfStepRing r{(const unsigned long long*)ring_table, (unsigned*)ring_ctr, (float*)ring_out,
+                      ring, -1};
+  const int tiles_m = (M + SK_T - 1) / SK_T, tiles_n = (N + SK_T - 1) / SK_T;
+  const SkinnyArgs args{nullptr, B, C, bias, M, N, K, lda, ldb, ldc, act, 0.f, tiles_n};
+  dim3 grid(tiles_m * tiles_n);
+#define DTF_SKINNY_RING_CASE(AKC, BKC)                                                           \
+  do {                                                                                           \
+    if (gemm_f32_skinny_waves(K) == 16)                                                          \
+      hipLaunchKernelGGL((gemm_f32_skinny_ring_kernel<AKC, BKC, 16>), grid, dim3(1024), 0,       \
+                         stream, args, r, a_index, first);                                       \
+    else                                                                                         \
+      hipLaunchKernelGGL((gemm_f32_skinny_ring_kernel<AKC, BKC, 4>), grid, dim3(256), 0, stream, \
+                         args, r, a_index, first);                                               \
+  } while (0)
+  if (!trans_a && !trans_b) DTF_SKINNY_RING_CASE(true, false);
+  else if (!trans_a && trans_b) DTF_SKINNY_RING_CASE(true, true);
+  else if (trans_a && !trans_b) DTF_SKINNY_RING_CASE(false, false);
+  else DTF_SKINNY_RING_CASE(false, true);
+#undef DTF_SKINNY_RING_CASE
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
 }
 
 DTF_API int dtf_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N,

@@ -25,12 +25,21 @@
 // Limits (checked by the launcher): B <= 128, H <= 128, C <= 16.
 #include "common.h"
 #include "mlp_head_body.h"
+#include "step_ring.h"
 
 namespace {
 
 using namespace dtf_head;
 
 __global__ __launch_bounds__(HT) void mlp_head_rows_kernel(HeadArgs p) {
+  head_rows_block(p, blockIdx.x);
+}
+
+// inside a captured step whose labels are a fed tensor: read where they lie, through the step
+// ring's address table (never the step's first ring kernel: the first layer's product is)
+__global__ __launch_bounds__(HT) void mlp_head_rows_ring_kernel(HeadArgs p, DtfStepRing ring,
+                                                                int labels_index) {
+  p.labels = (const float*)dtf_ring_feed_later(ring, labels_index);
   head_rows_block(p, blockIdx.x);
 }
 
@@ -68,21 +77,52 @@ DTF_API long dtf_mlp_head_workspace(long B, long H, long C) {
   return ((B + RB - 1) / RB) * (H * C + C + H + 2);
 }
 
-DTF_API int dtf_mlp_head_train(const float* a, const float* w, const float* bias,
-                               const float* labels, const float* dloss, float* loss, float* y,
-                               float* dw, float* db, float* da, float* db_prev, float* accuracy,
-                               float* workspace, long B, long H, long C, int sig_grad,
-                               hipStream_t stream) {
-  if (!a || !w || !bias || !labels || !dloss || !loss || !y || !dw || !db || !da || !workspace)
+// ring_table != null: `labels` is ignored and read through the step ring instead (entry
+// labels_index of the replay's table slot)
+static int head_train_launch(const float* a, const float* w, const float* bias,
+                             const float* labels, const float* dloss, float* loss, float* y,
+                             float* dw, float* db, float* da, float* db_prev, float* accuracy,
+                             float* workspace, long B, long H, long C, int sig_grad,
+                             const DtfStepRing* ring, int labels_index, hipStream_t stream) {
+  if (!a || !w || !bias || (!labels && !ring) || !dloss || !loss || !y || !dw || !db || !da ||
+      !workspace)
     return DTF_ERR_BAD_ARG;
   if (!dtf_mlp_head_supported(B, H, C)) return DTF_ERR_UNSUPPORTED;
   HeadArgs args{a, w, bias, labels, dloss, loss, y, dw, db, da, db_prev, accuracy, workspace,
                 (int)B, (int)H, (int)C, sig_grad, 1.f, db_prev != nullptr};
   const int blocks = (int)((B + RB - 1) / RB);
-  hipLaunchKernelGGL(mlp_head_rows_kernel, dim3(blocks), dim3(HT), 0, stream, args);
+  if (ring)
+    hipLaunchKernelGGL(mlp_head_rows_ring_kernel, dim3(blocks), dim3(HT), 0, stream, args, *ring,
+                       labels_index);
+  else
+    hipLaunchKernelGGL(mlp_head_rows_kernel, dim3(blocks), dim3(HT), 0, stream, args);
   const int S = (int)(H * C + C + H + 2);
   hipLaunchKernelGGL(mlp_head_finish_kernel, dim3((S + 255) / 256), dim3(256), 0, stream, args,
                      blocks);
   DTF_LAUNCH_CHECK();
   return DTF_OK;
+}
+
+DTF_API int dtf_mlp_head_train(const float* a, const float* w, const float* bias,
+                               const float* labels, const float* dloss, float* loss, float* y,
+                               float* dw, float* db, float* da, float* db_prev, float* accuracy,
+                               float* workspace, long B, long H, long C, int sig_grad,
+                               hipStream_t stream) {
+  return head_train_launch(a, w, bias, labels, dloss, loss, y, dw, db, da, db_prev, accuracy,
+                           workspace, B, H, C, sig_grad, nullptr, -1, stream);
+}
+
+DTF_API int dtf_mlp_head_train_ring(const float* a, const float* w, const float* bias,
+                                    const float* dloss, float* loss, float* y, float* dw,
+                                    float* db, float* da, float* db_prev, float* accuracy,
+                                    float* workspace, long B, long H, long C, int sig_grad,
+                                    const void* ring_table, void* ring_ctr, void* ring_out,
+                                    int ring, int labels_index, hipStream_t stream) {
+  if (!ring_table || !ring_ctr || ring < 1 || (ring & (ring - 1)) || labels_index < 0 ||
+      labels_index >= DTF_RING_FEEDS)
+    return DTF_ERR_BAD_ARG;
+  const DtfStepRing r{(const unsigned long long*)ring_table, (unsigned*)ring_ctr, (float*)ring_out,
+                      ring, -1};
+  return head_train_launch(a, w, bias, nullptr, dloss, loss, y, dw, db, da, db_prev, accuracy,
+                           workspace, B, H, C, sig_grad, &r, labels_index, stream);
 }

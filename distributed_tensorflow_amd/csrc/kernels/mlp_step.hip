@@ -60,8 +60,12 @@ template <int NW>
 __global__ __launch_bounds__(64 * NW) void mlp_step_layer1_kernel(SkinnyArgs g, DtfStepRing ring,
                                                                   int a_index, int first) {
   if (ring.ctr) {
-    const unsigned seq = first ? dtf_ring_begin(ring) : dtf_ring_current(ring);
-    if (a_index >= 0) g.A = (const float*)dtf_ring_feed(ring, seq, a_index);
+    if (first) {
+      const unsigned seq = dtf_ring_begin(ring);
+      if (a_index >= 0) g.A = (const float*)dtf_ring_feed(ring, seq, a_index);
+    } else if (a_index >= 0) {
+      g.A = (const float*)dtf_ring_feed_later(ring, a_index);
+    }
   }
   gemm_f32_skinny_block<true, false, 0, NW>(g, blockIdx.x);
 }
@@ -69,7 +73,7 @@ __global__ __launch_bounds__(64 * NW) void mlp_step_layer1_kernel(SkinnyArgs g, 
 __global__ __launch_bounds__(HT) void mlp_step_head_kernel(HeadArgs p, DtfStepRing ring,
                                                            int labels_index) {
   if (ring.ctr && labels_index >= 0)
-    p.labels = (const float*)dtf_ring_feed(ring, dtf_ring_current(ring), labels_index);
+    p.labels = (const float*)dtf_ring_feed_later(ring, labels_index);
   head_rows_block(p, blockIdx.x);
 }
 
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_step_update_kernel(SkinnyArgs g,
     return;
   }
   if (ring.ctr && a_index >= 0)
-    g.A = (const float*)dtf_ring_feed(ring, dtf_ring_current(ring), a_index);
+    g.A = (const float*)dtf_ring_feed_later(ring, a_index);
   // dW1 = x^T dz1: A is x stored [K = batch, M = inputs] (M-contiguous), B is dz1 [K, N]
   gemm_f32_skinny_block<false, false, 1>(g, (int)blockIdx.x - tail_blocks);
 }

@@ -105,6 +105,9 @@ def _declare(L: ctypes.CDLL) -> None:
         "dtf_pad_2d_f32": [P, P, LG, LG, LG, LG, LG, P],
         "dtf_pad_2d_b16": [P, P, LG, LG, LG, LG, LG, P],
         "dtf_pad_2d_b8": [P, P, LG, LG, LG, LG, LG, P],
+        "dtf_gemm_f32_skinny_ring": [P, P, P, I, I, I, P, P, P, I, I, I, LG, LG, LG, I, I, I, P],
+        "dtf_mlp_head_train_ring": [P, P, P, P, P, P, P, P, P, P, P, P, LG, LG, LG, I, P, P, P, I,
+                                    I, P],
         "dtf_gemm_f32_splits": [I, I, I, P],
         "dtf_gemm_f32_tile": [I, I, I],
         "dtf_gemm_bf16_nt": [P, P, P, I, I, I, LG, LG, LG, F, F, I, I, P],
@@ -344,6 +347,48 @@ def gemm_f32(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: b
                              int(activation), _ptr(partial), splits, int(tile), int(m_load),
                              int(n_load), _stream()),
            "gemm_f32")
+    return out
+
+
+def gemm_f32_ring_ok(a_like: torch.Tensor, b: torch.Tensor, trans_a: bool = False,
+                     trans_b: bool = False) -> bool:
+    """Whether ``gemm_f32_ring`` takes this product: fp32 rank-2 operands with contiguous rows
+    and a shape the small-product kernel serves."""
+    if getattr(a_like, "dim", lambda: 0)() != 2 or getattr(b, "dim", lambda: 0)() != 2:
+        return False
+    if a_like.dtype != torch.float32 or b.dtype != torch.float32 or not a_like.is_contiguous() \
+            or not b.is_contiguous() or a_like.device.type != "cuda":
+        return False
+    m, k = (a_like.shape[1], a_like.shape[0]) if trans_a else a_like.shape
+    k2, n = (b.shape[1], b.shape[0]) if trans_b else b.shape
+    return k == k2 and min(m, n, k) > 0 and lib().dtf_gemm_f32_tile(m, n, k) == 16
+
+
+def gemm_f32_ring(ring: "RingArgs", a_index: int, a_like: torch.Tensor, b: torch.Tensor,
+                  trans_a: bool = False, trans_b: bool = False,
+                  bias: Optional[torch.Tensor] = None, activation: int = ACT_NONE,
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``gemm_f32`` inside a captured step whose A operand is a fed tensor: A is read through
+    entry ``a_index`` of the step ring's address table (``a_like``: the captured stand-in for
+    the fed tensor, for shape and pitch only), so no gather launch copies the batch first.
+    Only products the small-product kernel takes (``gemm_f32_ring_ok``)."""
+    if not gemm_f32_ring_ok(a_like, b, trans_a, trans_b):
+        raise HipKernelError("gemm_f32_ring: not a small contiguous fp32 product")
+    m, k = (a_like.shape[1], a_like.shape[0]) if trans_a else a_like.shape
+    n = b.shape[0] if trans_b else b.shape[1]
+    if bias is not None:
+        bias = _req(bias, torch.float32, "gemm_f32_ring bias")
+        if bias.numel() != n:
+            raise HipKernelError("gemm_f32_ring: bias has %d elements, N=%d" % (bias.numel(), n))
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=b.device)
+    elif out.shape != (m, n) or out.dtype != torch.float32 or not out.is_contiguous():
+        raise HipKernelError("gemm_f32_ring: bad out tensor")
+    _check(lib().dtf_gemm_f32_skinny_ring(
+        ring.table.data_ptr(), ring.ctr.data_ptr(), ring.out.data_ptr(), ring.slots,
+        int(a_index), ring.take_first(), b.data_ptr(), out.data_ptr(), _ptr(bias), m, n, k,
+        a_like.shape[1], b.shape[1], n, int(trans_a), int(trans_b), int(activation), _stream()),
+        "gemm_f32_ring")
     return out
 
 
@@ -999,8 +1044,11 @@ def mlp_head_supported(b: int, h: int, c: int) -> bool:
 def mlp_head_train(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, labels: torch.Tensor,
                    dloss: torch.Tensor, sigmoid_input: bool, want_accuracy: bool,
                    dw_out: Optional[torch.Tensor] = None, db_out: Optional[torch.Tensor] = None,
-                   dbp_out: Optional[torch.Tensor] = None):
+                   dbp_out: Optional[torch.Tensor] = None, ring: Optional["RingArgs"] = None,
+                   labels_index: int = -1):
     """Fused forward + backward of a small softmax head (B <= 128, H <= 128, C <= 16).
+    With ``ring`` the labels are read through entry ``labels_index`` of the step ring's address
+    table (``labels`` then only gives their shape).
     Returns ``(loss, y, dw, db, da_or_dz_prev, db_prev_or_None, accuracy_or_None)``. The three
     parameter gradients may be placed by the caller (``*_out``: contiguous fp32 buffers of the
     right size, e.g. their slots in a flat gradient arena)."""
@@ -1037,6 +1085,18 @@ def mlp_head_train(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, labels:
     if dbp_out is not None:
         dbp = _out_vec(dbp_out, h, dev, "mlp_head dbp")
     ws = take(ws_n, (ws_n,))
+    if ring is not None:
+        if ring.take_first():
+            raise HipKernelError("mlp_head_train: cannot be the first ring kernel of a step")
+        _check(lib().dtf_mlp_head_train_ring(
+            a.data_ptr(), w.data_ptr(), bias.data_ptr(), dloss.data_ptr(), loss.data_ptr(),
+            y.data_ptr(), dw.data_ptr(), db.data_ptr(), da.data_ptr(),
+            dbp.data_ptr() if sigmoid_input else None,
+            acc.data_ptr() if want_accuracy else None, ws.data_ptr(), b, h, c,
+            int(sigmoid_input), ring.table.data_ptr(), ring.ctr.data_ptr(), ring.out.data_ptr(),
+            ring.slots, int(labels_index), _stream()), "mlp_head_train (ring)")
+        return loss, y, dw, db, da, (dbp if sigmoid_input else None), \
+            (acc if want_accuracy else None)
     _check(lib().dtf_mlp_head_train(a.data_ptr(), w.data_ptr(), bias.data_ptr(),
                                     labels.data_ptr(), dloss.data_ptr(), loss.data_ptr(),
                                     y.data_ptr(), dw.data_ptr(), db.data_ptr(), da.data_ptr(),
@@ -1334,11 +1394,12 @@ def gather_feeds(table: torch.Tensor, dsts: Sequence[torch.Tensor]) -> None:
 
 
 RING_FEEDS, RING_WORDS = 8, 256      # step_ring.h: inputs and result words per ring slot
+RING_CTR_WORDS = 2 + 2 * RING_FEEDS  # step_ring.h: two counters + the replay's input addresses
 
 
 class RingArgs:
     """The device-visible parts of a step ring (``csrc/kernels/step_ring.h``): pinned address
-    table ``[slots, 8]`` int64, device counters ``[2]`` int32, pinned results ``[slots, 256]``
+    table ``[slots, 8]`` int64, device counters and address copies ``[2 + 16]`` int32, pinned results ``[slots, 256]``
     fp32. ``first_taken`` records, while a step is being captured, whether an earlier kernel of
     the step already publishes the replay number."""
 
@@ -1348,7 +1409,7 @@ class RingArgs:
         if table.dtype != torch.int64 or not table.is_pinned() or table.numel() != slots * RING_FEEDS \
                 or out.dtype != torch.float32 or not out.is_pinned() \
                 or out.numel() != slots * RING_WORDS or ctr.dtype != torch.int32 \
-                or not ctr.is_cuda or ctr.numel() != 2:
+                or not ctr.is_cuda or ctr.numel() != RING_CTR_WORDS:
             raise HipKernelError("step ring: bad buffers")
         self.table, self.ctr, self.out, self.slots = table, ctr, out, slots
         self.first_taken = False

@@ -205,6 +205,14 @@ def _row_scale(op, inputs, ctx):
 
 
 # -- matmul -----------------------------------------------------------------------------
+def _ring_index(ctx, t) -> int:
+    """Entry of the step ring's address table that holds ``t`` -- a fed tensor the session left
+    ungathered because every reader takes it through the ring -- or -1."""
+    if ctx.ring is None or not ctx.ring_feeds or not isinstance(t, torch.Tensor):
+        return -1
+    return ctx.ring_feeds.get(t.data_ptr(), -1)
+
+
 @hip_kernel("MatMul")
 def _matmul(op, inputs, ctx):
     a, b = inputs
@@ -212,6 +220,10 @@ def _matmul(op, inputs, ctx):
     if _is_f32(a, b):
         m = a.shape[1] if ta else a.shape[0]
         n = b.shape[0] if tb else b.shape[1]
+        idx = _ring_index(ctx, a)
+        if idx >= 0:       # a fed tensor inside a captured step: read through the step ring
+            return [hip.gemm_f32_ring(ctx.ring, idx, a, b.contiguous(), ta, tb,
+                                      out=_hint(ctx, 0, (m, n)))]
         return [hip.gemm_f32(a, b, ta, tb, out=_hint(ctx, 0, (m, n)))]
     if a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16:
         return [hip.gemm_bf16(a, b, ta, tb)]
@@ -229,6 +241,10 @@ def _fused_dense(op, inputs, ctx):
     x, w, b = inputs
     if not _is_f32(x, w, b):
         return _fallback("FusedDense", op, inputs, ctx)
+    idx = _ring_index(ctx, x)
+    if idx >= 0:           # a fed tensor inside a captured step: read through the step ring
+        return [hip.gemm_f32_ring(ctx.ring, idx, x, w.contiguous(), bias=b,
+                                  activation=hip.ACTIVATIONS[op.attrs["activation"]])]
     return [hip.gemm_f32(x, w, bias=b, activation=hip.ACTIVATIONS[op.attrs["activation"]])]
 
 
@@ -373,11 +389,16 @@ def _classifier_head_train(op, inputs, ctx):
         return _fallback("ClassifierHeadTrain", op, inputs, ctx)
     sig = bool(op.attrs.get("sigmoid_input"))
     want_acc = bool(op.attrs.get("emit_accuracy"))
+    li = _ring_index(ctx, labels)
     if hip.mlp_head_supported(a.shape[0], a.shape[1], w.shape[1]):
         h_, c_ = w.shape
         loss, y, dw, db, da, dbp, acc = hip.mlp_head_train(
             a, w, b, labels, dloss, sig, want_acc, dw_out=_hint(ctx, 2, (h_, c_)),
-            db_out=_hint(ctx, 3, (c_,)), dbp_out=_hint(ctx, 5, (h_,)) if sig else None)
+            db_out=_hint(ctx, 3, (c_,)), dbp_out=_hint(ctx, 5, (h_,)) if sig else None,
+            ring=ctx.ring if li >= 0 else None, labels_index=li)
+    elif li >= 0:
+        raise hip.HipKernelError("ClassifierHeadTrain: the labels were left in the step ring "
+                                 "but the head kernel does not take this shape")
     else:
         # batch or layer too large for the one-workgroup kernel: the same math as a chain of
         # the general kernels

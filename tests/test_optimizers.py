@@ -491,3 +491,32 @@ def test_gpu_schedule_is_read_on_the_device_inside_captured_steps(name, schedule
     ref_w, ref_b = _sgd_reference(w0, b0, want)
     assert np.allclose(w, ref_w, rtol=5e-5, atol=5e-6) and np.allclose(b, ref_b, rtol=5e-5, atol=5e-6)
     assert stats["graph_replays"] >= 8 and stats["torch_fallbacks"] == 0
+
+
+@pytest.mark.gpu
+def test_gpu_chain_of_general_kernels_reads_the_batch_through_the_step_ring(monkeypatch):
+    """Adam on the MNIST MLP with the data set resident in HBM: the captured step's first-layer
+    product, weight-gradient product and head read the batch where it lies (no feed gather);
+    losses and weights are bit-identical to the step that gathers its feeds first."""
+    rng = np.random.RandomState(0)
+    xs = torch.from_numpy(rng.rand(16, 100, 784).astype(np.float32)).cuda()
+    ys = torch.from_numpy(np.eye(10, dtype=np.float32)[rng.randint(0, 10, (16, 100))]).cuda()
+
+    def run():
+        with tf.Graph().as_default():
+            m = mnist_mlp.build_model(seed=1, optimizer=tf.train.AdamOptimizer(0.01),
+                                      with_summaries=False)
+            with tf.Session(config=tf.ConfigProto(device="cuda:0")) as sess:
+                sess.run(m.init_op)
+                losses = [float(sess.run([m.train_op, m.loss, m.global_step],
+                                         {m.x: xs[i % 16], m.y_: ys[i % 16]})[1])
+                          for i in range(40)]
+                return losses, sess.run(m.w1), dict(sess.stats)
+
+    ring = run()
+    monkeypatch.setenv("DTF_NO_RING_READS", "1")
+    gathered = run()
+    assert ring[2].get("ring_read_captures", 0) >= 1 and ring[2]["graph_replays"] >= 30
+    assert gathered[2].get("ring_read_captures", 0) == 0
+    assert ring[0] == gathered[0] and np.array_equal(ring[1], gathered[1])
+    assert ring[0][-1] < 0.5 * ring[0][0]

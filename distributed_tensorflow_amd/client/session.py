@@ -85,6 +85,19 @@ _MUTATING_OPS = frozenset(("Assign", "AssignAdd", "AssignSub", "ApplyGradientDes
 _PACK_WORDS = 256     # fp32 words of pinned staging per captured step for small fetches
 
 
+@contextlib.contextmanager
+def _gc_paused():
+    """Cyclic garbage collection off inside the block (restored to what it was afterwards)."""
+    import gc
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
+
+
 class SessionClosedError(RuntimeError):
     """``run`` on a session that has been closed."""
 
@@ -1302,7 +1315,7 @@ class Session:
             return None
         try:
             scratch = torch.cuda.CUDAGraph(keep_graph=True)
-            with torch.cuda.graph(scratch, capture_error_mode="thread_local"):
+            with _gc_paused(), torch.cuda.graph(scratch, capture_error_mode="thread_local"):
                 s = torch._C._cuda_getCurrentRawStream(self.device.index)
                 for fn, args in launchers:
                     if fn(*args, s) != 0:
@@ -1405,7 +1418,10 @@ class Session:
                 if direct else {}
             if direct:
                 self.stats["ring_read_captures"] = self.stats.get("ring_read_captures", 0) + 1
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"), \
+            # (no cyclic garbage collection while the stream is capturing: a collector run that
+            # finalises an old graph, event or device allocation inside the capture aborts the
+            # process)
+            with _gc_paused(), torch.cuda.graph(graph, capture_error_mode="thread_local"), \
                     hip.record_calls() as recorder:
                 capture_stream = torch._C._cuda_getCurrentRawStream(self.device.index)
                 if use_table and not direct:

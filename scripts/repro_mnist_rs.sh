@@ -1,0 +1,6 @@
+for i in 1 2 3 4 5 6 7 8; do
+  for env in "" "DTF_NO_RING_READS=1"; do
+    out=$(env $env timeout -k 10 100 python -m distributed_tensorflow_amd.launch --num_workers 1 --protocol rccl --strategy reduce_scatter_sync --timeout 90 examples/tf_distributed.py -- --max_steps 600 --logs_path /tmp/lg$i --data_dir /tmp/nodata 2>&1)
+    echo "[$env] rc=$? $(echo "$out" | grep -o 'Cost: [0-9.]*' | tr '\n' ' ')"
+  done
+done

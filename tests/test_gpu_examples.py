@@ -37,7 +37,8 @@ def test_mnist_example_on_gpu(strategy, tmp_path):
     m = re.findall(r"Cost: (\d+\.\d{4}),\s+AvgTime:\s*(\d+\.\d\d)ms", out)
     assert len(m) >= 5
     costs = [float(c) for c, _ in m]
-    assert costs[-1] < costs[0]                                   # it learns
+    # it learns (single-batch costs scatter by about +-1 around the trend: compare pairs)
+    assert costs[-1] + costs[-2] < costs[0] + costs[1]
     assert min(float(t) for _, t in m) < 1.0                      # sub-millisecond steps
     acc = float(re.search(r"Test-Accuracy: (\d+\.\d\d)", out).group(1))
     assert 0.0 <= acc <= 1.0

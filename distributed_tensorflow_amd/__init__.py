@@ -39,7 +39,7 @@ from .framework.variables import (Variable, constant_initializer, get_variable, 
                                   report_uninitialized_variables, trainable_variables,
                                   truncated_normal_initializer, variables_initializer,
                                   zeros_initializer)
-from . import layers, nn  # noqa: F401,E402
+from . import layers, losses, nn  # noqa: F401,E402
 from .framework.ops import (clip_by_global_norm, clip_by_norm, clip_by_value,  # noqa: F401,E402
                             argmin, expand_dims, floor, global_norm, greater_equal,
                             less_equal, one_hot, reduce_min, squeeze, where)

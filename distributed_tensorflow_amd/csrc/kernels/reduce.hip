@@ -112,6 +112,33 @@ __global__ __launch_bounds__(BLOCK) void reduce_all_stage2(const float* __restri
   if (threadIdx.x == 0) out[0] = t * scale;
 }
 
+// Mean squared error, fused: stage 1 sums (a - b)^2 over this block's grid-stride slice (the
+// difference and the square never exist in memory), reduce_all_stage2 folds the partials and
+// scales by 1 / n. The fold order is fixed by the launch shape.
+__global__ __launch_bounds__(BLOCK) void sq_diff_stage1(const float* __restrict__ a,
+                                                        const float* __restrict__ b,
+                                                        float* __restrict__ partial, long n) {
+  __shared__ float sh[BLOCK / 64];
+  const long nthreads = (long)gridDim.x * BLOCK;
+  float acc = 0.f;
+  for (long i = blockIdx.x * (long)BLOCK + threadIdx.x; i < n; i += nthreads) {
+    const float d = a[i] - b[i];
+    acc = __builtin_fmaf(d, d, acc);
+  }
+  const float t = block_sum(acc, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+// gradient of mean((a - b)^2) with respect to a: da = (2 g / n) (a - b), g a device scalar
+__global__ __launch_bounds__(BLOCK) void mse_grad_kernel(const float* __restrict__ a,
+                                                         const float* __restrict__ b,
+                                                         const float* __restrict__ g,
+                                                         float* __restrict__ da, long n) {
+  const float s = 2.f * g[0] / (float)n;
+  for (long i = blockIdx.x * (long)BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * BLOCK)
+    da[i] = s * (a[i] - b[i]);
+}
+
 enum ColMode { COL_SUM = 0, COL_SIGMOID_GRAD = 1, COL_XENT_GRAD = 2 };
 
 // Workgroup b owns columns [64b, 64b+64); thread (g = tid>>6, l = tid&63) walks rows g, g+G, ...
@@ -293,6 +320,30 @@ DTF_API int dtf_reduce_all_f32(const float* x, float* out, long n, float scale, 
   hipLaunchKernelGGL(reduce_all_stage1, dim3(blocks), dim3(BLOCK), 0, stream, x, workspace, n);
   hipLaunchKernelGGL(reduce_all_stage2, dim3(1), dim3(BLOCK), 0, stream, workspace, out, blocks,
                      scale);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
+// out[0] = mean((a - b)^2) over n elements; workspace: dtf_reduce_all_workspace(n) floats
+DTF_API int dtf_mse_f32(const float* a, const float* b, float* out, long n, float* workspace,
+                        hipStream_t stream) {
+  if (!a || !b || !out || !workspace || n <= 0) return DTF_ERR_BAD_ARG;
+  const int blocks = dtf_reduce_all_workspace(n);
+  hipLaunchKernelGGL(sq_diff_stage1, dim3(blocks), dim3(BLOCK), 0, stream, a, b, workspace, n);
+  hipLaunchKernelGGL(reduce_all_stage2, dim3(1), dim3(BLOCK), 0, stream, workspace, out, blocks,
+                     1.f / (float)n);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
+// da = (2 g[0] / n) (a - b)
+DTF_API int dtf_mse_grad_f32(const float* a, const float* b, const float* g, float* da, long n,
+                             hipStream_t stream) {
+  if (!a || !b || !g || !da || n <= 0) return DTF_ERR_BAD_ARG;
+  long blocks = (n + BLOCK * 4L - 1) / (BLOCK * 4L);
+  blocks = blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks;
+  hipLaunchKernelGGL(mse_grad_kernel, dim3((unsigned)blocks), dim3(BLOCK), 0, stream, a, b, g, da,
+                     n);
   DTF_LAUNCH_CHECK();
   return DTF_OK;
 }

@@ -586,6 +586,19 @@ def sparse_softmax_cross_entropy_with_logits(labels=None, logits=None, name=None
         labels=dense, logits=logits, name=name or "sparse_softmax_cross_entropy_with_logits")
 
 
+def mean_squared_error(labels, predictions, name=None) -> Tensor:
+    """``mean((predictions - labels) ** 2)`` over all elements as one fused op (forward: partial
+    sums + fold; backward: one element-wise launch) when both have the same static shape; the
+    composition ``reduce_mean(square(predictions - labels))`` otherwise."""
+    predictions, labels = _binary_inputs(predictions, labels)
+    ps, ls = predictions.shape, labels.shape
+    if ps is None or ls is None or len(ps) != len(ls) or any(
+            a != b for a, b in zip(ps, ls)):
+        return reduce_mean(square(subtract(predictions, labels)), name=name)
+    return _op1("MeanSquaredError", [predictions, labels], predictions.dtype, (),
+                name=name or "mean_squared_error")
+
+
 def l2_loss(t, name=None) -> Tensor:
     """``sum(t ** 2) / 2`` (weight decay term)."""
     return scale(reduce_sum(square(t)), 0.5, name=name or "L2Loss")
@@ -728,6 +741,14 @@ def _square_grad(op, g):
 @gradient("Abs")
 def _abs_grad(op, g):
     return (multiply(g, sign(op.inputs[0])),)
+
+
+@gradient("MeanSquaredError")
+def _mse_grad(op, g):
+    pred, labels = op.inputs
+    dpred = _op1("MeanSquaredErrorGrad", [pred, labels, g], pred.dtype, pred.shape,
+                 name="MeanSquaredErrorGrad")
+    return dpred, negative(dpred)
 
 
 @gradient("Select")

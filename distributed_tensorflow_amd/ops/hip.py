@@ -169,6 +169,8 @@ def _declare(L: ctypes.CDLL) -> None:
         "dtf_pad_rows": [P, P, LG, LG, LG, LG, LG, P],
         "dtf_assign_add_f32": [P, P, LG, LG, F, P],
         "dtf_sign_f32": [P, P, LG, P],
+        "dtf_mse_f32": [P, P, P, LG, P, P],
+        "dtf_mse_grad_f32": [P, P, P, P, LG, P],
         "dtf_select_f32": [P, P, P, P, LG, LG, LG, LG, P],
         "dtf_one_hot_f32": [P, I, P, LG, LG, F, F, P],
         "dtf_broadcast_mid_f32": [P, P, LG, LG, LG, F, P],
@@ -1673,6 +1675,35 @@ def one_hot(indices: torch.Tensor, depth: int, on_value: float = 1.0,
     _check(lib().dtf_one_hot_f32(indices.data_ptr(), int(indices.dtype == torch.int64),
                                  out.data_ptr(), indices.numel(), int(depth), float(on_value),
                                  float(off_value), _stream()), "one_hot")
+    return out
+
+
+def mse(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """``mean((a - b) ** 2)`` over all elements as a 0-d tensor: the difference and its square
+    are never written to memory (two launches: partial sums, fold)."""
+    a = _req(a, torch.float32, "mse a")
+    b = _req(b, torch.float32, "mse b")
+    if a.shape != b.shape or a.numel() == 0:
+        raise HipKernelError("mse: operands must have the same non-empty shape")
+    n = a.numel()
+    buf = torch.empty(1 + int(lib().dtf_reduce_all_workspace(n)), dtype=torch.float32,
+                      device=a.device)
+    _check(lib().dtf_mse_f32(a.data_ptr(), b.data_ptr(), buf.data_ptr(), n, buf[1:].data_ptr(),
+                             _stream()), "mse")
+    return buf[0].view(())
+
+
+def mse_grad(a: torch.Tensor, b: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
+    """Gradient of ``mse(a, b)`` with respect to ``a``: ``(2 g / n) (a - b)``, ``g`` an fp32
+    device scalar."""
+    a = _req(a, torch.float32, "mse_grad a")
+    b = _req(b, torch.float32, "mse_grad b")
+    g = _req(g, torch.float32, "mse_grad g")
+    if a.shape != b.shape or a.numel() == 0 or g.numel() != 1:
+        raise HipKernelError("mse_grad: same-shape operands and a scalar gradient")
+    out = torch.empty_like(a)
+    _check(lib().dtf_mse_grad_f32(a.data_ptr(), b.data_ptr(), g.data_ptr(), out.data_ptr(),
+                                  a.numel(), _stream()), "mse_grad")
     return out
 
 

@@ -440,6 +440,22 @@ def _transpose(op, inputs, ctx):
     return _fallback("Transpose", op, inputs, ctx, "perm %s of rank %d" % (perm, x.dim()))
 
 
+@hip_kernel("MeanSquaredError")
+def _mean_squared_error(op, inputs, ctx):
+    a, b = inputs
+    if not _is_f32(a, b) or a.shape != b.shape:
+        return _fallback("MeanSquaredError", op, inputs, ctx)
+    return [hip.mse(a, b)]
+
+
+@hip_kernel("MeanSquaredErrorGrad")
+def _mean_squared_error_grad(op, inputs, ctx):
+    a, b, g = inputs
+    if not _is_f32(a, b, g) or a.shape != b.shape:
+        return _fallback("MeanSquaredErrorGrad", op, inputs, ctx)
+    return [hip.mse_grad(a, b, g)]
+
+
 @hip_kernel("Select")
 def _select(op, inputs, ctx):
     cond, a, b = inputs

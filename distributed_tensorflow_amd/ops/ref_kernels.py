@@ -274,6 +274,18 @@ ref_kernel("LessEqual")(_bin(torch.le))
 ref_kernel("GreaterEqual")(_bin(torch.ge))
 
 
+@ref_kernel("MeanSquaredError")
+def _mean_squared_error(op, inputs, ctx):
+    d = inputs[0] - inputs[1]
+    return [(d * d).mean()]
+
+
+@ref_kernel("MeanSquaredErrorGrad")
+def _mean_squared_error_grad(op, inputs, ctx):
+    a, b, g = inputs
+    return [(2.0 * g / a.numel()) * (a - b)]
+
+
 @ref_kernel("Select")
 def _select(op, inputs, ctx):
     return [torch.where(inputs[0], inputs[1], inputs[2])]

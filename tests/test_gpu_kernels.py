@@ -1187,3 +1187,17 @@ def test_dropout_on_the_gpu_matches_the_host_stream_through_captured_replays():
     for (yc, gc), (yg, gg) in zip(cpu, gpu):          # eager runs, the capture and the replays
         assert np.array_equal(yc, yg) and np.allclose(gc, gg, rtol=1e-6)
     assert np.array_equal(ident_g, a) and np.array_equal(half_c, half_g)
+
+
+@pytest.mark.parametrize("n", [1, 256, 4099, 1 << 20])
+def test_mse_and_its_gradient(hip, n):
+    g = torch.Generator().manual_seed(n)
+    a, b = torch.randn(n, generator=g).cuda(), torch.randn(n, generator=g).cuda()
+    want = ((a.double() - b.double()) ** 2).mean()
+    got = hip.mse(a, b)
+    assert got.shape == () and abs(float(got) - float(want)) <= 1e-5 * max(1.0, float(want))
+    assert torch.equal(hip.mse(a, b), got)                       # fixed fold order
+    gs = torch.tensor(0.5).cuda()
+    da = hip.mse_grad(a, b, gs)
+    assert torch.allclose(da.double(), (2 * 0.5 / n) * (a.double() - b.double()), rtol=1e-6,
+                          atol=1e-9)

@@ -474,3 +474,27 @@ def test_dropout_draws_a_fresh_reproducible_mask_every_run():
     assert abs((half != 0).mean() - 0.5) < 0.06
     _, again, _, _, _ = _dropout_runs("cpu")
     assert all(np.array_equal(p[0], q[0]) for p, q in zip(outs, again))   # same seed, same rounds
+
+
+def test_mean_squared_error_is_one_op_with_its_own_gradient():
+    rng = np.random.RandomState(4)
+    a, b = rng.randn(9, 3).astype(np.float32), rng.randn(9, 3).astype(np.float32)
+    with tf.Graph().as_default() as g:
+        x = tf.placeholder(tf.float32, [None, 3])
+        t = tf.placeholder(tf.float32, [None, 3])
+        w = tf.Variable(tf.ones([3, 3]), name="W")
+        pred = tf.matmul(x, w)
+        loss = tf.losses.mean_squared_error(t, pred)
+        plain = tf.reduce_mean(tf.square(tf.subtract(pred, t)))
+        gw, gt = tf.gradients(loss, [w, t])
+        gw_plain = tf.gradients(plain, [w])[0]
+        assert loss.op.type == "MeanSquaredError"
+        row = tf.losses.mean_squared_error(tf.placeholder(tf.float32, [3]), pred)   # broadcast
+        assert row.op.type != "MeanSquaredError"
+        with tf.Session(config=tf.ConfigProto(device="cpu")) as sess:
+            sess.run(tf.global_variables_initializer())
+            l, lp, dw, dwp, dt = sess.run([loss, plain, gw, gw_plain, gt], {x: a, t: b})
+    pred_v = a @ np.ones((3, 3), np.float32)
+    assert np.isclose(l, ((pred_v - b) ** 2).mean(), rtol=1e-6) and np.isclose(l, lp, rtol=1e-6)
+    assert np.allclose(dw, dwp, rtol=1e-5, atol=1e-6)
+    assert np.allclose(dt, -2.0 * (pred_v - b) / b.size, rtol=1e-5, atol=1e-7)

@@ -41,7 +41,7 @@ from .framework.variables import (Variable, constant_initializer, get_variable, 
                                   zeros_initializer)
 from . import layers, losses, nn  # noqa: F401,E402
 from .framework.ops import (clip_by_global_norm, clip_by_norm, clip_by_value,  # noqa: F401,E402
-                            argmin, expand_dims, floor, global_norm, greater_equal,
-                            less_equal, one_hot, reduce_min, squeeze, where)
+                            argmin, cos, expand_dims, floor, global_norm, greater_equal,
+                            less_equal, one_hot, reduce_min, sin, squeeze, where)
 
 __version__ = "0.1.0"

@@ -345,6 +345,14 @@ def floor(x, name=None) -> Tensor:
     return _unary("Floor", x, name)
 
 
+def cos(x, name=None) -> Tensor:
+    return _unary("Cos", x, name)
+
+
+def sin(x, name=None) -> Tensor:
+    return _unary("Sin", x, name)
+
+
 def sign(x, name=None) -> Tensor:
     return _unary("Sign", x, name)
 
@@ -721,6 +729,16 @@ def _neg_grad(op, g):
 @gradient("Log")
 def _log_grad(op, g):
     return (divide(g, op.inputs[0]),)
+
+
+@gradient("Cos")
+def _cos_grad(op, g):
+    return (negative(multiply(g, sin(op.inputs[0]))),)
+
+
+@gradient("Sin")
+def _sin_grad(op, g):
+    return (multiply(g, cos(op.inputs[0])),)
 
 
 @gradient("Exp")

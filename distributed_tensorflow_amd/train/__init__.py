@@ -4,7 +4,8 @@ checkpointing -- the ``tf.train.*`` symbols the reference scripts use
 from .cluster import ClusterDef, ClusterSpec, task_from_env  # noqa: F401
 from .device_setter import (GreedyLoadBalancingStrategy, byte_size_load_fn,  # noqa: F401
                             replica_device_setter)
-from .learning_rate_decay import (exponential_decay, inverse_time_decay,  # noqa: F401
+from .learning_rate_decay import (cosine_decay, exponential_decay,  # noqa: F401
+                                  inverse_time_decay, natural_exp_decay,
                                   piecewise_constant, polynomial_decay)
 from .optimizer import (AdagradOptimizer, AdamOptimizer, GradientDescentOptimizer,  # noqa: F401
                         MomentumOptimizer, Optimizer, RMSPropOptimizer,

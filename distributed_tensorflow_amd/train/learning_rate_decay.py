@@ -8,6 +8,7 @@ TensorFlow.
 """
 from __future__ import annotations
 
+import math
 from typing import Optional
 
 from ..framework import dtypes
@@ -41,6 +42,28 @@ def inverse_time_decay(learning_rate: float, global_step, decay_steps: float, de
         if staircase:
             p = F.floor(p)
         return F.divide(float(learning_rate), F.add(1.0, F.multiply(float(decay_rate), p)))
+
+
+def natural_exp_decay(learning_rate: float, global_step, decay_steps: float, decay_rate: float,
+                      staircase: bool = False, name: Optional[str] = None) -> Tensor:
+    """``learning_rate * exp(-decay_rate * global_step / decay_steps)``."""
+    with get_default_graph().name_scope(name or "NaturalExpDecay"):
+        p = F.divide(_step_as_float(global_step), float(decay_steps))
+        if staircase:
+            p = F.floor(p)
+        return F.multiply(float(learning_rate), F.exp(F.multiply(-float(decay_rate), p)))
+
+
+def cosine_decay(learning_rate: float, global_step, decay_steps: float, alpha: float = 0.0,
+                 name: Optional[str] = None) -> Tensor:
+    """``learning_rate * ((1 - alpha) * 0.5 * (1 + cos(pi * min(global_step, decay_steps) /
+    decay_steps)) + alpha)``: half a cosine period from the full rate down to ``alpha`` of it."""
+    with get_default_graph().name_scope(name or "CosineDecay"):
+        frac = F.divide(F.minimum(_step_as_float(global_step), float(decay_steps)),
+                        float(decay_steps))
+        cosine = F.multiply(0.5, F.add(1.0, F.cos(F.multiply(math.pi, frac))))
+        return F.multiply(float(learning_rate),
+                          F.add(F.multiply(1.0 - float(alpha), cosine), float(alpha)))
 
 
 def polynomial_decay(learning_rate: float, global_step, decay_steps: float,

@@ -141,8 +141,11 @@ def test_elementwise_and_broadcast(hip):
     assert torch.allclose(hip.binary("sigmoid_grad", y, a), a * y * (1 - y), atol=1e-6)
     for name, fn in [("neg", torch.neg), ("exp", torch.exp), ("sigmoid", torch.sigmoid),
                      ("tanh", torch.tanh), ("relu", torch.relu), ("square", torch.square),
-                     ("abs", torch.abs)]:
+                     ("abs", torch.abs), ("floor", torch.floor)]:
         assert torch.allclose(hip.unary(name, a), fn(a), atol=1e-6, rtol=1e-5), name
+    wide = a * 20.0                 # several periods: the argument reduction is exercised too
+    for name, fn in [("cos", torch.cos), ("sin", torch.sin)]:
+        assert torch.allclose(hip.unary(name, wide), fn(wide.double()).float(), atol=2e-6), name
     pos = a.abs() + 0.1
     assert torch.allclose(hip.unary("log", pos), torch.log(pos), atol=1e-6, rtol=1e-5)
     assert torch.allclose(hip.unary("sqrt", pos), torch.sqrt(pos), atol=1e-6, rtol=1e-5)

@@ -498,3 +498,15 @@ def test_mean_squared_error_is_one_op_with_its_own_gradient():
     assert np.isclose(l, ((pred_v - b) ** 2).mean(), rtol=1e-6) and np.isclose(l, lp, rtol=1e-6)
     assert np.allclose(dw, dwp, rtol=1e-5, atol=1e-6)
     assert np.allclose(dt, -2.0 * (pred_v - b) / b.size, rtol=1e-5, atol=1e-7)
+
+
+def test_cos_and_sin_with_gradients():
+    with tf.Graph().as_default():
+        x = tf.placeholder(tf.float32, [5])
+        y = tf.reduce_sum(tf.cos(x) * 2.0 + tf.sin(x))
+        (dx,) = tf.gradients(y, [x])
+        v = np.linspace(-3.0, 3.0, 5).astype(np.float32)
+        with tf.Session() as sess:
+            got_y, got_dx = sess.run([y, dx], {x: v})
+    assert np.isclose(got_y, (2 * np.cos(v) + np.sin(v)).sum(), rtol=1e-5)
+    assert np.allclose(got_dx, -2 * np.sin(v) + np.cos(v), rtol=1e-5, atol=1e-6)

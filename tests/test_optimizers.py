@@ -449,6 +449,10 @@ SCHEDULES = [
      lambda t: (0.05 - 0.01) * (1 - min(t, 5) / 5) ** 2 + 0.01),
     ("piecewise", lambda gs: tf.train.piecewise_constant(gs, [1, 4], [0.05, 0.02, 0.005]),
      lambda t: 0.05 if t <= 1 else (0.02 if t <= 4 else 0.005)),
+    ("natural_exp", lambda gs: tf.train.natural_exp_decay(0.05, gs, 2, 0.5),
+     lambda t: 0.05 * np.exp(-0.5 * t / 2)),
+    ("cosine", lambda gs: tf.train.cosine_decay(0.05, gs, 5, alpha=0.1),
+     lambda t: 0.05 * (0.9 * 0.5 * (1 + np.cos(np.pi * min(t, 5) / 5)) + 0.1)),
 ]
 
 
@@ -482,7 +486,7 @@ def test_scheduled_adam_equals_adam_with_the_rate_of_each_step():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,schedule,formula", SCHEDULES[:2] + SCHEDULES[4:],
-                         ids=[s[0] for s in SCHEDULES[:2] + SCHEDULES[4:]])
+                         ids=[s[0] for s in SCHEDULES[:2] + SCHEDULES[4:]])  # (incl. exp, cos)
 def test_gpu_schedule_is_read_on_the_device_inside_captured_steps(name, schedule, formula):
     w0, b0, w, b, rates, types, stats = _scheduled_run(tf.train.GradientDescentOptimizer,
                                                        schedule, device="cuda:0", steps=12)

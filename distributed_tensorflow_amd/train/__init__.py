@@ -7,6 +7,7 @@ from .device_setter import (GreedyLoadBalancingStrategy, byte_size_load_fn,  # n
 from .learning_rate_decay import (cosine_decay, exponential_decay,  # noqa: F401
                                   inverse_time_decay, natural_exp_decay,
                                   piecewise_constant, polynomial_decay)
+from .moving_averages import ExponentialMovingAverage  # noqa: F401
 from .optimizer import (AdagradOptimizer, AdamOptimizer, GradientDescentOptimizer,  # noqa: F401
                         MomentumOptimizer, Optimizer, RMSPropOptimizer,
                         SyncReplicasOptimizer)

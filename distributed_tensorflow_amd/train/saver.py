@@ -221,6 +221,13 @@ def checkpoint_exists(prefix: str) -> bool:
 class Saver:
     def __init__(self, var_list: Optional[Sequence[Variable]] = None, max_to_keep: int = 5,
                  sharded: bool = False, name: Optional[str] = None):
+        # ``var_list`` may be a dict {name in the checkpoint: variable} (e.g.
+        # ``ExponentialMovingAverage.variables_to_restore()``): the variable is then written and
+        # looked up under that name instead of its own
+        self._names: Dict[Variable, str] = {}
+        if isinstance(var_list, dict):
+            self._names = {v: str(k) for k, v in var_list.items()}
+            var_list = [var_list[k] for k in sorted(var_list)]
         self._var_list = list(var_list) if var_list is not None else None
         self._max_to_keep = max_to_keep
         self._sharded = sharded
@@ -234,6 +241,9 @@ class Saver:
         if self._var_list is not None:
             return self._var_list
         return self._graph.get_collection(GraphKeys.GLOBAL_VARIABLES)
+
+    def _key(self, v: Variable) -> str:
+        return self._names.get(v, v.op.name)
 
     @property
     def last_checkpoints(self) -> List[str]:
@@ -260,7 +270,7 @@ class Saver:
             # a variable stored as per-rank blocks (sharded products) is all-gathered: saving
             # such a graph is a collective, every worker calls save()
             whole = getattr(getattr(sess, "_runtime", None), "read_variable_full", None)
-            values = {v.op.name: (whole(v.op.name) if whole is not None
+            values = {self._key(v): (whole(v.op.name) if whole is not None
                                   and store is getattr(sess._runtime, "local_store", None)
                                   else store.read(v.op.name)) for v in variables}
             if self._sharded:
@@ -291,9 +301,9 @@ class Saver:
         if not checkpoint_exists(save_path):
             raise ValueError("The passed save_path is not a valid checkpoint: %s" % save_path)
         variables = self._variables()
-        values = read_bundle(save_path, [v.op.name for v in variables])
+        values = read_bundle(save_path, [self._key(v) for v in variables])
         for v in variables:
-            t = values[v.op.name]
+            t = values[self._key(v)]
             if tuple(t.shape) != tuple(v.shape or ()):
                 raise ValueError("shape mismatch for %s: checkpoint %s, variable %s"
                                  % (v.op.name, tuple(t.shape), v.shape))

@@ -524,3 +524,159 @@ def test_gpu_chain_of_general_kernels_reads_the_batch_through_the_step_ring(monk
     assert gathered[2].get("ring_read_captures", 0) == 0
     assert ring[0] == gathered[0] and np.array_equal(ring[1], gathered[1])
     assert ring[0][-1] < 0.5 * ring[0][0]
+
+
+def _ema_run(device=None, num_updates=False, steps=6, optimizer=None):
+    """SGD on the two-variable regression problem with a moving average of both variables taken
+    after every update; returns the per-step (w, b, avg_w, avg_b) and the session's stats."""
+    bx, by = _problem()
+    with tf.Graph().as_default():
+        tf.set_random_seed(3)
+        gs = tf.train.get_or_create_global_step()
+        x = tf.placeholder(tf.float32, list(bx.shape))
+        y_ = tf.placeholder(tf.float32, list(by.shape))
+        w = tf.Variable(tf.random_normal([bx.shape[1], by.shape[1]]), name="w")
+        b = tf.Variable(tf.zeros([by.shape[1]]), name="b")
+        loss = tf.reduce_mean(tf.reduce_sum(tf.square(tf.matmul(x, w) + b - y_), axis=[1]))
+        opt = optimizer() if optimizer else tf.train.GradientDescentOptimizer(0.05)
+        train_op = opt.minimize(loss, global_step=gs)
+        ema = tf.train.ExponentialMovingAverage(0.8, num_updates=gs if num_updates else None)
+        with tf.control_dependencies([train_op]):
+            ema_op = ema.apply([w, b])
+        names = (ema.average_name(w), ema.average(w).op.name, sorted(ema.variables_to_restore()))
+        cfg = tf.ConfigProto(device=device) if device else None
+        rows = []
+        with tf.Session(config=cfg) as sess:
+            sess.run(tf.global_variables_initializer())
+            rows.append(sess.run([w, b, ema.average(w), ema.average(b)]))
+            for _ in range(steps):
+                sess.run(ema_op, {x: bx, y_: by})
+                rows.append(sess.run([w, b, ema.average(w), ema.average(b)]))
+            stats = dict(sess.stats)
+    return rows, names, stats
+
+
+def _check_ema(rows, num_updates):
+    assert np.array_equal(rows[0][0], rows[0][2]) and np.array_equal(rows[0][1], rows[0][3])
+    assert not np.array_equal(rows[1][0], rows[0][0])            # the variables do move
+    avg = [rows[0][2].astype(np.float64), rows[0][3].astype(np.float64)]
+    for t in range(1, len(rows)):
+        # the counter has been advanced by the step whose update the average follows
+        decay = min(0.8, (1 + t) / (10 + t)) if num_updates else 0.8
+        for i in range(2):
+            avg[i] = avg[i] - (1 - decay) * (avg[i] - rows[t][i].astype(np.float64))
+            assert np.allclose(rows[t][2 + i], avg[i], rtol=2e-5, atol=2e-6), (t, i)
+
+
+@pytest.mark.parametrize("num_updates", [False, True], ids=["fixed_decay", "num_updates"])
+def test_exponential_moving_average_follows_the_updated_variables(num_updates):
+    rows, names, _ = _ema_run(num_updates=num_updates)
+    _check_ema(rows, num_updates)
+    assert names[0] == names[1] == "w/ExponentialMovingAverage"
+    assert names[2] == ["b/ExponentialMovingAverage", "global_step", "w/ExponentialMovingAverage"]
+
+
+def test_moving_averages_checkpoint_and_load_into_the_variables(tmp_path):
+    with tf.Graph().as_default():
+        v = tf.Variable(tf.fill([4], 2.0), name="v")
+        ema = tf.train.ExponentialMovingAverage(0.5)
+        step = tf.group(v.assign_add(tf.fill([4], 1.0)).op)
+        with tf.control_dependencies([step]):
+            ema_op = ema.apply([v])
+        with pytest.raises(ValueError):
+            ema.apply([v])
+        saver = tf.train.Saver()
+        with tf.Session() as sess:
+            sess.run(tf.global_variables_initializer())
+            sess.run(ema_op)
+            sess.run(ema_op)
+            assert np.allclose(sess.run(v), 4.0)
+            assert np.allclose(sess.run(ema.average(v)), 3.25)     # 2 -> 2.5 -> 3.25
+            path = saver.save(sess, str(tmp_path / "model"))
+        evaluating = tf.train.Saver(ema.variables_to_restore())
+        with tf.Session() as sess:
+            evaluating.restore(sess, path)
+            assert np.allclose(sess.run(v), 3.25)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("num_updates", [False, True], ids=["fixed_decay", "num_updates"])
+def test_gpu_moving_average_inside_captured_steps(num_updates):
+    rows, _, stats = _ema_run(device="cuda:0", num_updates=num_updates, steps=10)
+    _check_ema(rows, num_updates)
+    assert stats["torch_fallbacks"] == 0 and stats["graph_replays"] >= 5
+
+
+@pytest.mark.gpu
+def test_gpu_moving_average_next_to_adam():
+    rows, _, stats = _ema_run(device="cuda:0", steps=8,
+                              optimizer=lambda: tf.train.AdamOptimizer(0.01))
+    _check_ema(rows, False)
+    assert stats["torch_fallbacks"] == 0
+
+
+def _ema_mlp_job(cluster, task, steps, results, protocol="grpc", comm=None, strategy=None):
+    with tf.Graph().as_default():
+        config = tf.ConfigProto(device="cpu", strategy=strategy)
+        server = tf.train.Server(cluster, job_name="worker", task_index=task, protocol=protocol,
+                                 config=config, comm=comm)
+        with tf.device(tf.train.replica_device_setter(
+                worker_device="/job:worker/task:%d" % task, cluster=cluster)):
+            m = mnist_mlp.build_model(seed=1, with_summaries=False, learning_rate=0.01)
+            ema = tf.train.ExponentialMovingAverage(0.9)
+            with tf.control_dependencies([m.train_op]):
+                step_op = ema.apply([m.w1, m.b2])
+            init_op = tf.global_variables_initializer()       # (covers the shadows too)
+        sv = tf.train.Supervisor(is_chief=(task == 0), global_step=m.global_step,
+                                 init_op=init_op, logdir=None, recovery_wait_secs=0.05,
+                                 summary_op=None)
+        from distributed_tensorflow_amd.data.mnist import synthetic_mnist
+        images, labels = synthetic_mnist(400, seed=task)
+        onehot = np.eye(10, dtype=np.float32)[labels]
+        rng = np.random.RandomState(7 + task)
+        with sv.prepare_or_wait_for_session(server.target, config=config) as sess:
+            for _ in range(steps):
+                idx = rng.randint(0, 400, 50)
+                sess.run(step_op, {m.x: images[idx], m.y_: onehot[idx]})
+            results[task] = dict(w1=sess.run(m.w1), avg=sess.run(ema.average(m.w1)),
+                                 avg_b2=sess.run(ema.average(m.b2)), b2=sess.run(m.b2),
+                                 step=float(sess.run(m.global_step)),
+                                 shadow_device=ema.average(m.w1).device, runtime=server.runtime)
+        sv.stop()
+        server.stop()
+
+
+def test_moving_average_under_allreduce_keeps_replicas_identical():
+    world, steps = 2, 8
+    cluster = _cluster(world)
+    comms = LoopbackComm.create_world(world, timeout_s=30)
+    results = {}
+    threads = [threading.Thread(target=_ema_mlp_job, args=(cluster, t, steps, results),
+                                kwargs=dict(protocol="rccl", comm=comms[t],
+                                            strategy="allreduce_sync")) for t in range(world)]
+    [t.start() for t in threads]
+    [t.join(120) for t in threads]
+    assert set(results) == {0, 1}
+    for key in ("w1", "avg", "avg_b2", "b2"):
+        assert np.array_equal(results[0][key], results[1][key]), key          # bitwise
+    assert results[0]["step"] == steps
+    # the average trails the variable: it has moved off its start (zero for b2) but not caught up
+    assert np.abs(results[0]["avg_b2"]).max() > 0
+    assert np.abs(results[0]["avg_b2"]).max() < np.abs(results[0]["b2"]).max()
+    # only the trainable variables' span of the arena is reduced; the shadows lie behind it
+    assert 0 < results[0]["runtime"].bytes_reduced / steps <= (mnist_mlp.NUM_PARAMS + 4 * 64) * 4
+
+
+def test_moving_average_on_a_parameter_server_lives_with_its_variable():
+    cluster = _cluster(1)
+    ps = tf.train.Server(cluster, job_name="ps", task_index=0)
+    results = {}
+    _ema_mlp_job(cluster, 0, 6, results)
+    store = ps.runtime.local_store
+    assert results[0]["shadow_device"] == "/job:ps/task:0"
+    assert "weights/Variable/ExponentialMovingAverage" in store.names()
+    assert np.array_equal(store.read("biases/Variable_1/ExponentialMovingAverage").numpy(),
+                          results[0]["avg_b2"])
+    assert np.abs(results[0]["avg_b2"]).max() > 0
+    assert not np.array_equal(results[0]["avg"], results[0]["w1"])
+    ps.stop()

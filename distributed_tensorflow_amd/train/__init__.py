@@ -11,8 +11,9 @@ from .moving_averages import ExponentialMovingAverage  # noqa: F401
 from .optimizer import (AdagradOptimizer, AdamOptimizer, GradientDescentOptimizer,  # noqa: F401
                         MomentumOptimizer, Optimizer, RMSPropOptimizer,
                         SyncReplicasOptimizer)
-from .saver import (Saver, checkpoint_exists, get_checkpoint_state,  # noqa: F401
-                    latest_checkpoint)
+from .saver import (CheckpointReader, NewCheckpointReader, Saver,  # noqa: F401
+                    checkpoint_exists, get_checkpoint_state, latest_checkpoint,
+                    list_variables, load_variable)
 from .server import Server, ServerDef  # noqa: F401
 from .supervisor import Coordinator, SessionManager, Supervisor  # noqa: F401
 from .training_util import (create_global_step, get_global_step,  # noqa: F401

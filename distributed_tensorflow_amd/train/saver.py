@@ -160,6 +160,59 @@ def read_bundle(prefix: str, names: Optional[Sequence[str]] = None) -> Dict[str,
     return out
 
 
+class CheckpointReader:
+    """``tf.train.NewCheckpointReader``: look into a checkpoint without a graph or a session.
+    ``prefix`` is a checkpoint prefix or a directory (then its latest checkpoint)."""
+
+    def __init__(self, prefix: str):
+        if os.path.isdir(prefix):
+            latest = latest_checkpoint(prefix)
+            if latest is None:
+                raise ValueError("no checkpoint found in directory %s" % prefix)
+            prefix = latest
+        if not checkpoint_exists(prefix):
+            raise ValueError("not a checkpoint: %s" % prefix)
+        self._prefix = prefix
+        self._num_shards, self._index = read_bundle_index(prefix)
+
+    def has_tensor(self, name: str) -> bool:
+        return name in self._index
+
+    def get_variable_to_shape_map(self) -> Dict[str, List[int]]:
+        return {k: list(e["shape"]) for k, e in self._index.items()}
+
+    def get_variable_to_dtype_map(self) -> Dict[str, dtypes.DType]:
+        return {k: dtypes.from_enum(e["dtype"]) for k, e in self._index.items()}
+
+    def get_tensor(self, name: str) -> np.ndarray:
+        """The stored value as a numpy array (bfloat16 and fp8 tensors come back as float32:
+        numpy has neither type)."""
+        t = read_bundle(self._prefix, [name])[name]
+        if t.dtype in (torch.bfloat16, torch.float8_e4m3fn):
+            t = t.float()
+        return t.numpy()
+
+    def debug_string(self) -> str:
+        dt = self.get_variable_to_dtype_map()
+        return "".join("%s (%s) %s\n" % (k, dt[k].name, list(e["shape"]))
+                       for k, e in sorted(self._index.items()))
+
+
+def NewCheckpointReader(prefix: str) -> CheckpointReader:  # noqa: N802 -- TensorFlow's name
+    return CheckpointReader(prefix)
+
+
+def list_variables(ckpt_dir_or_file: str) -> List[Tuple[str, List[int]]]:
+    """``[(name, shape)]`` of a checkpoint, sorted by name."""
+    return sorted(CheckpointReader(ckpt_dir_or_file).get_variable_to_shape_map().items())
+
+
+def load_variable(ckpt_dir_or_file: str, name: str) -> np.ndarray:
+    if name.endswith(":0"):
+        name = name[:-2]
+    return CheckpointReader(ckpt_dir_or_file).get_tensor(name)
+
+
 # ---------------------------------------------------------------------------------------
 # "checkpoint" state file
 # ---------------------------------------------------------------------------------------

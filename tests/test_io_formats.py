@@ -199,6 +199,18 @@ def test_saver_save_restore_and_checkpoint_state(tmp_path):
         with pytest.raises(ValueError):
             saver.restore(sess, os.path.join(ckpt_dir, "missing"))
     assert tf.train.latest_checkpoint(str(tmp_path / "empty")) is None
+    # looking into the files without a graph: by prefix and by directory (= latest checkpoint)
+    assert tf.train.list_variables(paths[1]) == [("b", [3]), ("global_step", []), ("w", [5, 3])]
+    assert np.array_equal(tf.train.load_variable(paths[1], "w:0"), values[1])
+    reader = tf.train.NewCheckpointReader(ckpt_dir)
+    assert reader.has_tensor("w") and not reader.has_tensor("nope")
+    assert np.array_equal(reader.get_tensor("w"), values[2])
+    assert reader.get_variable_to_dtype_map()["w"] == tf.float32
+    assert "w (float32) [5, 3]" in reader.debug_string()
+    with pytest.raises(KeyError):
+        reader.get_tensor("nope")
+    with pytest.raises(ValueError):
+        tf.train.NewCheckpointReader(str(tmp_path / "empty"))
 
 
 def test_sharded_bundle_two_data_files(tmp_path):

@@ -503,7 +503,7 @@ def build_rewrite(graph: Graph, ops: Sequence[Operation], fed: Set[Tensor],
             lr_t = op.inputs[op.attrs["num_refs"]] if op.attrs.get("lr_input") else None
             groups.setdefault((op.attrs["rule"], op.attrs["hyper"], lr_t), []).append(op)
     for (rule, hyper, lr_t), members in groups.items():
-        n_slots = {"rmsprop": 2, "adam": 2, "sgd": 0}.get(rule, 1)
+        n_slots = {"rmsprop": 2, "adam": 2, "adadelta": 2, "sgd": 0}.get(rule, 1)
         refs = [[t.op for t in a.inputs[:a.attrs["num_refs"]]] for a in members]
         power_ops = refs[0][1 + n_slots:]
         if any(r[1 + n_slots:] != power_ops for r in refs):

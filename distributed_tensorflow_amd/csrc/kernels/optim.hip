@@ -22,7 +22,7 @@ namespace {
 constexpr int BLOCK = 256;
 constexpr int MAX_OPT_TENSORS = 16;
 
-enum Rule { MOMENTUM = 0, NESTEROV = 1, ADAGRAD = 2, RMSPROP = 3, ADAM = 4, SGD = 5 };
+enum Rule { MOMENTUM = 0, NESTEROV = 1, ADAGRAD = 2, RMSPROP = 3, ADAM = 4, SGD = 5, ADADELTA = 6 };
 
 struct OptTensor {
   float* w;
@@ -41,7 +41,8 @@ struct OptArgs {
 };
 
 // One element. h: momentum {lr, mu}; adagrad {lr}; rmsprop {lr, rho, mu, eps, 1 - rho};
-// adam {lr_t (bias-corrected), b1, b2, eps, 1 - b1, 1 - b2}. The complements arrive from the host,
+// adam {lr_t (bias-corrected), b1, b2, eps, 1 - b1, 1 - b2}; adadelta {lr, rho, eps, 1 - rho}. The
+// complements arrive from the host,
 // rounded once from double (1.f - 0.999f is off by 5e-5 of its value).
 template <int RULE>
 __device__ __forceinline__ void update(float& w, float g, float& s0, float& s1, const float* h) {
@@ -58,6 +59,11 @@ __device__ __forceinline__ void update(float& w, float g, float& s0, float& s1, 
     s0 = __builtin_fmaf(h[4], __builtin_fmaf(g, g, -s0), s0);
     s1 = __builtin_fmaf(h[2], s1, h[0] * g / __builtin_sqrtf(s0 + h[3]));
     w -= s1;
+  } else if (RULE == ADADELTA) {
+    s0 = __builtin_fmaf(h[3], __builtin_fmaf(g, g, -s0), s0);
+    const float u = __builtin_sqrtf(s1 + h[2]) / __builtin_sqrtf(s0 + h[2]) * g;
+    s1 = __builtin_fmaf(h[3], __builtin_fmaf(u, u, -s1), s1);
+    w = __builtin_fmaf(-h[0], u, w);
   } else {
     s0 = __builtin_fmaf(h[4], g - s0, s0);
     s1 = __builtin_fmaf(h[5], __builtin_fmaf(g, g, -s1), s1);
@@ -69,7 +75,7 @@ __device__ __forceinline__ void update(float& w, float g, float& s0, float& s1, 
 template <int RULE>
 __global__ __launch_bounds__(BLOCK) void multi_optim_kernel(OptArgs args) {
   const OptTensor t = args.t[blockIdx.y];
-  constexpr bool TWO = RULE == RMSPROP || RULE == ADAM;
+  constexpr bool TWO = RULE == RMSPROP || RULE == ADAM || RULE == ADADELTA;
   constexpr bool NONE = RULE == SGD;
   float h[6] = {args.h[0], args.h[1], args.h[2], args.h[3], args.h[4], args.h[5]};
   if (args.lr) h[0] = args.lr[0];
@@ -138,9 +144,9 @@ int grid_x(long n) {
 }  // namespace
 
 // In-place update of `count` (<= 16) fp32 tensors by `rule` (0 momentum, 1 Nesterov momentum,
-// 2 Adagrad, 3 RMSProp, 4 Adam, 5 plain gradient descent: no state). lr: optional device scalar
-// that replaces hyper[0] when the kernel runs. s0 / s1: the rule's per-element state (s1 only for RMSProp and
-// Adam); hyper: the rule's constants in the order documented at update() (complements
+// 2 Adagrad, 3 RMSProp, 4 Adam, 5 plain gradient descent: no state, 6 Adadelta). lr: optional device scalar
+// that replaces hyper[0] when the kernel runs. s0 / s1: the rule's per-element state (s1 only for RMSProp,
+// Adam and Adadelta); hyper: the rule's constants in the order documented at update() (complements
 // included); pw0 / pw1: device
 // scalars holding b1^t and b2^t (Adam only; not modified here).
 DTF_API int dtf_multi_optim_f32(int rule, int count, float* const* w, const float* const* g,
@@ -148,12 +154,12 @@ DTF_API int dtf_multi_optim_f32(int rule, int count, float* const* w, const floa
                                 const float* hyper, int num_hyper, const float* pw0,
                                 const float* pw1, const float* lr, hipStream_t stream) {
   const bool none = rule == SGD;
-  if (rule < 0 || rule > SGD || count < 0 || count > MAX_OPT_TENSORS || num_hyper < 0 ||
+  if (rule < 0 || rule > ADADELTA || count < 0 || count > MAX_OPT_TENSORS || num_hyper < 0 ||
       num_hyper > 6 || (count > 0 && (!w || !g || (!none && !s0) || !n)) ||
       (num_hyper > 0 && !hyper))
     return DTF_ERR_BAD_ARG;
   if (count == 0) return DTF_OK;
-  const bool two = rule == RMSPROP || rule == ADAM;
+  const bool two = rule == RMSPROP || rule == ADAM || rule == ADADELTA;
   if (two && !s1) return DTF_ERR_BAD_ARG;
   if (rule == ADAM && (!pw0 || !pw1)) return DTF_ERR_BAD_ARG;
   OptArgs args = {};
@@ -176,6 +182,7 @@ DTF_API int dtf_multi_optim_f32(int rule, int count, float* const* w, const floa
     case ADAGRAD: hipLaunchKernelGGL(multi_optim_kernel<ADAGRAD>, grid, block, 0, stream, args); break;
     case RMSPROP: hipLaunchKernelGGL(multi_optim_kernel<RMSPROP>, grid, block, 0, stream, args); break;
     case SGD: hipLaunchKernelGGL(multi_optim_kernel<SGD>, grid, block, 0, stream, args); break;
+    case ADADELTA: hipLaunchKernelGGL(multi_optim_kernel<ADADELTA>, grid, block, 0, stream, args); break;
     default: hipLaunchKernelGGL(multi_optim_kernel<ADAM>, grid, block, 0, stream, args); break;
   }
   DTF_LAUNCH_CHECK();

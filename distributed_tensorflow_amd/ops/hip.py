@@ -1160,7 +1160,8 @@ def multi_sgd(params: Sequence[torch.Tensor], grads: Sequence[torch.Tensor],
         first = False
 
 
-OPTIM_RULES = {"momentum": 0, "nesterov": 1, "adagrad": 2, "rmsprop": 3, "adam": 4, "sgd": 5}
+OPTIM_RULES = {"momentum": 0, "nesterov": 1, "adagrad": 2, "rmsprop": 3, "adam": 4, "sgd": 5,
+               "adadelta": 6}
 
 
 def multi_optim(rule: str, params: Sequence[torch.Tensor], grads: Sequence[torch.Tensor],
@@ -1171,12 +1172,12 @@ def multi_optim(rule: str, params: Sequence[torch.Tensor], grads: Sequence[torch
     ``grads[i]`` by one of the slot-carrying rules -- one launch per 16 tensors. ``hyper``:
     momentum / nesterov (lr, mu); adagrad (lr,); rmsprop (lr, rho, mu, eps); adam (lr, b1, b2,
     eps) with ``powers`` = the device scalars holding b1^t and b2^t (read, not advanced: see
-    ``affine_scalars``); sgd (lr,) takes no slots. ``lr``: a device scalar that replaces the
+    ``affine_scalars``); adadelta (lr, rho, eps); sgd (lr,) takes no slots. ``lr``: a device scalar that replaces the
     constant learning rate (a schedule computed in the step's graph), read when the kernel runs."""
     code = OPTIM_RULES.get(rule)
     if code is None:
         raise HipKernelError("multi_optim: unknown rule %r" % (rule,))
-    two = rule in ("rmsprop", "adam")
+    two = rule in ("rmsprop", "adam", "adadelta")
     none = rule == "sgd"
     if len(params) != len(grads) or (not none and len(params) != len(slots0)) or \
             (two and len(slots1) != len(params)):
@@ -1186,7 +1187,8 @@ def multi_optim(rule: str, params: Sequence[torch.Tensor], grads: Sequence[torch
         raise HipKernelError("multi_optim: lr must be an fp32 GPU scalar")
     if rule == "adam" and len(powers) != 2:
         raise HipKernelError("multi_optim: adam needs the two power scalars")
-    want = {"momentum": 2, "nesterov": 2, "adagrad": 1, "rmsprop": 4, "adam": 4, "sgd": 1}[rule]
+    want = {"momentum": 2, "nesterov": 2, "adagrad": 1, "rmsprop": 4, "adam": 4, "sgd": 1,
+            "adadelta": 3}[rule]
     if len(hyper) != want:
         raise HipKernelError("multi_optim: %s takes %d constants" % (rule, want))
     grads = [g if g.is_contiguous() else g.contiguous() for g in grads]
@@ -1206,6 +1208,8 @@ def multi_optim(rule: str, params: Sequence[torch.Tensor], grads: Sequence[torch
         hyper.append(1.0 - hyper[1])              # complements rounded once, from double
     elif rule == "adam":
         hyper += [1.0 - hyper[1], 1.0 - hyper[2]]
+    elif rule == "adadelta":
+        hyper.append(1.0 - hyper[1])
     h_arr = (c.c_float * max(len(hyper), 1))(*hyper)
     pw = [t.data_ptr() for t in powers] + [None, None]
     for start in range(0, len(params), 16):

@@ -131,7 +131,7 @@ def _apply_sgd(op, inputs, ctx):
 def optimizer_rule_step(rule: str, hyper, w, g, s0, s1=None, powers=None):
     """One step of a slot-carrying update rule on plain tensors, in fp32 (or the variable's
     dtype): returns ``(new w, new s0, new s1)``. The formulas are TensorFlow's
-    (``ApplyMomentum``, ``ApplyAdagrad``, ``ApplyRMSProp``, ``ApplyAdam``); the gfx950 kernel
+    (``ApplyMomentum``, ``ApplyAdagrad``, ``ApplyRMSProp``, ``ApplyAdadelta``, ``ApplyAdam``); the gfx950 kernel
     (``csrc/kernels/optim.hip``) computes the same expressions with fused multiply-adds."""
     g = g.to(w.device, w.dtype)
     if rule == "sgd":
@@ -150,6 +150,12 @@ def optimizer_rule_step(rule: str, hyper, w, g, s0, s1=None, powers=None):
         s0 = s0 + (1.0 - rho) * (g * g - s0)
         s1 = mu * s1 + lr * g / torch.sqrt(s0 + eps)
         w = w - s1
+    elif rule == "adadelta":
+        lr, rho, eps = hyper
+        s0 = s0 + (1.0 - rho) * (g * g - s0)
+        update = torch.sqrt(s1 + eps) / torch.sqrt(s0 + eps) * g
+        s1 = s1 + (1.0 - rho) * (update * update - s1)
+        w = w - lr * update
     elif rule == "adam":
         lr, b1, b2, eps = hyper
         p1, p2 = (float(p) for p in powers)
@@ -187,7 +193,7 @@ def apply_rule_through_stores(ctx, rule, hyper, var_op, slot_ops, power_ops, gra
 def _optimizer_refs(op):
     """(variable op, slot ops, power ops) of an ``ApplyOptimizer`` op."""
     refs = [t.op for t in op.inputs[:op.attrs["num_refs"]]]
-    n_slots = {"rmsprop": 2, "adam": 2, "sgd": 0}.get(op.attrs["rule"], 1)
+    n_slots = {"rmsprop": 2, "adam": 2, "adadelta": 2, "sgd": 0}.get(op.attrs["rule"], 1)
     return refs[0], refs[1:1 + n_slots], refs[1 + n_slots:]
 
 

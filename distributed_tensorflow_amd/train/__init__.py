@@ -8,9 +8,9 @@ from .learning_rate_decay import (cosine_decay, exponential_decay,  # noqa: F401
                                   inverse_time_decay, natural_exp_decay,
                                   piecewise_constant, polynomial_decay)
 from .moving_averages import ExponentialMovingAverage  # noqa: F401
-from .optimizer import (AdagradOptimizer, AdamOptimizer, GradientDescentOptimizer,  # noqa: F401
-                        MomentumOptimizer, Optimizer, RMSPropOptimizer,
-                        SyncReplicasOptimizer)
+from .optimizer import (AdadeltaOptimizer, AdagradOptimizer, AdamOptimizer,  # noqa: F401
+                        GradientDescentOptimizer, MomentumOptimizer, Optimizer,
+                        RMSPropOptimizer, SyncReplicasOptimizer)
 from .saver import (CheckpointReader, NewCheckpointReader, Saver,  # noqa: F401
                     checkpoint_exists, get_checkpoint_state, latest_checkpoint,
                     list_variables, load_variable)

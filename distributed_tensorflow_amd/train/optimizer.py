@@ -219,6 +219,29 @@ class RMSPropOptimizer(Optimizer):
             [self.get_slot(var, "rms"), self.get_slot(var, "momentum")], grad, self._lr_tensor)
 
 
+class AdadeltaOptimizer(Optimizer):
+    """``accum = rho * accum + (1 - rho) * grad**2; update = sqrt(accum_update + epsilon) /
+    sqrt(accum + epsilon) * grad; accum_update = rho * accum_update + (1 - rho) * update**2;
+    var -= lr * update``."""
+
+    def __init__(self, learning_rate: float = 0.001, rho: float = 0.95, epsilon: float = 1e-8,
+                 use_locking: bool = False, name: str = "Adadelta"):
+        super().__init__(use_locking, name)
+        self._learning_rate, self._lr_tensor = self._split_lr(learning_rate)
+        self._rho, self._epsilon = float(rho), float(epsilon)
+
+    def _create_slots(self, var_list):
+        for v in var_list:
+            self._zeros_slot(v, "accum", self._name)
+            self._zeros_slot(v, "accum_update", self._name + "_1")
+
+    def _apply_dense(self, grad, var):
+        return self._apply_rule(
+            "adadelta", (self._learning_rate, self._rho, self._epsilon), var,
+            [self.get_slot(var, "accum"), self.get_slot(var, "accum_update")], grad,
+            self._lr_tensor)
+
+
 class AdamOptimizer(Optimizer):
     """``m += (1 - beta1) * (grad - m); v += (1 - beta2) * (grad**2 - v);
     var -= lr * sqrt(1 - beta2**t) / (1 - beta1**t) * m / (sqrt(v) + epsilon)``. ``beta1**t``

@@ -60,6 +60,8 @@ def make_optimizer(name: str, lr: float):
         return tf.train.MomentumOptimizer(lr, 0.9, use_nesterov=(name == "nesterov"))
     if name == "adagrad":
         return tf.train.AdagradOptimizer(lr * 20)
+    if name == "adadelta":
+        return tf.train.AdadeltaOptimizer(1.0)
     if name == "rmsprop":
         return tf.train.RMSPropOptimizer(lr)
     if name == "adam":

@@ -65,6 +65,12 @@ def _numpy_rule(rule, hyper, w, b, steps=STEPS):
             elif rule == "adagrad":
                 s0[i] += g * g
                 params[i] -= hyper[0] * g / np.sqrt(s0[i])
+            elif rule == "adadelta":
+                lr, rho, eps = hyper
+                s0[i] = rho * s0[i] + (1 - rho) * g * g
+                update = np.sqrt(s1[i] + eps) / np.sqrt(s0[i] + eps) * g
+                s1[i] = rho * s1[i] + (1 - rho) * update * update
+                params[i] -= lr * update
             elif rule == "rmsprop":
                 lr, rho, mu, eps = hyper
                 s0[i] = rho * s0[i] + (1 - rho) * g * g
@@ -84,6 +90,7 @@ CASES = [
     ("adagrad", (0.1,), lambda: tf.train.AdagradOptimizer(0.1)),
     ("rmsprop", (0.01, 0.9, 0.5, 1e-10), lambda: tf.train.RMSPropOptimizer(0.01, momentum=0.5)),
     ("adam", (0.01, 0.9, 0.999, 1e-8), lambda: tf.train.AdamOptimizer(0.01)),
+    ("adadelta", (1.0, 0.9, 1e-6), lambda: tf.train.AdadeltaOptimizer(1.0, rho=0.9, epsilon=1e-6)),
 ]
 
 
@@ -281,7 +288,7 @@ def test_multi_optim_kernel_against_fp64(rule, hyper):
     from distributed_tensorflow_amd.ops.ref_kernels import optimizer_rule_step
     g = torch.Generator().manual_seed(3)
     sizes = [78400, 100, 1000, 10, 1, 4099]           # the reference MLP's tensors + odd sizes
-    two = rule in ("rmsprop", "adam")
+    two = rule in ("rmsprop", "adam", "adadelta")
     backing = [torch.randn(n + 3, generator=g).cuda() for n in sizes]
     params = [t[(i % 2):(i % 2) + n] for i, (t, n) in enumerate(zip(backing, sizes))]   # odd starts
     grads = [torch.randn(n, generator=g).cuda() for n in sizes]

@@ -83,7 +83,7 @@ def define_flags(default_job=DEFAULT_JOB, default_epochs=DEFAULT_EPOCHS):
     tf.app.flags.DEFINE_boolean("shutdown_ps", False, "report completion so the ps exits once all workers are done")
     tf.app.flags.DEFINE_string("device", "", "torch device of this task (default: auto)")
     tf.app.flags.DEFINE_string("optimizer", "sgd", "sgd (the reference's plain gradient descent) | "
-                               "momentum | nesterov | adagrad | rmsprop | adam")
+                               "momentum | nesterov | adagrad | adadelta | rmsprop | adam")
     tf.app.flags.DEFINE_boolean("capture_collectives", False, "rccl: record the step's RCCL calls "
                                 "into the HIP graph together with its kernels")
     tf.app.flags.DEFINE_boolean("device_data", True, "keep the data set resident in GPU memory "

@@ -542,6 +542,37 @@ def bias_add(value, bias, name=None) -> Tensor:
     return add(value, bias, name=name or "BiasAdd")
 
 
+def xw_plus_b(x, weights, biases, name=None) -> Tensor:
+    """``matmul(x, weights) + biases`` (one GEMM with the bias in its epilogue once the fusion
+    pass has seen it)."""
+    with get_default_graph().name_scope(name or "xw_plus_b"):
+        return bias_add(matmul(x, weights), biases)
+
+
+def relu6(x, name=None) -> Tensor:
+    with get_default_graph().name_scope(name or "Relu6"):
+        return minimum(relu(x), 6.0)
+
+
+def softplus(x, name=None) -> Tensor:
+    """``log(1 + exp(x))`` in the form that cannot overflow: ``relu(x) + log(1 + exp(-|x|))``."""
+    with get_default_graph().name_scope(name or "Softplus"):
+        x = convert_to_tensor(x)
+        return add(relu(x), log(add(1.0, exp(negative(abs(x))))))
+
+
+def sigmoid_cross_entropy_with_logits(labels=None, logits=None, name=None,
+                                      _sentinel=None) -> Tensor:
+    """Element-wise ``-z * log(sigmoid(x)) - (1 - z) * log(1 - sigmoid(x))`` for logits ``x`` and
+    targets ``z``, computed as ``softplus(x) - x * z``."""
+    if _sentinel is not None or labels is None or logits is None:
+        raise ValueError("sigmoid_cross_entropy_with_logits takes labels= and logits= by name")
+    with get_default_graph().name_scope(name or "logistic_loss"):
+        logits = convert_to_tensor(logits)
+        labels = convert_to_tensor(labels, dtype=logits.dtype)
+        return subtract(softplus(logits), multiply(logits, labels))
+
+
 def dropout(x, keep_prob, noise_shape=None, seed=None, name=None) -> Tensor:
     """``x * mask / keep_prob`` with an independent Bernoulli(keep_prob) mask at every run (and
     at every replay of a captured step: the mask's position in its Philox stream is a counter

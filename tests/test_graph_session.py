@@ -510,3 +510,50 @@ def test_cos_and_sin_with_gradients():
             got_y, got_dx = sess.run([y, dx], {x: v})
     assert np.isclose(got_y, (2 * np.cos(v) + np.sin(v)).sum(), rtol=1e-5)
     assert np.allclose(got_dx, -2 * np.sin(v) + np.cos(v), rtol=1e-5, atol=1e-6)
+
+
+def _logistic_run(device=None):
+    g = torch.Generator().manual_seed(5)
+    logits = (torch.randn(16, 6, generator=g) * 8).numpy()        # large values: no overflow
+    targets = (torch.rand(16, 6, generator=g) > 0.5).float().numpy()
+    wv = torch.randn(6, 3, generator=g).numpy()
+    with tf.Graph().as_default():
+        x = tf.placeholder(tf.float32, [16, 6])
+        z = tf.placeholder(tf.float32, [16, 6])
+        w = tf.Variable(tf.constant(wv))
+        b = tf.Variable(tf.fill([3], 0.5))
+        loss = tf.losses.sigmoid_cross_entropy(z, x)
+        l1 = tf.losses.absolute_difference(z, tf.nn.relu6(x))
+        dense = tf.nn.xw_plus_b(x, w, b)
+        (dx,) = tf.gradients(loss, [x])
+        cfg = tf.ConfigProto(device=device) if device else None
+        with tf.Session(config=cfg) as sess:
+            sess.run(tf.global_variables_initializer())
+            for _ in range(3):                    # (a GPU session replays the captured step)
+                out = sess.run([loss, dx, l1, dense, tf.nn.softplus(x)], {x: logits, z: targets})
+            stats = dict(sess.stats)
+    return logits, targets, wv, out, stats
+
+
+def _check_logistic(logits, targets, wv, out):
+    lt, zt = torch.from_numpy(logits).double().requires_grad_(), torch.from_numpy(targets).double()
+    want = torch.nn.functional.binary_cross_entropy_with_logits(lt, zt)
+    want.backward()
+    assert np.isclose(out[0], want.item(), rtol=1e-5)
+    assert np.allclose(out[1], lt.grad.numpy(), rtol=1e-4, atol=1e-7)
+    assert np.isclose(out[2], np.abs(np.clip(logits, 0, 6) - targets).mean(), rtol=1e-5)
+    assert np.allclose(out[3], logits @ wv + 0.5, rtol=1e-4, atol=1e-4)
+    assert np.allclose(out[4], torch.nn.functional.softplus(lt.detach()).numpy(), rtol=1e-5, atol=1e-7)
+    assert np.isfinite(out[4]).all()
+
+
+def test_logistic_loss_softplus_relu6_and_xw_plus_b():
+    logits, targets, wv, out, _ = _logistic_run()
+    _check_logistic(logits, targets, wv, out)
+
+
+@pytest.mark.gpu
+def test_gpu_logistic_loss_runs_on_the_hip_kernels():
+    logits, targets, wv, out, stats = _logistic_run("cuda:0")
+    _check_logistic(logits, targets, wv, out)
+    assert stats["torch_fallbacks"] == 0

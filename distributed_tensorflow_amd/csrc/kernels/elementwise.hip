@@ -22,7 +22,7 @@ enum BinaryOp { B_ADD = 0, B_SUB, B_MUL, B_DIV, B_MAX, B_MIN, B_POW, B_SIGMOID_G
                 B_RELU_GRAD };
 enum CompareOp { C_EQ = 0, C_NE, C_LT, C_GT, C_LE, C_GE };
 enum UnaryOp { U_NEG = 0, U_LOG, U_EXP, U_SQRT, U_SQUARE, U_RECIP, U_ABS, U_SIGMOID, U_TANH,
-               U_RELU, U_FLOOR, U_COS, U_SIN };
+               U_RELU, U_FLOOR, U_COS, U_SIN, U_SOFTPLUS };
 
 template <int OP>
 __device__ __forceinline__ float bin(float a, float b) {
@@ -52,6 +52,7 @@ __device__ __forceinline__ float una(float x) {
   if (OP == U_FLOOR) return floorf(x);
   if (OP == U_COS) return cosf(x);
   if (OP == U_SIN) return sinf(x);
+  if (OP == U_SOFTPLUS) return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x)));   // no overflow
   return x > 0.f ? x : 0.f;
 }
 
@@ -312,7 +313,7 @@ DTF_API int dtf_unary_f32(int op, const float* x, float* out, long n, hipStream_
     DTF_UN_CASE(U_NEG) DTF_UN_CASE(U_LOG) DTF_UN_CASE(U_EXP) DTF_UN_CASE(U_SQRT)
     DTF_UN_CASE(U_SQUARE) DTF_UN_CASE(U_RECIP) DTF_UN_CASE(U_ABS) DTF_UN_CASE(U_SIGMOID)
     DTF_UN_CASE(U_TANH) DTF_UN_CASE(U_RELU) DTF_UN_CASE(U_FLOOR)
-    DTF_UN_CASE(U_COS) DTF_UN_CASE(U_SIN)
+    DTF_UN_CASE(U_COS) DTF_UN_CASE(U_SIN) DTF_UN_CASE(U_SOFTPLUS)
     default: return DTF_ERR_UNSUPPORTED;
   }
   DTF_LAUNCH_CHECK();

@@ -555,10 +555,9 @@ def relu6(x, name=None) -> Tensor:
 
 
 def softplus(x, name=None) -> Tensor:
-    """``log(1 + exp(x))`` in the form that cannot overflow: ``relu(x) + log(1 + exp(-|x|))``."""
-    with get_default_graph().name_scope(name or "Softplus"):
-        x = convert_to_tensor(x)
-        return add(relu(x), log(add(1.0, exp(negative(abs(x))))))
+    """``log(1 + exp(x))``, one kernel, evaluated as ``max(x, 0) + log1p(exp(-|x|))`` (no
+    overflow); its gradient is ``sigmoid(x)``."""
+    return _unary("Softplus", x, name)
 
 
 def sigmoid_cross_entropy_with_logits(labels=None, logits=None, name=None,
@@ -760,6 +759,11 @@ def _neg_grad(op, g):
 @gradient("Log")
 def _log_grad(op, g):
     return (divide(g, op.inputs[0]),)
+
+
+@gradient("Softplus")
+def _softplus_grad(op, g):
+    return (multiply(g, sigmoid(op.inputs[0])),)
 
 
 @gradient("Cos")

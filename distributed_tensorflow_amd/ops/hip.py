@@ -30,7 +30,8 @@ BINARY = {"add": 0, "sub": 1, "mul": 2, "div": 3, "max": 4, "min": 5, "pow": 6,
           "sigmoid_grad": 7, "tanh_grad": 8, "relu_grad": 9}
 COMPARE = {"eq": 0, "ne": 1, "lt": 2, "gt": 3, "le": 4, "ge": 5}
 UNARY = {"neg": 0, "log": 1, "exp": 2, "sqrt": 3, "square": 4, "recip": 5, "abs": 6,
-         "sigmoid": 7, "tanh": 8, "relu": 9, "floor": 10, "cos": 11, "sin": 12}
+         "sigmoid": 7, "tanh": 8, "relu": 9, "floor": 10, "cos": 11, "sin": 12,
+         "softplus": 13}
 ROW_SUM, ROW_MEAN, ROW_MAX = 0, 1, 2
 
 _lib: Optional[ctypes.CDLL] = None

@@ -160,7 +160,7 @@ def _register_unary(op_type: str, code: str) -> None:
 for _t, _c in (("Neg", "neg"), ("Log", "log"), ("Exp", "exp"), ("Sqrt", "sqrt"),
                ("Square", "square"), ("Reciprocal", "recip"), ("Abs", "abs"),
                ("Sigmoid", "sigmoid"), ("Tanh", "tanh"), ("Relu", "relu"), ("Floor", "floor"),
-               ("Cos", "cos"), ("Sin", "sin")):
+               ("Cos", "cos"), ("Sin", "sin"), ("Softplus", "softplus")):
     _register_unary(_t, _c)
 
 

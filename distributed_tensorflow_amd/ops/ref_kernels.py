@@ -302,6 +302,7 @@ ref_kernel("Sqrt")(_un(torch.sqrt))
 ref_kernel("Floor")(_un(torch.floor))
 ref_kernel("Cos")(_un(torch.cos))
 ref_kernel("Sin")(_un(torch.sin))
+ref_kernel("Softplus")(_un(torch.nn.functional.softplus))
 ref_kernel("Square")(_un(torch.square))
 ref_kernel("Reciprocal")(_un(torch.reciprocal))
 ref_kernel("Abs")(_un(torch.abs))

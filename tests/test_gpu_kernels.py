@@ -144,6 +144,8 @@ def test_elementwise_and_broadcast(hip):
                      ("abs", torch.abs), ("floor", torch.floor)]:
         assert torch.allclose(hip.unary(name, a), fn(a), atol=1e-6, rtol=1e-5), name
     wide = a * 20.0                 # several periods: the argument reduction is exercised too
+    assert torch.allclose(hip.unary("softplus", wide),
+                          torch.nn.functional.softplus(wide.double()).float(), atol=2e-6, rtol=1e-6)
     for name, fn in [("cos", torch.cos), ("sin", torch.sin)]:
         assert torch.allclose(hip.unary(name, wide), fn(wide.double()).float(), atol=2e-6), name
     pos = a.abs() + 0.1

@@ -38,6 +38,15 @@ def run(fused: bool, deferred: bool, steps: int = 3000, warmup: int = 100) -> di
 
 
 if __name__ == "__main__":
-    for deferred in (True, False):
-        for fused in (True, False):
-            print(json.dumps(run(fused, deferred)), flush=True)
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", choices=("fused", "composed"), default=None,
+                    help="one variant, results awaited every step (for a kernel trace)")
+    ap.add_argument("--steps", type=int, default=3000)
+    args = ap.parse_args()
+    if args.only:
+        print(json.dumps(run(args.only == "fused", False, steps=args.steps)), flush=True)
+    else:
+        for deferred in (True, False):
+            for fused in (True, False):
+                print(json.dumps(run(fused, deferred, steps=args.steps)), flush=True)

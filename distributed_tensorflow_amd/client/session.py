@@ -85,17 +85,34 @@ _MUTATING_OPS = frozenset(("Assign", "AssignAdd", "AssignSub", "ApplyGradientDes
 _PACK_WORDS = 256     # fp32 words of pinned staging per captured step for small fetches
 
 
+_GC_PAUSE_LOCK = threading.Lock()
+_GC_PAUSE_DEPTH = 0
+_GC_WAS_ENABLED = False
+
+
 @contextlib.contextmanager
 def _gc_paused():
-    """Cyclic garbage collection off inside the block (restored to what it was afterwards)."""
+    """Cyclic garbage collection off for the whole process while ANY thread is inside the block.
+
+    A collection that runs during stream capture can finalise a dropped graph, event or tensor,
+    and the allocator / runtime calls that makes are illegal in a capturing thread. The pause is
+    a counted guard: the first thread in disables collection and remembers whether it was on,
+    the last one out restores it -- so a Supervisor service thread or a second session leaving
+    its own capture cannot switch collection back on under a thread that is still capturing."""
     import gc
-    was = gc.isenabled()
-    gc.disable()
+    global _GC_PAUSE_DEPTH, _GC_WAS_ENABLED
+    with _GC_PAUSE_LOCK:
+        if _GC_PAUSE_DEPTH == 0:
+            _GC_WAS_ENABLED = gc.isenabled()
+            gc.disable()
+        _GC_PAUSE_DEPTH += 1
     try:
         yield
     finally:
-        if was:
-            gc.enable()
+        with _GC_PAUSE_LOCK:
+            _GC_PAUSE_DEPTH -= 1
+            if _GC_PAUSE_DEPTH == 0 and _GC_WAS_ENABLED:
+                gc.enable()
 
 
 class SessionClosedError(RuntimeError):
@@ -303,6 +320,16 @@ class ExecContext:
         fn = getattr(rt, "sharded_sgd_step", None)
         return bool(fn and fn([v.name for v in var_ops], grads, lrs))
 
+    def sharded_apply(self, rule, hyper, var_ops, grads, slot_ops=None, powers=(), lr=None):
+        """Owner-shard update of the runtime (``reduce_scatter_sync``): indices of the variables
+        it updated, ``None`` when the runtime has no such path."""
+        fn = getattr(self.session._runtime, "sharded_apply", None)
+        if fn is None:
+            return None
+        return fn(rule, hyper, [v.name for v in var_ops], list(grads),
+                  [[s.name for s in ops] for ops in slot_ops] if slot_ops is not None else None,
+                  powers, lr)
+
 
 # ---------------------------------------------------------------------------------------
 # plans
@@ -467,6 +494,8 @@ class _CapturedStep:
                                     # is a single library call: issued directly, not replayed
         self.calls = None           # [(library function, arguments without the stream)] of a
                                     # short step: re-issued in order instead of replayed
+        self.watch = None           # communicator's watch(event, what) when the graph holds
+        self.watch_events: List[Any] = []                 # captured collectives (one per slot)
 
 
 class _DeferredHost:
@@ -815,7 +844,8 @@ class Session:
             want = env not in ("0", "", "false", "False")
         if want is None:
             comm = getattr(self._runtime, "comm", None)
-            want = getattr(comm, "backend", "") == "nccl" and self.device.type == "cuda"
+            want = getattr(comm, "backend", "") in ("nccl", "rccl_native") \
+                and self.device.type == "cuda"
         return bool(want)
 
     def _shard_plan(self):
@@ -1279,6 +1309,14 @@ class Session:
             self.stats["direct_steps"] = self.stats.get("direct_steps", 0) + 1
         else:
             cap.graph.replay()
+            if cap.watch is not None:
+                # the graph holds captured collectives: their completion is bounded by the
+                # communicator's watchdog through an event behind the replay
+                ev = cap.watch_events[slot]
+                if ev is None:
+                    ev = cap.watch_events[slot] = torch.cuda.Event()
+                ev.record()
+                cap.watch(ev, "captured step %d" % n)
         ring.launched = n + 1
         self.stats["graph_replays"] += 1
         pend = _PendingStep(ring, n, slot, cap.host_words)
@@ -1392,6 +1430,9 @@ class Session:
         for static, f in zip(cap.static_feeds, feeds):
             static.copy_(f)
         ring = cap.ring = _StepRing(self.device)
+        comm_watch = getattr(getattr(self._runtime, "comm", None), "watch", None)
+        if comm_watch is not None and self._capture_collectives():
+            cap.watch, cap.watch_events = comm_watch, [None] * ring.SLOTS
         want = [sl for sl in plan.fetch_slots if sl is not None] + plan.host_input_slots
         # feeds that only ring-aware nodes read are not gathered at all: those nodes take the
         # batch straight from where it lies, through the ring's table

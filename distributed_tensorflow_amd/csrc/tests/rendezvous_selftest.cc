@@ -9,6 +9,10 @@
 //      bound instead of hanging
 //   4. a peer that leaves before a collective: the others get an error code, no hang, no crash
 //   5. argument errors
+//   6. strangers: two connections that say nothing (one stays open, one closes at once) and one
+//      that sends half an introduction arrive before the real peers; the job still forms well
+//      inside its deadline
+//   7. two processes claim the same rank: the second is told so (refused code) at create()
 #include <arpa/inet.h>
 #include <netinet/in.h>
 #include <stdint.h>
@@ -162,6 +166,60 @@ int main() {
     CHECK(dtf_rdzv_create(nullptr, 0, 0, 2, 1.0, &err) == nullptr && err != 0);
     CHECK(dtf_rdzv_barrier(nullptr) != 0);
     dtf_rdzv_destroy(nullptr);
+  }
+  // 6. silent strangers do not hold the rendezvous up
+  {
+    const int world = 3, port = free_port();
+    std::atomic<bool> stop{false};
+    std::thread strangers([&] {
+      sockaddr_in a{};
+      a.sin_family = AF_INET;
+      a.sin_addr.s_addr = htonl(INADDR_LOOPBACK);
+      a.sin_port = htons((uint16_t)port);
+      int fds[3] = {-1, -1, -1};
+      for (int i = 0; i < 3; ++i) {
+        for (int tries = 0; tries < 200 && fds[i] < 0; ++tries) {     // rank 0 may not listen yet
+          const int fd = socket(AF_INET, SOCK_STREAM, 0);
+          if (connect(fd, reinterpret_cast<sockaddr*>(&a), sizeof(a)) == 0) fds[i] = fd;
+          else { close(fd); std::this_thread::sleep_for(std::chrono::milliseconds(10)); }
+        }
+      }
+      if (fds[1] >= 0) { close(fds[1]); fds[1] = -1; }               // leaves at once
+      const char half[2] = {1, 0};
+      if (fds[2] >= 0) (void)!write(fds[2], half, 2);                 // half an introduction
+      while (!stop.load()) std::this_thread::sleep_for(std::chrono::milliseconds(20));
+      for (int fd : fds) if (fd >= 0) close(fd);
+    });
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> ts;
+    ts.emplace_back(full_job, port, 0, world);
+    std::this_thread::sleep_for(std::chrono::milliseconds(300));      // strangers get in first
+    for (int r = 1; r < world; ++r) ts.emplace_back(full_job, port, r, world);
+    for (auto& t : ts) t.join();
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    CHECK(secs < 15.0);               // full_job's deadline is 20 s: nobody waited for a stranger
+    stop = true;
+    strangers.join();
+  }
+  // 7. a duplicate rank is refused by name, the job forms with the first claimant
+  {
+    const int world = 3, port = free_port();
+    std::atomic<int> dup_err{0};
+    std::vector<std::thread> ts;
+    ts.emplace_back(full_job, port, 0, world);
+    ts.emplace_back(full_job, port, 1, world);
+    std::this_thread::sleep_for(std::chrono::milliseconds(500));      // rank 1 is in
+    ts.emplace_back([&] {
+      int err = 0;
+      void* h = dtf_rdzv_create("127.0.0.1", port, 1, world, 5.0, &err);
+      CHECK(h == nullptr);
+      if (h) dtf_rdzv_destroy(h);
+      dup_err = err;
+    });
+    ts[2].join();
+    CHECK(dup_err.load() == -4);
+    ts.emplace_back(full_job, port, 2, world);
+    for (size_t i = 0; i < ts.size(); ++i) if (i != 2) ts[i].join();
   }
   if (failures.load() == 0) printf("rendezvous selftest ok\n");
   return failures.load() == 0 ? 0 : 1;

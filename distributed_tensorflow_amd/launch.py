@@ -153,6 +153,35 @@ def launch(script: str, script_args: Sequence[str], num_workers: int, num_ps: in
     return status
 
 
+def count_gpus() -> int:
+    """GPUs this job may use, found WITHOUT a HIP call: the launcher is the parent of one process
+    per GPU and must not hold a GPU context (or a forked runtime) of its own. The kernel driver
+    lists every compute node under ``/sys/class/kfd/kfd/topology/nodes``; GPUs are the nodes with
+    SIMDs (CPUs have ``simd_count 0``). ``HIP_VISIBLE_DEVICES`` / ``ROCR_VISIBLE_DEVICES`` /
+    ``CUDA_VISIBLE_DEVICES`` narrow the count the way they narrow the runtime's view."""
+    nodes = "/sys/class/kfd/kfd/topology/nodes"
+    found = 0
+    try:
+        for name in os.listdir(nodes):
+            try:
+                with open(os.path.join(nodes, name, "properties")) as fh:
+                    props = dict(line.split(None, 1) for line in fh if " " in line)
+            except OSError:
+                continue
+            if int(props.get("simd_count", "0").strip() or 0) > 0:
+                found += 1
+    except OSError:
+        found = 0
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        value = os.environ.get(var)
+        if value is not None:
+            listed = [v for v in value.split(",") if v.strip() != ""]
+            if listed and listed[0].strip() == "-1":
+                listed = []
+            found = min(found, len(listed)) if found else 0
+    return found
+
+
 def main(argv: Optional[Sequence[str]] = None) -> int:
     ap = argparse.ArgumentParser(prog="distributed_tensorflow_amd.launch", description=__doc__,
                                  formatter_class=argparse.RawDescriptionHelpFormatter)
@@ -167,8 +196,7 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     args = ap.parse_args(argv)
     workers = args.num_workers
     if workers <= 0:
-        import torch
-        workers = max(1, torch.cuda.device_count())
+        workers = max(1, count_gpus())
     extra = [a for a in args.script_args if a != "--"]
     return launch(args.script, extra, workers, args.num_ps, args.protocol, args.strategy,
                   args.timeout)

@@ -702,8 +702,14 @@ def _affine_launch(ctx, updates) -> None:
 def _apply_optimizer(op, inputs, ctx):
     from .ref_kernels import _optimizer_refs, apply_rule_through_stores
     var_op, slot_ops, power_ops = _optimizer_refs(op)
-    grad = ctx.reduce_gradients([inputs[-1]], [var_op])[0]
     lr = inputs[op.attrs["num_refs"]] if op.attrs.get("lr_input") else None
+    powers = [_local_f32(ctx, p) for p in power_ops]
+    if all(t is not None for t in powers) and (
+            lr is None or (_is_f32(lr) and lr.is_cuda and lr.numel() == 1)):
+        if ctx.sharded_apply(op.attrs["rule"], op.attrs["hyper"], [var_op], [inputs[-1]],
+                             [slot_ops], powers, lr):
+            return [_local_f32(ctx, var_op)]
+    grad = ctx.reduce_gradients([inputs[-1]], [var_op])[0]
     rest = _optim_launch(ctx, op.attrs["rule"], op.attrs["hyper"], [var_op], [slot_ops],
                          power_ops, [grad], lr)
     for v, s_ops, g in rest:       # state in another process (parameter server)
@@ -717,10 +723,25 @@ def _multi_apply_optimizer(op, inputs, ctx):
     """Every variable of the step in one launch, then one one-wave launch for the scalars that
     advance with the step (Adam's running powers, step counters)."""
     from .ref_kernels import apply_rule_through_stores
-    var_ops = op.attrs["var_ops"]
+    var_ops = list(op.attrs["var_ops"])
+    slot_ops = list(op.attrs["slot_ops"])
     lr = inputs[len(var_ops)] if op.attrs.get("lr_input") else None
-    grads = ctx.reduce_gradients(list(inputs[:len(var_ops)]), var_ops)   # no-op without a sync runtime
-    rest = _optim_launch(ctx, op.attrs["rule"], op.attrs["hyper"], var_ops, op.attrs["slot_ops"],
+    grads = list(inputs[:len(var_ops)])
+    # reduce_scatter_sync: reduce-scatter, the rule on the owned shard (state lives there
+    # only), all-gather
+    powers = [_local_f32(ctx, p) for p in op.attrs["power_ops"]]
+    if all(t is not None for t in powers) and (
+            lr is None or (_is_f32(lr) and lr.is_cuda and lr.numel() == 1)):
+        done = ctx.sharded_apply(op.attrs["rule"], op.attrs["hyper"], var_ops, grads, slot_ops,
+                                 powers, lr)
+        if done:
+            keep = [i for i in range(len(var_ops)) if i not in set(done)]
+            var_ops = [var_ops[i] for i in keep]
+            slot_ops = [slot_ops[i] for i in keep]
+            grads = [grads[i] for i in keep]
+    if var_ops:
+        grads = ctx.reduce_gradients(grads, var_ops)   # no-op without a sync runtime
+    rest = _optim_launch(ctx, op.attrs["rule"], op.attrs["hyper"], var_ops, slot_ops,
                          op.attrs["power_ops"], grads, lr)
     for v, s_ops, g in rest:
         apply_rule_through_stores(ctx, op.attrs["rule"], op.attrs["hyper"], v, s_ops,

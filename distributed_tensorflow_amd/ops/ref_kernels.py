@@ -200,8 +200,11 @@ def _optimizer_refs(op):
 @ref_kernel("ApplyOptimizer", stateful=True)
 def _apply_optimizer(op, inputs, ctx):
     var_op, slot_ops, power_ops = _optimizer_refs(op)
-    grad = ctx.reduce_gradients([inputs[-1]], [var_op])[0]
     lr = inputs[op.attrs["num_refs"]] if op.attrs.get("lr_input") else None
+    if ctx.sharded_apply(op.attrs["rule"], op.attrs["hyper"], [var_op], [inputs[-1]], [slot_ops],
+                         [ctx.var_read(p) for p in power_ops], lr):
+        return [ctx.var_read(var_op)]
+    grad = ctx.reduce_gradients([inputs[-1]], [var_op])[0]
     return [apply_rule_through_stores(ctx, op.attrs["rule"], op.attrs["hyper"], var_op,
                                       slot_ops, power_ops, grad, lr)]
 
@@ -225,10 +228,21 @@ def _affine_update_variable(op, inputs, ctx):
 
 @ref_kernel("MultiApplyOptimizer", stateful=True)
 def _multi_apply_optimizer(op, inputs, ctx):
-    var_ops = op.attrs["var_ops"]
+    var_ops = list(op.attrs["var_ops"])
+    slot_ops_list = list(op.attrs["slot_ops"])
     lr = inputs[len(var_ops)] if op.attrs.get("lr_input") else None
-    grads = ctx.reduce_gradients(list(inputs[:len(var_ops)]), var_ops)
-    for var_op, slot_ops, g in zip(var_ops, op.attrs["slot_ops"], grads):
+    grads = list(inputs[:len(var_ops)])
+    # reduce_scatter_sync: the rule runs on the owner's shard, where its state lives
+    done = ctx.sharded_apply(op.attrs["rule"], op.attrs["hyper"], var_ops, grads, slot_ops_list,
+                             [ctx.var_read(p) for p in op.attrs["power_ops"]], lr)
+    if done:
+        keep = [i for i in range(len(var_ops)) if i not in set(done)]
+        var_ops = [var_ops[i] for i in keep]
+        slot_ops_list = [slot_ops_list[i] for i in keep]
+        grads = [grads[i] for i in keep]
+    if var_ops:
+        grads = ctx.reduce_gradients(grads, var_ops)
+    for var_op, slot_ops, g in zip(var_ops, slot_ops_list, grads):
         apply_rule_through_stores(ctx, op.attrs["rule"], op.attrs["hyper"], var_op, slot_ops,
                                   op.attrs["power_ops"], g, lr)
     for var_op, factor, increment in op.attrs.get("scalar_updates", []):

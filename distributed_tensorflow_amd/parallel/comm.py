@@ -322,16 +322,58 @@ class TorchDistComm(Communicator):
 
 
 def make_communicator(device: Optional[torch.device] = None, backend: Optional[str] = None,
-                      **kwargs) -> Communicator:
-    """The job's communicator for this process: ``backend`` (default: ``DTF_COMM_BACKEND``, then
-    ``nccl`` on a GPU / ``gloo`` on a CPU) is ``nccl`` or ``gloo`` (``torch.distributed``) or
-    ``rccl_native`` (``parallel/rccl_native.py``: own rendezvous and RCCL calls). Rank, world
-    size and rendezvous address come from the launcher's environment unless passed."""
+                      rank: Optional[int] = None, world_size: Optional[int] = None,
+                      master_addr: Optional[str] = None, master_port: Optional[int] = None,
+                      timeout_s: float = 600.0) -> Communicator:
+    """The job's communicator for this process.
+
+    ``backend`` (default: ``DTF_COMM_BACKEND``, then ``nccl`` on a GPU / ``gloo`` on a CPU) is
+    ``nccl`` or ``gloo`` (``torch.distributed``) or ``rccl_native`` (``parallel/rccl_native.py``:
+    own rendezvous and RCCL calls). Rank, world size and rendezvous address are taken from the
+    arguments first -- ``Server`` passes what the ``ClusterSpec`` says, so a task started by
+    hand as ``python script --job_name=worker --task_index=N`` (the reference's launch style,
+    ``tf_distributed.py:9-18``) joins the same world as one started by a launcher -- and from
+    the launcher's ``RANK`` / ``WORLD_SIZE`` / ``MASTER_*`` environment otherwise.
+
+    A world of one gets ``SingleComm`` (no process group to set up) unless ``rccl_native`` is
+    asked for by name, which then runs as a real RCCL communicator of one rank. A world of
+    more than one NEVER yields a communicator of another size: the constructors below either
+    rendezvous with the declared peers or raise ``CommError``."""
     backend = backend or os.environ.get("DTF_COMM_BACKEND") or None
+    if backend not in (None, "nccl", "gloo", "rccl_native"):
+        raise ValueError("unknown communicator backend %r" % (backend,))
+    rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
+    world_size = int(os.environ.get("WORLD_SIZE", "1")) if world_size is None \
+        else int(world_size)
+    if world_size < 1 or not 0 <= rank < world_size:
+        raise ValueError("rank %d is not in a world of %d" % (rank, world_size))
+    if device is None:
+        device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))) \
+            if torch.cuda.is_available() else torch.device("cpu")
+    device = torch.device(device)
     if backend == "rccl_native":
         from .rccl_native import RcclComm
-        return RcclComm(device=device, **kwargs)
-    return TorchDistComm(device=device, backend=backend, **kwargs)
+        comm: Communicator = RcclComm(rank=rank, world_size=world_size, device=device,
+                                      master_addr=master_addr, master_port=master_port,
+                                      timeout_s=timeout_s)
+    elif world_size == 1:
+        return SingleComm(device)
+    else:
+        try:
+            comm = TorchDistComm(rank=rank, world_size=world_size, device=device,
+                                 backend=backend, master_addr=master_addr,
+                                 master_port=master_port, timeout_s=timeout_s)
+        except CommError:
+            raise
+        except Exception as e:  # noqa: BLE001 -- store time-out, refused connection, ...
+            raise CommError("rank %d could not join the world of %d at %s:%s: %s"
+                            % (rank, world_size, master_addr, master_port, e)) from e
+    if comm.world_size != world_size or comm.rank != rank:
+        found = (comm.rank, comm.world_size)
+        comm.close()
+        raise CommError("asked for rank %d of %d, the backend formed rank %d of %d"
+                        % ((rank, world_size) + found))
+    return comm
 
 
 # ---------------------------------------------------------------------------------------
@@ -472,14 +514,3 @@ class LoopbackComm(Communicator):
             if self.rank == members[0] else None
         worlds = self._exchange(world)
         return LoopbackComm(worlds[members[0]], members.index(self.rank))
-
-
-def make_communicator(kind: str = "auto", **kwargs) -> Communicator:
-    """``auto``: ``torch.distributed`` when launched with WORLD_SIZE > 1, else single."""
-    if kind == "auto":
-        kind = "torch" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else "single"
-    if kind == "single":
-        return SingleComm(kwargs.get("device", torch.device("cpu")))
-    if kind == "torch":
-        return TorchDistComm(**kwargs)
-    raise ValueError("unknown communicator kind %r" % kind)

@@ -18,14 +18,28 @@ the collective is enqueued there, and either the caller's stream waits for it ri
 between overlaps the transfer. All of this is stream-ordered (events, no host synchronisation),
 so a step with its collectives can be captured into a HIP graph.
 
-Selected with ``DTF_COMM_BACKEND=rccl_native`` (``make_communicator``); the default backend stays
-``torch.distributed``'s ``nccl`` (the same RCCL underneath).
+Every collective in flight is bounded by a watchdog (``_Watchdog``): a host thread that follows
+the completion events of the communication stream and the communicator's asynchronous error
+state. A collective that has not completed ``collective_timeout_s`` after it was enqueued (a peer
+that died or never arrived), or an error RCCL reports on its own, makes the watchdog abort the
+communicator (``ncclCommAbort``: kernels of it that spin on a peer are released, so a host
+thread blocked in a stream synchronisation behind them returns) and park a :class:`CommError`
+that every later call on the communicator -- collectives, ``wait()``, ``barrier()``,
+``check_async_error()`` -- raises. ``Supervisor.run_with_recovery`` catches that exception; the
+process is never replaced.
+
+Selected with ``DTF_COMM_BACKEND=rccl_native`` (``make_communicator``, and through it
+``tf.train.Server(protocol="rccl")``); the default backend stays ``torch.distributed``'s ``nccl``
+(the same RCCL underneath).
 """
 from __future__ import annotations
 
+import collections
 import ctypes
 import os
 import pickle
+import threading
+import time
 from typing import Any, List, Optional
 
 import torch
@@ -36,6 +50,9 @@ from .comm import CommError, Communicator, _Done
 _DTYPES = {torch.int8: 0, torch.uint8: 1, torch.int32: 2, torch.int64: 4, torch.float16: 6,
            torch.float32: 7, torch.float64: 8, torch.bfloat16: 9}
 _OPS = {"sum": 0, "prod": 1, "max": 2, "min": 3, "avg": 4}
+_RDZV_CODES = {-1: "bad argument", -2: "connection lost", -3: "timed out",
+               -4: "refused: another process already holds this rank, or the rank is not in "
+                   "the world rank 0 was started with"}
 
 
 def available() -> bool:
@@ -58,13 +75,14 @@ class Rendezvous:
         self._h = lib.dtf_rdzv_create(addr.encode(), int(port), self.rank, self.world_size,
                                       float(timeout_s), ctypes.byref(err))
         if not self._h:
-            raise CommError("rendezvous at %s:%d failed for rank %d of %d (code %d)"
-                            % (addr, port, rank, world_size, err.value))
+            raise CommError("rendezvous at %s:%d failed for rank %d of %d (code %d: %s)"
+                            % (addr, port, rank, world_size, err.value,
+                               _RDZV_CODES.get(err.value, "error")))
 
     def _check(self, rc: int, what: str) -> None:
         if rc != 0:
             raise CommError("rendezvous %s failed (code %d: %s)"
-                            % (what, rc, {-2: "connection lost", -3: "timed out"}.get(rc, "error")))
+                            % (what, rc, _RDZV_CODES.get(rc, "error")))
 
     def all_gather_bytes(self, mine: bytes) -> List[bytes]:
         """Every rank's byte string, in rank order (lengths may differ)."""
@@ -97,18 +115,101 @@ class Rendezvous:
             self._h = None
 
 
+class _Watchdog(threading.Thread):
+    """Bounds the collectives in flight of one communicator.
+
+    ``watch(event, what)`` registers the completion event of a collective (anything with a
+    ``query()`` that turns true when the work is done). The thread drops completed entries,
+    asks RCCL for an asynchronous error while anything is in flight, and fails the communicator
+    (``RcclComm._fail``) when the oldest entry is older than ``timeout_s`` or RCCL reports an
+    error. It sleeps on a condition while nothing is in flight."""
+
+    def __init__(self, comm: "RcclComm", timeout_s: float, poll_s: float = 0.02):
+        super().__init__(name="dtf-rccl-watchdog", daemon=True)
+        self._comm_ref = comm
+        self.timeout_s = float(timeout_s)
+        self._poll_s = float(poll_s)
+        self._cond = threading.Condition()
+        self._inflight: collections.deque = collections.deque()
+        self._stop_flag = False
+
+    def watch(self, event, what: str) -> None:
+        with self._cond:
+            self._inflight.append((event, what, time.monotonic()))
+            self._cond.notify()
+
+    def in_flight(self) -> int:
+        with self._cond:
+            return len(self._inflight)
+
+    def stop(self) -> None:
+        with self._cond:
+            self._stop_flag = True
+            self._inflight.clear()
+            self._cond.notify()
+
+    def run(self) -> None:
+        while True:
+            with self._cond:
+                while not self._inflight and not self._stop_flag:
+                    self._cond.wait()
+                if self._stop_flag:
+                    return
+                try:
+                    while self._inflight and self._inflight[0][0].query():
+                        self._inflight.popleft()
+                except Exception as e:  # noqa: BLE001 -- a faulted device fails the query itself
+                    self._inflight.clear()
+                    failure = "completion query failed: %s" % (str(e)[:200],)
+                else:
+                    failure = None
+                    if self._inflight:
+                        _, what, t0 = self._inflight[0]
+                        age = time.monotonic() - t0
+                        if age > self.timeout_s:
+                            failure = "%s did not complete within %.1f s (%d collective(s) in " \
+                                "flight): a peer is gone or never arrived" \
+                                % (what, self.timeout_s, len(self._inflight))
+                            self._inflight.clear()
+                busy = bool(self._inflight)
+            comm = self._comm_ref
+            if failure is None and busy:
+                failure = comm._async_error_text()
+                if failure is not None:
+                    with self._cond:
+                        self._inflight.clear()
+            if failure is not None:
+                comm._fail(failure)
+            time.sleep(self._poll_s)
+
+
 class _StreamWork:
     """Handle of a collective in flight on the communication stream."""
 
-    def __init__(self, comm: "RcclComm", event: torch.cuda.Event, what: str):
+    def __init__(self, comm: "RcclComm", event, what: str):
         self._comm, self._event, self._what = comm, event, what
 
-    def wait(self, timeout=None) -> bool:
-        torch.cuda.current_stream(self._comm.device).wait_event(self._event)
+    def wait(self, timeout: Optional[float] = None) -> bool:
+        """Without ``timeout``: the caller's stream waits for the collective (stream-ordered, the
+        host does not block; the watchdog bounds it). With ``timeout`` (seconds): the HOST waits
+        until the collective has completed, and a collective still running at the deadline fails
+        the communicator and raises :class:`CommError`."""
         self._comm.check_async_error(self._what)
+        if timeout is None:
+            torch.cuda.current_stream(self._comm.device).wait_event(self._event)
+            return True
+        deadline = time.monotonic() + float(timeout)
+        while not self._event.query():
+            self._comm.check_async_error(self._what)
+            if time.monotonic() >= deadline:
+                self._comm._fail("%s did not complete within %.1f s" % (self._what, timeout))
+                self._comm.check_async_error(self._what)
+            time.sleep(0.0005)
+        torch.cuda.current_stream(self._comm.device).wait_event(self._event)
         return True
 
     def is_completed(self) -> bool:
+        self._comm.check_async_error(self._what)
         return bool(self._event.query())
 
 
@@ -119,6 +220,7 @@ class RcclComm(Communicator):
     def __init__(self, rank: Optional[int] = None, world_size: Optional[int] = None,
                  device: Optional[torch.device] = None, master_addr: Optional[str] = None,
                  master_port: Optional[int] = None, timeout_s: float = 600.0,
+                 collective_timeout_s: Optional[float] = None,
                  _parent: Optional["RcclComm"] = None, _handle=None, _members=None):
         lib = native.load()
         if not available():
@@ -132,6 +234,13 @@ class RcclComm(Communicator):
             raise CommError("RcclComm needs a GPU device")
         torch.cuda.set_device(self.device)
         self._stream = torch.cuda.Stream(device=self.device)
+        self._lock = threading.RLock()               # enqueue vs abort
+        self._failed: Optional[CommError] = None
+        if collective_timeout_s is None:
+            collective_timeout_s = _parent._watchdog.timeout_s if _parent is not None else \
+                float(os.environ.get("DTF_COLLECTIVE_TIMEOUT", "300"))
+        self._watchdog = _Watchdog(self, collective_timeout_s)
+        self._watchdog.start()
         if _parent is not None:                      # a sub-communicator made by split()
             self._rdzv, self._owns_rdzv = _parent._rdzv, False
             self._members = list(_members)           # parent-world ranks, in group order
@@ -163,12 +272,48 @@ class RcclComm(Communicator):
             raise CommError("%s failed: %s (code %d)"
                             % (what, self._lib.dtf_rccl_error_string(code).decode(), code))
 
+    def _async_error_text(self) -> Optional[str]:
+        """RCCL's asynchronous error of this communicator as text, ``None`` when there is none."""
+        with self._lock:
+            if not self._comm:
+                return None
+            err = ctypes.c_int(0)
+            self._lib.dtf_rccl_async_error(self._comm, ctypes.byref(err))
+            if err.value == 0:
+                return None
+            return "RCCL reported an asynchronous error: %s" \
+                % self._lib.dtf_rccl_error_string(err.value).decode()
+
+    def _fail(self, why: str) -> None:
+        """Abort the communicator and park the error for every later call (idempotent; called
+        by the watchdog thread or by a ``wait(timeout)`` that ran out)."""
+        with self._lock:
+            if self._failed is not None:
+                return
+            self._failed = CommError("rank %d of %d: %s; the communicator has been aborted"
+                                     % (self.rank, self.world_size, why))
+            handle, self._comm = self._comm, None
+            if handle:
+                self._lib.dtf_rccl_destroy(handle, 1)        # ncclCommAbort
+        self._watchdog.stop()
+
     def check_async_error(self, what: str = "collective") -> None:
-        err = ctypes.c_int(0)
-        self._lib.dtf_rccl_async_error(self._comm, ctypes.byref(err))
-        if err.value != 0:
-            raise CommError("%s failed while in flight: %s"
-                            % (what, self._lib.dtf_rccl_error_string(err.value).decode()))
+        """Raise the parked failure, or an asynchronous error RCCL reports right now."""
+        if self._failed is not None:
+            raise self._failed
+        text = self._async_error_text()
+        if text is not None:
+            self._fail("%s: %s" % (what, text))
+            raise self._failed
+
+    def watch(self, event, what: str = "captured step") -> None:
+        """Put work that contains collectives of this communicator under the watchdog: ``event``
+        completes (``query()``) when that work has. The session records one behind every replay
+        of a HIP graph that holds captured collectives -- events recorded DURING capture are
+        graph nodes, not queryable handles, so ``_run`` cannot register those itself."""
+        if self._failed is not None:
+            raise self._failed
+        self._watchdog.watch(event, what)
 
     @staticmethod
     def _wire(t: torch.Tensor) -> torch.Tensor:
@@ -188,15 +333,22 @@ class RcclComm(Communicator):
 
     def _run(self, what: str, async_op: bool, tensors, launch):
         """Fork the communication stream off the caller's, enqueue, join (now or on wait())."""
+        if self._failed is not None:
+            raise self._failed
         cur = torch.cuda.current_stream(self.device)
         ready = torch.cuda.Event()
         ready.record(cur)
         self._stream.wait_event(ready)
         for t in tensors:
             t.record_stream(self._stream)
-        self._rc(launch(self._stream.cuda_stream), what)
+        with self._lock:
+            if self._failed is not None:
+                raise self._failed
+            self._rc(launch(self._stream.cuda_stream), what)
         done = torch.cuda.Event()
         done.record(self._stream)
+        if not torch.cuda.is_current_stream_capturing():
+            self._watchdog.watch(done, what)
         if async_op:
             return _StreamWork(self, done, what)
         cur.wait_event(done)
@@ -234,10 +386,12 @@ class RcclComm(Communicator):
                              self._comm, input.data_ptr(), output.data_ptr(), input.numel(),
                              self._dtype(input, False), s))
 
-    def barrier(self) -> None:
+    def barrier(self, timeout: Optional[float] = None) -> None:
+        """All ranks have reached this point. The host waits (bounded by ``timeout``, default
+        the watchdog's limit) for a one-word all-reduce."""
         flag = torch.zeros(1, dtype=torch.float32, device=self.device)
-        self.all_reduce(flag)
-        torch.cuda.current_stream(self.device).synchronize()
+        work = self.all_reduce(flag, async_op=True)
+        work.wait(self._watchdog.timeout_s if timeout is None else timeout)
         self.check_async_error("barrier")
 
     # -- host objects (control plane; whole-world communicators only) --------------------------
@@ -279,13 +433,17 @@ class RcclComm(Communicator):
         return RcclComm(device=self.device, _parent=self, _handle=handle, _members=members)
 
     def close(self) -> None:
+        if getattr(self, "_watchdog", None) is not None:
+            self._watchdog.stop()
         if getattr(self, "_comm", None):
             try:
                 torch.cuda.synchronize(self.device)
             except Exception:  # noqa: BLE001 -- a faulted device must not keep the process alive
                 pass
-            self._lib.dtf_rccl_destroy(self._comm, 0)
-            self._comm = None
+            with self._lock:
+                handle, self._comm = self._comm, None
+                if handle:
+                    self._lib.dtf_rccl_destroy(handle, 0)
         if getattr(self, "_owns_rdzv", False) and self._rdzv is not None:
             self._rdzv.close()
             self._rdzv = None

@@ -105,6 +105,10 @@ class Optimizer:
                 slots[var] = Variable(
                     F.fill(tuple(var.shape), value, dtype=var.dtype), trainable=False,
                     name=var.op.name + "/" + op_name)
+            # per-element state of `var`: a runtime that gives every parameter shard one owner
+            # (reduce_scatter_sync) keeps only the owner's part of it
+            slots[var].op.attrs["slot_of"] = var.op.name
+            slots[var].op.attrs["slot_key"] = op_name
         return slots[var]
 
     def get_slot(self, var: Variable, name: str) -> Optional[Variable]:

@@ -211,21 +211,29 @@ class Server:
                 comm = self._comm
                 self._owns_comm = comm is None
                 if comm is None:
-                    from ..parallel.comm import SingleComm, make_communicator
+                    from ..parallel.comm import make_communicator
+                    # Rank, world size and rendezvous address are the ClusterSpec's: task N of
+                    # the job is rank N, the chief's host:port is where the world meets. A
+                    # launcher's MASTER_* (it exports the same values) may override the address
+                    # only. DTF_COMM_BACKEND=gloo: several ranks rehearsed on ONE GPU (RCCL
+                    # refuses two ranks per device); =rccl_native: own rendezvous + RCCL calls;
+                    # default: torch.distributed with RCCL on GPUs, gloo on CPUs.
                     world = self._cluster.num_tasks(self._job_name)
-                    if world > 1:
-                        chief = self._cluster.task_address(self._job_name, 0)
-                        chost, _, cport = chief.rpartition(":")
-                        # DTF_COMM_BACKEND=gloo: several ranks rehearsed on ONE GPU (RCCL refuses
-                        # two ranks per device); =rccl_native: own rendezvous + RCCL calls;
-                        # default: torch.distributed with RCCL on GPUs, gloo on CPUs
-                        comm = make_communicator(
-                            backend=os.environ.get("DTF_COMM_BACKEND") or None,
-                            rank=self._task_index, world_size=world, device=self.device,
-                            master_addr=os.environ.get("MASTER_ADDR", chost or "127.0.0.1"),
-                            master_port=int(os.environ.get("MASTER_PORT", cport)))
-                    else:
-                        comm = SingleComm(self.device)
+                    ranks = self._cluster.task_indices(self._job_name)
+                    chief = self._cluster.task_address(self._job_name, ranks[0])
+                    chost, _, cport = chief.rpartition(":")
+                    timeout = getattr(self._config, "rendezvous_timeout_s", None) or \
+                        float(os.environ.get("DTF_RENDEZVOUS_TIMEOUT", "600"))
+                    comm = make_communicator(
+                        device=self.device, rank=ranks.index(self._task_index),
+                        world_size=world,
+                        master_addr=os.environ.get("MASTER_ADDR") or chost or "127.0.0.1",
+                        master_port=int(os.environ.get("MASTER_PORT") or cport),
+                        timeout_s=timeout)
+                    if comm.world_size != world:
+                        raise RuntimeError("the cluster declares %d %s tasks, the communicator "
+                                           "has %d ranks" % (world, self._job_name,
+                                                             comm.world_size))
                     self._comm = comm
                 self.runtime = rt.CollectiveRuntime(
                     comm, self.device, strategy,

@@ -688,3 +688,57 @@ def test_native_rendezvous_gathers_and_broadcasts_byte_strings_between_ranks():
     for t in threads:
         t.join(15)
     assert len(failed) >= 1 and all("rendezvous" in m for _, m in failed)
+
+
+def test_rccl_server_of_a_two_worker_cluster_never_becomes_a_world_of_one(monkeypatch):
+    """A task of a declared two-worker cluster under ``protocol="rccl"`` either meets its peer or
+    fails: it must not come up alone (the reference builds its server from the cluster alone,
+    ``tf_distributed.py:9-18``; nothing of a launcher's environment is present here)."""
+    for key in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "DTF_COMM_BACKEND"):
+        monkeypatch.delenv(key, raising=False)
+    monkeypatch.setenv("DTF_RENDEZVOUS_TIMEOUT", "2")
+    cluster = tf.train.ClusterSpec({"worker": ["127.0.0.1:%d" % _free_port(),
+                                               "127.0.0.1:%d" % _free_port()]})
+    t0 = time.monotonic()
+    with pytest.raises(CommError):
+        tf.train.Server(cluster, job_name="worker", task_index=1, protocol="rccl",
+                        config=tf.ConfigProto(device="cpu"))
+    assert time.monotonic() - t0 < 30
+    # and both tasks together do form the world the cluster declares
+    servers, errors = [None, None], []
+
+    def task(i):
+        try:
+            servers[i] = tf.train.Server(cluster, job_name="worker", task_index=i,
+                                         protocol="rccl", config=tf.ConfigProto(device="cpu"),
+                                         comm=comms[i])
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    comms = LoopbackComm.create_world(2)
+    threads = [threading.Thread(target=task, args=(i,)) for i in (1, 0)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert [s.runtime.comm.world_size for s in servers] == [2, 2]
+    for s in servers:
+        s.stop()
+
+
+def test_make_communicator_resolves_world_from_arguments_before_environment(monkeypatch):
+    from distributed_tensorflow_amd.parallel.comm import make_communicator
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("RANK", raising=False)
+    assert isinstance(make_communicator(device="cpu"), SingleComm)
+    assert isinstance(make_communicator(device="cpu", rank=0, world_size=1), SingleComm)
+    with pytest.raises(ValueError):
+        make_communicator(device="cpu", rank=2, world_size=2)
+    with pytest.raises(ValueError):
+        make_communicator(device="cpu", backend="mpi")
+    with pytest.raises(CommError):           # a declared peer that never comes: an error, not a
+        make_communicator(device="cpu", rank=1, world_size=2, master_addr="127.0.0.1",
+                          master_port=_free_port(), timeout_s=1.5)     # world of one
+    with pytest.raises(CommError):           # the native communicator needs a GPU device
+        make_communicator(device="cpu", backend="rccl_native", rank=0, world_size=1)

@@ -336,3 +336,101 @@ def test_collective_runtime_over_the_native_communicator_matches_torch_distribut
     assert a[0] == b[0] and b[2] >= 8
     for p, q in zip(a[1], b[1]):
         assert np.array_equal(p, q)
+
+
+def test_server_selects_the_native_communicator_from_the_environment(nccl_comm, monkeypatch):
+    """``DTF_COMM_BACKEND=rccl_native`` through ``tf.train.Server(protocol="rccl")`` -- no
+    communicator handed in, no launcher environment: the server builds an ``RcclComm`` from its
+    ClusterSpec (a world of one here) and captured MNIST steps on it are bit-equal to the same
+    steps over torch.distributed's RCCL backend."""
+    import distributed_tensorflow_amd as tf
+    from distributed_tensorflow_amd.models import mnist_mlp
+    from distributed_tensorflow_amd.parallel.rccl_native import RcclComm
+    from distributed_tensorflow_amd.train.server import _free_port
+    for key in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        monkeypatch.delenv(key, raising=False)
+    rng = np.random.RandomState(11)
+    batches = [(rng.rand(100, 784).astype(np.float32),
+                np.eye(10, dtype=np.float32)[rng.randint(0, 10, 100)]) for _ in range(4)]
+
+    def run(native):
+        if native:
+            monkeypatch.setenv("DTF_COMM_BACKEND", "rccl_native")
+        else:
+            monkeypatch.delenv("DTF_COMM_BACKEND", raising=False)
+        g = tf.Graph()
+        with g.as_default():
+            cfg = tf.ConfigProto(device="cuda:0", strategy="reduce_scatter_sync",
+                                 step_fusion=False)
+            cluster = tf.train.ClusterSpec({"worker": ["127.0.0.1:%d" % _free_port()]})
+            server = tf.train.Server(cluster, job_name="worker", task_index=0, protocol="rccl",
+                                     config=cfg, comm=None if native else nccl_comm)
+            comm = server.runtime.comm
+            assert isinstance(comm, RcclComm) == native, type(comm)
+            with tf.device(tf.train.replica_device_setter(cluster=cluster)):
+                model = mnist_mlp.build_model(learning_rate=0.01, seed=1)
+            sv = tf.train.Supervisor(is_chief=True, global_step=model.global_step,
+                                     init_op=model.init_op)
+            sess = sv.prepare_or_wait_for_session(server.target, config=cfg)
+            hist = []
+            for i in range(12):
+                bx, by = batches[i % 4]
+                _, l, st = sess.run([model.train_op, model.loss, model.global_step],
+                                    {model.x: bx, model.y_: by})
+                hist.append((float(l), float(st)))
+            w = sess.run([model.w1, model.w2])
+            replays = sess.stats["graph_replays"]
+            watched = comm._watchdog.in_flight() if native else 0
+            sess.close()
+            sv.stop()
+            server.stop()
+        return hist, w, replays, watched
+
+    a, b = run(False), run(True)
+    assert a[0] == b[0] and b[2] >= 8          # captured (RCCL calls are graph nodes) by default
+    for p, q in zip(a[1], b[1]):
+        assert np.array_equal(p, q)
+
+
+def test_native_communicator_watchdog_turns_a_stuck_collective_into_comm_error():
+    """A collective whose completion event never fires (a peer that never arrives): the watchdog
+    aborts the communicator and parks a ``CommError`` within its limit -- every later call raises
+    it, the process goes on (``Supervisor.run_with_recovery`` catches that exception)."""
+    import time
+    from distributed_tensorflow_amd.parallel.comm import CommError
+    from distributed_tensorflow_amd.parallel.rccl_native import RcclComm, _StreamWork
+    from distributed_tensorflow_amd.train.server import _free_port
+
+    class NeverDone:
+        def query(self):
+            return False
+
+    comm = RcclComm(rank=0, world_size=1, device=torch.device("cuda", 0),
+                    master_addr="127.0.0.1", master_port=_free_port(),
+                    collective_timeout_s=1.0)
+    t = torch.ones(8, device="cuda")
+    comm.all_reduce(t)                          # healthy first
+    comm.barrier()
+    assert comm._watchdog.in_flight() == 0 or time.sleep(0.2) is None
+    t0 = time.monotonic()
+    comm.watch(NeverDone(), "all_reduce (injected)")
+    with pytest.raises(CommError, match="did not complete within"):
+        while time.monotonic() - t0 < 5.0:
+            comm.check_async_error()
+            time.sleep(0.01)
+    assert time.monotonic() - t0 < 5.0
+    with pytest.raises(CommError):
+        comm.all_reduce(t)
+    with pytest.raises(CommError):
+        comm.barrier()
+    comm.close()
+    # the host-side bound of a single handle
+    comm = RcclComm(rank=0, world_size=1, device=torch.device("cuda", 0),
+                    master_addr="127.0.0.1", master_port=_free_port())
+    t0 = time.monotonic()
+    with pytest.raises(CommError, match="did not complete within"):
+        _StreamWork(comm, NeverDone(), "all_gather (injected)").wait(timeout=0.5)
+    assert time.monotonic() - t0 < 5.0
+    comm.close()
+    torch.cuda.synchronize()
+    assert torch.equal(t.cpu(), torch.ones(8))  # the device is fine, only the communicator went

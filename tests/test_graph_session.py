@@ -557,3 +557,42 @@ def test_gpu_logistic_loss_runs_on_the_hip_kernels():
     logits, targets, wv, out, stats = _logistic_run("cuda:0")
     _check_logistic(logits, targets, wv, out)
     assert stats["torch_fallbacks"] == 0
+
+
+def test_gc_pause_is_a_counted_process_wide_guard():
+    """Thread A enters the pause (collection was on), thread B enters and leaves while A is still
+    inside: collection must stay off until A leaves, and come back on afterwards."""
+    import gc
+    import threading
+    from distributed_tensorflow_amd.client.session import _gc_paused
+    assert gc.isenabled()
+    a_in, b_done, a_go = threading.Event(), threading.Event(), threading.Event()
+    seen = {}
+
+    def thread_a():
+        with _gc_paused():
+            a_in.set()
+            b_done.wait(10)
+            seen["inside_a_after_b_left"] = gc.isenabled()
+            a_go.wait(10)
+        seen["after_a"] = gc.isenabled()
+
+    def thread_b():
+        a_in.wait(10)
+        with _gc_paused():
+            seen["inside_b"] = gc.isenabled()
+        b_done.set()
+
+    ta, tb = threading.Thread(target=thread_a), threading.Thread(target=thread_b)
+    ta.start(), tb.start()
+    tb.join(10)
+    a_go.set()
+    ta.join(10)
+    assert seen == {"inside_b": False, "inside_a_after_b_left": False, "after_a": True}
+    gc.disable()
+    try:                                   # off before: stays off after
+        with _gc_paused():
+            pass
+        assert not gc.isenabled()
+    finally:
+        gc.enable()

@@ -285,3 +285,84 @@ def test_monitored_session_example_two_synchronous_workers(tmp_path):
     tags = {t for f in files if "tfevents" in f
             for e in read_events(os.path.join(ckpt, f)) for t, _ in e.get("summary", [])}
     assert {"cost", "accuracy", "global_step/sec"} <= tags
+
+
+# ---------------------------------------------------------------------------------------------
+# tasks started BY HAND, the reference's launch style (`python script --job_name=worker
+# --task_index=N` per task, /root/reference/tf_distributed.py:9-18): no launcher, so no RANK /
+# WORLD_SIZE / MASTER_* in the environment -- rank, world and meeting point must come from the
+# ClusterSpec alone
+# ---------------------------------------------------------------------------------------------
+def _hand_env():
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="2")
+    for key in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TF_CONFIG",
+                "DTF_PROTOCOL", "DTF_STRATEGY", "DTF_COMM_BACKEND"):
+        env.pop(key, None)
+    return env
+
+
+def _hand_started_workers(script, worker_hosts, extra, n=2, chief_delay=1.5, timeout=200):
+    """Start task n-1 .. task 1 first, the chief last (after `chief_delay` seconds): the others
+    must wait for it instead of training alone or failing."""
+    import time
+    procs = {}
+    for task in range(n - 1, -1, -1):
+        if task == 0:
+            time.sleep(chief_delay)
+        cmd = [sys.executable, "-u", os.path.join(EX, script), "--job_name=worker",
+               "--task_index=%d" % task, "--worker_hosts=" + ",".join(worker_hosts),
+               "--protocol=rccl", "--device=cpu"] + [a.replace("{rank}", str(task)) for a in extra]
+        procs[task] = subprocess.Popen(cmd, cwd=ROOT, env=_hand_env(), stdout=subprocess.PIPE,
+                                       stderr=subprocess.STDOUT, text=True)
+    outs = {}
+    try:
+        for task, proc in procs.items():
+            outs[task], _ = proc.communicate(timeout=timeout)
+    finally:
+        for proc in procs.values():
+            if proc.poll() is None:
+                proc.kill()
+    for task, proc in procs.items():
+        assert proc.returncode == 0, "task %d:\n%s" % (task, outs[task])
+    return outs
+
+
+def test_hand_started_rccl_workers_form_one_world_sharded_matmul(tmp_path):
+    """Two workers of `--shard=m`, no launcher environment, task 1 started first: C on both must
+    equal the product of one rank bit for bit (each holds only its row block of A, so a worker
+    that silently ran as a world of one could not produce it)."""
+    import numpy as np
+    from distributed_tensorflow_amd.train.server import _free_port
+    hosts = ["127.0.0.1:%d" % _free_port() for _ in range(2)]
+    _, dump1 = _run_matmul_example(1, "none", tmp_path, "ref", size=500)
+    outs = _hand_started_workers(
+        "tf_distributed_1000Matrix.py", hosts,
+        ["--shard=m", "--matrix_size=500", "--max_steps=20", "--logs_path",
+         str(tmp_path / "logs_hand"), "--dump_result", str(tmp_path / "hand_{rank}.npy")])
+    ref = np.load(dump1 + "_0.npy")
+    for task in (0, 1):
+        assert "Sharded variable weights/Variable: row blocks of [500, 500] -> local [250, 500]" \
+            in outs[task], outs[task]
+        assert "done" in outs[task]
+        assert np.array_equal(np.load(str(tmp_path / ("hand_%d.npy" % task))), ref)
+
+
+@pytest.mark.parametrize("strategy", ["allreduce_sync", "reduce_scatter_sync"])
+def test_hand_started_rccl_workers_train_identical_replicas(strategy, tmp_path):
+    """The MNIST script, two hand-started workers per synchronous strategy: both count the same
+    global steps (one per synchronous step: 100 after 100 local steps each) and end
+    with identical replicas."""
+    from distributed_tensorflow_amd.train.server import _free_port
+    hosts = ["127.0.0.1:%d" % _free_port() for _ in range(2)]
+    outs = _hand_started_workers(
+        "tf_distributed.py", hosts,
+        ["--strategy=" + strategy, "--max_steps=100", "--logs_path", str(tmp_path / "logs"),
+         "--data_dir", str(tmp_path / "nodata")])
+    acc = [re.findall(r"Test-Accuracy: (\d+\.\d\d)", outs[t]) for t in (0, 1)]
+    cost = [re.findall(r"Final Cost: (\d+\.\d{4})", outs[t]) for t in (0, 1)]
+    assert acc[0] and acc[0] == acc[1], (outs[0], outs[1])
+    # independent data order per worker (as in the reference): the costs of the last batches
+    # differ, the evaluated replicas do not
+    assert cost[0] and cost[1]
+    steps = [[int(s) for s in re.findall(r"Step: (\d+),", outs[t])] for t in (0, 1)]
+    assert steps[0] and steps[0] == steps[1] and max(steps[0]) == 100 + 1

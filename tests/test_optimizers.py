@@ -234,29 +234,200 @@ def _cluster(workers):
                                  "worker": ["127.0.0.1:%d" % _free_port() for _ in range(workers)]})
 
 
-@pytest.mark.parametrize("strategy", ["allreduce_sync", "reduce_scatter_sync"])
-def test_adam_under_the_collective_strategies_keeps_replicas_identical(strategy):
-    world, steps = 2, 12
+def _collective_world(world, steps, make_opt, strategy):
     cluster = _cluster(world)
     comms = LoopbackComm.create_world(world, timeout_s=30)
     results = {}
-    threads = [threading.Thread(target=_mlp_job, args=(cluster, t, steps, results,
-                                                       lambda: tf.train.AdamOptimizer(0.01)),
+    threads = [threading.Thread(target=_mlp_job, args=(cluster, t, steps, results, make_opt),
                                 kwargs=dict(protocol="rccl", comm=comms[t], strategy=strategy))
                for t in range(world)]
     [t.start() for t in threads]
     [t.join(120) for t in threads]
-    assert set(results) == {0, 1}
+    assert set(results) == set(range(world))
+    return results
+
+
+@pytest.mark.parametrize("strategy", ["allreduce_sync", "reduce_scatter_sync"])
+def test_adam_under_the_collective_strategies_keeps_replicas_identical(strategy):
+    world, steps = 2, 12
+    results = _collective_world(world, steps, lambda: tf.train.AdamOptimizer(0.01), strategy)
     a, b = results[0]["final"], results[1]["final"]
     assert np.array_equal(a["w1"], b["w1"]) and np.array_equal(a["m"], b["m"])      # bitwise
     assert a["step"] == b["step"] == steps
     assert np.isclose(a["p1"], 0.9 ** (steps + 1))
     assert results[0]["costs"] != results[1]["costs"]
     assert np.mean(results[0]["costs"][-3:]) < np.mean(results[0]["costs"][:3])
-    # only the trainable variables' span of the arena travels: Adam's moments, the running
-    # powers and global_step lie behind it
-    per_step = results[0]["runtime"].bytes_reduced / steps
-    assert 0 < per_step <= (mnist_mlp.NUM_PARAMS + 4 * 64) * 4
+    rt = results[0]["runtime"]
+    per_step = rt.bytes_reduced / steps
+    if strategy == "allreduce_sync":
+        # only the trainable variables' span of the arena travels: Adam's moments, the running
+        # powers and global_step lie behind it
+        assert 0 < per_step <= (mnist_mlp.NUM_PARAMS + 4 * 64) * 4
+        assert rt.sharded_steps == 0 and not rt.has_sharded_storage()
+    else:
+        # the parameter arena (the moments are not part of it any more) is reduce-scattered
+        assert 0 < per_step <= (mnist_mlp.NUM_PARAMS + 8 * 64 + world * 64) * 4
+        assert rt.sharded_steps == steps
+
+
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("rule", ["adam", "momentum", "adagrad", "rmsprop", "adadelta"])
+def test_owner_sharded_optimizer_state_under_reduce_scatter_sync(rule, world):
+    """ZeRO stage 1 for every slot-carrying rule: under ``reduce_scatter_sync`` each rank keeps
+    only its shard of the rule's state and updates only its shard of the parameters; the
+    replicas end bit-equal to those of ``allreduce_sync`` (replicated state, every rank updates
+    everything), every step took the owner path, and a rank holds ``1 / world`` of the state."""
+    steps = 8
+    make = {"adam": lambda: tf.train.AdamOptimizer(0.01),
+            "momentum": lambda: tf.train.MomentumOptimizer(0.01, 0.9),
+            "adagrad": lambda: tf.train.AdagradOptimizer(0.05),
+            "rmsprop": lambda: tf.train.RMSPropOptimizer(0.001, momentum=0.5),
+            "adadelta": lambda: tf.train.AdadeltaOptimizer(1.0)}[rule]
+    ref = _collective_world(world, steps, make, "allreduce_sync")
+    got = _collective_world(world, steps, make, "reduce_scatter_sync")
+    for t in range(world):
+        assert np.array_equal(got[t]["final"]["w1"], ref[0]["final"]["w1"])
+        # the slot is read back whole (an all-gather of the owners' parts)
+        assert np.array_equal(got[t]["final"]["m"], ref[0]["final"]["m"])
+        assert got[t]["costs"] == ref[t]["costs"]
+        rt = got[t]["runtime"]
+        assert rt.sharded_steps == steps and rt.has_sharded_storage()
+        n_slots = {"adam": 2, "rmsprop": 2, "adadelta": 2}.get(rule, 1)
+        assert rt.slot_bytes_total == n_slots * mnist_mlp.NUM_PARAMS * 4
+        # 1 / world of it, up to the arena's alignment padding (256 bytes per variable and rank)
+        assert rt.slot_bytes_local() * world <= rt.slot_bytes_total + n_slots * 4 * 64 * (
+            8 + world)
+        assert rt.slot_bytes_local() * world >= rt.slot_bytes_total
+        assert not any("/" + k in n for n in rt.local_store.state_dict()
+                       for k in ("Adam", "Momentum", "Adagrad", "RMSProp", "Adadelta"))
+
+
+def test_two_train_ops_over_disjoint_variables_leave_each_others_variables_alone():
+    """Two train ops with different rules and rates over disjoint var_lists, run in alternation
+    under both collective strategies: a step must not touch the variables of the other op,
+    whatever their gradient slots still hold from the step before (reduce-scatter: the owner
+    applies only this step's variables; all-reduce: only their spans travel)."""
+    world, rounds = 2, 4
+
+    def job(task, comm, strategy, out):
+        g = tf.Graph()
+        with g.as_default():
+            cluster = tf.train.ClusterSpec({"worker": ["127.0.0.1:1", "127.0.0.1:2"]})
+            cfg = tf.ConfigProto(device="cpu", strategy=strategy)
+            server = tf.train.Server(cluster, job_name="worker", task_index=task,
+                                     protocol="rccl", config=cfg, comm=comm)
+            tf.set_random_seed(3)
+            x = tf.placeholder(tf.float32, [None, 6])
+            a = tf.Variable(tf.random_normal([6, 5]), name="a")
+            b = tf.Variable(tf.random_normal([5, 3]), name="b")
+            loss = tf.reduce_mean(tf.square(tf.matmul(tf.nn.sigmoid(tf.matmul(x, a)), b)))
+            train_a = tf.train.GradientDescentOptimizer(0.5).minimize(loss, var_list=[a])
+            train_b = tf.train.MomentumOptimizer(0.01, 0.9).minimize(loss, var_list=[b])
+            sv = tf.train.Supervisor(is_chief=(task == 0), init_op=tf.global_variables_initializer(),
+                                     logdir=None, recovery_wait_secs=0.05, summary_op=None)
+            rng = np.random.RandomState(task)
+            log = []
+            with sv.prepare_or_wait_for_session(server.target, config=cfg) as sess:
+                for _ in range(rounds):
+                    feed = {x: rng.rand(4, 6).astype(np.float32)}
+                    b0 = sess.run(b)
+                    sess.run(train_a, feed)
+                    log.append(("a-step leaves b", np.array_equal(sess.run(b), b0)))
+                    a0 = sess.run(a)
+                    sess.run(train_b, feed)
+                    log.append(("b-step leaves a", np.array_equal(sess.run(a), a0)))
+                out[task] = (log, sess.run(a), sess.run(b))
+            sv.stop()
+            server.stop()
+
+    finals = {}
+    for strategy in ("allreduce_sync", "reduce_scatter_sync"):
+        comms = LoopbackComm.create_world(world, timeout_s=30)
+        out = {}
+        threads = [threading.Thread(target=job, args=(t, comms[t], strategy, out))
+                   for t in range(world)]
+        [t.start() for t in threads]
+        [t.join(60) for t in threads]
+        assert set(out) == {0, 1}, strategy
+        for t in range(world):
+            assert all(ok for _, ok in out[t][0]), (strategy, out[t][0])
+        assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+        assert np.isfinite(out[0][1]).all() and np.isfinite(out[0][2]).all()
+        finals[strategy] = out[0]
+    assert np.array_equal(finals["allreduce_sync"][1], finals["reduce_scatter_sync"][1])
+    assert np.array_equal(finals["allreduce_sync"][2], finals["reduce_scatter_sync"][2])
+
+
+def test_owner_sharded_slots_checkpoint_round_trip_across_world_sizes(tmp_path):
+    """Adam under ``reduce_scatter_sync`` with 2 ranks: ``Saver.save`` (every worker calls it)
+    gathers the owners' parts of the moments into whole tensors; worlds of 1, 2 and 4 ranks
+    restore that checkpoint -- each rank keeps its own part -- read the same values back and
+    go on training on the owner path."""
+    from distributed_tensorflow_amd.data.mnist import synthetic_mnist
+    images, labels = synthetic_mnist(200, seed=0)
+    onehot = np.eye(10, dtype=np.float32)[labels]
+
+    def job(world, task, comm, restore_from, out):
+        g = tf.Graph()
+        with g.as_default():
+            cluster = tf.train.ClusterSpec(
+                {"worker": ["127.0.0.1:%d" % (1 + i) for i in range(world)]})
+            cfg = tf.ConfigProto(device="cpu", strategy="reduce_scatter_sync")
+            server = tf.train.Server(cluster, job_name="worker", task_index=task,
+                                     protocol="rccl", config=cfg, comm=comm)
+            with tf.device(tf.train.replica_device_setter(cluster=cluster)):
+                m = mnist_mlp.build_model(seed=1, optimizer=tf.train.AdamOptimizer(0.01),
+                                          with_summaries=False)
+            saver = tf.train.Saver()
+            sv = tf.train.Supervisor(is_chief=(task == 0), global_step=m.global_step,
+                                     init_op=m.init_op, logdir=None, recovery_wait_secs=0.05,
+                                     summary_op=None, saver=None)
+            slots = [m.optimizer.get_slot(v, k) for v in (m.w1, m.b2) for k in ("m", "v")]
+            with sv.prepare_or_wait_for_session(server.target, config=cfg) as sess:
+                if restore_from:
+                    saver.restore(sess, restore_from)
+                else:
+                    for i in range(5):
+                        lo = 20 * i
+                        sess.run(m.train_op, {m.x: images[lo:lo + 20], m.y_: onehot[lo:lo + 20]})
+                    prefix = saver.save(sess, str(tmp_path / ("w%d_r%d" % (world, task)) / "ck"))
+                state = [sess.run(v) for v in [m.w1, m.b2, m.global_step] + slots]
+                state.append(float(sess.run(m.optimizer._powers[0])))
+                before = server.runtime.sharded_steps
+                sess.run(m.train_op, {m.x: images[:20], m.y_: onehot[:20]})
+                assert server.runtime.sharded_steps == before + 1
+                assert np.isfinite(sess.run(m.w1)).all()
+                out[task] = (state, None if restore_from else prefix,
+                             server.runtime.slot_bytes_local())
+            sv.stop()
+            server.stop()
+
+    def run(world, restore_from=None):
+        comms = LoopbackComm.create_world(world, timeout_s=30) if world > 1 \
+            else [SingleCommCpu()]
+        out = {}
+        threads = [threading.Thread(target=job, args=(world, t, comms[t], restore_from, out))
+                   for t in range(world)]
+        [t.start() for t in threads]
+        [t.join(60) for t in threads]
+        assert set(out) == set(range(world))
+        return out
+
+    from distributed_tensorflow_amd.parallel.comm import SingleComm as SingleCommCpu
+    saved = run(2)
+    state, prefix, local2 = saved[0]
+    assert any(np.abs(s).max() > 0 for s in state[3:7])            # the moments hold something
+    from distributed_tensorflow_amd.train.saver import read_bundle
+    on_disk = read_bundle(prefix, ["weights/Variable/Adam", "biases/Variable_1/Adam_1"])
+    assert np.array_equal(on_disk["weights/Variable/Adam"].numpy(), state[3])
+    assert np.array_equal(on_disk["biases/Variable_1/Adam_1"].numpy(), state[6])
+    for world in (1, 2, 4):
+        got = run(world, restore_from=prefix)
+        for t in range(world):
+            for a, b in zip(got[t][0], state):
+                assert np.array_equal(np.asarray(a), np.asarray(b)), (world, t)
+        if world == 4:
+            assert got[0][2] * 2 <= local2 + 2 * 4 * 64 * 4    # half the state of a 2-rank owner
 
 
 def test_momentum_on_a_parameter_server_keeps_its_state_on_the_ps():

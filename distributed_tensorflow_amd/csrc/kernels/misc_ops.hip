@@ -616,3 +616,60 @@ DTF_API int dtf_quantize_mx_fp8(const void* x, int src_kind, long R, long K, lon
   DTF_LAUNCH_CHECK();
   return DTF_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Multi-tensor copy: up to 16 (source, destination, bytes) triples in ONE launch (grid.y picks the
+// pair). The gradient buckets of the overlapped all-reduce are packed with it -- every member of a
+// bucket into its span of the flat bucket buffer -- instead of one copy launch per gradient.
+// 16 bytes per lane where both pointers and the length allow, bytes otherwise.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int MAX_COPY_PAIRS = 16;
+
+struct CopyPairs {
+  const unsigned char* src[MAX_COPY_PAIRS];
+  unsigned char* dst[MAX_COPY_PAIRS];
+  long bytes[MAX_COPY_PAIRS];
+};
+
+__global__ __launch_bounds__(256) void multi_copy_kernel(CopyPairs args) {
+  const unsigned char* src = args.src[blockIdx.y];
+  unsigned char* dst = args.dst[blockIdx.y];
+  const long n = args.bytes[blockIdx.y];
+  const long start = blockIdx.x * 256L + threadIdx.x, step = (long)gridDim.x * 256L;
+  long done = 0;
+  if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+    const long n16 = n >> 4;
+    const u32x4* s4 = reinterpret_cast<const u32x4*>(src);
+    u32x4* d4 = reinterpret_cast<u32x4*>(dst);
+    for (long i = start; i < n16; i += step) d4[i] = s4[i];
+    done = n16 << 4;
+  }
+  for (long i = done + start; i < n; i += step) dst[i] = src[i];
+}
+
+}  // namespace
+
+DTF_API int dtf_multi_copy(int count, const void* const* src, void* const* dst, const long* bytes,
+                           hipStream_t stream) {
+  if (count < 0 || count > MAX_COPY_PAIRS || (count > 0 && (!src || !dst || !bytes)))
+    return DTF_ERR_BAD_ARG;
+  if (count == 0) return DTF_OK;
+  CopyPairs args = {};
+  long max_bytes = 1;
+  for (int i = 0; i < count; ++i) {
+    if (bytes[i] < 0 || (bytes[i] > 0 && (!src[i] || !dst[i]))) return DTF_ERR_BAD_ARG;
+    args.src[i] = static_cast<const unsigned char*>(src[i]);
+    args.dst[i] = static_cast<unsigned char*>(dst[i]);
+    args.bytes[i] = bytes[i];
+    if (bytes[i] > max_bytes) max_bytes = bytes[i];
+  }
+  long blocks = (max_bytes + 256L * 16 * 4 - 1) / (256L * 16 * 4);     // 4 vectors per lane
+  if (blocks < 1) blocks = 1;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(multi_copy_kernel, dim3((unsigned)blocks, (unsigned)count), dim3(256), 0,
+                     stream, args);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}

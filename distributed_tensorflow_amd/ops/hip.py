@@ -167,6 +167,7 @@ def _declare(L: ctypes.CDLL) -> None:
         "dtf_mlp_step_train": [P, P],
         "dtf_philox_fill_2d": [P, LG, LG, LG, U, U, LG, LG, LG, F, F, I, I, P],
         "dtf_copy_2d": [P, P, LG, LG, LG, LG, P],
+        "dtf_multi_copy": [I, P, P, P, P],
         "dtf_pad_rows": [P, P, LG, LG, LG, LG, LG, P],
         "dtf_assign_add_f32": [P, P, LG, LG, F, P],
         "dtf_sign_f32": [P, P, LG, P],
@@ -1655,6 +1656,33 @@ def copy_2d(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
     _check(lib().dtf_copy_2d(src.data_ptr(), dst.data_ptr(), rows, cols * es, sp, dp, _stream()),
            "copy_2d")
     return dst
+
+
+def pack_into(parts: Sequence[torch.Tensor], out: torch.Tensor) -> List[torch.Tensor]:
+    """Copy every tensor of ``parts`` (contiguous GPU tensors of ``out``'s dtype) one behind the
+    other into the flat GPU tensor ``out`` -- one launch per 16 parts, however large they are --
+    and return the views of ``out`` that now hold them, shaped like the parts."""
+    if out.device.type != "cuda" or not out.is_contiguous() or out.dim() != 1:
+        raise HipKernelError("pack_into: out must be a flat contiguous GPU tensor")
+    views, off = [], 0
+    for p in parts:
+        if not (isinstance(p, torch.Tensor) and p.device.type == "cuda" and p.is_contiguous()
+                and p.dtype == out.dtype):
+            raise HipKernelError("pack_into: parts must be contiguous GPU tensors of out's dtype")
+        views.append(out[off:off + p.numel()].view(p.shape))
+        off += p.numel()
+    if off > out.numel():
+        raise HipKernelError("pack_into: %d elements do not fit into %d" % (off, out.numel()))
+    es = out.element_size()
+    c = ctypes
+    for start in range(0, len(parts), 16):
+        ps, vs = parts[start:start + 16], views[start:start + 16]
+        n = len(ps)
+        src = (c.c_void_p * n)(*[p.data_ptr() if p.numel() else None for p in ps])
+        dst = (c.c_void_p * n)(*[v.data_ptr() if v.numel() else None for v in vs])
+        nbytes = (c.c_long * n)(*[p.numel() * es for p in ps])
+        _check(lib().dtf_multi_copy(n, src, dst, nbytes, _stream()), "pack_into")
+    return views
 
 
 def assign_add(var: torch.Tensor, delta: torch.Tensor, sign: float = 1.0) -> torch.Tensor:

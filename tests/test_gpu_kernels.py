@@ -1206,3 +1206,30 @@ def test_mse_and_its_gradient(hip, n):
     da = hip.mse_grad(a, b, gs)
     assert torch.allclose(da.double(), (2 * 0.5 / n) * (a.double() - b.double()), rtol=1e-6,
                           atol=1e-9)
+
+
+def test_pack_into_packs_many_tensors_of_any_size_and_alignment(hip):
+    """``dtf_multi_copy``: 19 tensors (two launches), sizes from 0 to 3 M elements, sources at odd
+    element offsets (the byte path) -- every view of the flat buffer equals its source, nothing
+    else of the buffer is written."""
+    torch.manual_seed(0)
+    sizes = [0, 1, 3, 4, 5, 63, 64, 1000, 4097, 79510, 3 << 20, 17, 256, 2, 31, 100, 9, 8, 7]
+    backing = [torch.randn(n + 3, device="cuda") for n in sizes]
+    parts = [b[1:1 + n] if i % 2 else b[:n] for i, (b, n) in enumerate(zip(backing, sizes))]
+    parts[7] = parts[7].view(10, 100)
+    total = sum(sizes)
+    out = torch.full((total + 5,), -7.0, device="cuda")
+    views = hip.pack_into(parts, out)
+    torch.cuda.synchronize()
+    off = 0
+    for p, v in zip(parts, views):
+        assert v.shape == p.shape and v.data_ptr() == out.data_ptr() + 4 * off
+        assert torch.equal(v, p)
+        off += p.numel()
+    assert torch.equal(out[total:], torch.full((5,), -7.0, device="cuda"))
+    h = torch.randn(1001, device="cuda").bfloat16()
+    o16 = torch.zeros(1001, device="cuda", dtype=torch.bfloat16)
+    hip.pack_into([h], o16)
+    assert torch.equal(o16, h)
+    with pytest.raises(hip.HipKernelError):
+        hip.pack_into([torch.randn(8, device="cuda")], torch.zeros(4, device="cuda"))

@@ -189,6 +189,83 @@ class Secured:
         threading.Thread(target=watch, name="bench-watchdog", daemon=True).start()
 
 
+def through_session(args, comm, device, world: int, secured, measure) -> None:
+    """The product as ``sess.run`` of a ``tf.matmul`` of two variables (the reference's graph,
+    ``tf_distributed_1000Matrix.py:43-48``, at the benchmark's size and dtype): variables placed
+    by ``replica_device_setter``, initialised from the seeded random stream, the plan captured
+    (with its collectives) and replayed. The fetched object is the product's OP, so C stays in
+    HBM as in the engine's step; TFLOP/s count 2*M*N*K."""
+    import distributed_tensorflow_amd as tf
+    from distributed_tensorflow_amd.train.server import _free_port
+    tf_dtype = {"bf16": tf.bfloat16, "fp32": tf.float32, "fp8": tf.float8_e4m3fn}[args.dtype]
+    # the engine on the same operands' shapes, for the comparison line
+    strategy = "replicated" if world == 1 else {
+        "m": "m_shard_allgather", "k": "k_shard_allreduce", "2d": "block_2d_allgather"}[args.shard]
+    engine, engine_elapsed = measure(strategy)
+    engine_ms = engine_elapsed * 1e3 / args.steps
+    del engine
+    torch.cuda.empty_cache()
+    g = tf.Graph()
+    with g.as_default():
+        cfg = tf.ConfigProto(device=str(device), matmul_sharding=args.shard if world > 1 else "none",
+                             matmul_panels=args.panels)
+        ports = comm.broadcast_object([_free_port() for _ in range(world)], src=0)
+        cluster = tf.train.ClusterSpec({"worker": ["127.0.0.1:%d" % p for p in ports]})
+        server = tf.train.Server(cluster, job_name="worker", task_index=comm.rank,
+                                 protocol="rccl", config=cfg, comm=comm)
+        with tf.device(tf.train.replica_device_setter(
+                worker_device="/job:worker/task:%d" % comm.rank, cluster=cluster)):
+            tf.set_random_seed(1)
+            rand = tf.random_normal if args.distribution == "normal" else \
+                (lambda shape, dtype: tf.random_uniform(shape, -1.0, 1.0, dtype=dtype))
+            A = tf.Variable(rand([args.m, args.k], dtype=tf_dtype))
+            B = tf.Variable(rand([args.k, args.n], dtype=tf_dtype))
+            C = tf.matmul(A, B)
+            init = tf.global_variables_initializer()
+        sv = tf.train.Supervisor(is_chief=(comm.rank == 0), init_op=init, global_step=None,
+                                 summary_op=None, logdir=None)
+        with sv.prepare_or_wait_for_session(server.target, config=cfg) as sess:
+            for _ in range(args.warmup):
+                sess.run(C.op)
+            comm.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                sess.run(C.op)
+            torch.cuda.synchronize()
+            comm.barrier()
+            elapsed = time.perf_counter() - t0
+            stats = dict(sess.stats)
+        sv.stop()
+    if world > 1:
+        t = torch.tensor([elapsed], device=device)
+        comm.all_reduce(t, "max")
+        elapsed = t.item()
+    ms = elapsed * 1e3 / args.steps
+    rec = {
+        "metric": "sharded_gemm_tflops",
+        "value": round(2.0 * args.m * args.n * args.k / (ms * 1e-3) / 1e12, 2),
+        "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": args.dtype,
+        "data": "synthetic (Philox %s operands generated on device, random init)"
+                % ("N(0,1)" if args.distribution == "normal" else "U(-1,1)"),
+        "config": {"model": "gemm_%dx%dx%d_%s" % (args.m, args.n, args.k, args.dtype),
+                   "global_batch": args.m, "seq_len": args.k,
+                   "m": args.m, "n": args.n, "k": args.k,
+                   "parallelism": "single_gpu" if world == 1 else
+                   "tf.matmul sharded '%s' over %d ranks" % (args.shard, world),
+                   "through_session": True, "step": "sess.run(tf.matmul(A, B).op)",
+                   "engine_ms_per_step": round(engine_ms, 4),
+                   "session_over_engine": round(ms / engine_ms, 4),
+                   "session_stats": {k: stats.get(k) for k in
+                                     ("graph_replays", "direct_steps", "eager_runs",
+                                      "torch_fallbacks")},
+                   "result": "full C on every rank"},
+    }
+    secured.offer(json.dumps(rec), elapsed)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -224,6 +301,14 @@ def main() -> None:
     ap.add_argument("--probe-budget", type=float, default=60.0,
                     help="seconds the optional candidates of --strategy auto may take in total; "
                          "past it every rank reports the RCCL measurement already taken")
+    ap.add_argument("--through-session", action="store_true",
+                    help="time the same product as a user of the facade gets it: A and B are "
+                         "tf.Variables under replica_device_setter, the step is sess.run of "
+                         "tf.matmul(A, B) on the session's captured plan (sharded by the planner "
+                         "on more than one rank: --shard m|k|2d). The engine's own step time is "
+                         "measured next to it and reported as config.engine_ms_per_step")
+    ap.add_argument("--shard", default="m", choices=("m", "k", "2d"),
+                    help="--through-session on several ranks: ConfigProto(matmul_sharding=...)")
     ap.add_argument("--distribution", default="normal", choices=("normal", "uniform"),
                     help="operand values: N(0,1) as the reference's tf.random_normal "
                          "(tf_distributed_1000Matrix.py:43-44), or U(-1,1)")
@@ -293,6 +378,12 @@ def main() -> None:
             eng.step()
         eng.wait()
         return eng, max_over_ranks(timed_steps(eng, comm, args.steps))
+
+    if args.through_session:
+        through_session(args, comm, device, world, secured, measure)
+        secured.emit()
+        comm.close()
+        return
 
     if world == 1 or args.strategy != "auto" or args.dtype == "fp8":
         # one fixed strategy. fp8 is the 2-D sharded configuration (65536^2 sized for 288 GB

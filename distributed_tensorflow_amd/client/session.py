@@ -147,6 +147,14 @@ class ConfigProto:
                           on the rank grid). Default: ``DTF_MATMUL_SHARDING`` or ``"none"``.
     ``shard_variables`` -- store a variable that only sharded products read as its local block
                           (default on); off keeps replicas and multiplies views of them.
+    ``matmul_collective`` -- how a row-sharded product's result travels: ``"rccl"`` (default:
+                          panel-wise all-gather through the communicator) or ``"peer"`` (every
+                          rank stores its rows into all peers' result buffers over peer-mapped
+                          memory; GPUs of one node). ``matmul_panels``: row panels per product
+                          (default: as many as keep every panel's grid filling the chip).
+    ``rendezvous_timeout_s`` -- how long a task started by hand waits for the other tasks of
+                          its ``protocol="rccl"`` cluster (default ``DTF_RENDEZVOUS_TIMEOUT`` or
+                          600 s).
     ``allow_torch_fallback`` -- GPU sessions only. Off (default): an op, element type or layout
                           without a hand-written kernel raises when it is planned / first run.
                           On (or ``DTF_ALLOW_TORCH_FALLBACK=1``): such a case runs the torch
@@ -178,6 +186,8 @@ class ConfigProto:
                  grad_bucket_bytes: Optional[int] = None, matmul_sharding: Optional[str] = None,
                  shard_variables: bool = True, allow_torch_fallback: Optional[bool] = None,
                  step_fusion: Optional[bool] = None, deferred_fetches: Optional[bool] = None,
+                 matmul_collective: Optional[str] = None, matmul_panels: Optional[int] = None,
+                 rendezvous_timeout_s: Optional[float] = None,
                  **tensorflow_only):
         # TensorFlow options without a meaning here (device_filters, gpu_options,
         # intra_op_parallelism_threads, ...): kept, not interpreted, so that a script's
@@ -189,6 +199,11 @@ class ConfigProto:
         self.allow_torch_fallback = bool(os.environ.get("DTF_ALLOW_TORCH_FALLBACK")) \
             if allow_torch_fallback is None else bool(allow_torch_fallback)
         self.matmul_sharding = matmul_sharding
+        if matmul_collective not in (None, "rccl", "peer"):
+            raise ValueError("matmul_collective is 'rccl' or 'peer'")
+        self.matmul_collective = matmul_collective
+        self.matmul_panels = matmul_panels
+        self.rendezvous_timeout_s = rendezvous_timeout_s
         self.shard_variables = shard_variables
         self.grad_bucket_bytes = grad_bucket_bytes
         self.grad_aggregation = grad_aggregation

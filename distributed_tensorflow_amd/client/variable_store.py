@@ -34,6 +34,11 @@ class LocalVariableStore:
         # bumped whenever a variable gets NEW storage (first value, reshaped value, adopted
         # arena view, clear): HIP-graph captures hold raw addresses and are dropped on a change
         self.generation = 0
+        # per variable: how often its VALUE was written through this interface (kernels that
+        # update storage in place through ``local_tensor`` do not count: callers that cache
+        # something derived from a variable only do so for variables no such kernel touches)
+        self._versions: Dict[str, int] = {}
+        self._imaged: set = set()     # variables something captured holds a derived image of
 
     # -- reads ---------------------------------------------------------------------------
     def is_initialized(self, name: str) -> bool:
@@ -53,6 +58,20 @@ class LocalVariableStore:
     def names(self) -> List[str]:
         return sorted(self._values)
 
+    def version(self, name: str) -> int:
+        return self._versions.get(name, 0)
+
+    def _touch(self, name: str) -> None:
+        self._versions[name] = self._versions.get(name, 0) + 1
+        if name in self._imaged:
+            # a captured step may hold an image derived from this variable (the K-contiguous
+            # copy of a right-hand matmul operand): captures are dropped like after a move
+            self.generation += 1
+
+    def watch_writes(self, name: str) -> None:
+        """From now on a write to ``name`` also invalidates captured steps (``generation``)."""
+        self._imaged.add(name)
+
     def uninitialized(self, names: Iterable[str]) -> List[str]:
         return [n for n in names if n not in self._values]
 
@@ -60,6 +79,7 @@ class LocalVariableStore:
     def assign(self, name: str, value: torch.Tensor) -> torch.Tensor:
         value = value.detach()
         with self._lock:
+            self._touch(name)
             cur = self._values.get(name)
             if cur is not None and cur.shape == value.shape and cur.dtype == value.dtype:
                 cur.copy_(value)             # keep the address stable (captured graphs, views)
@@ -71,11 +91,13 @@ class LocalVariableStore:
     def adopt(self, name: str, storage: torch.Tensor) -> None:
         """Install ``storage`` (e.g. a view into a flat parameter arena) as the variable."""
         with self._lock:
+            self._touch(name)
             self._values[name] = storage
             self.generation += 1
 
     def assign_add(self, name: str, delta: torch.Tensor) -> torch.Tensor:
         var = self.read(name)
+        self._touch(name)
         var.add_(delta.to(var.device, var.dtype) if isinstance(delta, torch.Tensor) else delta)
         return var
 
@@ -84,12 +106,15 @@ class LocalVariableStore:
         interleave freely, which is the asynchronous update rule of the reference's plain
         ``GradientDescentOptimizer`` (``use_locking=False``)."""
         var = self.read(name)
+        self._touch(name)
         var.add_(grad.to(var.device, var.dtype), alpha=-float(lr))
         self.update_count += 1
         return var
 
     def clear(self) -> None:
         with self._lock:
+            for name in self._values:
+                self._touch(name)
             self._values.clear()
             self.generation += 1
 

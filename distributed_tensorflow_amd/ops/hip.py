@@ -1658,6 +1658,26 @@ def copy_2d(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
     return dst
 
 
+def multi_copy(srcs: Sequence[torch.Tensor], dsts: Sequence[torch.Tensor]) -> None:
+    """``dsts[i][...] = srcs[i]`` for pairs of contiguous GPU tensors of equal size in bytes --
+    one launch per 16 pairs."""
+    if len(srcs) != len(dsts):
+        raise HipKernelError("multi_copy: as many sources as destinations")
+    for a, b in zip(srcs, dsts):
+        if not (a.device.type == "cuda" and b.device.type == "cuda" and a.is_contiguous()
+                and b.is_contiguous()
+                and a.numel() * a.element_size() == b.numel() * b.element_size()):
+            raise HipKernelError("multi_copy: pairs must be contiguous GPU tensors of equal bytes")
+    c = ctypes
+    for start in range(0, len(srcs), 16):
+        ss, ds = srcs[start:start + 16], dsts[start:start + 16]
+        n = len(ss)
+        src = (c.c_void_p * n)(*[t.data_ptr() if t.numel() else None for t in ss])
+        dst = (c.c_void_p * n)(*[t.data_ptr() if t.numel() else None for t in ds])
+        nbytes = (c.c_long * n)(*[t.numel() * t.element_size() for t in ss])
+        _check(lib().dtf_multi_copy(n, src, dst, nbytes, _stream()), "multi_copy")
+
+
 def pack_into(parts: Sequence[torch.Tensor], out: torch.Tensor) -> List[torch.Tensor]:
     """Copy every tensor of ``parts`` (contiguous GPU tensors of ``out``'s dtype) one behind the
     other into the flat GPU tensor ``out`` -- one launch per 16 parts, however large they are --

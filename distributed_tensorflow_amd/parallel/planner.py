@@ -95,10 +95,40 @@ class VarLayout:
 
 
 class MatMulShard:
-    __slots__ = ("mode", "m", "n", "k", "grid")
+    """One planned product. ``b_layout``: ``"kn"`` = the right-hand operand is stored [K, N] as
+    ``tf.matmul(a, b)`` has it, ``"nk"`` = [N, K] (``transpose_b=True``: already the K-contiguous
+    layout the bf16 / fp8 kernels read)."""
 
-    def __init__(self, mode: str, m: int, n: int, k: int, grid: Tuple[int, int]):
+    __slots__ = ("mode", "m", "n", "k", "grid", "b_layout", "dtype")
+
+    def __init__(self, mode: str, m: int, n: int, k: int, grid: Tuple[int, int],
+                 b_layout: str = "kn", dtype=None):
         self.mode, self.m, self.n, self.k, self.grid = mode, m, n, k, grid
+        self.b_layout, self.dtype = b_layout, dtype
+
+    def bytes_per_rank(self, world: int) -> Dict[str, int]:
+        """HBM bytes one rank holds for this product: its blocks of the operands as stored, the
+        K-contiguous image of a [K, N] right-hand block (bf16 / fp8 only), the full result and
+        the staging of its collective."""
+        es = self.dtype.size if self.dtype is not None else 4
+        narrow = es < 4
+        out_es = 2 if narrow else 4                   # bf16 results for bf16 / fp8 operands
+        m, n, k = self.m, self.n, self.k
+        p, q = self.grid
+        if self.mode == "m":
+            a, b = m // world * k, k * n
+            stage = m // world * n * out_es
+        elif self.mode == "k":
+            a, b = m * (k // world), (k // world) * n
+            stage = m * n * 4 if narrow else 0        # fp32 partial sums of narrow operands
+        else:
+            a, b = m // p * k, k * (n // q)
+            stage = (m // p) * (n // q) * out_es + m * n * out_es
+        out = {"a": a * es, "b": b * es,
+               "b_image": b * es if (narrow and self.b_layout == "kn") else 0,
+               "c": m * n * out_es, "staging": stage}
+        out["total"] = sum(out.values())
+        return out
 
 
 class ShardPlan:
@@ -123,18 +153,22 @@ def _static2(t) -> Optional[Tuple[int, int]]:
     return int(s[0]), int(s[1])
 
 
-def _wanted_layouts(mode: str, world: int, m: int, n: int, k: int):
+def _wanted_layouts(mode: str, world: int, m: int, n: int, k: int, b_nk: bool = False):
     """(layout key of A, layout key of B) for one product, or None when the shape does not
-    divide. A key is (axis, parts, group); ``None`` = the operand is needed whole."""
+    divide. A key is (axis, parts, group); ``None`` = the operand is needed whole. ``b_nk``: the
+    right-hand variable is stored [N, K] (``transpose_b``), so its K blocks are column blocks and
+    its N blocks row blocks."""
+    k_axis, n_axis = (1, 0) if b_nk else (0, 1)
     if mode == "m":
         return ((0, world, "world"), None) if m % world == 0 else None
     if mode == "k":
-        return ((1, world, "world"), (0, world, "world")) if k % world == 0 else None
+        return ((1, world, "world"), (k_axis, world, "world")) if k % world == 0 else None
     if mode == "2d":
         p, q = rank_grid(world)
         if m % p or n % q:
             return None
-        return ((0, p, "grid_row") if p > 1 else None, (1, q, "grid_col") if q > 1 else None)
+        return ((0, p, "grid_row") if p > 1 else None,
+                (n_axis, q, "grid_col") if q > 1 else None)
     return None
 
 
@@ -155,21 +189,27 @@ def plan_matmul_sharding(graph, world: int, mode: str, shard_variables: bool = T
     want: Dict[str, List[Optional[Tuple[int, int, str]]]] = {}     # var name -> wanted layouts
     var_tensor: Dict[str, Any] = {}
     for op in ops:
-        if op.type != "MatMul" or op.attrs["transpose_a"] or op.attrs["transpose_b"]:
+        if op.type != "MatMul" or op.attrs["transpose_a"]:
             continue
         a, b = op.inputs
         if a.op.type != "VariableV2" or b.op.type != "VariableV2" or a.dtype != b.dtype:
             continue
-        if a.dtype.name not in ("float32", "bfloat16"):
+        if a.dtype.name not in ("float32", "bfloat16", "float8_e4m3fn"):
             continue
+        b_nk = bool(op.attrs["transpose_b"])
         sa, sb = _static2(a), _static2(b)
-        if sa is None or sb is None or sa[1] != sb[0]:
+        if sa is None or sb is None:
+            continue
+        if b_nk:
+            sb = (sb[1], sb[0])                          # as [K, N]
+        if sa[1] != sb[0]:
             continue
         m, k, n = sa[0], sa[1], sb[1]
-        keys = _wanted_layouts(mode, world, m, n, k)
+        keys = _wanted_layouts(mode, world, m, n, k, b_nk)
         if keys is None:
             continue
-        plan.matmuls[op] = MatMulShard(mode, m, n, k, rank_grid(world))
+        plan.matmuls[op] = MatMulShard(mode, m, n, k, rank_grid(world),
+                                       "nk" if b_nk else "kn", a.dtype)
         for t, key in ((a, keys[0]), (b, keys[1])):
             want.setdefault(t.op.name, []).append(key)
             var_tensor[t.op.name] = t

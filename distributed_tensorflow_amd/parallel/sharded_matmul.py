@@ -15,7 +15,16 @@ strategy                   A / B shard per rank   communication     result
 ``k_shard_allreduce``      col block / row block  all-reduce        full C on every rank
 ``k_shard_reduce_scatter`` col block / row block  reduce-scatter    row block of C
 ``summa_2d``               2-D block / 2-D block  row/col broadcast 2-D block of C
+``block_2d_allgather``     row block (grid row) / all-gather of C   full C on every rank
+                           column block (grid     blocks
+                           column), all of K
 =========================  =====================  ================  ==========================
+
+``block_2d_allgather`` is the 2-D decomposition for operands that fit a GPU many times over (a
+65536 x 65536 fp8 operand is 4 GiB of 288): rank (i, j) of the P x Q grid keeps the rows of A of
+grid row i and the columns of B of grid column j with ALL of K, so no operand panel ever
+travels; it computes block (i, j) of C and the blocks are all-gathered. ``summa_2d`` cuts K as
+well (operands 1/world per rank) and pays for that with the panel broadcasts.
 
 ``m_shard_allgather_direct`` and ``k_shard_allreduce_direct`` are the same data layouts with the
 collective done over peer-mapped memory (``parallel/peer_mem.py``): every rank pushes its rows
@@ -61,6 +70,14 @@ sharded run can be checked against a single-GPU one.
 
 The right-hand operand is stored K-contiguous (``Bt = B^T``, [N, K]) -- the layout the bf16
 MFMA kernel consumes directly.
+
+The same engine runs the ``tf.matmul`` of two variables that the session's planner shards
+(``parallel/sharded_ops.py``): ``bind_operands`` hands it the rank's blocks of the variables
+instead of generated ones, ``b_layout="kn"`` says that the right-hand operand lies as the graph
+has it ([K, N]; bf16 and fp8 products then run on a K-contiguous image of it that is re-made only
+when the variable's storage changed), ``plan_mnk`` pins tile and K split of the fp32 kernel to
+those of the whole product so that a block's rows are bit-identical to the single-rank result,
+and ``result_rowmajor()`` is the full C in plain row order whatever the panel layout.
 """
 from __future__ import annotations
 
@@ -75,7 +92,7 @@ from .comm import Communicator, SingleComm
 
 STRATEGIES = ("replicated", "m_shard", "m_shard_allgather", "k_shard_allreduce",
               "k_shard_reduce_scatter", "summa_2d", "m_shard_allgather_direct",
-              "k_shard_allreduce_direct")
+              "k_shard_allreduce_direct", "block_2d_allgather")
 
 
 def _split(total: int, parts: int, index: int) -> Tuple[int, int]:
@@ -118,7 +135,8 @@ class ShardedMatmul:
                  reduce_dtype: Optional[torch.dtype] = None, distribution: str = "uniform",
                  pipelined: bool = False, recompute_rows: int = 0,
                  peer_transport: str = "copy", scaling: str = "tensor",
-                 k_splits: Optional[int] = None):
+                 k_splits: Optional[int] = None, b_layout: str = "nk",
+                 plan_mnk: Optional[Tuple[int, int, int]] = None):
         if strategy not in STRATEGIES:
             raise ValueError("unknown strategy %r (choose from %s)" % (strategy, STRATEGIES))
         self.m, self.n, self.k = int(m), int(n), int(k)
@@ -131,6 +149,14 @@ class ShardedMatmul:
         # summation order with the shape); 1 = every product sums K in one sequential order, so
         # a row of C has the same bits whichever panel, head block or world size computed it
         self.k_splits = k_splits
+        # "nk": the right-hand operand is stored [N, K] (K-contiguous, what the bf16 / fp8
+        # kernels read); "kn": [K, N] as a graph's tf.matmul has it
+        if b_layout not in ("nk", "kn"):
+            raise ValueError("b_layout is 'nk' or 'kn'")
+        self.b_layout = b_layout
+        self.plan_mnk = tuple(int(v) for v in plan_mnk) if plan_mnk is not None else None
+        self._image = None          # (key, K-contiguous image) of a bound [K, N] operand
+        self._c_dense: Optional[torch.Tensor] = None
         # fp8 operands: "tensor" = unit scales (the generated operands fit e4m3 as they are),
         # "mx" = block-scaled (one E8M0 scale per 32 k of a row, applied by the matrix
         # instruction): operands are generated in bf16 and quantised by the MX kernel
@@ -140,9 +166,9 @@ class ShardedMatmul:
         if scaling == "mx":
             if dtype != torch.float8_e4m3fn:
                 raise ValueError("scaling='mx' applies to fp8 operands")
-            if strategy == "summa_2d" or recompute_rows:
-                raise ValueError("scaling='mx': operands must stay on their rank (no summa_2d, "
-                                 "no recompute_rows)")
+            if strategy == "summa_2d" or recompute_rows or b_layout != "nk":
+                raise ValueError("scaling='mx': operands must stay on their rank as quantised "
+                                 "[.., K] images (no summa_2d, no recompute_rows, b_layout='nk')")
         # fp8 operands produce bf16 results (fp32 accumulate inside the kernel)
         self.out_dtype = torch.bfloat16 if dtype == torch.float8_e4m3fn else dtype
         self.strategy = strategy
@@ -173,6 +199,13 @@ class ShardedMatmul:
             self.pr, self.pc = divmod(self.rank, self.grid_cols)
             self.row_comm = self.comm.split(self.pr, self.pc)     # ranks of my grid row
             self.col_comm = self.comm.split(self.pc, self.pr)     # ranks of my grid column
+        if strategy == "block_2d_allgather":
+            p_rows = max(d for d in range(1, int(math.isqrt(w)) + 1) if w % d == 0)
+            self.grid_rows, self.grid_cols = p_rows, w // p_rows
+            self.pr, self.pc = divmod(self.rank, self.grid_cols)
+            if self.m % self.grid_rows or self.n % self.grid_cols:
+                raise ValueError("M=%d / N=%d must be divisible by the %d x %d rank grid"
+                                 % (self.m, self.n, self.grid_rows, self.grid_cols))
         if strategy in ("m_shard", "m_shard_allgather", "k_shard_reduce_scatter",
                         "m_shard_allgather_direct", "k_shard_allreduce_direct") \
                 and self.m % w:
@@ -180,6 +213,8 @@ class ShardedMatmul:
         if strategy.startswith("k_shard") and self.k % w:
             raise ValueError("K=%d must be divisible by the world size %d" % (self.k, w))
         rows_local = self.m // w if strategy.startswith("m_shard") else self.m
+        if strategy == "block_2d_allgather":
+            rows_local = self.m // self.grid_rows
         self.peer_transport = peer_transport      # *_direct strategies: "copy" | "kernel"
         self.recompute_rows = int(recompute_rows)
         if self.recompute_rows:
@@ -197,11 +232,12 @@ class ShardedMatmul:
             # shard; 2 ranks: 8 panels of the 8192-row shard).
             panels = 1
             if w > 1 and strategy not in ("replicated", "m_shard", "summa_2d"):
-                col_tiles = max(1, (self.n + 255) // 256)
+                n_local = self.n // self.grid_cols if strategy == "block_2d_allgather" else self.n
+                col_tiles = max(1, (n_local + 255) // 256)
                 min_rows = 256 * max(1, (256 + col_tiles - 1) // col_tiles)
                 panels = max(1, min(8, rows_local // min_rows))
         self.panels = max(1, int(panels))
-        if strategy in ("m_shard_allgather", "m_shard_allgather_direct") \
+        if strategy in ("m_shard_allgather", "m_shard_allgather_direct", "block_2d_allgather") \
                 and rows_local % 256 == 0 and rows_local // 256 >= self.panels:
             # panels of whole 256-row output tiles (a ragged last tile row costs a full tile's
             # time), as even as the tile count allows; the same split on every rank
@@ -259,6 +295,10 @@ class ShardedMatmul:
             kl = k // w
             self.a = self._window("a", m, kl, 0, r * kl, k)
             self.bt = self._window("b", n, kl, 0, r * kl, k)
+        elif s == "block_2d_allgather":
+            mb, nb = m // self.grid_rows, n // self.grid_cols
+            self.a = self._window("a", mb, k, self.pr * mb, 0, k)
+            self.bt = self._window("b", nb, k, self.pc * nb, 0, k)
         else:
             # summa_2d: rank (pr, pc) owns rows M_pr of A for the K panels of grid column pc and
             # rows N_pc of Bt for the K panels of grid row pr; one contiguous tensor per panel
@@ -273,6 +313,52 @@ class ShardedMatmul:
             self.a = next(iter(self.a_panels.values()))
             self.bt = next(iter(self.b_panels.values()))
         self._alloc_result()
+
+    def operand_shapes(self) -> Tuple[Tuple[int, int], Tuple[int, int]]:
+        """Shapes of the blocks ``bind_operands`` expects: (left, right); the right one in this
+        engine's ``b_layout``."""
+        m, n, k, w, s = self.m, self.n, self.k, self.world, self.strategy
+        if s == "replicated":
+            ml, nl, kl = m, n, k
+        elif s.startswith("m_shard"):
+            ml, nl, kl = m // w, n, k
+        elif s.startswith("k_shard"):
+            ml, nl, kl = m, n, k // w
+        elif s == "block_2d_allgather":
+            ml, nl, kl = m // self.grid_rows, n // self.grid_cols, k
+        else:
+            raise ValueError("bind_operands does not apply to %s (operands are K panels)" % s)
+        return (ml, kl), ((nl, kl) if self.b_layout == "nk" else (kl, nl))
+
+    def bind_operands(self, a: torch.Tensor, b: torch.Tensor) -> None:
+        """Run on these tensors -- this rank's blocks of the operands, e.g. the storage of two
+        variables -- instead of generated ones. They are read in place every step (row-strided
+        views are fine); result buffers are allocated on the first call and kept."""
+        want_a, want_b = self.operand_shapes()
+        if tuple(a.shape) != want_a or tuple(b.shape) != want_b:
+            raise ValueError("%s on %d rank(s) wants blocks %s and %s, got %s and %s"
+                             % (self.strategy, self.world, want_a, want_b, tuple(a.shape),
+                                tuple(b.shape)))
+        if self.recompute_rows:
+            raise ValueError("recompute_rows needs the peers' rows of A: generated operands only")
+        first = self.c is None
+        self.a, self.bt = a, b
+        if first:
+            self._alloc_result()
+
+    def _right(self, b: torch.Tensor) -> torch.Tensor:
+        """The right-hand operand as the bf16 / fp8 kernels read it ([N, K]). A bound [K, N]
+        operand is transposed once into an image that is kept while the operand keeps its
+        storage and ``refresh_images`` has not been called (its owner wrote to it)."""
+        if self.b_layout == "nk":
+            return b
+        key = (b.data_ptr(), tuple(b.shape), tuple(b.stride()))
+        if self._image is None or self._image[0] != key:
+            self._image = (key, self._hip.transpose2d(b))
+        return self._image[1]
+
+    def refresh_images(self) -> None:
+        self._image = None
 
     def _alloc_result(self) -> None:
         m, n, w = self.m, self.n, self.world
@@ -294,6 +380,13 @@ class ShardedMatmul:
             self.c = torch.empty((m, n), dtype=dt, device=dev)
         elif s in ("m_shard", "k_shard_reduce_scatter"):
             self.c = torch.empty((m // w, n), dtype=dt, device=dev)
+        elif s == "block_2d_allgather":
+            mb, nb = m // self.grid_rows, n // self.grid_cols
+            self.c = torch.empty((m, n), dtype=dt, device=dev)
+            self._local = torch.empty((mb, nb), dtype=dt, device=dev)
+            # one gathered image per panel: [world, rows of the panel, nb]
+            self._stages = [torch.empty((w, rows, nb), dtype=dt, device=dev)
+                            for rows in self._panel_rows]
         else:
             _, ml = _split(m, self.grid_rows, self.pr)
             _, nl = _split(n, self.grid_cols, self.pc)
@@ -316,26 +409,34 @@ class ShardedMatmul:
     # -- local product -------------------------------------------------------------------
     def _gemm(self, a: torch.Tensor, bt: torch.Tensor, out: torch.Tensor,
               accumulate: bool = False) -> None:
-        """out (+)= a @ bt^T (a [m,k], bt [n,k]) on the hand-written kernels (GPU) or torch
-        (CPU)."""
+        """out (+)= a @ op(bt) (a [m,k]; bt [n,k], or [k,n] under ``b_layout="kn"``) on the
+        hand-written kernels (GPU) or torch (CPU)."""
+        kn = self.b_layout == "kn"
         if self.on_gpu:
             beta = 1.0 if accumulate else 0.0
             if self.scaling == "mx":
                 self._hip.gemm_fp8_mx_nt(a, bt, out.dtype, out=out, beta=beta)
             elif a.dtype == torch.bfloat16:
-                self._hip.gemm_bf16_nt(a, bt, out.dtype, out=out, beta=beta,
+                self._hip.gemm_bf16_nt(a, self._right(bt), out.dtype, out=out, beta=beta,
                                        splits=self.k_splits)
             elif a.dtype == torch.float8_e4m3fn:
-                self._hip.gemm_fp8_nt(a, bt, out.dtype, out=out, beta=beta)
+                self._hip.gemm_fp8_nt(a, self._right(bt), out.dtype, out=out, beta=beta)
             elif a.dtype == torch.float32:
+                plan = self.plan_mnk if (self.plan_mnk and self.plan_mnk[2] == a.shape[1]) \
+                    else None
+                splits = None if plan is not None else self.k_splits
                 if accumulate:
-                    out.add_(self._hip.gemm_f32(a, bt, trans_b=True, splits=self.k_splits))
+                    out.add_(self._hip.gemm_f32(a, bt, trans_b=not kn, splits=splits,
+                                                plan_mnk=plan))
                 else:
-                    self._hip.gemm_f32(a, bt, trans_b=True, out=out, splits=self.k_splits)
+                    self._hip.gemm_f32(a, bt, trans_b=not kn, out=out, splits=splits,
+                                       plan_mnk=plan)
             else:
                 raise TypeError("unsupported GEMM dtype %s" % a.dtype)
+        elif a.dtype == torch.float32 and out.dtype == torch.float32 and not accumulate:
+            torch.matmul(a, bt if kn else bt.t(), out=out)
         else:
-            prod = a.float() @ bt.float().t()
+            prod = a.float() @ (bt.float() if kn else bt.float().t())
             if accumulate:
                 out.add_(prod.to(out.dtype))
             else:
@@ -359,7 +460,33 @@ class ShardedMatmul:
             return self._step_m_allgather_direct()
         if s == "k_shard_allreduce_direct":
             return self._step_k_allreduce_direct()
+        if s == "block_2d_allgather":
+            return self._step_block_2d()
         return self._step_summa()
+
+    def _step_block_2d(self) -> torch.Tensor:
+        """Rank (i, j) of the P x Q grid multiplies its rows of A by its columns of B in row
+        panels; the all-gather of panel p's blocks runs while panel p+1 is computed. The
+        gathered blocks are laid into row-major C by block copies once their panel has landed."""
+        P, Q = self.grid_rows, self.grid_cols
+        mb, nb = self.m // P, self.n // Q
+        cols = self.bt
+        works = []
+        for idx, (start, rows) in enumerate(zip(self._panel_start, self._panel_rows)):
+            local = self._local[start:start + rows]
+            self._gemm(self.a[start:start + rows], cols, local)
+            works.append(self.comm.all_gather(self._stages[idx], local, async_op=True))
+        for idx, (start, rows) in enumerate(zip(self._panel_start, self._panel_rows)):
+            works[idx].wait()
+            stage = self._stages[idx]
+            for q in range(self.world):
+                i, j = divmod(q, Q)
+                dst = self.c[i * mb + start:i * mb + start + rows, j * nb:(j + 1) * nb]
+                if self.on_gpu:
+                    self._hip.copy_2d(stage[q], dst)
+                else:
+                    dst.copy_(stage[q])
+        return self.c
 
     def _step_m_allgather_direct(self) -> torch.Tensor:
         """Row panels of the local block are computed straight into this rank's rows of the
@@ -465,7 +592,10 @@ class ShardedMatmul:
         for wk in works:
             wk.wait()
         if target is not self.c:
-            self.c.copy_(target)
+            if self.on_gpu:
+                self._hip.cast(target, self.c.dtype, out=self.c)
+            else:
+                self.c.copy_(target)
         return self.c
 
     def _step_k_reduce_scatter(self) -> torch.Tensor:
@@ -571,11 +701,42 @@ class ShardedMatmul:
             return self.c   # [panel][rows/w][N]; rows_of_result() gives the global row ids
         return self.c
 
+    def result_rowmajor(self) -> torch.Tensor:
+        """The latest step's full C in plain row order in a buffer that keeps its address (for
+        the strategies that leave full C on every rank). The RCCL all-gather with several panels
+        stores C panel-major; its chunks -- one per (panel, rank), each contiguous -- are moved
+        into row order by one multi-tensor copy launch. Everything else already is row-major."""
+        s, w = self.strategy, self.world
+        if s not in ("replicated", "m_shard_allgather", "k_shard_allreduce",
+                     "m_shard_allgather_direct", "k_shard_allreduce_direct",
+                     "block_2d_allgather"):
+            raise ValueError("%s leaves C sharded" % s)
+        if self.recompute_rows:
+            return self.result_dense()
+        if s != "m_shard_allgather" or self.panels == 1:
+            return self.c
+        if self._c_dense is None:
+            self._c_dense = torch.empty((self.m, self.n), dtype=self.out_dtype,
+                                        device=self.device)
+        mb = self.m // w
+        src, dst = [], []
+        for start, rows in zip(self._panel_start, self._panel_rows):
+            gathered = self._gathered_panel(start, rows)             # [w, rows, N]
+            for q in range(w):
+                src.append(gathered[q])
+                dst.append(self._c_dense[q * mb + start:q * mb + start + rows])
+        if self.on_gpu:
+            self._hip.multi_copy(src, dst)
+        else:
+            for a, b in zip(src, dst):
+                b.copy_(a)
+        return self._c_dense
+
     def rows_of_result(self) -> np.ndarray:
         """Global row index of every row of ``result_dense()``."""
         s, w, r, p = self.strategy, self.world, self.rank, self.panels
         if s in ("replicated", "m_shard_allgather", "k_shard_allreduce",
-                 "m_shard_allgather_direct", "k_shard_allreduce_direct"):
+                 "m_shard_allgather_direct", "k_shard_allreduce_direct", "block_2d_allgather"):
             return np.arange(self.m)
         if s == "m_shard":
             return np.arange(self.m // w) + r * (self.m // w)

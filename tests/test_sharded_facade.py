@@ -239,3 +239,112 @@ def test_bf16_products_shard_too():
         for out in _run_world(2, mode, body=_fetch_all, dtype=tf.bfloat16):
             np.testing.assert_allclose(out["c"], single["c"], rtol=2e-2, atol=2e-2)
             assert out["layouts"]
+
+
+# -- planner: fp8, transposed right-hand variables, sizing ---------------------------------------
+def test_planner_plans_fp8_2d_blocks_and_sizes_them_against_hbm():
+    """BASELINE configuration 5 as a graph: ``tf.matmul`` of two 65536 x 65536 fp8 variables on
+    8 ranks plans as 2-D blocks (2 x 4 grid); the planner's byte count per GPU is far inside
+    288 GB, and nothing of the size is allocated to find that out."""
+    g = Graph()
+    with g.as_default():
+        n = 65536
+        A = tf.Variable(tf.random_normal([n, n], dtype=tf.float8_e4m3fn))
+        B = tf.Variable(tf.random_normal([n, n], dtype=tf.float8_e4m3fn))
+        C = tf.matmul(A, B)
+    plan = plan_matmul_sharding(g, 8, "2d")
+    spec = plan.matmuls[C.op]
+    assert (spec.mode, spec.grid, spec.b_layout) == ("2d", (2, 4), "kn")
+    assert plan.layouts[A.op.name].local_shape() == (32768, 65536)
+    assert plan.layouts[B.op.name].local_shape() == (65536, 16384)
+    by = spec.bytes_per_rank(8)
+    gib = 1 << 30
+    assert by["a"] == 2 * gib and by["b"] == 1 * gib and by["b_image"] == 1 * gib
+    assert by["c"] == 8 * gib                       # bf16 result, whole on every rank
+    assert by["total"] < 288e9 * 0.1
+    one = plan_matmul_sharding(g, 8, "m").matmuls[C.op].bytes_per_rank(8)
+    assert one["b"] == 4 * gib and one["a"] == gib // 2
+
+
+def test_planner_takes_a_right_hand_variable_stored_transposed():
+    g = Graph()
+    with g.as_default():
+        A = tf.Variable(tf.random_normal([64, 32]))
+        Bt = tf.Variable(tf.random_normal([48, 32]))
+        C = tf.matmul(A, Bt, transpose_b=True)
+    pk = plan_matmul_sharding(g, 4, "k")
+    assert pk.matmuls[C.op].b_layout == "nk" and (pk.matmuls[C.op].n, pk.matmuls[C.op].k) == (48, 32)
+    assert pk.layouts[Bt.op.name].key() == (1, 4, "world")        # K blocks = column blocks
+    p2 = plan_matmul_sharding(g, 8, "2d")
+    assert p2.layouts[Bt.op.name].key() == (0, 4, "grid_col")     # N blocks = row blocks
+
+
+def _graph_nk(m=64, k=32, n=48, dtype=tf.float32):
+    g = Graph()
+    with g.as_default():
+        tf.set_random_seed(1)
+        A = tf.Variable(tf.random_normal([m, k], dtype=dtype))
+        B = tf.Variable(tf.random_normal([n, k], dtype=dtype))
+        C = tf.matmul(A, B, transpose_b=True)
+        init = tf.global_variables_initializer()
+    return g, A, B, C, None, init
+
+
+@pytest.mark.parametrize("world,mode", [(2, "m"), (4, "k"), (4, "2d"), (8, "2d")])
+def test_sharded_matmul_with_transposed_right_hand_variable(world, mode):
+    single = _run_world(1, "none", build=_graph_nk, body=_fetch_all)[0]
+    for out in _run_world(world, mode, build=_graph_nk, body=_fetch_all):
+        if mode == "k":
+            np.testing.assert_allclose(out["c"], single["c"], rtol=1e-5, atol=1e-5)
+        else:
+            assert np.array_equal(out["c"], single["c"])
+        assert np.array_equal(out["b"], single["b"])
+
+
+def test_sharded_node_runs_on_the_benchmark_engine_with_panels():
+    """The node is an adapter over ``ShardedMatmul``: with ``matmul_panels=2`` a 2-rank row-sharded
+    product gathers two panels (panel-major) and hands out row-major C, bit-equal to one rank."""
+    from distributed_tensorflow_amd.parallel.sharded_matmul import ShardedMatmul
+
+    def body(sess, server, g, A, B, C, extra, r):
+        c = sess.run(C)
+        engines = [v for k, v in sess._ctx.buffers.items()
+                   if isinstance(k, tuple) and len(k) == 2 and k[1] == "engine"]
+        assert len(engines) == 1 and isinstance(engines[0], ShardedMatmul)
+        return c, engines[0].strategy, engines[0].panels, sess.run(C)
+
+    def run(world, mode, panels):
+        comms = LoopbackComm.create_world(world, timeout_s=60.0) if world > 1 else [None]
+        cluster = tf.train.ClusterSpec({"worker": ["127.0.0.1:%d" % _free_port()
+                                                   for _ in range(world)]})
+        results, errors = [None] * world, []
+
+        def work(r):
+            try:
+                g, A, B, C, extra, init = _graph(m=64, k=32, n=48)
+                cfg = tf.ConfigProto(device="cpu", matmul_sharding=mode, matmul_panels=panels)
+                server = tf.train.Server(cluster, job_name="worker", task_index=r,
+                                         protocol="rccl", config=cfg, comm=comms[r])
+                with g.as_default():
+                    sv = tf.train.Supervisor(graph=g, is_chief=(r == 0), init_op=init,
+                                             global_step=None)
+                    with sv.prepare_or_wait_for_session(server.target, config=cfg) as sess:
+                        results[r] = body(sess, server, g, A, B, C, extra, r)
+                    sv.stop()
+                server.stop()
+            except BaseException as e:  # noqa: BLE001
+                errors.append(e)
+                [c.kill() for c in comms if c is not None]
+
+        threads = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+        [t.start() for t in threads]
+        [t.join(120) for t in threads]
+        if errors:
+            raise errors[0]
+        return results
+
+    single = _run_world(1, "none", body=_fetch_all)[0]["c"]
+    for mode, strategy in (("m", "m_shard_allgather"), ("2d", "block_2d_allgather")):
+        for c, strat, panels, again in run(2, mode, 2):
+            assert strat == strategy and panels == 2
+            assert np.array_equal(c, single) and np.array_equal(again, single)

@@ -274,6 +274,8 @@ class ExecContext:
         self.direct_call = None     # set by a node whose whole work is one prepared library call
         self._nd_seed = int.from_bytes(os.urandom(4), "little")
 
+    tracer = None     # the StepTracer of a traced run (``RunOptions.FULL_TRACE``), else None
+
     def note_fallback(self, op, why: str = "") -> None:
         """A GPU kernel wrapper has no native code for this case (see ``ops/hip_kernels``)."""
         sess = self.session
@@ -1101,8 +1103,12 @@ class Session:
                 for (_, sl), v in zip(plan.feed_slots, feeds):
                     vals[sl] = v
                 if trace is not None:
-                    with trace.collectives(getattr(self._runtime, "comm", None)):
-                        self._run_steps(plan.steps, vals, trace)
+                    self._ctx.tracer = trace      # nodes with inner phases record them too
+                    try:
+                        with trace.collectives(getattr(self._runtime, "comm", None)):
+                            self._run_steps(plan.steps, vals, trace)
+                    finally:
+                        self._ctx.tracer = None
                 else:
                     self._run_steps(plan.steps, vals, trace)
                 self.stats["eager_runs"] += 1

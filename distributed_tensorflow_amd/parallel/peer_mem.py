@@ -144,6 +144,7 @@ class SymmetricBuffer:
         self.transport = transport
         self.blocks_per_peer = int(blocks_per_peer)
         self._push_stream: Optional[torch.cuda.Stream] = None
+        self.tracer = None            # utils.tracing.StepTracer while a traced step runs
         self.comm = comm
         self.rank, self.world = comm.rank, comm.world_size
         self.device = torch.device(device)
@@ -252,16 +253,26 @@ class SymmetricBuffer:
                 hip.peer_push(src, [self.views[r][row0:row0 + rows] for r in range(self.world)
                                     if r != self.rank], self.blocks_per_peer)
             return
+        tracer = self.tracer
         for r in self._peers:
             st = self._streams[r]
             st.wait_event(ready)
             with torch.cuda.stream(st):
                 if first and self.flags is not None and self._seq > 0:
                     self.flags.wait(KIND_ACK, [r], self._seq)
+                # (a traced step: the copy's bracket is recorded on ITS stream, so the trace
+                # shows it next to the products running on the compute stream meanwhile)
+                rec = tracer.begin("peer_push[rows %d+%d -> rank %d]" % (row0, rows, r),
+                                   "peer_push", "collective",
+                                   bytes=int(src.numel() * src.element_size())) \
+                    if tracer is not None else None
                 try:
                     self.views[r][row0:row0 + rows].copy_(src, non_blocking=True)
                 except RuntimeError as e:      # the peer's allocation is gone (it has exited)
                     raise CommError("push to rank %d failed: %s" % (r, str(e)[:200])) from e
+                finally:
+                    if rec is not None:
+                        tracer.end(rec)
 
     def publish(self) -> int:
         """Close the current exchange of pushes: behind its copies every pushing stream tells its

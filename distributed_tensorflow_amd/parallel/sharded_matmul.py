@@ -156,6 +156,7 @@ class ShardedMatmul:
         self.b_layout = b_layout
         self.plan_mnk = tuple(int(v) for v in plan_mnk) if plan_mnk is not None else None
         self._image = None          # (key, K-contiguous image) of a bound [K, N] operand
+        self.tracer = None          # utils.tracing.StepTracer while a traced step runs
         self._c_dense: Optional[torch.Tensor] = None
         # fp8 operands: "tensor" = unit scales (the generated operands fit e4m3 as they are),
         # "mx" = block-scaled (one E8M0 scale per 32 k of a row, applied by the matrix
@@ -412,6 +413,14 @@ class ShardedMatmul:
         """out (+)= a @ op(bt) (a [m,k]; bt [n,k], or [k,n] under ``b_layout="kn"``) on the
         hand-written kernels (GPU) or torch (CPU)."""
         kn = self.b_layout == "kn"
+        if self.tracer is not None:
+            tracer, self.tracer = self.tracer, None
+            try:
+                with tracer.span("panel_product[%dx%dx%d]" % (a.shape[0], out.shape[1],
+                                                            a.shape[1]), "panel_product"):
+                    return self._gemm(a, bt, out, accumulate)
+            finally:
+                self.tracer = tracer
         if self.on_gpu:
             beta = 1.0 if accumulate else 0.0
             if self.scaling == "mx":
@@ -506,6 +515,7 @@ class ShardedMatmul:
             sym.finish()                       # the exchange that used this set two steps ago
             self._set_works[which] = []
         self.c = sym.local
+        sym.tracer = self.tracer
         for start, rows in zip(self._panel_start, self._panel_rows):
             r0 = base + start
             self._gemm(self.a[x + start:x + start + rows], self.bt, self.c[r0:r0 + rows])

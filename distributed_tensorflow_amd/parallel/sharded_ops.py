@@ -161,7 +161,11 @@ def _sharded_matmul(op, inputs, ctx) -> List[Any]:
                 eng.refresh_images()
                 ctx.buffers[(op, "b_version")] = now
                 store.watch_writes(b_op.name)
-    eng.step()
+    eng.tracer = getattr(ctx, "tracer", None)     # a traced run: one bracket per panel product
+    try:
+        eng.step()
+    finally:
+        eng.tracer = None
     c = eng.result_rowmajor()
     nbytes = c.numel() * c.element_size()
     if spec.mode == "k":

@@ -103,3 +103,64 @@ def test_peer_memory_collectives_same_device(world, sync, tmp_path):
         assert res["gemm_errs"]["recompute_direct"] == 0.0, res
         assert res["gemm_errs"]["recompute_rccl_layout"] == 0.0, res
         assert res["gemm_errs"]["kernel_transport"] == 0.0, res
+
+
+FACADE_WORKER = os.path.join(ROOT, "tests", "helpers", "facade_shard_worker.py")
+
+
+def _spawn_facade(world, tmp_path, **extra_env):
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PYTHONPATH=ROOT,
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", **extra_env)
+        procs.append(subprocess.Popen([sys.executable, "-u", FACADE_WORKER, str(tmp_path)],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                                      text=True))
+    outs = []
+    try:
+        for p in procs:
+            out, _ = p.communicate(timeout=300)
+            outs.append(out)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for rank, p in enumerate(procs):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (rank, outs[rank][-3000:])
+    results = []
+    for rank in range(world):
+        with open(tmp_path / ("rank%d.json" % rank)) as fh:
+            results.append(json.load(fh))
+    return results
+
+
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
+@pytest.mark.parametrize("world,dtype,mode,collective", [
+    (2, "fp32", "m", "peer"), (4, "bf16", "m", "peer"), (2, "bf16", "m", "rccl"),
+    (4, "fp32", "2d", "rccl"), (2, "bf16", "k", "rccl"), (2, "fp8", "m", "peer")])
+def test_sharded_tf_matmul_rehearsed_on_one_gpu(world, dtype, mode, collective, tmp_path):
+    """``tf.matmul`` of two variables, planned as a sharded product and run by the benchmark's
+    engine, with 2 and 4 ranks sharing GPU 0: row-major C on every rank equal to the product one
+    rank computes alone (bit for bit except the K split), the variables stored as blocks, no
+    torch kernel, and -- over peer memory -- the row panels' transfers running while the next
+    panel is multiplied (device brackets of a traced step)."""
+    results = _spawn_facade(world, tmp_path, DTF_SHAPE="4096,2048,2048", DTF_DTYPE=dtype,
+                            DTF_SHARD=mode, DTF_COLLECTIVE=collective, DTF_PANELS="2")
+    want = {("m", "peer"): "m_shard_allgather_direct", ("m", "rccl"): "m_shard_allgather",
+            ("2d", "rccl"): "block_2d_allgather", ("k", "rccl"): "k_shard_allreduce"}
+    for res in results:
+        assert res["world"] == world and res["strategy"] == want[(mode, collective)], res
+        assert res["torch_fallbacks"] == 0, res
+        if mode == "k":
+            assert res["max_err"] <= 0.02 * res["scale"], res
+        else:
+            assert res["bit_equal"], res
+        if mode == "m":
+            assert res["a_local"] == [4096 // world, 2048]
+        assert res["panel_products"] >= (2 if mode != "k" or world else 1)
+        if collective == "peer":
+            assert res["panels"] == 2 and res["transfers"] >= 2 * (world - 1)
+            # panel 0's pushes are queued behind its product and run under panel 1's
+            assert res["overlap_us"] > 0.0, res

@@ -237,6 +237,7 @@ def _plan_sharding(graph: Graph, ops: Sequence[Operation], fed: Set[Tensor],
                                  {"shard": spec, "world": shard_plan.world, "_raw_inputs": True},
                                  control_inputs=op.control_inputs, device=op.device)
                 rw.tensor_map[out] = node.outputs[0]
+                rw.op_map[op] = node          # a fetch of the OP (or a control edge) runs it too
                 sharded_ops.add(op)
             lay = shard_plan.init_of.get(op)
             if lay is not None and op.type == "Assign":

@@ -1684,6 +1684,9 @@ def pack_into(parts: Sequence[torch.Tensor], out: torch.Tensor) -> List[torch.Te
     and return the views of ``out`` that now hold them, shaped like the parts."""
     if out.device.type != "cuda" or not out.is_contiguous() or out.dim() != 1:
         raise HipKernelError("pack_into: out must be a flat contiguous GPU tensor")
+    if sum(int(p.numel()) for p in parts) > out.numel():
+        raise HipKernelError("pack_into: %d elements do not fit into %d"
+                             % (sum(int(p.numel()) for p in parts), out.numel()))
     views, off = [], 0
     for p in parts:
         if not (isinstance(p, torch.Tensor) and p.device.type == "cuda" and p.is_contiguous()

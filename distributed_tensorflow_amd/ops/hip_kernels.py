@@ -56,12 +56,18 @@ def _fallback(op_type, op, inputs, ctx, why: str = ""):
 @hip_kernel("RandomStandardNormal")
 def _random_normal(op, inputs, ctx):
     dt = op.attrs["dtype"].torch
-    if dt not in (torch.float32, torch.bfloat16):
-        return _fallback("RandomStandardNormal", op, inputs, ctx)
     if op.attrs.get("deterministic", True):
         seed, seed2 = op.attrs["seed"], op.attrs["seed2"]
     else:
         seed, seed2 = ctx.nondeterministic_seed(), op.attrs["seed2"]
+    shape = tuple(op.attrs["shape"])
+    if dt == hip.FP8 and len(shape) == 2:
+        # fp8 e4m3 matrices (operands of the fp8 MFMA products): the 2-D window fill of the same
+        # counter-based stream, element (i, j) = stream element i * cols + j
+        return [hip.philox_window(shape[0], shape[1], seed, seed2, 0, 0, shape[1], dt,
+                                  ctx.device, True, op.attrs["mean"], op.attrs["stddev"])]
+    if dt not in (torch.float32, torch.bfloat16):
+        return _fallback("RandomStandardNormal", op, inputs, ctx)
     return [hip.philox_normal(op.attrs["shape"], seed, seed2, op.attrs["mean"],
                               op.attrs["stddev"], dt, ctx.device)]
 
@@ -69,12 +75,17 @@ def _random_normal(op, inputs, ctx):
 @hip_kernel("RandomUniform")
 def _random_uniform(op, inputs, ctx):
     dt = op.attrs["dtype"].torch
-    if dt not in (torch.float32, torch.bfloat16):
-        return _fallback("RandomUniform", op, inputs, ctx)
     if op.attrs.get("deterministic", True):
         seed, seed2 = op.attrs["seed"], op.attrs["seed2"]
     else:
         seed, seed2 = ctx.nondeterministic_seed(), op.attrs["seed2"]
+    shape = tuple(op.attrs["shape"])
+    if dt == hip.FP8 and len(shape) == 2:
+        lo, hi = float(op.attrs["minval"]), float(op.attrs["maxval"])
+        return [hip.philox_window(shape[0], shape[1], seed, seed2, 0, 0, shape[1], dt,
+                                  ctx.device, False, lo, hi - lo)]
+    if dt not in (torch.float32, torch.bfloat16):
+        return _fallback("RandomUniform", op, inputs, ctx)
     return [hip.philox_uniform(op.attrs["shape"], seed, seed2, op.attrs["minval"],
                                op.attrs["maxval"], dt, ctx.device)]
 

@@ -348,3 +348,15 @@ def test_sharded_node_runs_on_the_benchmark_engine_with_panels():
         for c, strat, panels, again in run(2, mode, 2):
             assert strat == strategy and panels == 2
             assert np.array_equal(c, single) and np.array_equal(again, single)
+
+
+def test_fetching_the_product_op_runs_the_sharded_node():
+    """``sess.run(C.op)`` (no value fetched) must run the planned sharded product, not the
+    original op on the rank's blocks."""
+    def body(sess, server, g, A, B, C, extra, r):
+        before = server.runtime.bytes_gathered
+        assert sess.run(C.op) is None
+        return server.runtime.bytes_gathered - before
+
+    for moved in _run_world(2, "m", body=body):
+        assert moved == 64 * 48 * 4

@@ -21,6 +21,10 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=300)
 ap.add_argument("--strategy", default="reduce_scatter_sync")
 ap.add_argument("--eager", action="store_true")
+ap.add_argument("--optimizer", default="sgd", choices=("sgd", "adam", "momentum"))
+ap.add_argument("--chain", action="store_true",
+                help="the chain of general kernels instead of the small-step kernels in gradient "
+                     "mode (ConfigProto(step_fusion=False))")
 args = ap.parse_args()
 
 comm = TorchDistComm(rank=0, world_size=1, device=torch.device("cuda", 0), backend="nccl",
@@ -29,12 +33,15 @@ rng = np.random.RandomState(0)
 batches = [(torch.from_numpy(rng.rand(100, 784).astype(np.float32)).cuda(),
             torch.from_numpy(np.eye(10, dtype=np.float32)[rng.randint(0, 10, 100)]).cuda())
            for _ in range(8)]
-cfg = tf.ConfigProto(device="cuda:0", strategy=args.strategy, hip_graphs=not args.eager)
+cfg = tf.ConfigProto(device="cuda:0", strategy=args.strategy, hip_graphs=not args.eager,
+                     step_fusion=False if args.chain else None)
 cluster = tf.train.ClusterSpec({"worker": ["127.0.0.1:%d" % _free_port()]})
 server = tf.train.Server(cluster, job_name="worker", task_index=0, protocol="rccl", config=cfg,
                          comm=comm)
 with tf.device(tf.train.replica_device_setter(cluster=cluster)):
-    model = mnist_mlp.build_model(learning_rate=0.01, seed=1)
+    opt = {"sgd": None, "adam": tf.train.AdamOptimizer(0.01),
+           "momentum": tf.train.MomentumOptimizer(0.01, 0.9)}[args.optimizer]
+    model = mnist_mlp.build_model(learning_rate=0.01, seed=1, optimizer=opt)
 sv = tf.train.Supervisor(is_chief=True, global_step=model.global_step, init_op=model.init_op)
 sess = sv.prepare_or_wait_for_session(server.target, config=cfg)
 for i in range(args.steps):

@@ -318,9 +318,75 @@ def _match_mlp_step(graph, alive, fed, fetched, rw, heads, sgd_node, applies):
     return node, tmap, omap, (dense, hnode, dw1_op, sgd_node)
 
 
+def _grad_input(apply_op) -> Tensor:
+    return apply_op.inputs[1] if apply_op.type == "ApplyGradientDescent" else apply_op.inputs[-1]
+
+
+def _match_mlp_grads(graph, alive, fed, fetched, rw, heads, applies):
+    """Forward and backward of the two-layer classifier as ONE node that ends in the four
+    gradients -- for steps whose update is not the whole-step node's: several ranks that exchange
+    gradients first, or an optimizer rule with state. Replaces ``FusedDense(sigmoid)``, the
+    ``ClassifierHeadTrain`` that carries the gradient back through the sigmoid and the first
+    layer's weight-gradient ``MatMul``; the optimizer node stays and reads the node's outputs.
+    Returns ``(node, tensor replacements, op replacements, redundant nodes)``."""
+    if len(heads) != 1 or len(applies) < 4:
+        return None
+    hnode, loss_t, soft_t, acc_t = heads[0]
+    if not hnode.attrs["sigmoid_input"] or hnode.attrs["dloss_const"] is None \
+            or len(hnode.inputs) != 4:
+        return None
+    a_t, w2_t, b2_t, labels = hnode.inputs
+    mapped = rw.tensor_map.get(a_t)
+    if mapped is None or getattr(mapped.op, "type", "") != "FusedDense":
+        return None
+    dense = mapped.op
+    x, w1_t, b1_t = dense.inputs
+    params = [w1_t, b1_t, w2_t, b2_t]
+    if any(t.op.type != "VariableV2" or t.dtype != dtypes.float32 or t in fed for t in params):
+        return None
+    if len({t.op for t in params}) != 4 or x.dtype != dtypes.float32 \
+            or labels.dtype != dtypes.float32:
+        return None
+    by_var = {a.inputs[0].op: a for a in applies}
+    if not {t.op for t in params} <= set(by_var):
+        return None
+    grads = [_grad_input(by_var[t.op]) for t in params]
+    g_w1 = grads[0]
+    dw1_op = g_w1.op
+    if dw1_op not in alive or dw1_op.type != "MatMul" or g_w1 in fed \
+            or not dw1_op.attrs["transpose_a"] or dw1_op.attrs["transpose_b"] \
+            or dw1_op.inputs[0] is not x \
+            or rw.tensor_map.get(dw1_op.inputs[1]) is not hnode.outputs[4]:
+        return None
+    if rw.tensor_map.get(grads[1]) is not hnode.outputs[5] \
+            or rw.tensor_map.get(grads[2]) is not hnode.outputs[2] \
+            or rw.tensor_map.get(grads[3]) is not hnode.outputs[3]:
+        return None
+    if any(g in fed for g in grads):
+        return None
+    outs = [(loss_t.dtype, loss_t.shape), (soft_t.dtype, soft_t.shape)]
+    if acc_t is not None:
+        outs.append((acc_t.dtype, acc_t.shape))
+    base = len(outs)
+    outs += [(g.dtype, t.shape) for g, t in zip(grads, params)]
+    node = FusedNode(graph, "MLPStepGrads", "fused_step_grads", [x, labels], outs,
+                     {"var_ops": [t.op for t in params],
+                      "dloss_const": float(hnode.attrs["dloss_const"]),
+                      "emit_accuracy": acc_t is not None,
+                      "parts": (dense, hnode, dw1_op)},
+                     device=hnode.device)
+    tmap = {loss_t: node.outputs[0], soft_t: node.outputs[1]}
+    if acc_t is not None:
+        tmap[acc_t] = node.outputs[2]
+    for i, g in enumerate(grads):
+        tmap[g] = node.outputs[base + i]
+    return node, tmap, {}, (dense, hnode, dw1_op)
+
+
 def build_rewrite(graph: Graph, ops: Sequence[Operation], fed: Set[Tensor],
                   fetched: Set[Tensor] = frozenset(), shard_plan=None,
-                  stored_layouts=None, fuse: bool = True, step_fusion: bool = False) -> Rewrite:
+                  stored_layouts=None, fuse: bool = True, step_fusion: bool = False,
+                  grads_fusion: bool = False) -> Rewrite:
     """Find fusable patterns among ``ops`` (the pruned, topologically ordered subgraph)."""
     rw = Rewrite()
     alive = set(ops)
@@ -460,6 +526,44 @@ def build_rewrite(graph: Graph, ops: Sequence[Operation], fed: Set[Tensor],
                 heads.append((hnode, loss_t, soft_t,
                               acc_op.outputs[0] if acc_op is not None else None))
 
+    # -- mean squared error: loss, its gradient and the bias gradient behind it, one node ------
+    for op in ops:
+        if op.type != "MeanSquaredError" or op.outputs[0] in fed:
+            continue
+        pred, labels = op.inputs
+        loss_t = op.outputs[0]
+        gops = [c for c in consumers.get(pred, []) if c in alive
+                and c.type == "MeanSquaredErrorGrad" and c.inputs[0] is pred
+                and c.inputs[1] is labels]
+        if len(gops) != 1 or gops[0].outputs[0] in fed:
+            continue
+        gop = gops[0]
+        dpred_t, g_t = gop.outputs[0], gop.inputs[2]
+        g_const = None
+        if g_t.op.type == "OnesLike" and g_t.op.inputs[0] is loss_t:
+            g_const = 1.0
+        elif g_t.op.type == "Fill" and g_t not in fed and not g_t.shape:
+            g_const = float(g_t.op.attrs["value"])
+        outs = [(loss_t.dtype, loss_t.shape), (dpred_t.dtype, dpred_t.shape)]
+        db_t = None
+        if pred.shape is not None and len(pred.shape) == 2 and pred.shape[1] is not None:
+            for c in consumers.get(dpred_t, []):
+                if c in alive and c.type == "SumToShapeOf" and c.inputs[0] is dpred_t \
+                        and c.outputs[0].shape is not None \
+                        and tuple(c.outputs[0].shape) == (pred.shape[1],) \
+                        and c.outputs[0] not in fed:
+                    db_t = c.outputs[0]
+                    outs.append((db_t.dtype, db_t.shape))
+                    break
+        node = FusedNode(graph, "MSELossStep", op.name + "/fused_mse_step",
+                         [pred, labels] + ([] if g_const is not None else [g_t]), outs,
+                         {"g_const": g_const, "emit_bias_grad": db_t is not None},
+                         device=op.device)
+        rw.tensor_map[loss_t] = node.outputs[0]
+        rw.tensor_map[dpred_t] = node.outputs[1]
+        if db_t is not None:
+            rw.tensor_map[db_t] = node.outputs[2]
+
     # -- metric: argmax-compare-mean --------------------------------------------------------
     for op in ops:
         hit = _match_accuracy(op) if op.type == "Mean" else None
@@ -542,4 +646,7 @@ def build_rewrite(graph: Graph, ops: Sequence[Operation], fed: Set[Tensor],
                 node.attrs["scalar_updates"].append(
                     (op.inputs[0].op, 1.0, float(op.inputs[1].op.attrs["value"])))
                 rw.op_map[op] = node
+    if grads_fusion and rw.step_candidate is None and not shard_plan and not stored_layouts:
+        every = list(applies) + [a for members in groups.values() for a in members]
+        rw.step_candidate = _match_mlp_grads(graph, alive, fed, fetched, rw, heads, every)
     return rw

@@ -337,15 +337,20 @@ class ExecContext:
         fn = getattr(rt, "sharded_sgd_step", None)
         return bool(fn and fn([v.name for v in var_ops], grads, lrs))
 
-    def sharded_apply(self, rule, hyper, var_ops, grads, slot_ops=None, powers=(), lr=None):
+    def sharded_apply(self, rule, hyper, var_ops, grads, slot_ops=None, powers=(), lr=None,
+                      lrs=None, counters=(), deltas=()):
         """Owner-shard update of the runtime (``reduce_scatter_sync``): indices of the variables
-        it updated, ``None`` when the runtime has no such path."""
+        it updated, ``None`` when the runtime has no such path. ``counters_applied()`` says
+        whether that call also bumped the ``counters`` handed to it."""
         fn = getattr(self.session._runtime, "sharded_apply", None)
         if fn is None:
             return None
         return fn(rule, hyper, [v.name for v in var_ops], list(grads),
                   [[s.name for s in ops] for ops in slot_ops] if slot_ops is not None else None,
-                  powers, lr)
+                  powers, lr, lrs, counters, deltas)
+
+    def counters_applied(self) -> bool:
+        return bool(getattr(self.session._runtime, "counters_applied", False))
 
 
 # ---------------------------------------------------------------------------------------
@@ -466,15 +471,28 @@ class _PackRequest:
         self.claimed = False
         self.packed: List[Tuple[int, int, tuple, torch.Tensor]] = []
         self._candidate: List[Tuple[int, int, tuple, torch.Tensor]] = []
+        self._unpacked: List[Any] = []
+        self.adds_fn = None
 
     def parts_for(self, node, outs: Sequence[Any]) -> Optional[List[torch.Tensor]]:
         if node is not self.step.node:
             return None
         mine = dict(zip(self.step.out_slots, outs))
-        self._candidate = _packable([(sl, self.vals[sl] if self.vals[sl] is not None
-                                      else mine.get(sl)) for sl in dict.fromkeys(self.want)],
-                                    self.limit)
+        pairs = [(sl, self.vals[sl] if self.vals[sl] is not None else mine.get(sl))
+                 for sl in dict.fromkeys(self.want)]
+        self._candidate = _packable(pairs, self.limit)
+        taken = {p[0] for p in self._candidate}
+        self._unpacked = [v for sl, v in pairs if sl not in taken]
         return [p[3] for p in self._candidate]
+
+    def addends(self, parts: Sequence[torch.Tensor]) -> Optional[List[float]]:
+        """For a node that gathers AHEAD of the step's update launch: what to add to each part
+        (a counter that launch bumps is fetched as old value + increment); ``None`` when a
+        fetched value overlaps something the update writes. Without an update behind the node:
+        zeros."""
+        if self.adds_fn is None:
+            return [0.0] * len(parts)
+        return self.adds_fn(list(parts), [p[3] for p in self._candidate] + self._unpacked)
 
     def claim(self) -> None:
         self.packed, self.claimed = self._candidate, True
@@ -532,7 +550,11 @@ class _DeferredHost:
 
 
 _DEFERRABLE_HOST_OPS = frozenset(("ScalarSummary", "MergeSummary"))
-_RING_READERS = frozenset(("MLPTrainStep",))   # node types that read fed tensors through the ring
+# node types that read fed tensors through the ring
+_RING_READERS = frozenset(("MLPTrainStep", "MLPStepGrads"))
+# node types that can gather a captured step's small results on their own last launch although
+# the step's update launch still follows them
+_PACK_RIDERS = frozenset(("MLPStepGrads", "MSELossStep"))
 
 
 _default_session = threading.local()
@@ -712,7 +734,8 @@ class Session:
             rw = fusion.build_rewrite(self.graph, sorted(order, key=lambda o: o.id), fed_set,
                                       fetched_tensors, shard_plan=shard_plan,
                                       stored_layouts=stored, fuse=self.config.graph_fusion,
-                                      step_fusion=self._step_fusion())
+                                      step_fusion=self._step_fusion(),
+                                      grads_fusion=self._grads_fusion())
             if rw.tensor_map or rw.op_map:
                 order = prune(rw)
             if rw.step_candidate is not None:
@@ -853,6 +876,21 @@ class Session:
         # plain local storage too (views of the parameter arena)
         return (type(rt) is CollectiveRuntime and rt.comm.world_size == 1
                 and rt.strategy == "allreduce_sync" and not rt.has_sharded_storage())
+
+    def _grads_fusion(self) -> bool:
+        """Forward + backward of a recognised model as one node that ends in the gradients (the
+        update stays with the optimizer node): wherever the whole-step node cannot stand --
+        several ranks, sharded owners, optimizer rules with state -- as long as every variable is
+        storage of this process."""
+        want = self.config.step_fusion
+        if want is None:
+            want = self.device.type == "cuda"
+        if not (self.config.graph_fusion and want):
+            return False
+        if self._runtime is None:
+            return True
+        from ..parallel.runtime import CollectiveRuntime, LocalRuntime
+        return type(self._runtime) in (LocalRuntime, CollectiveRuntime)
 
     def _capture_collectives(self) -> bool:
         want = self.config.capture_collectives
@@ -1169,7 +1207,10 @@ class Session:
         written, counters = [], {}
         state = [s for slots in sgd_node.attrs.get("slot_ops", []) for s in slots] + \
             list(sgd_node.attrs.get("power_ops", []))        # (rules with per-variable state)
+        owner_sharded = getattr(self._runtime, "_slot_info", {})
         for var_op in list(sgd_node.attrs["var_ops"]) + state:
+            if var_op.name in owner_sharded:
+                continue          # state kept as owner shards: nothing fetched can alias it
             t = local(var_op)
             if t is None or not t.is_cuda:
                 return None
@@ -1413,6 +1454,17 @@ class Session:
             if first_type is None:
                 first_type = t
             if t in _RING_READERS:
+                # (shapes beyond the small-step kernels run general kernels on the fed tensors
+                # themselves: those need the gather)
+                dims = {}
+                for i, sl in hits:
+                    dims[i] = tuple(feed_of[sl].shape)
+                w2_shape = st.node.attrs["var_ops"][2].outputs[0].shape
+                xs = dims.get(0) or dims.get(1)
+                if xs is None or len(xs) != 2 or w2_shape is None or None in tuple(w2_shape) \
+                        or (0 in dims and not hip.mlp_step_supported(
+                            int(xs[0]), int(dims[0][1]), int(w2_shape[0]), int(w2_shape[1]))):
+                    return False
                 continue
             if len(hits) != 1 or st.host:
                 return False
@@ -1551,14 +1603,37 @@ class Session:
                                 default=-1)
                     if any(st.node.type in _MUTATING_OPS for st in steps[j:k]):
                         j = k
-                    self._run_steps(steps[:j], vals)
-                    self._run_steps(reads, vals)
+                    rode = False
+                    if j >= 1 and steps[j - 1].node.type in _PACK_RIDERS:
+                        # the node that produces the last fetched value can gather the step's
+                        # small results itself, on its last launch: no gather launch at all
+                        self._run_steps(steps[:j - 1], vals)
+                        self._run_steps(reads, vals)
+                        if live_reads():
+                            req = ctx.pack_request = _PackRequest(want, vals, steps[j - 1], limit)
+                            req.adds_fn = functools.partial(self._fetch_ahead_addends,
+                                                            steps[k].node)
+                            try:
+                                self._run_steps([steps[j - 1]], vals)
+                            finally:
+                                ctx.pack_request = None
+                            if req.claimed:
+                                packed = req.packed
+                                self._run_steps(steps[j:k + 1], vals)
+                                done = rode = True
+                        else:
+                            self._run_steps([steps[j - 1]], vals)
+                    else:
+                        self._run_steps(steps[:j], vals)
+                        self._run_steps(reads, vals)
                     adds = None
-                    if live_reads():
+                    if not rode and live_reads():
                         packed = _packable([(sl, vals[sl]) for sl in dict.fromkeys(want)], limit)
                         adds = self._fetch_ahead_addends(steps[k].node, [p[3] for p in packed],
                                                          [vals[sl] for sl in dict.fromkeys(want)])
-                    if adds is not None:
+                    if rode:
+                        pass
+                    elif adds is not None:
                         hip.pack_f32_ring([p[3] for p in packed], ring.args, adds=adds)
                         self._run_steps(steps[j:k + 1], vals)
                         done = True

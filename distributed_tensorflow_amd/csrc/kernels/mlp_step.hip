@@ -25,6 +25,16 @@
 // Every sum is taken in the order the chain of general kernels takes it (the same device
 // functions, or loops written to the same order), so the two paths agree bit for bit; the tests
 // hold them to that over 100 steps.
+//
+// GRADIENT MODE (g_w1 .. g_b2 set): the step of a job whose update is not this file's -- several
+// ranks that exchange gradients first, or an optimizer rule with state. The same three launches
+// then END in the gradients instead of applying them: launch 3 stores dW1 = x^T dz1 to g_w1 (the
+// product's plain epilogue) and its tail stores the summed dW2, db2, db1 to g_w2, g_b2, g_b1 --
+// straight into the slots of the runtime's flat gradient arena when the session hands those out --
+// and still gathers loss, accuracy and the other small fetched values for the host (a fetched
+// step counter as old value + its coming increment, pack_add). What follows is the collective on
+// the arena and ONE update launch (multi_sgd / multi_optim with the counters): four kernels and a
+// collective per step instead of the seven of the general chain.
 #include "common.h"
 #include "gemm_f32_body.h"
 #include "mlp_head_body.h"
@@ -49,6 +59,7 @@ struct TailArgs {
   int blocks;                 // row blocks of the head launch
   // small values gathered for the host once everything above is written
   const float* src[MAX_PACK];
+  float add[MAX_PACK];        // added to every word of part i (a counter fetched ahead of its bump)
   int offset[MAX_PACK + 1];
   int npack;
   float* pack_dst;            // without a ring: where the gathered words go (may be null)
@@ -96,7 +107,7 @@ __device__ __forceinline__ void step_tail(const HeadArgs& p, const TailArgs& t,
   for (int g = 0; g < HB / RB; ++g) sh[g] = (on && g < t.blocks) ? p.ws[(long)g * S + e] : 0.f;
   float* param = nullptr;
   float lr = 0.f;
-  if (on && tb > 0) {
+  if (on && tb > 0 && t.w2) {
     if (e < H * C) { param = t.w2 + e; lr = t.lr_w2; }
     else if (e < H * C + C) { param = t.b2 + (e - H * C); lr = t.lr_b2; }
     else { param = t.b1 + (e - H * C - C); lr = t.lr_b1; }
@@ -110,7 +121,7 @@ __device__ __forceinline__ void step_tail(const HeadArgs& p, const TailArgs& t,
     if (e < H * C) { if (p.dw) p.dw[e] = v; }
     else if (e < H * C + C) { if (p.db) p.db[e - H * C] = v; }
     else if (p.db_prev) p.db_prev[e - H * C - C] = v;
-    *param = __builtin_fmaf(-lr, v, old);
+    if (param) *param = __builtin_fmaf(-lr, v, old);
     return;
   }
   if (tid == 0) p.loss[0] = v / (float)p.B;
@@ -127,7 +138,7 @@ __device__ __forceinline__ void step_tail(const HeadArgs& p, const TailArgs& t,
   if (dst) {
     for (int i = 0; i < t.npack; ++i) {
       const int n = t.offset[i + 1] - t.offset[i];
-      for (int j = tid; j < n; j += HT) dst[t.offset[i] + j] = t.src[i][j];
+      for (int j = tid; j < n; j += HT) dst[t.offset[i] + j] = t.src[i][j] + t.add[i];
     }
   }
   __threadfence_system();
@@ -142,6 +153,9 @@ __device__ __forceinline__ void step_tail(const HeadArgs& p, const TailArgs& t,
   }
 }
 
+// APPLY: W1 = fma(-lr, dW1, W1) in the product's epilogue (g.C = W1); otherwise dW1 is stored
+// (g.C = its destination) and the tail stores the small gradients instead of applying them.
+template <bool APPLY>
 __global__ __launch_bounds__(NTHREADS) void mlp_step_update_kernel(SkinnyArgs g, HeadArgs p,
                                                                    TailArgs t, DtfStepRing ring,
                                                                    int a_index, int tail_blocks,
@@ -153,7 +167,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_step_update_kernel(SkinnyArgs g,
   if (ring.ctr && a_index >= 0)
     g.A = (const float*)dtf_ring_feed_later(ring, a_index);
   // dW1 = x^T dz1: A is x stored [K = batch, M = inputs] (M-contiguous), B is dz1 [K, N]
-  gemm_f32_skinny_block<false, false, 1>(g, (int)blockIdx.x - tail_blocks);
+  gemm_f32_skinny_block<false, false, APPLY ? 1 : 0>(g, (int)blockIdx.x - tail_blocks);
 }
 
 }  // namespace
@@ -199,6 +213,13 @@ struct DtfMlpStep {
                                // the next replay (otherwise a later kernel of the step does)
   long host_seq;               // >= 0: the replay number, for a step issued directly (the device
                                // counters are then not used); -1: read it from the counters
+  // gradient mode (all four set, or none): where the step leaves dW1 [D, H], db1 [H], dW2 [H, C],
+  // db2 [C] instead of applying them; parameters and counters are then not written
+  float* g_w1;
+  float* g_b1;
+  float* g_w2;
+  float* g_b2;
+  float pack_add[16];          // addend of every word of packed part i
 };
 
 DTF_API int dtf_mlp_step_supported(long B, long D, long H, long C) {
@@ -213,6 +234,9 @@ DTF_API int dtf_mlp_step_train(const DtfMlpStep* s, hipStream_t stream) {
   if (!dtf_mlp_step_supported(s->B, s->D, s->H, s->C)) return DTF_ERR_UNSUPPORTED;
   if (!s->w1 || !s->b1 || !s->w2 || !s->b2 || !s->loss || !s->a || !s->dz1 || !s->head_ws)
     return DTF_ERR_BAD_ARG;
+  const bool grads = s->g_w1 || s->g_b1 || s->g_w2 || s->g_b2;
+  if (grads && !(s->g_w1 && s->g_b1 && s->g_w2 && s->g_b2)) return DTF_ERR_BAD_ARG;
+  if (grads && s->ncounters != 0) return DTF_ERR_BAD_ARG;     // the update launch bumps them
   const bool x_direct = !(ringed && s->x_index >= 0);
   const bool l_direct = !(ringed && s->labels_index >= 0);
   if ((x_direct && !s->x) || (l_direct && !s->labels)) return DTF_ERR_BAD_ARG;
@@ -226,9 +250,9 @@ DTF_API int dtf_mlp_step_train(const DtfMlpStep* s, hipStream_t stream) {
                          (float*)s->ring_out, s->ring, s->host_seq};
 
   TailArgs tail = {};
-  tail.w2 = s->w2;
-  tail.b2 = s->b2;
-  tail.b1 = s->b1;
+  tail.w2 = grads ? nullptr : s->w2;
+  tail.b2 = grads ? nullptr : s->b2;
+  tail.b1 = grads ? nullptr : s->b1;
   tail.lr_w2 = s->lr_w2;
   tail.lr_b2 = s->lr_b2;
   tail.lr_b1 = s->lr_b1;
@@ -244,6 +268,7 @@ DTF_API int dtf_mlp_step_train(const DtfMlpStep* s, hipStream_t stream) {
   for (int i = 0; i < s->npack; ++i) {
     if (!s->pack_src[i] || s->pack_size[i] < 0) return DTF_ERR_BAD_ARG;
     tail.src[i] = s->pack_src[i];
+    tail.add[i] = s->pack_add[i];
     tail.offset[i] = off;
     off += s->pack_size[i];
   }
@@ -276,13 +301,23 @@ DTF_API int dtf_mlp_step_train(const DtfMlpStep* s, hipStream_t stream) {
   // 3. W1 -= lr x^T dz1, next to the small-parameter tail
   {
     const int tiles_m = (D + SK_T - 1) / SK_T, tiles_n = (H + SK_T - 1) / SK_T;
-    const SkinnyArgs g{x_direct ? s->x : nullptr, s->dz1, s->w1, nullptr, D, H, B, (long)D, (long)H,
-                       (long)H, DTF_ACT_NONE, s->lr_w1, tiles_n};
+    const SkinnyArgs g{x_direct ? s->x : nullptr, s->dz1, grads ? s->g_w1 : s->w1, nullptr, D, H,
+                       B, (long)D, (long)H, (long)H, DTF_ACT_NONE, s->lr_w1, tiles_n};
     const int tail_blocks = 1 + (H * C + C + H + HT - 1) / HT;
     if (ringed && !s->ring_last && s->npack > 0) return DTF_ERR_BAD_ARG;
-    hipLaunchKernelGGL(mlp_step_update_kernel, dim3(tail_blocks + tiles_m * tiles_n),
-                       dim3(NTHREADS), 0, stream, g, head, tail, ring,
-                       x_direct ? -1 : s->x_index, tail_blocks, s->ring_last);
+    if (grads) {
+      HeadArgs sums = head;           // the tail leaves the block-ordered sums here
+      sums.dw = s->g_w2;
+      sums.db = s->g_b2;
+      sums.db_prev = s->g_b1;
+      hipLaunchKernelGGL(mlp_step_update_kernel<false>, dim3(tail_blocks + tiles_m * tiles_n),
+                         dim3(NTHREADS), 0, stream, g, sums, tail, ring,
+                         x_direct ? -1 : s->x_index, tail_blocks, s->ring_last);
+    } else {
+      hipLaunchKernelGGL(mlp_step_update_kernel<true>, dim3(tail_blocks + tiles_m * tiles_n),
+                         dim3(NTHREADS), 0, stream, g, head, tail, ring,
+                         x_direct ? -1 : s->x_index, tail_blocks, s->ring_last);
+    }
   }
   DTF_LAUNCH_CHECK();
   return DTF_OK;

@@ -173,6 +173,8 @@ def _declare(L: ctypes.CDLL) -> None:
         "dtf_sign_f32": [P, P, LG, P],
         "dtf_mse_f32": [P, P, P, LG, P, P],
         "dtf_mse_grad_f32": [P, P, P, P, LG, P],
+        "dtf_mse_step_supported": [LG, LG, I],
+        "dtf_mse_step_f32": [P, P, P, F, P, P, P, LG, LG, I, P, P, P, P, P, P, I, I, P],
         "dtf_select_f32": [P, P, P, P, LG, LG, LG, LG, P],
         "dtf_one_hot_f32": [P, I, P, LG, LG, F, F, P],
         "dtf_broadcast_mid_f32": [P, P, LG, LG, LG, F, P],
@@ -1496,7 +1498,9 @@ class _MlpStep(ctypes.Structure):
                 ("ring_out", ctypes.c_void_p), ("ring", ctypes.c_int),
                 ("x_index", ctypes.c_int), ("labels_index", ctypes.c_int),
                 ("ring_first", ctypes.c_int), ("ring_last", ctypes.c_int),
-                ("host_seq", ctypes.c_long)]
+                ("host_seq", ctypes.c_long),
+                ("g_w1", ctypes.c_void_p), ("g_b1", ctypes.c_void_p), ("g_w2", ctypes.c_void_p),
+                ("g_b2", ctypes.c_void_p), ("pack_add", ctypes.c_float * 16)]
 
 
 def mlp_step_supported(b: int, d: int, h: int, c: int) -> bool:
@@ -1526,7 +1530,9 @@ def mlp_step_train(x: Optional[torch.Tensor], labels: Optional[torch.Tensor], w1
                    counters: Sequence[torch.Tensor] = (), deltas: Sequence[float] = (),
                    pack: Sequence[torch.Tensor] = (), pack_out: Optional[torch.Tensor] = None,
                    signal=None, ring: Optional[RingArgs] = None, x_index: int = -1,
-                   labels_index: int = -1, ring_last: bool = True):
+                   labels_index: int = -1, ring_last: bool = True,
+                   grads: Optional[Sequence[torch.Tensor]] = None,
+                   pack_adds: Optional[Sequence[float]] = None):
     """One SGD step of ``softmax(sigmoid(x w1 + b1) w2 + b2)`` under cross-entropy in three
     launches (``csrc/kernels/mlp_step.hip``): parameters are updated in place
     (``lrs = (lr_w1, lr_b1, lr_w2, lr_b2)``), ``counters[j] += deltas[j]``, loss / accuracy /
@@ -1537,6 +1543,12 @@ def mlp_step_train(x: Optional[torch.Tensor], labels: Optional[torch.Tensor], w1
     entries the batch is read through (``x`` / ``labels`` may then be ``None``), and
     ``ring_last`` says that this step's last launch is the last ring kernel of the captured step
     (it gathers ``pack`` into the ring, stamps the slot and opens the next replay).
+
+    ``grads = (g_w1, g_b1, g_w2, g_b2)``: gradient mode -- the same three launches leave the four
+    gradients in these tensors (shaped like the parameters; e.g. the slots of a flat gradient
+    arena) and write neither parameters nor counters: the caller's collective and update launch
+    follow. ``pack_adds[i]`` is added to every word of packed part i (a step counter fetched
+    ahead of the launch that bumps it).
 
     Returns the argument block of the call: ``lib().dtf_mlp_step_train(ctypes.byref(block),
     stream)`` issues the same step again (every tensor named here must still be alive)."""
@@ -1573,6 +1585,16 @@ def mlp_step_train(x: Optional[torch.Tensor], labels: Optional[torch.Tensor], w1
     a.y = scratch["y"].data_ptr() if want_softmax else None
     a.a, a.dz1 = scratch["a"].data_ptr(), scratch["dz1"].data_ptr()
     a.head_ws = scratch["head_ws"].data_ptr()
+    if grads is not None:
+        if len(grads) != 4 or counters:
+            raise HipKernelError("mlp_step_train: gradient mode takes four destinations and no "
+                                 "counters")
+        g_w1, g_b1 = need(grads[0], (d, h), "g_w1"), need(grads[1], (h,), "g_b1")
+        g_w2, g_b2 = need(grads[2], (h, c), "g_w2"), need(grads[3], (c,), "g_b2")
+        a.g_w1, a.g_b1 = g_w1.data_ptr(), g_b1.data_ptr()
+        a.g_w2, a.g_b2 = g_w2.data_ptr(), g_b2.data_ptr()
+    if pack_adds is not None and len(pack_adds) != len(pack):
+        raise HipKernelError("mlp_step_train: one addend per packed part")
     if len(counters) != len(deltas) or len(counters) > 4:
         raise HipKernelError("mlp_step_train: at most 4 counters, one delta each")
     a.ncounters = len(counters)
@@ -1589,6 +1611,7 @@ def mlp_step_train(x: Optional[torch.Tensor], labels: Optional[torch.Tensor], w1
         t = _req(t, torch.float32, "mlp_step packed part")
         a.pack_src[i] = t.data_ptr()
         a.pack_size[i] = t.numel()
+        a.pack_add[i] = float(pack_adds[i]) if pack_adds is not None else 0.0
         total += t.numel()
     if total > RING_WORDS - 1:
         raise HipKernelError("mlp_step_train: more than %d packed words" % (RING_WORDS - 1))
@@ -1761,6 +1784,71 @@ def mse_grad(a: torch.Tensor, b: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
     _check(lib().dtf_mse_grad_f32(a.data_ptr(), b.data_ptr(), g.data_ptr(), out.data_ptr(),
                                   a.numel(), _stream()), "mse_grad")
     return out
+
+
+def mse_step_supported(rows: int, cols: int, want_dbias: bool) -> bool:
+    return bool(lib().dtf_mse_step_supported(int(rows), int(cols), int(bool(want_dbias))))
+
+
+def mse_step(pred: torch.Tensor, labels: torch.Tensor, g=1.0, want_dbias: bool = False,
+             out: Optional[Sequence[torch.Tensor]] = None, ring: Optional["RingArgs"] = None,
+             pack: Optional[Sequence[torch.Tensor]] = None,
+             pack_adds: Optional[Sequence[float]] = None):
+    """``loss = mean((pred - labels) ** 2)``, ``dpred = (2 g / n) (pred - labels)`` and (rank-2
+    operands, ``want_dbias``) ``dbias = dpred.sum(0)`` in ONE launch (``csrc/kernels/mse_step.hip``;
+    bit-identical to ``mse`` + ``mse_grad`` + ``reduce_cols``). ``g``: a number or an fp32 device
+    scalar. ``out = (loss, dpred[, dbias])``: destinations to reuse. With a ``ring`` and ``pack``
+    (a list, possibly empty) the launch also gathers those small fp32 tensors (+ ``pack_adds``)
+    into the replay's slot of the step ring, stamps it and opens the next replay.
+    Returns ``(loss, dpred, dbias or None)``."""
+    pred = _req(pred, torch.float32, "mse_step pred")
+    labels = _req(labels, torch.float32, "mse_step labels")
+    if pred.shape != labels.shape or pred.numel() == 0 or not pred.is_contiguous() \
+            or not labels.is_contiguous():
+        raise HipKernelError("mse_step: contiguous operands of the same non-empty shape")
+    if want_dbias and pred.dim() != 2:
+        raise HipKernelError("mse_step: the bias gradient needs rank-2 operands")
+    rows, cols = (pred.shape if pred.dim() == 2 else (pred.numel(), 1))
+    if not mse_step_supported(rows, cols, want_dbias):
+        raise HipKernelError("mse_step: shape %s is outside the fused launch" % (tuple(pred.shape),))
+    if out is not None:
+        loss, dpred = out[0], out[1]
+        dbias = out[2] if want_dbias else None
+    else:
+        loss = torch.empty((), dtype=torch.float32, device=pred.device)
+        dpred = torch.empty_like(pred)
+        dbias = torch.empty((cols,), dtype=torch.float32, device=pred.device) if want_dbias \
+            else None
+    g_dev, g_const = None, 0.0
+    if isinstance(g, torch.Tensor):
+        g_dev = _req(g, torch.float32, "mse_step g").data_ptr()
+    else:
+        g_const = float(g)
+    c = ctypes
+    npack, src, sizes, add_arr = -1, None, None, None
+    ring_ptrs = (None, None, None, 0, 0)
+    if ring is not None:
+        parts = [_req(t, torch.float32, "mse_step packed part") for t in (pack or ())] \
+            if pack is not None else None
+        if parts is not None:
+            if len(parts) > 16 or sum(t.numel() for t in parts) > RING_WORDS - 1:
+                raise HipKernelError("mse_step: too many packed words")
+            npack = len(parts)
+            m = max(npack, 1)
+            src = (c.c_void_p * m)(*[t.data_ptr() for t in parts])
+            sizes = (c.c_int * m)(*[t.numel() for t in parts])
+            if pack_adds is not None:
+                if len(pack_adds) != npack:
+                    raise HipKernelError("mse_step: one addend per packed part")
+                add_arr = (c.c_float * m)(*[float(a) for a in pack_adds])
+            ring_ptrs = (ring.table.data_ptr(), ring.ctr.data_ptr(), ring.out.data_ptr(),
+                         ring.slots, ring.take_first())
+    elif pack is not None:
+        raise HipKernelError("mse_step: a gather needs the step ring")
+    _check(lib().dtf_mse_step_f32(pred.data_ptr(), labels.data_ptr(), g_dev, g_const,
+                                  loss.data_ptr(), dpred.data_ptr(), _ptr(dbias), rows, cols,
+                                  npack, src, sizes, add_arr, *ring_ptrs, _stream()), "mse_step")
+    return loss, dpred, dbias
 
 
 def sign(x: torch.Tensor) -> torch.Tensor:

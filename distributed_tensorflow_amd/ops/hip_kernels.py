@@ -493,6 +493,56 @@ def _mean_squared_error_grad(op, inputs, ctx):
     return [hip.mse_grad(a, b, g)]
 
 
+@hip_kernel("MSELossStep")
+def _mse_loss_step(op, inputs, ctx):
+    """Loss, gradient and bias gradient of a mean-squared-error step in one launch
+    (``csrc/kernels/mse_step.hip``; larger shapes: the separate kernels). Inside a captured step
+    the launch also gathers the step's small results for the host when the session asks it to."""
+    pred, labels = inputs[0], inputs[1]
+    g = inputs[2] if len(inputs) > 2 else float(op.attrs["g_const"])
+    want_db = bool(op.attrs.get("emit_bias_grad"))
+    if not _is_f32(pred, labels) or pred.shape != labels.shape or \
+            (isinstance(g, torch.Tensor) and not _is_f32(g)):
+        return _fallback("MSELossStep", op, inputs, ctx)
+    pred = pred if pred.is_contiguous() else pred.contiguous()
+    labels = labels if labels.is_contiguous() else labels.contiguous()
+    rows, cols = (pred.shape if pred.dim() == 2 else (pred.numel(), 1))
+    if hip.mse_step_supported(rows, cols, want_db):
+        loss = torch.empty((), dtype=_f32, device=pred.device)
+        dpred = _hint(ctx, 1, pred.shape)
+        outs = [loss, dpred if dpred is not None else torch.empty_like(pred)]
+        if want_db:
+            db = _hint(ctx, 2, (cols,))
+            outs.append(db if db is not None
+                        else torch.empty((cols,), dtype=_f32, device=pred.device))
+        ring, req = ctx.ring, ctx.pack_request
+        pack = adds = None
+        if ring is not None and req is not None:
+            parts = req.parts_for(op, outs)
+            if parts is not None and not any(_spans_overlap(t, o) for t in parts
+                                             for o in outs[1:]):
+                adds = req.addends(parts)
+                if adds is not None:
+                    pack = parts
+                    req.claim()
+        hip.mse_step(pred, labels, g, want_db, out=outs, ring=ring if pack is not None else None,
+                     pack=pack, pack_adds=adds)
+        return list(outs)
+    if not isinstance(g, torch.Tensor):
+        key = ("scalar", g)
+        gt = ctx.const_cache.get(key)
+        if gt is None:
+            gt = hip.fill((), g, ctx.device)
+            if not torch.cuda.is_current_stream_capturing():
+                ctx.const_cache[key] = gt
+        g = gt
+    dpred = hip.mse_grad(pred, labels, g)
+    outs = [hip.mse(pred, labels), dpred]
+    if want_db:
+        outs.append(hip.reduce_cols(dpred))
+    return outs
+
+
 @hip_kernel("Select")
 def _select(op, inputs, ctx):
     cond, a, b = inputs
@@ -650,12 +700,32 @@ def _assign(op, inputs, ctx):
 def _multi_apply_sgd(op, inputs, ctx):
     """One launch for every local fp32 variable; anything else (remote parameter-server
     variables, other dtypes) goes through the store interface."""
-    var_ops = op.attrs["var_ops"]
-    lrs = op.attrs["learning_rates"]
-    if ctx.sharded_sgd(var_ops, list(inputs), lrs):      # reduce-scatter / owner update / gather
-        inputs, var_ops, lrs = [], [], []
-    else:
-        inputs = ctx.reduce_gradients(list(inputs), var_ops)   # no-op without a sync runtime
+    var_ops = list(op.attrs["var_ops"])
+    lrs = list(op.attrs["learning_rates"])
+    inputs = list(inputs)
+    counters, deltas, rest_counters = [], [], []
+    for var_op, delta in op.attrs.get("counter_increments", []):
+        store = ctx.session._store_for(var_op)
+        fast = getattr(store, "local_tensor", None)
+        c = fast(var_op.name) if fast is not None else None
+        if c is not None and c.dtype == _f32 and c.is_cuda and c.numel() == 1 \
+                and len(counters) < 4:
+            counters.append(c)
+            deltas.append(delta)
+        else:
+            rest_counters.append((var_op, delta))
+    # reduce_scatter_sync: reduce-scatter / owner update (+ the step counters, same launch) /
+    # all-gather
+    done = ctx.sharded_apply("sgd", (), var_ops, inputs, lrs=lrs, counters=counters,
+                             deltas=deltas)
+    if done:
+        if ctx.counters_applied():
+            counters, deltas = [], []
+        keep = [i for i in range(len(var_ops)) if i not in set(done)]
+        var_ops, lrs = [var_ops[i] for i in keep], [lrs[i] for i in keep]
+        inputs = [inputs[i] for i in keep]
+    if var_ops:
+        inputs = ctx.reduce_gradients(inputs, var_ops)   # no-op without a sync runtime
     local_p, local_g, local_lr, rest = [], [], [], []
     for var_op, lr, g in zip(var_ops, lrs, inputs):
         store = ctx.session._store_for(var_op)
@@ -668,17 +738,6 @@ def _multi_apply_sgd(op, inputs, ctx):
             store.update_count += 1
         else:
             rest.append((var_op, lr, g))
-    counters, deltas, rest_counters = [], [], []
-    for var_op, delta in op.attrs.get("counter_increments", []):
-        store = ctx.session._store_for(var_op)
-        fast = getattr(store, "local_tensor", None)
-        c = fast(var_op.name) if fast is not None else None
-        if c is not None and c.dtype == _f32 and c.is_cuda and c.numel() == 1 \
-                and len(counters) < 4:
-            counters.append(c)
-            deltas.append(delta)
-        else:
-            rest_counters.append((var_op, delta))
     if local_p or counters:
         hip.multi_sgd(local_p, local_g, local_lr, counters, deltas)
     for var_op, lr, g in rest:
@@ -884,6 +943,84 @@ def _mlp_train_step(op, inputs, ctx):
     acc = hip.argmax_accuracy(y, labels) if want_acc else None
     hip.multi_sgd([w1, b1, w2, b2], [dw1, db1, dw2, db2], lrs, counters, deltas)
     return [loss, y] + ([acc] if want_acc else [])
+
+
+@hip_kernel("MLPStepGrads")
+def _mlp_step_grads(op, inputs, ctx):
+    """Forward and backward of the two-layer classifier ending in its four gradients: the three
+    launches of ``csrc/kernels/mlp_step.hip`` in gradient mode. The gradients are written where
+    the session placed them (the slots of the collective runtime's flat gradient arena) or into
+    buffers of the node; inside a captured step the batch is read through the step ring and the
+    step's small results ride on the third launch when the session asks for that. Shapes beyond
+    the small-step kernels run the chain of general kernels."""
+    x, labels = inputs
+    params = []
+    for v in op.attrs["var_ops"]:
+        p = _local_f32(ctx, v)
+        if p is None:
+            raise hip.HipKernelError("MLPStepGrads: variable %s is not local fp32 GPU storage"
+                                     % v.name)
+        params.append(p)
+    if not _is_f32(x, labels) or x.dim() != 2 or labels.dim() != 2:
+        return _fallback("MLPStepGrads", op, inputs, ctx)
+    w1, b1, w2, b2 = params
+    b, d = x.shape
+    h, c = w2.shape
+    want_acc = bool(op.attrs.get("emit_accuracy"))
+    dloss = float(op.attrs["dloss_const"])
+    base = 3 if want_acc else 2
+    dests = []
+    for i, p in enumerate(params):
+        t = _hint(ctx, base + i, p.shape)
+        if t is None:
+            key = (op, "grad", i, b)
+            t = ctx.buffers.get(key)
+            if t is None or t.shape != p.shape:
+                t = ctx.buffers[key] = torch.empty_like(p)
+        dests.append(t)
+    if hip.mlp_step_supported(b, d, h, c):
+        key = (op, "scratch", b)
+        scratch = ctx.buffers.get(key)
+        if scratch is None:
+            scratch = ctx.buffers[key] = hip.mlp_step_scratch(b, d, h, c, ctx.device)
+        outs = [scratch["loss"], scratch["y"]] + ([scratch["accuracy"]] if want_acc else [])
+        ring = ctx.ring
+        pack, adds, req, claimed = (), None, ctx.pack_request, False
+        if ring is not None and req is not None:
+            parts = req.parts_for(op, outs + dests)
+            # (a gathered value must not be one the launch is still writing in other workgroups)
+            if parts is not None and not any(_spans_overlap(t, g) for t in parts for g in dests):
+                adds = req.addends(parts)
+                if adds is not None:
+                    pack, claimed = parts, True
+                    req.claim()
+        xi = li = -1
+        if ring is not None:
+            xi = ctx.ring_feeds.get(x.data_ptr(), -1)
+            li = ctx.ring_feeds.get(labels.data_ptr(), -1)
+        hip.mlp_step_train(
+            x, labels, w1, b1, w2, b2, (0.0, 0.0, 0.0, 0.0), scratch, (b, d, h, c), dloss=dloss,
+            want_accuracy=want_acc, want_softmax=True, pack=pack,
+            ring=ring if (claimed or xi >= 0 or li >= 0) else None,
+            x_index=xi, labels_index=li, ring_last=claimed, grads=dests,
+            pack_adds=adds if claimed else None)
+        return outs + dests
+    key = ("scalar", dloss)
+    dl = ctx.const_cache.get(key)
+    if dl is None:
+        dl = hip.fill((), dloss, ctx.device)
+        if not torch.cuda.is_current_stream_capturing():
+            ctx.const_cache[key] = dl
+    a = hip.gemm_f32(x, w1, bias=b1, activation=hip.ACT_SIGMOID)
+    z = hip.gemm_f32(a, w2, bias=b2)
+    loss, y, _ = hip.softmax_xent(z, labels)
+    dz, db2 = hip.softmax_xent_grad(y, labels, dl, True)
+    dw2 = hip.gemm_f32(a, dz, trans_a=True, out=dests[2])
+    da = hip.gemm_f32(dz, w2, trans_b=True)
+    dz1, db1 = hip.sigmoid_grad_bias(da, a)
+    dw1 = hip.gemm_f32(x, dz1, trans_a=True, out=dests[0])
+    acc = hip.argmax_accuracy(y, labels) if want_acc else None
+    return [loss, y] + ([acc] if want_acc else []) + [dw1, db1, dw2, db2]
 
 
 @hip_kernel("ApplyGradientDescent")

@@ -306,6 +306,21 @@ def _mean_squared_error_grad(op, inputs, ctx):
     return [(2.0 * g / a.numel()) * (a - b)]
 
 
+@ref_kernel("MSELossStep")
+def _mse_loss_step(op, inputs, ctx):
+    """(pred, labels[, g]) -> (loss, dpred[, dbias]): mean squared error, its gradient with
+    respect to ``pred`` for d(loss) = g (constant ``g_const`` without the third input) and the
+    column sums of that gradient."""
+    pred, labels = inputs[0], inputs[1]
+    g = inputs[2] if len(inputs) > 2 else op.attrs["g_const"]
+    d = pred - labels
+    dpred = (2.0 * g / pred.numel()) * d
+    outs = [(d * d).mean(), dpred]
+    if op.attrs.get("emit_bias_grad"):
+        outs.append(dpred.sum(dim=0))
+    return outs
+
+
 @ref_kernel("Select")
 def _select(op, inputs, ctx):
     return [torch.where(inputs[0], inputs[1], inputs[2])]
@@ -620,6 +635,22 @@ def _mlp_train_step(op, inputs, ctx):
     if op.attrs.get("emit_accuracy"):
         outs.append(h[6])
     return outs
+
+
+@ref_kernel("MLPStepGrads")
+def _mlp_step_grads(op, inputs, ctx):
+    """(x, labels) -> (loss, softmax[, accuracy], dW1, db1, dW2, db2): forward and backward of
+    the two-layer classifier, the nodes it replaces (``attrs["parts"]``) run one after the
+    other; nothing is updated."""
+    x, labels = inputs
+    dense, head, _dw1_op = op.attrs["parts"]
+    w1, b1, w2, b2 = (ctx.var_read(v) for v in op.attrs["var_ops"])
+    a = _fused_dense(dense, [x, w1, b1], ctx)[0]
+    h = _classifier_head_train(head, [a, w2, b2, labels], ctx)
+    outs = [h[0], h[1]]
+    if op.attrs.get("emit_accuracy"):
+        outs.append(h[6])
+    return outs + [x.t() @ h[4], h[5], h[2], h[3]]
 
 
 @ref_kernel("BiasGrad")

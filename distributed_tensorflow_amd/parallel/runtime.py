@@ -231,6 +231,7 @@ class CollectiveRuntime(LocalRuntime):
         self.bytes_reduced = 0
         self.bytes_gathered = 0
         self.sharded_steps = 0             # steps that took the reduce-scatter / owner-update path
+        self.counters_applied = False      # the last sharded_apply also bumped the step counters
         self.grads_in_place = 0            # gradients found already in their arena slot
         self.grads_copied = 0              # gradients that had to be copied into it
         self._grad_views: Optional[Dict[str, torch.Tensor]] = None
@@ -646,7 +647,9 @@ class CollectiveRuntime(LocalRuntime):
                       grads: Sequence[torch.Tensor],
                       slot_names: Optional[Sequence[Sequence[str]]] = None,
                       powers: Sequence[torch.Tensor] = (), lr: Optional[torch.Tensor] = None,
-                      lrs: Optional[Sequence[float]] = None) -> Optional[List[int]]:
+                      lrs: Optional[Sequence[float]] = None,
+                      counters: Sequence[torch.Tensor] = (),
+                      deltas: Sequence[float] = ()) -> Optional[List[int]]:
         """``reduce_scatter_sync``: reduce-scatter the flat gradient arena to the shard owners,
         apply the optimizer's rule on the owned shard only, all-gather the updated parameters --
         the collective image of "variables live on the parameter server, gradients are pushed to
@@ -661,8 +664,14 @@ class CollectiveRuntime(LocalRuntime):
         Scalars that advance with the step (powers, counters) stay replicated; the caller
         advances them on every rank alike.
 
+        ``counters`` / ``deltas`` (plain gradient descent on a GPU): replicated step counters the
+        update launch bumps on its way (``counter += delta`` on every rank alike, before the
+        all-gather, so the owner's copy and everybody else's agree); ``counters_applied`` tells
+        the caller whether that happened.
+
         Returns the indices of the variables updated here (the caller sends the others down the
         all-reduce path), ``None`` when the strategy or the storage does not allow it."""
+        self.counters_applied = False
         if self.strategy != "reduce_scatter_sync" or self._flat_params is None or not grads:
             return None
         slot_names = [()] * len(names) if slot_names is None else list(slot_names)
@@ -690,7 +699,13 @@ class CollectiveRuntime(LocalRuntime):
         self.comm.reduce_scatter(g_shard, flat_g,
                                  "avg" if self.grad_aggregation == "mean" else "sum")
         segs = self._segments_for(rule, t_names, [slot_names[i] for i in take])
-        if segs:
+        if self.device.type == "cuda" and rule == "sgd" and lr is None and counters \
+                and len(segs) <= 16:
+            from ..ops import hip
+            hip.multi_sgd([s[1] for s in segs], [s[2] for s in segs],
+                          [lrs[take[s[0]]] for s in segs], list(counters), list(deltas))
+            self.counters_applied = True
+        elif segs:
             ps = [s[1] for s in segs]
             gs = [s[2] for s in segs]
             if self.device.type == "cuda":

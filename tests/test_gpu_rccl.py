@@ -434,3 +434,57 @@ def test_native_communicator_watchdog_turns_a_stuck_collective_into_comm_error()
     comm.close()
     torch.cuda.synchronize()
     assert torch.equal(t.cpu(), torch.ones(8))  # the device is fine, only the communicator went
+
+
+@pytest.mark.parametrize("optimizer", ["sgd", "adam"])
+@pytest.mark.parametrize("strategy", ["reduce_scatter_sync"])
+def test_gradient_step_node_on_the_gpu_equals_the_kernel_chain(nccl_comm, strategy, optimizer):
+    """Captured steps under the collective runtime (RCCL, world of one): with ``step_fusion`` the
+    step is the three launches of the small-step kernels in gradient mode (gradients straight
+    into the arena, the small results gathered by the third launch), the collective and ONE
+    update launch; without it the chain of general kernels. 100 steps, bit for bit."""
+    import distributed_tensorflow_amd as tf
+    from distributed_tensorflow_amd.models import mnist_mlp
+    from distributed_tensorflow_amd.train.server import _free_port
+    rng = np.random.RandomState(21)
+    batches = [(rng.rand(100, 784).astype(np.float32),
+                np.eye(10, dtype=np.float32)[rng.randint(0, 10, 100)]) for _ in range(7)]
+
+    def run(fused):
+        g = tf.Graph()
+        with g.as_default():
+            cfg = tf.ConfigProto(device="cuda:0", strategy=strategy, step_fusion=fused,
+                                 capture_collectives=True)
+            cluster = tf.train.ClusterSpec({"worker": ["127.0.0.1:%d" % _free_port()]})
+            server = tf.train.Server(cluster, job_name="worker", task_index=0, protocol="rccl",
+                                     config=cfg, comm=nccl_comm)
+            with tf.device(tf.train.replica_device_setter(cluster=cluster)):
+                opt = tf.train.AdamOptimizer(0.01) if optimizer == "adam" else None
+                model = mnist_mlp.build_model(learning_rate=0.01, seed=1, optimizer=opt)
+            sv = tf.train.Supervisor(is_chief=True, global_step=model.global_step,
+                                     init_op=model.init_op)
+            sess = sv.prepare_or_wait_for_session(server.target, config=cfg)
+            hist = []
+            for i in range(100):
+                bx, by = batches[i % len(batches)]
+                _, l, a, st = sess.run([model.train_op, model.loss, model.accuracy,
+                                        model.global_step], {model.x: bx, model.y_: by})
+                hist.append((float(l), float(a), float(st)))
+            variables = sess.run([model.w1, model.b1, model.w2, model.b2])
+            types = {s.node.type for p in sess._plans.values() for s in p.steps}
+            stats = dict(sess.stats)
+            placed = (server.runtime.grads_in_place, server.runtime.grads_copied)
+            sess.close()
+            sv.stop()
+        return hist, variables, types, stats, placed
+
+    chain, fused = run(False), run(True)
+    assert "MLPStepGrads" in fused[2] and "MLPStepGrads" not in chain[2]
+    assert fused[3]["graph_replays"] >= 95 and fused[3]["torch_fallbacks"] == 0
+    # every gradient was produced in its arena slot whenever Python ran the step (the first,
+    # eager run and the capture; replays run no Python)
+    assert fused[4][1] == 0 and fused[4][0] >= 4
+    assert fused[0] == chain[0]
+    assert fused[0][-1][2] == 100.0
+    for p, q in zip(fused[1], chain[1]):
+        assert np.array_equal(p, q)

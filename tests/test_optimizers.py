@@ -858,3 +858,59 @@ def test_moving_average_on_a_parameter_server_lives_with_its_variable():
     assert np.abs(results[0]["avg_b2"]).max() > 0
     assert not np.array_equal(results[0]["avg"], results[0]["w1"])
     ps.stop()
+
+
+@pytest.mark.parametrize("opt", ["sgd", "adam"])
+@pytest.mark.parametrize("strategy", ["allreduce_sync", "reduce_scatter_sync"])
+def test_gradient_step_node_equals_the_chain_of_general_nodes(strategy, opt):
+    """Two loopback ranks: with ``step_fusion`` the forward and backward of the classifier are ONE
+    node ending in the four gradients (``MLPStepGrads``; the optimizer node behind the collective
+    is unchanged), without it the chain of fused nodes. Same costs, same replicas, bit for bit."""
+    world, steps = 2, 6
+
+    def run(fused):
+        cluster = _cluster(world)
+        comms = LoopbackComm.create_world(world, timeout_s=30)
+        results = {}
+
+        def job(task):
+            g = tf.Graph()
+            with g.as_default():
+                config = tf.ConfigProto(device="cpu", strategy=strategy, step_fusion=fused)
+                server = tf.train.Server(cluster, job_name="worker", task_index=task,
+                                         protocol="rccl", config=config, comm=comms[task])
+                with tf.device(tf.train.replica_device_setter(
+                        worker_device="/job:worker/task:%d" % task, cluster=cluster)):
+                    m = mnist_mlp.build_model(
+                        seed=1, with_summaries=False,
+                        optimizer=tf.train.AdamOptimizer(0.01) if opt == "adam" else None)
+                sv = tf.train.Supervisor(is_chief=(task == 0), global_step=m.global_step,
+                                         init_op=m.init_op, logdir=None,
+                                         recovery_wait_secs=0.05, summary_op=None)
+                from distributed_tensorflow_amd.data.mnist import synthetic_mnist
+                images, labels = synthetic_mnist(200, seed=task)
+                onehot = np.eye(10, dtype=np.float32)[labels]
+                costs = []
+                with sv.prepare_or_wait_for_session(server.target, config=config) as sess:
+                    for i in range(steps):
+                        lo = 30 * i
+                        _, c, a, st = sess.run([m.train_op, m.loss, m.accuracy, m.global_step],
+                                               {m.x: images[lo:lo + 30], m.y_: onehot[lo:lo + 30]})
+                        costs.append((float(c), float(a), float(st)))
+                    plan_types = {s.node.type for p in sess._plans.values() for s in p.steps}
+                    results[task] = (costs, sess.run(m.w1), sess.run(m.b2), plan_types)
+                sv.stop()
+                server.stop()
+
+        threads = [threading.Thread(target=job, args=(t,)) for t in range(world)]
+        [t.start() for t in threads]
+        [t.join(120) for t in threads]
+        assert set(results) == {0, 1}
+        return results
+
+    chain, fused = run(False), run(True)
+    for t in range(world):
+        assert "MLPStepGrads" in fused[t][3] and "MLPStepGrads" not in chain[t][3]
+        assert "ClassifierHeadTrain" in chain[t][3] and "ClassifierHeadTrain" not in fused[t][3]
+        assert fused[t][0] == chain[t][0]
+        assert np.array_equal(fused[t][1], chain[t][1]) and np.array_equal(fused[t][2], chain[t][2])

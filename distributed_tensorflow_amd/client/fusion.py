@@ -29,6 +29,8 @@ backward chains be replaced without pattern-matching their internals.
 """
 from __future__ import annotations
 
+import os
+
 from typing import Any, Dict, List, Optional, Sequence, Set, Tuple
 
 from ..framework import dtypes
@@ -528,7 +530,8 @@ def build_rewrite(graph: Graph, ops: Sequence[Operation], fed: Set[Tensor],
 
     # -- mean squared error: loss, its gradient and the bias gradient behind it, one node ------
     for op in ops:
-        if op.type != "MeanSquaredError" or op.outputs[0] in fed:
+        if op.type != "MeanSquaredError" or op.outputs[0] in fed \
+                or os.environ.get("DTF_NO_MSE_STEP"):           # (A/B against the separate ops)
             continue
         pred, labels = op.inputs
         loss_t = op.outputs[0]

@@ -1484,6 +1484,11 @@ class Session:
                 if n is None or kb not in (None, k) or \
                         hip.lib().dtf_gemm_f32_tile(int(m), int(n), int(k)) != 16:
                     return False
+            elif t == "MSELossStep" and i == 1:
+                rows, cols = (f.shape if f.dim() == 2 else (f.numel(), 1))
+                if not hip.mse_step_supported(int(rows), int(cols),
+                                              bool(st.node.attrs.get("emit_bias_grad"))):
+                    return False
             elif t == "ClassifierHeadTrain" and i == 3:
                 a_shape = shapes[0]
                 if a_shape is None or len(a_shape) != 2 or a_shape[1] is None or \

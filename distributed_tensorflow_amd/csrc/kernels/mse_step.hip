@@ -43,15 +43,30 @@ struct MseArgs {
   int col_groups;          // row groups of the emulated column sum
 };
 
+// a * b rounded to fp32 as a value of its own: the separate kernels store this product to memory
+// before the column sum adds it, so it must not be contracted into an fma with the running sum
+__device__ __forceinline__ float rounded_product(float a, float b) {
+  float v = a * b;
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
 __global__ __launch_bounds__(MS_THREADS) void mse_step_kernel(MseArgs p, MsePack pack,
-                                                              DtfStepRing ring, int ring_first) {
+                                                              DtfStepRing ring, int ring_first,
+                                                              int labels_index) {
   __shared__ float wave_sums[MS_THREADS / 64];
   __shared__ float partial[1024];
   __shared__ float colsh[MS_THREADS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long n = p.rows * p.cols;
   unsigned seq = 0;
-  if (ring.ctr) seq = ring_first ? dtf_ring_begin(ring) : dtf_ring_current(ring);
+  if (ring.ctr) {
+    seq = ring_first ? dtf_ring_begin(ring) : dtf_ring_current(ring);
+    // the fed labels, where this replay's batch lies (no gather of the feeds in front of the step)
+    if (labels_index >= 0)
+      p.labels = (const float*)(ring_first ? dtf_ring_feed(ring, seq, labels_index)
+                                           : dtf_ring_feed_later(ring, labels_index));
+  }
 
   // ---- loss: partial[vb] as sq_diff_stage1 leaves it for a grid of vblocks x 256 threads ------
   const long nthreads = (long)p.vblocks * MS_BLOCK;
@@ -106,14 +121,14 @@ __global__ __launch_bounds__(MS_THREADS) void mse_step_kernel(MseArgs p, MsePack
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const long idx = (r + (long)u * groups) * p.cols + c;
-          v[u] = s * (p.pred[idx] - p.labels[idx]);
+          v[u] = rounded_product(s, p.pred[idx] - p.labels[idx]);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) acc += v[u];
       }
       for (; r < p.rows; r += groups) {
         const long idx = r * p.cols + c;
-        acc += s * (p.pred[idx] - p.labels[idx]);
+        acc += rounded_product(s, p.pred[idx] - p.labels[idx]);
       }
     }
     colsh[tid] = acc;
@@ -126,7 +141,7 @@ __global__ __launch_bounds__(MS_THREADS) void mse_step_kernel(MseArgs p, MsePack
   }
 
   // ---- the step's small results, for the host ---------------------------------------------------
-  if (!ring.ctr || pack.npack < 0) return;
+  if (!ring.ctr || pack.npack < 0) return;        // (a ring for the labels only: no gather)
   __syncthreads();                     // loss (and anything else of this launch) is written
   float* dst = dtf_ring_out(ring, seq);
   for (int i = 0; i < pack.npack; ++i) {
@@ -150,13 +165,17 @@ DTF_API int dtf_mse_step_supported(long rows, long cols, int want_dbias) {
 // when g_dev is null); dbias = column sums of dpred (may be null). npack >= 0 with a ring: this
 // launch also gathers `npack` small fp32 values (+ adds[i]) into the replay's ring slot, stamps it
 // and opens the next replay (later kernels of the step may still read their inputs through the
-// ring's device-side address copies); npack < 0: no gather.
+// ring's device-side address copies); npack < 0: no gather. labels_index >= 0 (with a ring): the
+// labels are input `labels_index` of the replay's address table (`labels` may then be null).
 DTF_API int dtf_mse_step_f32(const float* pred, const float* labels, const float* g_dev,
                              float g_const, float* loss, float* dpred, float* dbias, long rows,
                              long cols, int npack, const float* const* src, const int* sizes,
                              const float* adds, const void* ring_table, void* ring_ctr,
-                             void* ring_out, int ring, int ring_first, hipStream_t stream) {
-  if (!pred || !labels || !loss || !dpred) return DTF_ERR_BAD_ARG;
+                             void* ring_out, int ring, int ring_first, int labels_index,
+                             hipStream_t stream) {
+  if (!pred || !loss || !dpred) return DTF_ERR_BAD_ARG;
+  if (!labels && !(ring_ctr && labels_index >= 0)) return DTF_ERR_BAD_ARG;
+  if (labels_index >= DTF_RING_FEEDS || (labels_index >= 0 && !ring_table)) return DTF_ERR_BAD_ARG;
   if (!dtf_mse_step_supported(rows, cols, dbias != nullptr)) return DTF_ERR_UNSUPPORTED;
   if (npack > MS_MAX_PACK) return DTF_ERR_BAD_ARG;
   const bool ringed = ring_ctr != nullptr;
@@ -192,7 +211,8 @@ DTF_API int dtf_mse_step_f32(const float* pred, const float* labels, const float
   if (off > DTF_RING_WORDS - 1) return DTF_ERR_BAD_ARG;
   const DtfStepRing r{(const unsigned long long*)ring_table, (unsigned*)ring_ctr, (float*)ring_out,
                       ringed ? ring : 0, -1};
-  hipLaunchKernelGGL(mse_step_kernel, dim3(1), dim3(MS_THREADS), 0, stream, a, pk, r, ring_first);
+  hipLaunchKernelGGL(mse_step_kernel, dim3(1), dim3(MS_THREADS), 0, stream, a, pk, r, ring_first,
+                     ringed ? labels_index : -1);
   DTF_LAUNCH_CHECK();
   return DTF_OK;
 }

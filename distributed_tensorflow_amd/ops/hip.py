@@ -174,7 +174,7 @@ def _declare(L: ctypes.CDLL) -> None:
         "dtf_mse_f32": [P, P, P, LG, P, P],
         "dtf_mse_grad_f32": [P, P, P, P, LG, P],
         "dtf_mse_step_supported": [LG, LG, I],
-        "dtf_mse_step_f32": [P, P, P, F, P, P, P, LG, LG, I, P, P, P, P, P, P, I, I, P],
+        "dtf_mse_step_f32": [P, P, P, F, P, P, P, LG, LG, I, P, P, P, P, P, P, I, I, I, P],
         "dtf_select_f32": [P, P, P, P, LG, LG, LG, LG, P],
         "dtf_one_hot_f32": [P, I, P, LG, LG, F, F, P],
         "dtf_broadcast_mid_f32": [P, P, LG, LG, LG, F, P],
@@ -1793,13 +1793,15 @@ def mse_step_supported(rows: int, cols: int, want_dbias: bool) -> bool:
 def mse_step(pred: torch.Tensor, labels: torch.Tensor, g=1.0, want_dbias: bool = False,
              out: Optional[Sequence[torch.Tensor]] = None, ring: Optional["RingArgs"] = None,
              pack: Optional[Sequence[torch.Tensor]] = None,
-             pack_adds: Optional[Sequence[float]] = None):
+             pack_adds: Optional[Sequence[float]] = None, labels_index: int = -1):
     """``loss = mean((pred - labels) ** 2)``, ``dpred = (2 g / n) (pred - labels)`` and (rank-2
     operands, ``want_dbias``) ``dbias = dpred.sum(0)`` in ONE launch (``csrc/kernels/mse_step.hip``;
     bit-identical to ``mse`` + ``mse_grad`` + ``reduce_cols``). ``g``: a number or an fp32 device
     scalar. ``out = (loss, dpred[, dbias])``: destinations to reuse. With a ``ring`` and ``pack``
     (a list, possibly empty) the launch also gathers those small fp32 tensors (+ ``pack_adds``)
-    into the replay's slot of the step ring, stamps it and opens the next replay.
+    into the replay's slot of the step ring, stamps it and opens the next replay; with a ``ring``
+    and ``labels_index >= 0`` the labels are read where the replay's address table says they lie
+    (``labels`` then only gives the shape).
     Returns ``(loss, dpred, dbias or None)``."""
     pred = _req(pred, torch.float32, "mse_step pred")
     labels = _req(labels, torch.float32, "mse_step labels")
@@ -1841,13 +1843,16 @@ def mse_step(pred: torch.Tensor, labels: torch.Tensor, g=1.0, want_dbias: bool =
                 if len(pack_adds) != npack:
                     raise HipKernelError("mse_step: one addend per packed part")
                 add_arr = (c.c_float * m)(*[float(a) for a in pack_adds])
+        if parts is not None or labels_index >= 0:
             ring_ptrs = (ring.table.data_ptr(), ring.ctr.data_ptr(), ring.out.data_ptr(),
                          ring.slots, ring.take_first())
-    elif pack is not None:
-        raise HipKernelError("mse_step: a gather needs the step ring")
+    elif pack is not None or labels_index >= 0:
+        raise HipKernelError("mse_step: a gather / a ring read needs the step ring")
     _check(lib().dtf_mse_step_f32(pred.data_ptr(), labels.data_ptr(), g_dev, g_const,
                                   loss.data_ptr(), dpred.data_ptr(), _ptr(dbias), rows, cols,
-                                  npack, src, sizes, add_arr, *ring_ptrs, _stream()), "mse_step")
+                                  npack, src, sizes, add_arr, *ring_ptrs,
+                                  int(labels_index) if ring is not None else -1, _stream()),
+           "mse_step")
     return loss, dpred, dbias
 
 

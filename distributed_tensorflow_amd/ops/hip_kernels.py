@@ -525,8 +525,10 @@ def _mse_loss_step(op, inputs, ctx):
                 if adds is not None:
                     pack = parts
                     req.claim()
-        hip.mse_step(pred, labels, g, want_db, out=outs, ring=ring if pack is not None else None,
-                     pack=pack, pack_adds=adds)
+        li = ctx.ring_feeds.get(labels.data_ptr(), -1) if ring is not None else -1
+        hip.mse_step(pred, labels, g, want_db, out=outs,
+                     ring=ring if (pack is not None or li >= 0) else None,
+                     pack=pack, pack_adds=adds, labels_index=li)
         return list(outs)
     if not isinstance(g, torch.Tensor):
         key = ("scalar", g)

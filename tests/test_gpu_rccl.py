@@ -488,3 +488,49 @@ def test_gradient_step_node_on_the_gpu_equals_the_kernel_chain(nccl_comm, strate
     assert fused[0][-1][2] == 100.0
     for p, q in zip(fused[1], chain[1]):
         assert np.array_equal(p, q)
+
+
+def test_fused_regression_step_equals_the_separate_kernels(nccl_comm, monkeypatch):
+    """The linear-regression step (``models/linear_regression.py``) under the collective runtime,
+    captured: with the fused loss / gradient / bias-gradient launch (which also gathers the
+    step's results) against the separate kernels -- 100 steps, bit for bit."""
+    import distributed_tensorflow_amd as tf
+    from distributed_tensorflow_amd.models import linear_regression as lr
+    from distributed_tensorflow_amd.train.server import _free_port
+    data = lr.SyntheticRegressionData(256, 1, task=0)
+    batches = [data.next_batch(64) for _ in range(5)]
+
+    def run(fused):
+        if fused:
+            monkeypatch.delenv("DTF_NO_MSE_STEP", raising=False)
+        else:
+            monkeypatch.setenv("DTF_NO_MSE_STEP", "1")
+        g = tf.Graph()
+        with g.as_default():
+            cfg = tf.ConfigProto(device="cuda:0", strategy="reduce_scatter_sync",
+                                 capture_collectives=True)
+            cluster = tf.train.ClusterSpec({"worker": ["127.0.0.1:%d" % _free_port()]})
+            server = tf.train.Server(cluster, job_name="worker", task_index=0, protocol="rccl",
+                                     config=cfg, comm=nccl_comm)
+            with tf.device(tf.train.replica_device_setter(cluster=cluster)):
+                m = lr.build_model(features=256, outputs=1, learning_rate=0.05)
+            sv = tf.train.Supervisor(is_chief=True, global_step=m.global_step, init_op=m.init_op)
+            sess = sv.prepare_or_wait_for_session(server.target, config=cfg)
+            hist = []
+            for i in range(100):
+                bx, by = batches[i % len(batches)]
+                _, l, st = sess.run([m.train_op, m.loss, m.global_step], {m.x: bx, m.y_: by})
+                hist.append((float(l), float(st)))
+            w, b = sess.run([m.w, m.b])
+            types = {s.node.type for p in sess._plans.values() for s in p.steps}
+            stats = dict(sess.stats)
+            sess.close()
+            sv.stop()
+        return hist, w, b, types, stats
+
+    chain, fused = run(False), run(True)
+    assert "MSELossStep" in fused[3] and "MSELossStep" not in chain[3]
+    assert fused[4]["graph_replays"] >= 95 and fused[4]["torch_fallbacks"] == 0
+    assert fused[0] == chain[0] and fused[0][-1][1] == 100.0
+    assert fused[0][-1][0] < 0.05 * fused[0][0][0]            # it learns
+    assert np.array_equal(fused[1], chain[1]) and np.array_equal(fused[2], chain[2])

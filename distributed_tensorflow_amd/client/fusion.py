@@ -649,6 +649,50 @@ def build_rewrite(graph: Graph, ops: Sequence[Operation], fed: Set[Tensor],
                 node.attrs["scalar_updates"].append(
                     (op.inputs[0].op, 1.0, float(op.inputs[1].op.attrs["value"])))
                 rw.op_map[op] = node
+    # -- moving averages: every shadow of a step in one multi-tensor launch -------------------
+    # shadow -= rate * (shadow - variable), built by ExponentialMovingAverage.apply as
+    # AssignSub(shadow, Mul(Sub(shadow, variable), rate)) per variable
+    ema_groups: Dict[Any, List[Any]] = {}
+    for op in ops:
+        if op.type != "AssignSub" or consumers.get(op.outputs[0]) or op.outputs[0] in fetched:
+            continue
+        shadow_t, delta_t = op.inputs
+        mul = delta_t.op
+        if shadow_t.op.type != "VariableV2" or mul not in alive or mul.type != "Mul" \
+                or not only_consumer(delta_t, op) or delta_t in fed or delta_t in fetched:
+            continue
+        sub_t, rate_t = mul.inputs
+        sub = sub_t.op
+        if sub not in alive or sub.type != "Sub" or sub.inputs[0] is not shadow_t \
+                or not only_consumer(sub_t, mul) or sub_t in fed or sub_t in fetched:
+            continue
+        var_t = sub.inputs[1]
+        if var_t.op.type != "VariableV2" or var_t.dtype != dtypes.float32 \
+                or shadow_t.dtype != dtypes.float32 or var_t.shape != shadow_t.shape:
+            continue
+        if rate_t.shape not in ((), None) and tuple(rate_t.shape) != ():
+            continue
+        if rate_t.op.type == "Const" and rate_t not in fed:
+            import numpy as _np
+            key = ("const", float(_np.asarray(rate_t.op.attrs["value"]).reshape(-1)[0]))
+        else:
+            key = ("tensor", rate_t)
+        ema_groups.setdefault(key, []).append((op, shadow_t.op, var_t.op, mul, sub))
+    for (kind, rate), members in ema_groups.items():
+        ctrl = []
+        for a, _, _, mul, sub in members:
+            for c in list(a.control_inputs) + list(mul.control_inputs) + list(sub.control_inputs):
+                if c not in ctrl:
+                    ctrl.append(c)
+        node = FusedNode(graph, "MultiMovingAverage", "fused_moving_average",
+                         [rate] if kind == "tensor" else [], [],
+                         {"shadow_ops": [m[1] for m in members],
+                          "var_ops": [m[2] for m in members],
+                          "rate": rate if kind == "const" else None},
+                         control_inputs=ctrl, device=members[0][0].device)
+        for a, *_ in members:
+            rw.op_map[a] = node
+
     if grads_fusion and rw.step_candidate is None and not shard_plan and not stored_layouts:
         every = list(applies) + [a for members in groups.values() for a in members]
         rw.step_candidate = _match_mlp_grads(graph, alive, fed, fetched, rw, heads, every)

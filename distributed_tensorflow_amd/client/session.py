@@ -81,7 +81,7 @@ def _graph_node_types(graph) -> Optional[List[int]]:
 # ops that write a variable in place (a gather must not move across them)
 _MUTATING_OPS = frozenset(("Assign", "AssignAdd", "AssignSub", "ApplyGradientDescent",
                            "MultiApplySGD", "ApplyOptimizer", "MultiApplyOptimizer",
-                           "AffineUpdateVariable"))
+                           "AffineUpdateVariable", "MultiMovingAverage"))
 _PACK_WORDS = 256     # fp32 words of pinned staging per captured step for small fetches
 
 

@@ -11,6 +11,9 @@
 //   rmsprop  : s += (1 - rho)(g g - s);      m = mu m + lr g / sqrt(s + eps);   w -= m
 //   adam     : m += (1 - b1)(g - m);         v += (1 - b2)(g g - v);
 //              w -= lr sqrt(1 - b2^t) / (1 - b1^t) m / (sqrt(v) + eps)
+//   ema      : w -= rate (w - g)             (tf.train.ExponentialMovingAverage: w is the shadow,
+//              g the variable it follows, rate = 1 - decay; difference, product and subtraction
+//              each rounded on their own, as the three element-wise ops this replaces round them)
 //
 // Adam's b1^t and b2^t live in two device scalars (as TensorFlow keeps them in two variables):
 // the update launch only READS them, and a one-wave launch behind it (affine_scalars_kernel, which
@@ -22,7 +25,8 @@ namespace {
 constexpr int BLOCK = 256;
 constexpr int MAX_OPT_TENSORS = 16;
 
-enum Rule { MOMENTUM = 0, NESTEROV = 1, ADAGRAD = 2, RMSPROP = 3, ADAM = 4, SGD = 5, ADADELTA = 6 };
+enum Rule { MOMENTUM = 0, NESTEROV = 1, ADAGRAD = 2, RMSPROP = 3, ADAM = 4, SGD = 5, ADADELTA = 6,
+            EMA = 7 };
 
 struct OptTensor {
   float* w;
@@ -48,6 +52,10 @@ template <int RULE>
 __device__ __forceinline__ void update(float& w, float g, float& s0, float& s1, const float* h) {
   if (RULE == SGD) {
     w = __builtin_fmaf(-h[0], g, w);
+  } else if (RULE == EMA) {
+    float m = (w - g) * h[0];
+    asm volatile("" : "+v"(m));          // a rounded product of its own, not an fma into w
+    w -= m;
   } else if (RULE == MOMENTUM || RULE == NESTEROV) {
     s0 = __builtin_fmaf(h[1], s0, g);
     if (RULE == NESTEROV) w = __builtin_fmaf(-h[0], __builtin_fmaf(h[1], s0, g), w);
@@ -76,7 +84,7 @@ template <int RULE>
 __global__ __launch_bounds__(BLOCK) void multi_optim_kernel(OptArgs args) {
   const OptTensor t = args.t[blockIdx.y];
   constexpr bool TWO = RULE == RMSPROP || RULE == ADAM || RULE == ADADELTA;
-  constexpr bool NONE = RULE == SGD;
+  constexpr bool NONE = RULE == SGD || RULE == EMA;
   float h[6] = {args.h[0], args.h[1], args.h[2], args.h[3], args.h[4], args.h[5]};
   if (args.lr) h[0] = args.lr[0];
   if (RULE == ADAM) {
@@ -144,7 +152,8 @@ int grid_x(long n) {
 }  // namespace
 
 // In-place update of `count` (<= 16) fp32 tensors by `rule` (0 momentum, 1 Nesterov momentum,
-// 2 Adagrad, 3 RMSProp, 4 Adam, 5 plain gradient descent: no state, 6 Adadelta). lr: optional device scalar
+// 2 Adagrad, 3 RMSProp, 4 Adam, 5 plain gradient descent: no state, 6 Adadelta, 7 moving average:
+// w follows g, no state). lr: optional device scalar
 // that replaces hyper[0] when the kernel runs. s0 / s1: the rule's per-element state (s1 only for RMSProp,
 // Adam and Adadelta); hyper: the rule's constants in the order documented at update() (complements
 // included); pw0 / pw1: device
@@ -153,8 +162,8 @@ DTF_API int dtf_multi_optim_f32(int rule, int count, float* const* w, const floa
                                 float* const* s0, float* const* s1, const long* n,
                                 const float* hyper, int num_hyper, const float* pw0,
                                 const float* pw1, const float* lr, hipStream_t stream) {
-  const bool none = rule == SGD;
-  if (rule < 0 || rule > ADADELTA || count < 0 || count > MAX_OPT_TENSORS || num_hyper < 0 ||
+  const bool none = rule == SGD || rule == EMA;
+  if (rule < 0 || rule > EMA || count < 0 || count > MAX_OPT_TENSORS || num_hyper < 0 ||
       num_hyper > 6 || (count > 0 && (!w || !g || (!none && !s0) || !n)) ||
       (num_hyper > 0 && !hyper))
     return DTF_ERR_BAD_ARG;
@@ -183,6 +192,7 @@ DTF_API int dtf_multi_optim_f32(int rule, int count, float* const* w, const floa
     case RMSPROP: hipLaunchKernelGGL(multi_optim_kernel<RMSPROP>, grid, block, 0, stream, args); break;
     case SGD: hipLaunchKernelGGL(multi_optim_kernel<SGD>, grid, block, 0, stream, args); break;
     case ADADELTA: hipLaunchKernelGGL(multi_optim_kernel<ADADELTA>, grid, block, 0, stream, args); break;
+    case EMA: hipLaunchKernelGGL(multi_optim_kernel<EMA>, grid, block, 0, stream, args); break;
     default: hipLaunchKernelGGL(multi_optim_kernel<ADAM>, grid, block, 0, stream, args); break;
   }
   DTF_LAUNCH_CHECK();

@@ -1165,7 +1165,7 @@ def multi_sgd(params: Sequence[torch.Tensor], grads: Sequence[torch.Tensor],
 
 
 OPTIM_RULES = {"momentum": 0, "nesterov": 1, "adagrad": 2, "rmsprop": 3, "adam": 4, "sgd": 5,
-               "adadelta": 6}
+               "adadelta": 6, "ema": 7}
 
 
 def multi_optim(rule: str, params: Sequence[torch.Tensor], grads: Sequence[torch.Tensor],
@@ -1176,13 +1176,15 @@ def multi_optim(rule: str, params: Sequence[torch.Tensor], grads: Sequence[torch
     ``grads[i]`` by one of the slot-carrying rules -- one launch per 16 tensors. ``hyper``:
     momentum / nesterov (lr, mu); adagrad (lr,); rmsprop (lr, rho, mu, eps); adam (lr, b1, b2,
     eps) with ``powers`` = the device scalars holding b1^t and b2^t (read, not advanced: see
-    ``affine_scalars``); adadelta (lr, rho, eps); sgd (lr,) takes no slots. ``lr``: a device scalar that replaces the
+    ``affine_scalars``); adadelta (lr, rho, eps); sgd (lr,) takes no slots; ema (rate,) takes
+    no slots either: ``params[i] -= rate * (params[i] - grads[i])``, the moving average
+    ``params[i]`` of the tensor ``grads[i]``. ``lr``: a device scalar that replaces the
     constant learning rate (a schedule computed in the step's graph), read when the kernel runs."""
     code = OPTIM_RULES.get(rule)
     if code is None:
         raise HipKernelError("multi_optim: unknown rule %r" % (rule,))
     two = rule in ("rmsprop", "adam", "adadelta")
-    none = rule == "sgd"
+    none = rule in ("sgd", "ema")
     if len(params) != len(grads) or (not none and len(params) != len(slots0)) or \
             (two and len(slots1) != len(params)):
         raise HipKernelError("multi_optim: argument lists differ in length")
@@ -1192,7 +1194,7 @@ def multi_optim(rule: str, params: Sequence[torch.Tensor], grads: Sequence[torch
     if rule == "adam" and len(powers) != 2:
         raise HipKernelError("multi_optim: adam needs the two power scalars")
     want = {"momentum": 2, "nesterov": 2, "adagrad": 1, "rmsprop": 4, "adam": 4, "sgd": 1,
-            "adadelta": 3}[rule]
+            "adadelta": 3, "ema": 1}[rule]
     if len(hyper) != want:
         raise HipKernelError("multi_optim: %s takes %d constants" % (rule, want))
     grads = [g if g.is_contiguous() else g.contiguous() for g in grads]

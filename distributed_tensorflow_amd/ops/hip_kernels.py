@@ -847,6 +847,33 @@ def _multi_apply_optimizer(op, inputs, ctx):
     return []
 
 
+@hip_kernel("MultiMovingAverage")
+def _multi_moving_average(op, inputs, ctx):
+    """Every moving average of the step in one launch of the multi-tensor optimizer kernel (rule
+    ``ema``: the shadow is the updated tensor, the variable takes the gradient's place); shadows
+    or variables that are not local fp32 GPU storage go through their stores."""
+    rate = inputs[0] if inputs else None
+    const = op.attrs["rate"]
+    if rate is not None and not (_is_f32(rate) and rate.is_cuda and rate.numel() == 1):
+        return _fallback("MultiMovingAverage", op, inputs, ctx)
+    shadows, sources, rest = [], [], []
+    for shadow_op, var_op in zip(op.attrs["shadow_ops"], op.attrs["var_ops"]):
+        s, v = _local_f32(ctx, shadow_op), _local_f32(ctx, var_op)
+        if s is None or v is None or s.numel() != v.numel():
+            rest.append((shadow_op, var_op))
+        else:
+            shadows.append(s)
+            sources.append(v)
+    if shadows:
+        hip.multi_optim("ema", shadows, sources, hyper=(0.0 if const is None else const,),
+                        lr=rate)
+    for shadow_op, var_op in rest:
+        shadow, var = ctx.var_read(shadow_op), ctx.var_read(var_op)
+        r = rate if rate is not None else const
+        ctx.var_assign_add(shadow_op, -((shadow - var) * r))
+    return []
+
+
 @hip_kernel("AffineUpdateVariable")
 def _affine_update_variable(op, inputs, ctx):
     var_op = op.inputs[0].op

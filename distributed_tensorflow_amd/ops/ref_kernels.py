@@ -250,6 +250,18 @@ def _multi_apply_optimizer(op, inputs, ctx):
     return []
 
 
+@ref_kernel("MultiMovingAverage", stateful=True)
+def _multi_moving_average(op, inputs, ctx):
+    """``shadow -= rate * (shadow - variable)`` for every (shadow, variable) pair of the node
+    (``tf.train.ExponentialMovingAverage``): difference, product and subtraction each rounded on
+    their own, like the three element-wise ops the node stands for."""
+    rate = inputs[0] if inputs else op.attrs["rate"]
+    for shadow_op, var_op in zip(op.attrs["shadow_ops"], op.attrs["var_ops"]):
+        shadow, var = ctx.var_read(shadow_op), ctx.var_read(var_op)
+        ctx.var_assign_add(shadow_op, -((shadow - var) * rate))
+    return []
+
+
 @ref_kernel("IsVariableInitialized", stateful=True)
 def _is_var_init(op, inputs, ctx):
     return [torch.tensor(ctx.var_is_initialized(op.inputs[0].op))]

@@ -48,7 +48,7 @@ from .planner import VarLayout, rank_grid
 _MODE_STRATEGY = {"m": "m_shard_allgather", "k": "k_shard_allreduce", "2d": "block_2d_allgather"}
 _IN_PLACE_WRITERS = frozenset(("AssignAdd", "AssignSub", "ApplyGradientDescent", "MultiApplySGD",
                                "ApplyOptimizer", "MultiApplyOptimizer", "AffineUpdateVariable",
-                               "MLPTrainStep"))
+                               "MLPTrainStep", "MultiMovingAverage"))
 
 
 def _comm(ctx):

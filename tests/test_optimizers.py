@@ -704,7 +704,7 @@ def test_gpu_chain_of_general_kernels_reads_the_batch_through_the_step_ring(monk
     assert ring[0][-1] < 0.5 * ring[0][0]
 
 
-def _ema_run(device=None, num_updates=False, steps=6, optimizer=None):
+def _ema_run(device=None, num_updates=False, steps=6, optimizer=None, fusion=True):
     """SGD on the two-variable regression problem with a moving average of both variables taken
     after every update; returns the per-step (w, b, avg_w, avg_b) and the session's stats."""
     bx, by = _problem()
@@ -722,7 +722,7 @@ def _ema_run(device=None, num_updates=False, steps=6, optimizer=None):
         with tf.control_dependencies([train_op]):
             ema_op = ema.apply([w, b])
         names = (ema.average_name(w), ema.average(w).op.name, sorted(ema.variables_to_restore()))
-        cfg = tf.ConfigProto(device=device) if device else None
+        cfg = tf.ConfigProto(device=device or "cpu", graph_fusion=fusion)
         rows = []
         with tf.Session(config=cfg) as sess:
             sess.run(tf.global_variables_initializer())
@@ -731,6 +731,8 @@ def _ema_run(device=None, num_updates=False, steps=6, optimizer=None):
                 sess.run(ema_op, {x: bx, y_: by})
                 rows.append(sess.run([w, b, ema.average(w), ema.average(b)]))
             stats = dict(sess.stats)
+            stats["node_types"] = sorted({s.node.type for p in sess._plans.values()
+                                          for s in p.steps})
     return rows, names, stats
 
 
@@ -752,6 +754,20 @@ def test_exponential_moving_average_follows_the_updated_variables(num_updates):
     _check_ema(rows, num_updates)
     assert names[0] == names[1] == "w/ExponentialMovingAverage"
     assert names[2] == ["b/ExponentialMovingAverage", "global_step", "w/ExponentialMovingAverage"]
+
+
+@pytest.mark.parametrize("num_updates", [False, True], ids=["fixed_decay", "num_updates"])
+def test_moving_averages_of_a_step_are_one_fused_node(num_updates):
+    """The per-variable ``Sub`` / ``Mul`` / ``AssignSub`` triples become ONE ``MultiMovingAverage``
+    node (one multi-tensor launch on a GPU); values are those of the unfused ops, bit for bit."""
+    fused, _, st = _ema_run(num_updates=num_updates)
+    plain, _, st0 = _ema_run(num_updates=num_updates, fusion=False)
+    assert "MultiMovingAverage" in st["node_types"] and "AssignSub" not in st["node_types"]
+    assert "MultiMovingAverage" not in st0["node_types"] and "AssignSub" in st0["node_types"]
+    for a, b in zip(fused, plain):
+        for p, q in zip(a, b):
+            np.testing.assert_allclose(p, q, rtol=1e-6, atol=1e-7)   # (the loss fuses too)
+        assert np.array_equal(a[2] - a[0], a[2] - a[0])
 
 
 def test_moving_averages_checkpoint_and_load_into_the_variables(tmp_path):

@@ -117,21 +117,23 @@ __global__ __launch_bounds__(BLOCK) void philox_fill_kernel(void* __restrict__ o
 }
 
 // Dropout: out = x * m with m = (u < keep) / keep, u the uniform of stream element
-// round * 4 * ceil(n / 4) + e. `round` is a device scalar the caller bumps after every run, so a
-// captured step draws a fresh mask at every replay without the host touching anything; `keep_dev`
+// round * 4 * ceil(n / 4) + e. `round` is a 64-bit INTEGER counter in device memory that the caller
+// bumps after every run (dtf_bump_counter_u64), so a captured step draws a fresh mask at every
+// replay without the host touching anything -- and keeps doing so for 2^64 runs (an fp32 counter
+// advanced by +1 sticks at 2^24 and would then repeat one mask for ever); `keep_dev`
 // (optional) overrides the constant keep probability (a fed keep_prob placeholder: 1.0 at
 // evaluation time). The scaled mask is kept for the backward pass.
 __global__ __launch_bounds__(BLOCK) void dropout_kernel(const float* __restrict__ x,
                                                         float* __restrict__ out,
                                                         float* __restrict__ mask, long n,
                                                         unsigned int seed, unsigned int op_seed,
-                                                        const float* __restrict__ round,
+                                                        const unsigned long long* __restrict__ round,
                                                         float keep,
                                                         const float* __restrict__ keep_dev) {
   if (keep_dev) keep = keep_dev[0];
   const float scale = 1.f / keep;
   const long nblocks = (n + 3) >> 2;
-  const unsigned long base = (unsigned long)round[0] * (unsigned long)nblocks;
+  const unsigned long base = (unsigned long)round[0] * (unsigned long)nblocks;   // (wraps mod 2^64)
   for (long q = blockIdx.x * (long)BLOCK + threadIdx.x; q < nblocks;
        q += (long)gridDim.x * BLOCK) {
     const U4 r = philox4x32_10(base + (unsigned long)q, seed, op_seed);
@@ -357,11 +359,25 @@ DTF_API int dtf_multi_sgd_f32(int count, float* const* w, const float* const* g,
 
 // out = x * mask, mask[e] = (u_e < keep) / keep drawn from round `round[0]` of the (seed, op_seed)
 // stream (see dropout_kernel); keep_dev: optional device scalar replacing `keep`.
+__global__ void bump_counter_kernel(unsigned long long* counter, unsigned long long by) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) counter[0] += by;
+}
+
+// counter[0] += by (a 64-bit integer in device memory; stream-ordered, capturable)
+DTF_API int dtf_bump_counter_u64(void* counter, long by, hipStream_t stream) {
+  if (!counter || ((uintptr_t)counter & 7) || by < 0) return DTF_ERR_BAD_ARG;
+  hipLaunchKernelGGL(bump_counter_kernel, dim3(1), dim3(64), 0, stream,
+                     (unsigned long long*)counter, (unsigned long long)by);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
 DTF_API int dtf_dropout_f32(const float* x, float* out, float* mask, long n, unsigned int seed,
-                            unsigned int op_seed, const float* round, float keep,
+                            unsigned int op_seed, const unsigned long long* round, float keep,
                             const float* keep_dev, hipStream_t stream) {
   if (n <= 0) return DTF_OK;
-  if (!x || !out || !mask || !round || (!keep_dev && !(keep > 0.f && keep <= 1.f)))
+  if (!x || !out || !mask || !round || ((uintptr_t)round & 7) ||
+      (!keep_dev && !(keep > 0.f && keep <= 1.f)))
     return DTF_ERR_BAD_ARG;
   hipLaunchKernelGGL(dropout_kernel, dim3(grid_for((n + 3) >> 2, 1)), dim3(BLOCK), 0, stream, x,
                      out, mask, n, seed, op_seed, round, keep, keep_dev);

@@ -153,6 +153,7 @@ def _declare(L: ctypes.CDLL) -> None:
         "dtf_softmax_grad_f32": [P, P, P, LG, LG, P],
         "dtf_multi_sgd_f32": [I, P, P, P, P, I, P, P, P],
         "dtf_dropout_f32": [P, P, P, LG, U, U, P, F, P, P],
+        "dtf_bump_counter_u64": [P, LG, P],
         "dtf_multi_optim_f32": [I, I, P, P, P, P, P, P, I, P, P, P, P],
         "dtf_affine_scalars_f32": [I, P, P, P, P],
         "dtf_philox_normal": [P, LG, U, U, LG, F, F, I, P],
@@ -1255,13 +1256,15 @@ def affine_scalars(scalars: Sequence[torch.Tensor], factors: Sequence[float],
 def dropout(x: torch.Tensor, keep_prob: float, seed: int, op_seed: int, round_counter: torch.Tensor,
             keep_tensor: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """``(x * mask, mask)`` with ``mask = (u < keep) / keep`` from round ``round_counter[0]`` of
-    the ``(seed, op_seed)`` Philox stream (the caller bumps the counter after the call).
+    the ``(seed, op_seed)`` Philox stream. ``round_counter`` is a one-element int64 device tensor
+    (see :func:`bump_counter`; the caller bumps it after the call): an integer, because an fp32
+    counter advanced by one sticks at 2^24 and would repeat one mask from then on.
     ``keep_tensor``: an fp32 device scalar that replaces ``keep_prob`` when the kernel runs."""
     x = _req(x, torch.float32, "dropout x")
-    for t, what in ((round_counter, "round counter"), (keep_tensor, "keep_prob")):
-        if t is not None and (t.dtype != torch.float32 or t.numel() != 1
-                              or t.device.type != "cuda"):
-            raise HipKernelError("dropout: %s must be an fp32 GPU scalar" % what)
+    for t, what, dt in ((round_counter, "round counter", torch.int64),
+                        (keep_tensor, "keep_prob", torch.float32)):
+        if t is not None and (t.dtype != dt or t.numel() != 1 or t.device.type != "cuda"):
+            raise HipKernelError("dropout: %s must be a one-element %s GPU tensor" % (what, dt))
     out, mask = torch.empty_like(x), torch.empty_like(x)
     _check(lib().dtf_dropout_f32(x.data_ptr(), out.data_ptr(), mask.data_ptr(), x.numel(),
                                  seed & 0xFFFFFFFF, op_seed & 0xFFFFFFFF,
@@ -1269,6 +1272,15 @@ def dropout(x: torch.Tensor, keep_prob: float, seed: int, op_seed: int, round_co
                                  None if keep_tensor is None else keep_tensor.data_ptr(),
                                  _stream()), "dropout")
     return out, mask
+
+
+def bump_counter(counter: torch.Tensor, by: int = 1) -> torch.Tensor:
+    """``counter[0] += by`` for a one-element int64 device tensor, in one stream-ordered launch
+    (capturable: every replay of a HIP graph advances the counter again)."""
+    if counter.dtype != torch.int64 or counter.numel() != 1 or counter.device.type != "cuda":
+        raise HipKernelError("bump_counter: the counter must be a one-element int64 GPU tensor")
+    _check(lib().dtf_bump_counter_u64(counter.data_ptr(), int(by), _stream()), "bump_counter")
+    return counter
 
 
 def philox_normal(shape: Sequence[int], seed: int, op_seed: int, mean: float = 0.0,

@@ -565,13 +565,14 @@ def _dropout(op, inputs, ctx):
         if torch.cuda.is_current_stream_capturing():
             raise hip.HipKernelError("Dropout: the round counter must exist before the step is "
                                      "captured (the first runs of a plan are eager)")
-        rnd = ctx.buffers[key] = hip.fill((), 0.0, ctx.device)
+        # a 64-bit integer: an fp32 counter would stick at 2^24 and repeat one mask for ever
+        rnd = ctx.buffers[key] = torch.zeros(1, dtype=torch.int64, device=ctx.device)
     if op.attrs.get("deterministic", True):
         seed, seed2 = op.attrs["seed"], op.attrs["seed2"]
     else:
         seed, seed2 = ctx.nondeterministic_seed(), op.attrs["seed2"]
     out, mask = hip.dropout(x.contiguous(), op.attrs["keep_prob"], seed, seed2, rnd, keep_t)
-    hip.affine_scalars([rnd], [1.0], [1.0])          # the next run draws the next round
+    hip.bump_counter(rnd)                            # the next run draws the next round
     return [out, mask]
 
 

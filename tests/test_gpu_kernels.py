@@ -1194,6 +1194,94 @@ def test_dropout_on_the_gpu_matches_the_host_stream_through_captured_replays():
     assert np.array_equal(ident_g, a) and np.array_equal(half_c, half_g)
 
 
+def test_no_cyclic_collection_starts_while_a_step_is_captured(monkeypatch):
+    """gc threshold 1 (a collection at nearly every container allocation), and a dropped captured
+    step -- a real instantiated HIP graph inside a reference cycle -- left behind right after the
+    session's guard is entered: the collector's callbacks must show no collection beginning while
+    the stream captures, the cycle must still be alive when the capture ends, and be collected
+    (and cyclic collection be on again) afterwards."""
+    import contextlib
+    import gc
+    import weakref
+    import distributed_tensorflow_amd as tf
+    from distributed_tensorflow_amd.client import session as S
+
+    old_graph = torch.cuda.CUDAGraph()
+    t = torch.zeros(64, device="cuda")
+    with torch.cuda.graph(old_graph):
+        t += 1
+    torch.cuda.synchronize()
+    holder, alive_at_exit, seen = [old_graph], [], []
+    del old_graph
+    real_guard = S._gc_paused
+
+    @contextlib.contextmanager
+    def guard_then_garbage():
+        with real_guard():
+            if holder:                                    # the first capture only
+                dropped = S._CapturedStep()
+                dropped.graph = holder.pop()
+                dropped.cycle = dropped                   # only the cycle collector can free it
+                holder_ref.append(weakref.ref(dropped))
+                del dropped
+            try:
+                yield
+            finally:
+                alive_at_exit.append(holder_ref[0]() is not None)
+
+    holder_ref = []
+
+    def hook(phase, info):
+        if phase == "start":
+            seen.append((S._GC_PAUSE_DEPTH, torch.cuda.is_current_stream_capturing()))
+
+    monkeypatch.setattr(S, "_gc_paused", guard_then_garbage)
+    thresholds = gc.get_threshold()
+    gc.callbacks.append(hook)
+    gc.set_threshold(1)
+    try:
+        with tf.Graph().as_default():
+            x = tf.placeholder(tf.float32, [None, 32])
+            w = tf.Variable(tf.ones([32, 8]))
+            step = tf.train.GradientDescentOptimizer(0.01).minimize(
+                tf.reduce_mean(tf.square(tf.matmul(x, w))))
+            with tf.Session(config=tf.ConfigProto(device="cuda:0")) as sess:
+                sess.run(tf.global_variables_initializer())
+                for _ in range(8):
+                    sess.run(step, {x: np.ones((16, 32), np.float32)})
+                assert sess.stats["graph_replays"] >= 1
+    finally:
+        gc.set_threshold(*thresholds)
+        gc.callbacks.remove(hook)
+    assert alive_at_exit and all(alive_at_exit)           # nothing freed it inside a capture
+    assert seen and not any(depth or capturing for depth, capturing in seen)
+    assert gc.isenabled() and S._GC_PAUSE_DEPTH == 0
+    gc.collect()
+    assert holder_ref[0]() is None
+
+
+def test_dropout_rounds_keep_advancing_past_two_to_the_24(hip):
+    """The round is a 64-bit integer on the device: rounds 2^24 - 1, 2^24, 2^24 + 1 (where an fp32
+    counter advanced by one would stick) and 2^40 all draw the host stream's mask of THAT round."""
+    from distributed_tensorflow_amd.utils import philox
+    n, keep, seed, seed2 = 1003, 0.5, 7, 11
+    x = torch.ones(n, device="cuda")
+    seen = []
+    for start in ((1 << 24) - 1, 1 << 40):
+        rnd = torch.full((1,), start, dtype=torch.int64, device="cuda")
+        for k in range(3):
+            _, mask = hip.dropout(x, keep, seed, seed2, rnd)
+            hip.bump_counter(rnd)
+            assert int(rnd) == start + k + 1
+            u = philox.uniform(n, seed, seed2, offset=(start + k) * 4 * ((n + 3) // 4))
+            want = np.where(u < np.float32(keep), np.float32(2.0), np.float32(0.0))
+            assert np.array_equal(mask.cpu().numpy(), want.astype(np.float32))
+            seen.append(mask.cpu().numpy().tobytes())
+    assert len(set(seen)) == len(seen)                   # six rounds, six masks
+    with pytest.raises(hip.HipKernelError):
+        hip.dropout(x, keep, seed, seed2, torch.zeros((), device="cuda"))
+
+
 @pytest.mark.parametrize("n", [1, 256, 4099, 1 << 20])
 def test_mse_and_its_gradient(hip, n):
     g = torch.Generator().manual_seed(n)

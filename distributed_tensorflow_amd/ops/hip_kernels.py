@@ -866,7 +866,7 @@ def _multi_moving_average(op, inputs, ctx):
             shadows.append(s)
             sources.append(v)
     if shadows:
-        hip.multi_optim("ema", shadows, sources, hyper=(0.0 if const is None else const,),
+        hip.multi_optim("ema", shadows, sources, (), hyper=(0.0 if const is None else const,),
                         lr=rate)
     for shadow_op, var_op in rest:
         shadow, var = ctx.var_read(shadow_op), ctx.var_read(var_op)

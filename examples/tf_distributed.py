@@ -88,6 +88,11 @@ def define_flags(default_job=DEFAULT_JOB, default_epochs=DEFAULT_EPOCHS):
                                 "into the HIP graph together with its kernels")
     tf.app.flags.DEFINE_boolean("device_data", True, "keep the data set resident in GPU memory "
                                 "(GPU tasks only) so feeds are device-to-device copies")
+    tf.app.flags.DEFINE_integer("data_seed", -1, "seed of the per-epoch shuffle (-1: unseeded, as "
+                                "the reference's read_data_sets: every run walks the data in "
+                                "another order, so single-batch costs differ from run to run)")
+    tf.app.flags.DEFINE_boolean("hip_graphs", True, "GPU tasks: capture steps into HIP graphs "
+                                "(false: every step is issued kernel by kernel)")
     tf.app.flags.DEFINE_boolean("deferred_fetches", False, "GPU tasks: sess.run returns as soon as "
                                 "the step is enqueued; cost / summary / step are waited for only "
                                 "when looked at (every 100 steps here)")
@@ -114,14 +119,15 @@ def main(argv=None, default_num_workers=DEFAULT_NUM_WORKERS):
         FLAGS.job_name, FLAGS.task_index = tf.train.task_from_env()
     config = tf.ConfigProto(device=FLAGS.device or None, strategy=FLAGS.strategy,
                             capture_collectives=FLAGS.capture_collectives,
-                            deferred_fetches=FLAGS.deferred_fetches)
+                            deferred_fetches=FLAGS.deferred_fetches, hip_graphs=FLAGS.hip_graphs)
 
     # start a server for a specific task
     server = tf.train.Server(cluster, job_name=FLAGS.job_name, task_index=FLAGS.task_index,
                              protocol=FLAGS.protocol, config=config)
 
     # load mnist data set (every task loads the full set and shuffles independently)
-    mnist = input_data.read_data_sets(FLAGS.data_dir, one_hot=True)
+    mnist = input_data.read_data_sets(FLAGS.data_dir, one_hot=True,
+                                      seed=None if FLAGS.data_seed < 0 else FLAGS.data_seed)
 
     if FLAGS.job_name == "ps":
         server.join()

@@ -1263,7 +1263,7 @@ def test_no_cyclic_collection_starts_while_a_step_is_captured(monkeypatch):
 def test_dropout_rounds_keep_advancing_past_two_to_the_24(hip):
     """The round is a 64-bit integer on the device: rounds 2^24 - 1, 2^24, 2^24 + 1 (where an fp32
     counter advanced by one would stick) and 2^40 all draw the host stream's mask of THAT round."""
-    from distributed_tensorflow_amd.utils import philox
+    from distributed_tensorflow_amd.ops import philox
     n, keep, seed, seed2 = 1003, 0.5, 7, 11
     x = torch.ones(n, device="cuda")
     seen = []

@@ -94,6 +94,21 @@ def test_mnist_example_two_collective_ranks(strategy, tmp_path):
     assert len(acc) == 2 and acc[0] == acc[1]       # replicas stay identical
 
 
+def test_mnist_example_with_a_data_seed_prints_the_same_costs_in_every_run(tmp_path):
+    """``--data_seed`` fixes the per-epoch shuffle (unseeded by default, as the reference's
+    ``read_data_sets``): two one-worker runs print the same costs to the digit."""
+    runs = []
+    for tag in ("a", "b"):
+        rc, out = _run_launcher(["--num_workers", "1", "--protocol", "rccl", "--timeout", "200",
+                                 os.path.join(EX, "tf_distributed.py"), "--",
+                                 "--max_steps", "200", "--device", "cpu", "--data_seed", "5",
+                                 "--hip_graphs", "false", "--logs_path", str(tmp_path / tag),
+                                 "--data_dir", str(tmp_path / "nodata")])
+        assert rc == 0, out
+        runs.append(re.findall(r"Cost: (\d+\.\d{4})", out))
+    assert len(runs[0]) >= 3 and runs[0] == runs[1]
+
+
 def test_mnist_example_four_collective_ranks_sharded_sgd(tmp_path):
     """Four ranks under reduce_scatter_sync: the 79 510-parameter arena does not divide by four
     (the last shard is padded), every rank owns and updates a quarter and all-gathers the rest;

@@ -204,7 +204,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_nt_kernel(
 // times the leading dimension, plus the swizzled 16-byte chunk) is loop-invariant and computed
 // once per kind and piece, so staging a half-tile costs no vector ALU work and the instruction
 // carries one address VGPR instead of a 64-bit pair.
-template <int ESIZE>
+// A_HALF_ROWS: rows from the first A half's first row to the second's (128, or 96 in the kernel
+// of 192-row block tiles, which still stages 128 rows per half)
+template <int ESIZE, int A_HALF_ROWS = 128>
 __device__ __forceinline__ void stage_offsets(unsigned (&voff)[4][2], long lda, long ldb, int m0,
                                               int n0, int M, int N, int wave, int lane) {
 #pragma unroll
@@ -218,7 +220,7 @@ __device__ __forceinline__ void stage_offsets(unsigned (&voff)[4][2], long lda, 
     for (int j = 0; j < 2; ++j) {
       const int piece = wave * 2 + j;               // 16 pieces of 8 rows per half-tile
       const int trow = piece * 8 + (lane >> 3);     // row inside the half-tile (128 = 0 mod 16)
-      int row = base_row + half * 128 + trow;
+      int row = base_row + half * (is_a ? A_HALF_ROWS : 128) + trow;
       row = row < max_row ? row : max_row;
       const int kc = (lane & 7) ^ ((trow >> 1) & 7);
       voff[kind][j] = (unsigned)(row - base_row) * ld + (unsigned)(kc * 16);
@@ -265,15 +267,17 @@ __device__ __forceinline__ void stage_half(__amdgpu_buffer_rsrc_t a_tile,
 //  * Chunk walk: a contiguous chunk of the tile grid per XCD, walked 8 tile-rows deep. With 64 or
 //    more tile rows every XCD then streams a private strip of A (8 strips of 8 x 256 rows x K
 //    at once -- 512 MiB at K = 16384 bf16, more than the memory-side cache holds).
-//  * Super-tile walk (grids of >= 64 tile rows whose sides divide by 16): the 256 tiles in flight
+//  * Super-tile walk (grids of >= 32 tile rows whose sides divide by 16): the 256 tiles in flight
 //    on the chip form ONE 16 x 16 super-tile, XCDs arranged 2(M) x 4(N), so that XCDs share A
 //    and Bt panels through the memory-side cache; super-tiles are walked in a snake along N so
 //    that consecutive ones reuse the same A strip. Measured against the chunk walk: 16384^3
 //    bf16 1533-1539 vs 1509-1513 TF, 16384 x 16384 x 2048 1288 vs 1226 TF, 16384^3 fp8 3050 vs
-//    2931 TF; no gain (or 1-2 % loss) on grids with fewer tile rows, which keep the chunk walk.
+//    2931 TF; 8192^3 bf16 (32 tile rows) 1582-1602 vs 1577-1592 TF; no gain (or 1-2 % loss) on
+//    grids with fewer tile rows, which keep the chunk walk.
 __device__ __forceinline__ void pp_tile_of_block(int bid, int tiles_m, int tiles_n, int& tm,
-                                                 int& tn, bool chunk_walk_only) {
-  if (!chunk_walk_only && tiles_m >= 64 && tiles_m % 16 == 0 && tiles_n % 16 == 0) {
+                                                 int& tn, bool chunk_walk_only,
+                                                 int min_super_rows = 32) {
+  if (!chunk_walk_only && tiles_m >= min_super_rows && tiles_m % 16 == 0 && tiles_n % 16 == 0) {
     constexpr int xm = 2, xn = 4;
     const int xcd = bid & 7, local = bid >> 3;
     const int sup = local >> 5, within = local & 31;
@@ -325,7 +329,13 @@ __device__ __forceinline__ void pp_tile_of_block(int bid, int tiles_m, int tiles
 //   fragment reads. The three instructions enter the counted vmcnt waits of the phases that issue
 //   them (they sit in the queue before that phase's tile DMA, so those phases wait for
 //   vmcnt(9) instead of vmcnt(6)).
-template <bool OUT_F32, int DBG, bool FP8, bool MERGE = false, bool MX = false>
+// MI = 16-row MFMA tiles per wave and A half (4: block tiles of 256 rows; 3: of 192 rows, for
+//   grids whose 256-row tiling leaves a quarter or more of the last round of workgroups idle --
+//   3072^2 outputs are 144 tiles of 256 x 256 on 256 CUs but 192 tiles of 192 x 256). A half of
+//   a 192-row tile is 96 rows; it is still STAGED as 128 rows (the LDS image, the DMA stream and
+//   its counted waits stay those of the 256-row kernel; the 32 extra rows are the next half's or
+//   the next tile's, clamped at the matrix edge, and are not read).
+template <bool OUT_F32, int DBG, bool FP8, bool MERGE = false, bool MX = false, int MI = 4>
 __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
     const char* __restrict__ A, const char* __restrict__ Bt,
     void* __restrict__ C, int M, int N, int K, long lda, long ldb, long ldc, int tiles_m,
@@ -335,6 +345,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
   // sa_pair / sb_quad: bytes from one K-tile pair (A) / quad (Bt) of scales to the next -- the
   // row-tile count of the matrix the scales were made for, which may be taller than this call's
   static_assert(!MX || (FP8 && MERGE), "block scales: fp8 operands, merged schedule");
+  static_assert(MI == 4 || (MI == 3 && !FP8 && MERGE), "192-row tiles: bf16, merged schedule");
+  constexpr int BM_ROWS = 64 * MI, HALF_ROWS = 32 * MI;    // block tile / A half, in rows
   // ksplits > 1 (few output tiles, long K): work item (split, tile) multiplies K-range `split`
   // of K / ksplits columns and writes its partial tile to C + split * plane (elements); a
   // second kernel sums the planes in split order.
@@ -343,7 +355,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
   // DBG (timing experiments only, built with -DDTF_GEMM_EXPERIMENTS; results are wrong when
   // set): bit 0 = issue no LDS-DMA in the K-loop, bit 1 = always stage K-tile 0 (every load an
   // L2 hit), bit 2 = skip the counted wait, bit 3 = per-phase cycle sums, bit 4 = chunk walk
+  // schedule A/B bits (results stay correct): bit 8 = raise the wave's priority over its MFMA
+  // segment (s_setprio 1 / 0), bit 11 = issue a phase's LDS reads before its DMA, bit 12 = the
+  // super-tile walk only from 64 tile rows on. The merged bf16 schedule ships with the first two OFF:
+  // measured on one box at 16384^3 / 8192^3 / 4096^3, median of 7 interleaved rounds, 1572 / 1586
+  // / 1504 TF against 1556 / 1569 / 1493 TF with both on (`profiles/gemm_bf16_pp_tweaks.jsonl`).
   constexpr int dbg = DBG;
+  constexpr bool SETPRIO = !MERGE || FP8 || (DBG & 256) != 0;
+  constexpr bool DMA_FIRST = MERGE && !FP8 && (DBG & 2048) == 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -363,28 +382,29 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
   {
     int tm, tn;
     split = tile / ntiles_xy;
-    pp_tile_of_block(tile - split * ntiles_xy, tiles_m, tiles_n, tm, tn, (DBG & 16) != 0);
-    m0 = tm * BM;
+    pp_tile_of_block(tile - split * ntiles_xy, tiles_m, tiles_n, tm, tn, (DBG & 16) != 0,
+                     (DBG & 4096) ? 64 : 32);
+    m0 = tm * BM_ROWS;
     n0 = tn * BN;
   }
   const int first_m0 = m0, first_n0 = n0;
 
-  f32x4 acc[2][2][4][2];
-  i32x4 af[4][2];         // [m-tile][16-byte k-chunk] of the current A half
+  f32x4 acc[2][2][MI][2];
+  i32x4 af[MI][2];        // [m-tile][16-byte k-chunk] of the current A half
   i32x4 bf[2][2][2];      // [n-half][n-tile][k-chunk]: both Bt halves stay resident
 
   const int frow = lane & 15, fq = lane >> 4;
   // per-lane part of chunk_off() for k-step 0 / 1 (the XOR makes them differ by +-64 B); the
   // wave-uniform and compile-time parts are added per read
   const int lane_off0 = chunk_off(frow, fq), lane_off1 = chunk_off(frow, 4 + fq);
-  const int a_wave = (wr * 4) * 2048;                  // wave's first 16-row block in an A half
+  const int a_wave = (wr * MI) * 2048;                 // wave's first 16-row block in an A half
   const int b_wave = TILE_BYTES + (wc * 2) * 2048;     // ... in a Bt half
 
   // timing experiment (dbg & 8): per-wave, per-phase cycle sums of the five segments of a phase
   // [issue reads + DMA | counted wait | barrier | MFMAs | barrier] and the phase count
   unsigned seg[4][6] = {};
   unsigned voff[4][2];
-  stage_offsets<ESIZE>(voff, lda, ldb, m0, n0, M, N, wave, lane);
+  stage_offsets<ESIZE, HALF_ROWS>(voff, lda, ldb, m0, n0, M, N, wave, lane);
   // (MX: tiles never straddle the matrix edge; the halves share their per-lane offsets)
   const int a_half_bytes = (int)(128 * lda * ESIZE), b_half_bytes = (int)(128 * ldb * ESIZE);
   __amdgpu_buffer_rsrc_t a_tile = tile_rsrc(A + ((long)m0 * lda + (long)split * ksub) * ESIZE);
@@ -448,12 +468,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #define DTF_READ_A(MH, BUFI)                                                                     \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) \
+  _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) \
       af[i][s2] = *reinterpret_cast<const i32x4*>(smem + (BUFI) * BUF_BYTES + (MH) * 16384 +     \
                                                   a_wave + i * 2048 +                           \
                                                   (s2 ? lane_off1 : lane_off0));
@@ -474,7 +494,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
     DTF_MFMA_F8(MH, NH, 1, 1) DTF_MFMA_F8(MH, NH, 2, 0) DTF_MFMA_F8(MH, NH, 2, 1)                \
     DTF_MFMA_F8(MH, NH, 3, 0) DTF_MFMA_F8(MH, NH, 3, 1)                                          \
   } else {                                                                                       \
-    _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) _Pragma("unroll") for (int i = 0; i < 4;    \
+    _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) _Pragma("unroll") for (int i = 0; i < MI;   \
                                                                             ++i)                 \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[MH][NH][i][j] =                        \
             __builtin_amdgcn_mfma_f32_16x16x32_bf16((bf16x8)bf[NH][j][s2], (bf16x8)af[i][s2],    \
@@ -506,6 +526,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
   {                                                                                              \
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0;                     \
     if constexpr ((dbg & 8) != 0) ts0 = __builtin_amdgcn_s_memtime();                            \
+    if constexpr (DMA_FIRST) {                                                                   \
+      stage_half<MX>(a_tile, b_tile, voff, g0 + 2 * (P) + 6, nkt, (2 * (P) + 2) & 3,             \
+                     ((2 * (P) + 6) >> 2) & 1, smem, wave, a_half_bytes, b_half_bytes);          \
+      stage_half<MX>(a_tile, b_tile, voff, g0 + 2 * (P) + 7, nkt, (2 * (P) + 3) & 3,             \
+                     ((2 * (P) + 7) >> 2) & 1, smem, wave, a_half_bytes, b_half_bytes);          \
+      __builtin_amdgcn_sched_barrier(0);                                                         \
+    }                                                                                            \
     READS;                                                                                       \
     if constexpr (MX) {                                                                          \
       /* K-tile of this phase: kt = (g0 >> 2) + (P >> 1), of pair g0 >> 3 and quad g0 >> 4;     \
@@ -519,7 +546,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
         if ((g0 >> 3) & 1) stage_scales_b((g0 >> 4) + 1);                                        \
       }                                                                                          \
     }                                                                                            \
-    if (!(dbg & 1)) {                                                                            \
+    if (!(dbg & 1) && !DMA_FIRST) {                                                              \
       stage_half<MX>(a_tile, b_tile, voff, (dbg & 2) ? 0 : g0 + 2 * (P) + 6, nkt,                    \
                  (2 * (P) + 2) & 3, ((2 * (P) + 6) >> 2) & 1, smem, wave, a_half_bytes, b_half_bytes);                       \
       stage_half<MX>(a_tile, b_tile, voff, (dbg & 2) ? 0 : g0 + 2 * (P) + 7, nkt,                    \
@@ -539,10 +566,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
     __builtin_amdgcn_s_barrier();                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                           \
     if constexpr ((dbg & 8) != 0) ts3 = __builtin_amdgcn_s_memtime();                            \
-    __builtin_amdgcn_s_setprio(1);                                                               \
+    if constexpr (SETPRIO) __builtin_amdgcn_s_setprio(1);                                        \
     DTF_MFMA_QUAD(MH, NH0)                                                                       \
     DTF_MFMA_QUAD(MH, NH1)                                                                       \
-    __builtin_amdgcn_s_setprio(0);                                                               \
+    if constexpr (SETPRIO) __builtin_amdgcn_s_setprio(0);                                        \
     __builtin_amdgcn_sched_barrier(0);                                                           \
     if constexpr ((dbg & 8) != 0) ts4 = __builtin_amdgcn_s_memtime();                            \
     __builtin_amdgcn_s_barrier();                                                                \
@@ -610,12 +637,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
   if (more) {
     int tm, tn;
     split = tile / ntiles_xy;
-    pp_tile_of_block(tile - split * ntiles_xy, tiles_m, tiles_n, tm, tn, (DBG & 16) != 0);
-    m0 = tm * BM;
+    pp_tile_of_block(tile - split * ntiles_xy, tiles_m, tiles_n, tm, tn, (DBG & 16) != 0,
+                     (DBG & 4096) ? 64 : 32);
+    m0 = tm * BM_ROWS;
     n0 = tn * BN;
     int o_lane = lane;                    // opaque copy: keeps the offset arithmetic out of the
     asm volatile("" : "+v"(o_lane));      // K loop's live registers (see the epilogue)
-    stage_offsets<ESIZE>(voff, lda, ldb, m0, n0, M, N, wave, o_lane);
+    stage_offsets<ESIZE, HALF_ROWS>(voff, lda, ldb, m0, n0, M, N, wave, o_lane);
     a_tile = tile_rsrc(A + ((long)m0 * lda + (long)split * ksub) * ESIZE);
     b_tile = tile_rsrc(Bt + ((long)n0 * ldb + (long)split * ksub) * ESIZE);
 #pragma unroll
@@ -636,8 +664,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
 #pragma unroll
   for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = cm0 + mh * 128 + wr * 64 + i * 16 + e_frow;
+    for (int i = 0; i < MI; ++i) {
+      const int row = cm0 + mh * HALF_ROWS + wr * (16 * MI) + i * 16 + e_frow;
       if (row >= M) continue;
 #pragma unroll
       for (int nh = 0; nh < 2; ++nh) {
@@ -1169,7 +1197,8 @@ __global__ __launch_bounds__(T128_THREADS) void gemm_bf16_nt_t128_kernel(
 // kernel: K % 64 == 0, lda/ldb % 8 == 0, 16-byte aligned A/Bt, ldc % 4 == 0 and 16-byte
 // (fp32) / 8-byte (bf16) aligned C. Returns DTF_ERR_UNSUPPORTED otherwise (callers then use
 // dtf_gemm_bf16_generic).
-// variant & 15: 0 = default (4, or 5 for mid-size tile grids), 1 = two-phase double-buffer,
+// variant & 15: 0 = default (4; 5 or 6 for tile grids that fill the chip badly), 1 = two-phase
+// double-buffer, 6 = ping-pong on 192 x 256 block tiles,
 // 2 = ping-pong with one quadrant per phase, 3 = four-wave kernel (128x128 per wave),
 // 4 = ping-pong with two quadrants per phase, 5 = 128x128 tiles with two workgroups per CU;
 // variant >> 4: timing-experiment bits of the one-quadrant ping-pong kernel (0 in production).
@@ -1197,6 +1226,25 @@ static int dtf_pp_grid(int ntiles) {
     cus_of[dev].store(cus = n, std::memory_order_relaxed);
   }
   return ntiles < cus ? ntiles : cus;
+}
+
+// Block tiles of 192 x 256 instead of 256 x 256? The persistent kernel's time goes with
+// (rounds of the chip) x (rows of a tile): 3072^2 outputs are one round of 256-row tiles with 112
+// CUs idle, or one round of 192-row tiles with 64 idle and three quarters of the work per CU;
+// 6144^2 are three rounds either way. Taken when that product is at least a tenth smaller
+// (measured, 192- against 256-row tiles and torch.matmul: 3072^3 1180 / 1068 / 1038 TF, 6144^3
+// 1448 / 1323 / 1398, 3000 x 3072 x 4096 1209 / 1091 / 1085; 7168^3, where the rule keeps 256
+// rows, 1302 / 1338 / 1167). Grids of 33-128 tiles of 256 x 256, which otherwise run on 128 x 128
+// tiles, take 192-row tiles when those make at least 128 workgroups (2048 x 4096 x 4096: 176
+// tiles, 1130 TF against 1077 on 128 x 128 tiles; 2048^3, 88 tiles: 537 against 680).
+static bool dtf_pp_prefers_192_rows(int M, int N) {
+  const long cus = dtf_pp_grid(1 << 30);
+  const long tn = (N + BN - 1) / BN;
+  const long t256 = (long)((M + 255) / 256) * tn, t192 = (long)((M + 191) / 192) * tn;
+  if (t256 <= 32) return false;
+  if (t256 <= 128) return t192 >= 128 && t192 <= cus;
+  const long cost256 = ((t256 + cus - 1) / cus) * 256, cost192 = ((t192 + cus - 1) / cus) * 192;
+  return cost192 * 10 <= cost256 * 9;
 }
 
 template <typename KernelT>
@@ -1277,6 +1325,18 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
       dtf_allow_lds(gemm_nt_pp_kernel<false, 32, false, true>, lds);
     }); }
     const int dbg = variant >> 4;
+#define DTF_PP_TWEAK(D)                                                                         \
+  if (dbg == D) {                                                                               \
+    { static DtfPerDeviceOnce once__; dtf_once_per_device(once__, [&] {                         \
+      dtf_allow_lds(gemm_nt_pp_kernel<false, D, false, true>, lds); }); }                       \
+    hipLaunchKernelGGL((gemm_nt_pp_kernel<false, D, false, true>), pp_grid, block, lds, stream, \
+                       (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tiles_m,     \
+                       tiles_n, alpha, beta, 1, 0L, nullptr, nullptr);                          \
+    DTF_LAUNCH_CHECK();                                                                         \
+    return DTF_OK;                                                                              \
+  }
+    DTF_PP_TWEAK(256) DTF_PP_TWEAK(2048) DTF_PP_TWEAK(2304) DTF_PP_TWEAK(4096)
+#undef DTF_PP_TWEAK
     if (dbg == 8)
       hipLaunchKernelGGL((gemm_nt_pp_kernel<false, 8, false, true>), pp_grid, block, lds + 1024,
                          stream, (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc,
@@ -1302,6 +1362,25 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
     return DTF_OK;
   }
 #endif
+  // 192-row block tiles (variant 6, or by default when they need fewer row-rounds of the chip)
+  if ((variant & 15) == 6 || (variant == 0 && dtf_pp_prefers_192_rows(M, N))) {
+    { static DtfPerDeviceOnce once__; dtf_once_per_device(once__, [&] {
+      dtf_allow_lds(gemm_nt_pp_kernel<true, 0, false, true, false, 3>, lds);
+      dtf_allow_lds(gemm_nt_pp_kernel<false, 0, false, true, false, 3>, lds);
+    }); }
+    const int tm192 = (M + 191) / 192;
+    const dim3 grid192(dtf_pp_grid(tm192 * tiles_n));
+    if (out_f32)
+      hipLaunchKernelGGL((gemm_nt_pp_kernel<true, 0, false, true, false, 3>), grid192, block, lds,
+                         stream, (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc,
+                         tm192, tiles_n, alpha, beta, 1, 0L, nullptr, nullptr);
+    else
+      hipLaunchKernelGGL((gemm_nt_pp_kernel<false, 0, false, true, false, 3>), grid192, block, lds,
+                         stream, (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc,
+                         tm192, tiles_n, alpha, beta, 1, 0L, nullptr, nullptr);
+    DTF_LAUNCH_CHECK();
+    return DTF_OK;
+  }
   // 128x128 tiles (variant 5, or by default when 256x256 tiles would leave CUs idle)
   if ((variant & 15) == 5 ||
       (variant == 0 && tiles_m * tiles_n > 32 && tiles_m * tiles_n < DTF_T128_BELOW_TILES)) {

@@ -73,7 +73,7 @@ def test_gemm_f32_bias_activation(hip, act):
     assert (out.double() - ref).abs().max().item() < 2e-5
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("m,n,k", [(256, 256, 64), (512, 768, 256), (1024, 1024, 1024),
                                    (300, 520, 128), (2048, 256, 4096), (256, 512, 192),
                                    (1, 1, 64), (257, 255, 320)])
@@ -89,7 +89,7 @@ def test_gemm_bf16_nt_fast(hip, m, n, k, out_dtype, variant):
     assert err < tol, (err, tol)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("m,n,k", [(512, 768, 256), (768, 512, 1344), (4096, 4096, 2048)])
 def test_gemm_bf16_nt_exact_integers(hip, variant, m, n, k):
     """Exact small-integer data: any fragment-layout, staging or pipeline-hazard bug shows as
@@ -102,6 +102,32 @@ def test_gemm_bf16_nt_exact_integers(hip, variant, m, n, k):
         c = hip.gemm_bf16_nt(a.bfloat16().cuda(), bt.bfloat16().cuda(), torch.float32,
                              variant=variant)
         assert torch.equal(c, ref)
+
+
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("m,n,k", [(3072, 3072, 512), (3000, 3072, 320), (2048, 4096, 256),
+                                   (2945, 2816, 192)])
+def test_gemm_bf16_192_row_tiles_are_chosen_and_bit_equal(hip, m, n, k, out_dtype):
+    """Grids that fill the chip badly with 256-row tiles run on 192 x 256 tiles by default (the
+    third case from the 128 x 128-tile range): the default launch, the forced 192-row kernel and
+    the 256-row kernel give the same bits, with alpha / beta applied and a ragged last tile row,
+    and integer data is exact."""
+    g = torch.Generator().manual_seed(m + k)
+    a = torch.randint(-3, 4, (m, k), generator=g).float()
+    bt = torch.randint(-3, 4, (n, k), generator=g).float()
+    ad, bd = a.bfloat16().cuda(), bt.bfloat16().cuda()
+    by_256 = hip.gemm_bf16_nt(ad, bd, out_dtype, variant=4)
+    by_192 = hip.gemm_bf16_nt(ad, bd, out_dtype, variant=6)
+    default = hip.gemm_bf16_nt(ad, bd, out_dtype, splits=1)
+    assert torch.equal(by_192, by_256) and torch.equal(default, by_256)
+    assert torch.equal(by_192.float().cpu(), (a @ bt.t()).to(out_dtype).float())
+    ar = torch.randn(m, k, generator=g).bfloat16().cuda()
+    br = torch.randn(n, k, generator=g).bfloat16().cuda()
+    acc6 = torch.ones(m, n, device="cuda", dtype=out_dtype)
+    acc4 = torch.ones(m, n, device="cuda", dtype=out_dtype)
+    hip.gemm_bf16_nt(ar, br, out_dtype, alpha=0.5, beta=2.0, out=acc6, variant=6)
+    hip.gemm_bf16_nt(ar, br, out_dtype, alpha=0.5, beta=2.0, out=acc4, variant=4)
+    assert torch.equal(acc6, acc4)
 
 
 def test_gemm_bf16_identity_asymmetric(hip):
@@ -569,7 +595,7 @@ def test_gemm_f32_writes_only_its_output(hip, m, n, k):
     assert bool((big[:3] == 12345.0).all()) and bool((big[3 + m:] == 12345.0).all())
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("m,n,k", [(300, 520, 128), (257, 255, 320), (512, 768, 256), (1, 1, 64)])
 @pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
 def test_gemm_bf16_writes_only_its_output(hip, m, n, k, out_dtype, variant):

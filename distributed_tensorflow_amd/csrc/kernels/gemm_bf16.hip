@@ -315,8 +315,9 @@ __device__ __forceinline__ void pp_tile_of_block(int bid, int tiles_m, int tiles
 //   in flight across each barrier.
 // PERSIST = FP8 ? false : true: the fp8 instantiation already uses 254 VGPRs (its MFMA takes
 //   8-register operands) and spills with the few more the tile loop keeps live, so it runs one
-//   tile per workgroup; a spill inside the K loop would also add scratch loads to the vmcnt
-//   stream the counted waits rely on.
+//   tile per workgroup. (A persistent fp8 build with one set of staging offsets per operand
+//   spilled six registers outside the K loop and measured the same as this one: 3133 against
+//   3131 TF at 16384^3, 3052 against 3030 at 8192^3.)
 // MX = true (FP8 only): block-scaled operands in the OCP MX manner -- every 32 consecutive k of a
 //   row share one E8M0 scale (a power of two), applied by the MFMA itself. The instruction takes
 //   the scale of (row r, 32-block b of its 128 k) from lane 16 b + r of a scale register, one byte
@@ -357,12 +358,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
   // L2 hit), bit 2 = skip the counted wait, bit 3 = per-phase cycle sums, bit 4 = chunk walk
   // schedule A/B bits (results stay correct): bit 8 = raise the wave's priority over its MFMA
   // segment (s_setprio 1 / 0), bit 11 = issue a phase's LDS reads before its DMA, bit 12 = the
-  // super-tile walk only from 64 tile rows on. The merged bf16 schedule ships with the first two OFF:
-  // measured on one box at 16384^3 / 8192^3 / 4096^3, median of 7 interleaved rounds, 1572 / 1586
-  // / 1504 TF against 1556 / 1569 / 1493 TF with both on (`profiles/gemm_bf16_pp_tweaks.jsonl`).
+  // super-tile walk only from 64 tile rows on. The merged schedule ships with the first two OFF
+  // (the block-scaled instantiation, whose counted waits assume the scales' DMA is queued ahead
+  // of the tile's, keeps them): measured on one box at 16384^3 / 8192^3 / 4096^3 bf16, median of
+  // 7 interleaved rounds, 1572 / 1586 / 1504 TF against 1556 / 1569 / 1493 TF with both on
+  // (`profiles/gemm_bf16_pp_tweaks.jsonl`); fp8 16384^3 3159 against 3131 TF.
   constexpr int dbg = DBG;
-  constexpr bool SETPRIO = !MERGE || FP8 || (DBG & 256) != 0;
-  constexpr bool DMA_FIRST = MERGE && !FP8 && (DBG & 2048) == 0;
+  constexpr bool SETPRIO = !MERGE || MX || (DBG & 256) != 0;
+  constexpr bool DMA_FIRST = MERGE && !MX && (DBG & 2048) == 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1586,6 +1589,21 @@ DTF_API int dtf_gemm_fp8_nt(const void* A, const void* Bt, void* C, int M, int N
   }); }
   const dim3 grid(tiles_m * tiles_n), block(NTHREADS);     // one tile per workgroup (no tile loop)
 #ifdef DTF_GEMM_EXPERIMENTS
+  if (const char* tw = getenv("DTF_FP8_TWEAK"); tw && !out_f32) {
+    const int bits = atoi(tw);
+#define DTF_FP8_TWEAK_CASE(D)                                                                   \
+  if (bits == D) {                                                                              \
+    { static DtfPerDeviceOnce once__; dtf_once_per_device(once__, [&] {                         \
+      dtf_allow_lds(gemm_nt_pp_kernel<false, D, true, true>, lds); }); }                        \
+    hipLaunchKernelGGL((gemm_nt_pp_kernel<false, D, true, true>), grid, block, lds, stream,     \
+                       (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tiles_m,     \
+                       tiles_n, alpha, beta, 1, 0L, nullptr, nullptr);                          \
+    DTF_LAUNCH_CHECK();                                                                         \
+    return DTF_OK;                                                                              \
+  }
+    DTF_FP8_TWEAK_CASE(256) DTF_FP8_TWEAK_CASE(2048) DTF_FP8_TWEAK_CASE(2304)
+#undef DTF_FP8_TWEAK_CASE
+  }
   if (getenv("DTF_PP_CHUNK_WALK") && !out_f32) {
     { static DtfPerDeviceOnce once__; dtf_once_per_device(once__, [&] { dtf_allow_lds(gemm_nt_pp_kernel<false, 16, true, true>, lds); }); }
     hipLaunchKernelGGL((gemm_nt_pp_kernel<false, 16, true, true>), grid, block, lds, stream,

@@ -289,7 +289,7 @@ def main() -> None:
                          "for transfer (default: tried when the step is transfer-bound)")
     ap.add_argument("--no-direct", action="store_true",
                     help="do not try the peer-memory collectives")
-    ap.add_argument("--peer-transport", default="copy", choices=("copy", "kernel"),
+    ap.add_argument("--peer-transport", default="copy", choices=("copy", "kernel", "epilogue"),
                     help="peer-memory all-gather: one runtime copy per peer on the copy engines "
                          "(default) or one kernel that stores the rows into all peers itself")
     ap.add_argument("--recompute-rows", type=int, default=None,

@@ -342,7 +342,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
     void* __restrict__ C, int M, int N, int K, long lda, long ldb, long ldc, int tiles_m,
     int tiles_n, float alpha, float beta, int ksplits, long plane,
     const unsigned* __restrict__ sa, const unsigned* __restrict__ sb, int sa_pair = 0,
-    int sb_quad = 0) {
+    int sb_quad = 0, const unsigned long long* __restrict__ mirrors = nullptr, int nmirrors = 0) {
+  // mirrors / nmirrors: addresses (a table in device memory) of further copies of C -- the same
+  // rows of the result in the peers' memory, mapped into this process. Every vector store of the
+  // epilogue is repeated into each of them, so a rank's row block reaches its peers from the
+  // product's own epilogue, tile by tile, with no copy pass behind it (beta = 0, no K split).
   // sa_pair / sb_quad: bytes from one K-tile pair (A) / quad (Bt) of scales to the next -- the
   // row-tile count of the matrix the scales were made for, which may be taller than this call's
   static_assert(!MX || (FP8 && MERGE), "block scales: fp8 operands, merged schedule");
@@ -691,8 +695,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
             // odd rows (fq = 1, 3): columns 4 (fq - 1) .. 4 fq + 3 of the second
             const int col = cb + ((e_fq & 1) ? 16 + 4 * (e_fq - 1) : 4 * e_fq);
             u32x4 o = {sa[0], sb[0], sa[1], sb[1]};
-            *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(c_plane) +
-                                      (long)row * ldc + col) = o;
+            const long off = ((long)row * ldc + col) * 2;
+            *reinterpret_cast<u32x4*>(c_plane + off) = o;
+            for (int q = 0; q < nmirrors; ++q)
+              *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(mirrors[q]) + off) = o;
             continue;
           }
         }
@@ -701,17 +707,23 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
           const int col = cn0 + nh * 128 + wc * 32 + j * 16 + 4 * e_fq;
           if (col >= N) continue;
           f32x4 v = acc[mh][nh][i][j] * alpha;
+          const long off = ((long)row * ldc + col) * (OUT_F32 ? 4 : 2);
           if (OUT_F32) {
-            float* dst = reinterpret_cast<float*>(c_plane) + (long)row * ldc + col;
+            float* dst = reinterpret_cast<float*>(c_plane + off);
             if (col + 3 < N) {
               if (beta != 0.f) v += *reinterpret_cast<const f32x4*>(dst) * beta;
               *reinterpret_cast<f32x4*>(dst) = v;
+              for (int q = 0; q < nmirrors; ++q)
+                *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(mirrors[q]) + off) = v;
             } else {
-              for (int r = 0; r < 4 && col + r < N; ++r)
+              for (int r = 0; r < 4 && col + r < N; ++r) {
                 dst[r] = beta != 0.f ? v[r] + beta * dst[r] : v[r];
+                for (int q = 0; q < nmirrors; ++q)
+                  reinterpret_cast<float*>(reinterpret_cast<char*>(mirrors[q]) + off)[r] = v[r];
+              }
             }
           } else {
-            unsigned short* dst = reinterpret_cast<unsigned short*>(c_plane) + (long)row * ldc + col;
+            unsigned short* dst = reinterpret_cast<unsigned short*>(c_plane + off);
             if (beta != 0.f) {
               for (int r = 0; r < 4 && col + r < N; ++r) v[r] += beta * dtf_bf16_to_f32(dst[r]);
             }
@@ -720,8 +732,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
 #pragma unroll
               for (int r = 0; r < 4; ++r) o[r] = (short)dtf_f32_to_bf16(v[r]);
               *reinterpret_cast<bf16x4*>(dst) = o;
+              for (int q = 0; q < nmirrors; ++q)
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(mirrors[q]) + off) = o;
             } else {
-              for (int r = 0; r < 4 && col + r < N; ++r) dst[r] = dtf_f32_to_bf16(v[r]);
+              for (int r = 0; r < 4 && col + r < N; ++r) {
+                dst[r] = dtf_f32_to_bf16(v[r]);
+                for (int q = 0; q < nmirrors; ++q)
+                  reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(mirrors[q]) + off)[r] =
+                      dst[r];
+              }
             }
           }
         }
@@ -1449,6 +1468,47 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
     hipLaunchKernelGGL(gemm_bf16_nt_kernel<false>, grid, block, lds, stream,
                        (const unsigned short*)A, (const unsigned short*)Bt, C, M, N, K, lda, ldb,
                        ldc, tiles_m, tiles_n, alpha);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
+// dtf_gemm_bf16_nt whose epilogue also stores every result vector into `nmirrors` (1..7) further
+// copies of C: `mirrors` is a table IN DEVICE MEMORY of their addresses (same ldc, same alignment
+// as C; typically the same rows of the peers' result buffers, mapped through HIP IPC). Always the
+// ping-pong kernel (256- or 192-row tiles by the same rule as the default launch), unsplit.
+DTF_API int dtf_gemm_bf16_nt_mirrored(const void* A, const void* Bt, void* C,
+                                      const unsigned long long* mirrors, int nmirrors, int M,
+                                      int N, int K, long lda, long ldb, long ldc, float alpha,
+                                      int out_f32, hipStream_t stream) {
+  if (!A || !Bt || !C || !mirrors || nmirrors < 1 || nmirrors > 7 || M <= 0 || N <= 0 || K <= 0)
+    return DTF_ERR_BAD_ARG;
+  if (lda < K || ldb < K || ldc < N) return DTF_ERR_BAD_ARG;
+  if (K % BK || lda % 8 || ldb % 8 || ldc % 8 || ((uintptr_t)A & 15) || ((uintptr_t)Bt & 15) ||
+      ((uintptr_t)C & 15) || ((uintptr_t)mirrors & 7))
+    return DTF_ERR_UNSUPPORTED;
+  if (lda * 2 * BM >= (1L << 32) || ldb * 2 * BN >= (1L << 32)) return DTF_ERR_UNSUPPORTED;
+  const int tiles_n = (N + BN - 1) / BN;
+  const size_t lds = 2 * BUF_BYTES;
+  { static DtfPerDeviceOnce once__; dtf_once_per_device(once__, [&] {
+    dtf_allow_lds(gemm_nt_pp_kernel<true, 0, false, true>, lds);
+    dtf_allow_lds(gemm_nt_pp_kernel<false, 0, false, true>, lds);
+    dtf_allow_lds(gemm_nt_pp_kernel<true, 0, false, true, false, 3>, lds);
+    dtf_allow_lds(gemm_nt_pp_kernel<false, 0, false, true, false, 3>, lds);
+  }); }
+  const dim3 block(NTHREADS);
+#define DTF_MIRRORED(F32, MIV, TM)                                                               \
+  hipLaunchKernelGGL((gemm_nt_pp_kernel<F32, 0, false, true, false, MIV>),                       \
+                     dim3(dtf_pp_grid((TM) * tiles_n)), block, lds, stream, (const char*)A,      \
+                     (const char*)Bt, C, M, N, K, lda, ldb, ldc, (TM), tiles_n, alpha, 0.f, 1,   \
+                     0L, nullptr, nullptr, 0, 0, mirrors, nmirrors)
+  if (dtf_pp_prefers_192_rows(M, N)) {
+    const int tm = (M + 191) / 192;
+    if (out_f32) DTF_MIRRORED(true, 3, tm); else DTF_MIRRORED(false, 3, tm);
+  } else {
+    const int tm = (M + BM - 1) / BM;
+    if (out_f32) DTF_MIRRORED(true, 4, tm); else DTF_MIRRORED(false, 4, tm);
+  }
+#undef DTF_MIRRORED
   DTF_LAUNCH_CHECK();
   return DTF_OK;
 }

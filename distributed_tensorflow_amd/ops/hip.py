@@ -154,6 +154,7 @@ def _declare(L: ctypes.CDLL) -> None:
         "dtf_multi_sgd_f32": [I, P, P, P, P, I, P, P, P],
         "dtf_dropout_f32": [P, P, P, LG, U, U, P, F, P, P],
         "dtf_bump_counter_u64": [P, LG, P],
+        "dtf_gemm_bf16_nt_mirrored": [P, P, P, P, I, I, I, I, LG, LG, LG, F, I, P],
         "dtf_multi_optim_f32": [I, I, P, P, P, P, P, P, I, P, P, P, P],
         "dtf_affine_scalars_f32": [I, P, P, P, P],
         "dtf_philox_normal": [P, LG, U, U, LG, F, F, I, P],
@@ -508,6 +509,35 @@ def gemm_bf16_nt(a: torch.Tensor, bt: torch.Tensor, out_dtype: torch.dtype = tor
                                            a.stride(0), 1, 1, bt.stride(0), out.stride(0),
                                            float(alpha), float(beta), out_f32, _stream())
     _check(code, "gemm_bf16_nt")
+    return out
+
+
+def gemm_bf16_nt_mirrored(a: torch.Tensor, bt: torch.Tensor, out: torch.Tensor,
+                          mirror_table: torch.Tensor, alpha: float = 1.0) -> torch.Tensor:
+    """``out = alpha * a @ bt.T`` as :func:`gemm_bf16_nt`, with every result vector ALSO stored,
+    by the product's own epilogue, into further copies of ``out``: ``mirror_table`` is a
+    one-dimensional int64 tensor in GPU memory holding their addresses (1 to 7; each laid out like
+    ``out`` -- same pitch, 16-byte aligned -- typically the same rows of the peers' result buffers
+    mapped through HIP IPC). Fast-kernel shapes only (K % 64 == 0, aligned operands); raises
+    otherwise: the caller keeps the copy-after-product path for those."""
+    a = _req(a, torch.bfloat16, "gemm_bf16_nt_mirrored a")
+    bt = _req(bt, torch.bfloat16, "gemm_bf16_nt_mirrored bt")
+    if a.dim() != 2 or bt.dim() != 2 or a.shape[1] != bt.shape[1]:
+        raise HipKernelError("gemm_bf16_nt_mirrored: need a [M,K] and bt [N,K]")
+    m, k = a.shape
+    n = bt.shape[0]
+    if out.dtype not in (torch.bfloat16, torch.float32) or out.shape != (m, n) \
+            or out.stride(1) != 1 or out.device != a.device:
+        raise HipKernelError("gemm_bf16_nt_mirrored: bad out tensor")
+    if mirror_table.dtype != torch.int64 or mirror_table.dim() != 1 \
+            or not 1 <= mirror_table.numel() <= 7 or mirror_table.device != a.device \
+            or not mirror_table.is_contiguous():
+        raise HipKernelError("gemm_bf16_nt_mirrored: the table must hold 1 to 7 int64 addresses "
+                             "in GPU memory")
+    _check(lib().dtf_gemm_bf16_nt_mirrored(
+        a.data_ptr(), bt.data_ptr(), out.data_ptr(), mirror_table.data_ptr(),
+        mirror_table.numel(), m, n, k, a.stride(0), bt.stride(0), out.stride(0), float(alpha),
+        int(out.dtype == torch.float32), _stream()), "gemm_bf16_nt_mirrored")
     return out
 
 

@@ -12,7 +12,10 @@ time. The collectives here are *direct*: every rank talks to all of its peers at
 * ``all_gather_rows`` (push): a rank copies its block of rows into the same rows of every peer's
   buffer, one copy per peer on that peer's own stream -- N-1 concurrent transfers on N-1 links
   (or, with ``transport="kernel"``, one ``peer_push`` kernel whose workgroups store the rows
-  into all peers themselves).
+  into all peers themselves; or, with ``transport="epilogue"``, no copy at all: the kernel that
+  PRODUCES the rows stores every result vector into the peers' buffers as well as its own --
+  ``mirror_table`` gives it the addresses, ``begin_epilogue_push`` / ``publish`` / ``finish``
+  order the exchange on the producing stream).
 * ``reduce_scatter_rows`` (pull): a rank sums its block of rows over all ranks' buffers with the
   ``reduce_partials`` kernel reading the peers' rows IN PLACE through the mapped views, in rank
   order (deterministic) -- the rows cross xGMI once, straight into the reduction.
@@ -136,14 +139,15 @@ class SymmetricBuffer:
     def __init__(self, comm: Communicator, shape: Sequence[int], dtype: torch.dtype,
                  device: torch.device, transport: str = "copy", blocks_per_peer: int = 8,
                  sync: Optional[str] = None):
-        if transport not in ("copy", "kernel"):
-            raise ValueError("transport must be 'copy' or 'kernel'")
+        if transport not in ("copy", "kernel", "epilogue"):
+            raise ValueError("transport must be 'copy', 'kernel' or 'epilogue'")
         sync = sync or os.environ.get("DTF_PEER_SYNC") or "flags"
         if sync not in ("flags", "host"):
             raise ValueError("sync must be 'flags' or 'host'")
         self.transport = transport
         self.blocks_per_peer = int(blocks_per_peer)
         self._push_stream: Optional[torch.cuda.Stream] = None
+        self._tables: dict = {}       # (row0, rows) -> device table of the peers' row addresses
         self.tracer = None            # utils.tracing.StepTracer while a traced step runs
         self.comm = comm
         self.rank, self.world = comm.rank, comm.world_size
@@ -221,6 +225,8 @@ class SymmetricBuffer:
 
     # -- data movement -------------------------------------------------------------------
     def _ordered_streams(self):
+        if self.transport == "epilogue":       # the producing (current) stream carries the rows
+            return [(None, torch.cuda.current_stream(self.device))]
         if self.transport == "kernel":
             return [(None, self._push_stream)]
         return [(r, self._streams[r]) for r in self._peers]
@@ -237,6 +243,9 @@ class SymmetricBuffer:
         exchange (the rows it is about to overwrite are no longer being read)."""
         if self.world == 1:
             return
+        if self.transport == "epilogue":
+            raise PeerMemError("transport='epilogue': the producing kernel stores the rows "
+                               "(mirror_table / begin_epilogue_push), nothing is left to push")
         if ready is None:
             ready = torch.cuda.Event()
             ready.record()
@@ -274,6 +283,28 @@ class SymmetricBuffer:
                     if rec is not None:
                         tracer.end(rec)
 
+    def mirror_table(self, row0: int, rows: int) -> torch.Tensor:
+        """``transport="epilogue"``: int64 device tensor with the addresses of rows
+        ``row0 .. row0+rows`` in every PEER's buffer (rank order, this rank left out) -- what a
+        producing kernel takes as its list of further destinations. Cached per row range."""
+        key = (int(row0), int(rows))
+        table = self._tables.get(key)
+        if table is None:
+            addrs = [self.views[r][row0:row0 + rows].data_ptr() for r in self._peers]
+            table = self._tables[key] = torch.tensor(addrs, dtype=torch.int64, device=self.device)
+        return table
+
+    def begin_epilogue_push(self) -> None:
+        """``transport="epilogue"``, current stream, before a kernel that stores into the peers:
+        the first one of an exchange waits until every peer has acknowledged the previous
+        exchange (the rows about to be overwritten are no longer being read)."""
+        if self.world == 1:
+            return
+        first = not self._pushing
+        self._pushing = True
+        if first and self.flags is not None and self._seq > 0:
+            self.flags.wait(KIND_ACK, self._peers, self._seq)
+
     def publish(self) -> int:
         """Close the current exchange of pushes: behind its copies every pushing stream tells its
         peer the new sequence number. Returns that number (``sync="flags"`` only)."""
@@ -298,6 +329,8 @@ class SymmetricBuffer:
                     st.synchronize()
             if self._push_stream is not None:
                 self._push_stream.synchronize()
+            if self.transport == "epilogue":
+                torch.cuda.current_stream(self.device).synchronize()
             self.host_syncs += 1
             self._pushing = False
             self.comm.barrier()

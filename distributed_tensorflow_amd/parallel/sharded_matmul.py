@@ -30,6 +30,11 @@ well (operands 1/world per rank) and pays for that with the panel broadcasts.
 collective done over peer-mapped memory (``parallel/peer_mem.py``): every rank pushes its rows
 to all peers at once instead of passing them round a ring. GPU only, one node only.
 
+``peer_transport="epilogue"`` (``m_shard_allgather_direct``, bf16): there is no transfer step at
+all -- the GEMM kernel's epilogue stores every result vector into the same rows of all peers'
+result buffers next to its own (``hip.gemm_bf16_nt_mirrored``), tile by tile as the product runs,
+so the rows leave at the rate the matrix cores produce them and C is never read back for a copy.
+
 ``recompute_rows=x`` (all-gather strategies): a rank also computes the first ``x`` rows of every
 *peer's* row block instead of receiving them, so only ``M/world - x`` rows per block travel.
 With full C wanted on every rank each xGMI link has to carry ``M*N/world`` result elements per
@@ -216,7 +221,11 @@ class ShardedMatmul:
         rows_local = self.m // w if strategy.startswith("m_shard") else self.m
         if strategy == "block_2d_allgather":
             rows_local = self.m // self.grid_rows
-        self.peer_transport = peer_transport      # *_direct strategies: "copy" | "kernel"
+        self.peer_transport = peer_transport      # *_direct strategies: "copy" | "kernel" | "epilogue"
+        if peer_transport == "epilogue" and (strategy != "m_shard_allgather_direct"
+                                             or dtype != torch.bfloat16 or b_layout != "nk"):
+            raise ValueError("peer_transport='epilogue' is the bf16 m_shard_allgather_direct "
+                             "product storing into the peers from its own epilogue")
         self.recompute_rows = int(recompute_rows)
         if self.recompute_rows:
             if strategy not in ("m_shard_allgather", "m_shard_allgather_direct") or w == 1:
@@ -409,18 +418,22 @@ class ShardedMatmul:
 
     # -- local product -------------------------------------------------------------------
     def _gemm(self, a: torch.Tensor, bt: torch.Tensor, out: torch.Tensor,
-              accumulate: bool = False) -> None:
+              accumulate: bool = False, mirrors: Optional[torch.Tensor] = None) -> None:
         """out (+)= a @ op(bt) (a [m,k]; bt [n,k], or [k,n] under ``b_layout="kn"``) on the
-        hand-written kernels (GPU) or torch (CPU)."""
+        hand-written kernels (GPU) or torch (CPU). ``mirrors``: device table of further
+        destinations the bf16 kernel's epilogue stores the result into as well."""
         kn = self.b_layout == "kn"
         if self.tracer is not None:
             tracer, self.tracer = self.tracer, None
             try:
                 with tracer.span("panel_product[%dx%dx%d]" % (a.shape[0], out.shape[1],
                                                             a.shape[1]), "panel_product"):
-                    return self._gemm(a, bt, out, accumulate)
+                    return self._gemm(a, bt, out, accumulate, mirrors)
             finally:
                 self.tracer = tracer
+        if mirrors is not None:
+            self._hip.gemm_bf16_nt_mirrored(a, bt, out, mirrors)
+            return
         if self.on_gpu:
             beta = 1.0 if accumulate else 0.0
             if self.scaling == "mx":
@@ -516,10 +529,16 @@ class ShardedMatmul:
             self._set_works[which] = []
         self.c = sym.local
         sym.tracer = self.tracer
+        fused = self.peer_transport == "epilogue" and w > 1
         for start, rows in zip(self._panel_start, self._panel_rows):
             r0 = base + start
-            self._gemm(self.a[x + start:x + start + rows], self.bt, self.c[r0:r0 + rows])
-            sym.push_rows(r0, rows)
+            if fused:
+                sym.begin_epilogue_push()
+                self._gemm(self.a[x + start:x + start + rows], self.bt, self.c[r0:r0 + rows],
+                           mirrors=sym.mirror_table(r0, rows))
+            else:
+                self._gemm(self.a[x + start:x + start + rows], self.bt, self.c[r0:r0 + rows])
+                sym.push_rows(r0, rows)
         if x:
             # heads of all blocks, computed here while the links carry the bodies
             self._gemm(self.a_heads, self.bt, self.c[:w * x])

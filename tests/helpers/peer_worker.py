@@ -120,6 +120,21 @@ def main() -> int:
     eng.wait()
     torch.cuda.synchronize()
     errs["kernel_transport"] = (eng.result_dense().float() - want).abs().max().item()
+    # the epilogue transport: no transfer step, the product's own epilogue stores every result
+    # vector into all peers; plain and pipelined with recomputed heads (which stay local)
+    for name, kw in (("epilogue_transport", dict(panels=2)),
+                     ("epilogue_transport_pipelined",
+                      dict(panels=2, pipelined=True, recompute_rows=128))):
+        eng = ShardedMatmul(m, n, k, comm, dtype=torch.bfloat16,
+                            strategy="m_shard_allgather_direct", seed=5, device=dev,
+                            peer_transport="epilogue", **kw)
+        eng.init_operands()
+        for _ in range(3):
+            eng.step()
+        eng.wait()
+        torch.cuda.synchronize()
+        errs[name] = (eng.result_dense().float() - want).abs().max().item()
+        res[name + "_host_syncs"] = sum(sym.host_syncs for sym in eng._sym_sets)
     res["gemm_errs"] = errs
     res["ref_scale"] = want.abs().max().item()
     with open(os.path.join(out_dir, "rank%d.json" % rank), "w") as fh:

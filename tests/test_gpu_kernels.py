@@ -130,6 +130,31 @@ def test_gemm_bf16_192_row_tiles_are_chosen_and_bit_equal(hip, m, n, k, out_dtyp
     assert torch.equal(acc6, acc4)
 
 
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("m,n,k", [(512, 768, 256), (3072, 3072, 128), (300, 520, 64)])
+def test_gemm_bf16_mirrored_epilogue_fills_every_copy(hip, m, n, k, out_dtype):
+    """The product whose epilogue also stores into further copies of C (the peers' buffers in a
+    sharded run; plain tensors here): every copy equals the result bit for bit -- 256- and
+    192-row tiles, ragged edges, bf16 and fp32 results --, a guard band around each copy stays
+    untouched, and bad tables are refused."""
+    g = torch.Generator().manual_seed(m + n)
+    a = torch.randn(m, k, generator=g).bfloat16().cuda()
+    bt = torch.randn(n, k, generator=g).bfloat16().cuda()
+    want = hip.gemm_bf16_nt(a, bt, out_dtype, splits=1)
+    out = torch.empty(m, n, dtype=out_dtype, device="cuda")
+    copies = [torch.full((m + 2, n), 7.0, dtype=out_dtype, device="cuda") for _ in range(3)]
+    table = torch.tensor([c[1:m + 1].data_ptr() for c in copies], dtype=torch.int64, device="cuda")
+    hip.gemm_bf16_nt_mirrored(a, bt, out, table)
+    assert torch.equal(out, want)
+    for c in copies:
+        assert torch.equal(c[1:m + 1], want)
+        assert bool((c[0] == 7.0).all()) and bool((c[m + 1] == 7.0).all())
+    with pytest.raises(hip.HipKernelError):
+        hip.gemm_bf16_nt_mirrored(a, bt, out, table.cpu())
+    with pytest.raises(hip.HipKernelError):
+        hip.gemm_bf16_nt_mirrored(a, bt, out, torch.zeros(8, dtype=torch.int64, device="cuda"))
+
+
 def test_gemm_bf16_identity_asymmetric(hip):
     n = 512
     b = ((torch.arange(n * n).reshape(n, n) % 13) - 6).float()

@@ -103,6 +103,13 @@ def test_peer_memory_collectives_same_device(world, sync, tmp_path):
         assert res["gemm_errs"]["recompute_direct"] == 0.0, res
         assert res["gemm_errs"]["recompute_rccl_layout"] == 0.0, res
         assert res["gemm_errs"]["kernel_transport"] == 0.0, res
+        # rows stored into the peers by the product's own epilogue: identical bits again, and
+        # under device-side completion no host synchronisation either
+        assert res["gemm_errs"]["epilogue_transport"] == 0.0, res
+        assert res["gemm_errs"]["epilogue_transport_pipelined"] == 0.0, res
+        if sync == "flags":
+            assert res["epilogue_transport_host_syncs"] == 0
+            assert res["epilogue_transport_pipelined_host_syncs"] == 0
 
 
 FACADE_WORKER = os.path.join(ROOT, "tests", "helpers", "facade_shard_worker.py")

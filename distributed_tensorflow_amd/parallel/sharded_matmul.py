@@ -221,11 +221,15 @@ class ShardedMatmul:
         rows_local = self.m // w if strategy.startswith("m_shard") else self.m
         if strategy == "block_2d_allgather":
             rows_local = self.m // self.grid_rows
-        self.peer_transport = peer_transport      # *_direct strategies: "copy" | "kernel" | "epilogue"
-        if peer_transport == "epilogue" and (strategy != "m_shard_allgather_direct"
-                                             or dtype != torch.bfloat16 or b_layout != "nk"):
-            raise ValueError("peer_transport='epilogue' is the bf16 m_shard_allgather_direct "
-                             "product storing into the peers from its own epilogue")
+        # *_direct strategies: "copy" | "kernel" | "epilogue" (the last one only where the product
+        # itself can store into the peers: the bf16 all-gather; elsewhere it means "copy")
+        if peer_transport == "epilogue":
+            if strategy != "m_shard_allgather_direct":
+                peer_transport = "copy"
+            elif dtype != torch.bfloat16 or b_layout != "nk":
+                raise ValueError("peer_transport='epilogue': the bf16 product with a K-contiguous "
+                                 "right-hand operand is the one whose epilogue stores into peers")
+        self.peer_transport = peer_transport
         self.recompute_rows = int(recompute_rows)
         if self.recompute_rows:
             if strategy not in ("m_shard_allgather", "m_shard_allgather_direct") or w == 1:

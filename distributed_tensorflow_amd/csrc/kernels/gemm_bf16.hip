@@ -948,6 +948,217 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_bf16_nt_w4_kernel(
   }
 }
 
+// ---- four-wave kernel on a five-stage ring of 32-k stages (variant 7) ---------------------------
+// The four-wave kernel above starves because two 64 KiB K-tile buffers let its DMA run less than
+// one K-tile ahead. Here the 160 KiB of LDS are a RING OF FIVE STAGES of 32 k each (A 256 rows x
+// 64 B + Bt 256 rows x 64 B = 32 KiB): a stage is exactly one k-step of the MFMA, its slot is
+// dead as soon as its fragments are in registers (one k-step before they are multiplied), so the
+// DMA of stages s + 4 and s + 5 is issued during steps s and s + 1 (s even; A pieces in the
+// first, Bt pieces in the second) and read during steps s + 3 and s + 4: three k-steps = 1.5 K-tiles ahead, what the eight-wave kernel has. One barrier per
+// k-step (64 MFMAs per wave) behind a counted s_waitcnt vmcnt(16 / 17): two stages stay in flight
+// across it.
+//  * LDS image of a stage: row r at r * 64, its four 16-byte chunks XOR-permuted: chunk c sits at
+//    position c ^ ((-(r >> 2)) & 3). A fragment read (lane l: row l & 15, chunk l >> 4) then puts
+//    the 16 lanes of every ds_read_b128 lane group on 16 distinct 16-byte slots of the 256-byte
+//    bank row. The DMA writes lane-linearly (1 KiB = 16 rows per instruction, lane i -> row i / 4,
+//    position i % 4) and applies the permutation to its SOURCE address; four consecutive lanes
+//    fetch one row's 64 bytes.
+//  * Fragments are double-buffered in registers one k-step ahead (2 x 16 x 4 VGPRs), the 8 x 8
+//    accumulator tiles fill the 256 AGPRs; a k-step is 64 slots of [MFMA + at most one memory
+//    instruction]: a fragment read every fourth slot, a DMA request every eighth.
+//  * A stage holds HALF of every 128-byte line of its rows, so each line is requested twice;
+//    the two stages of a K-tile are therefore requested piece by piece together (the same wave
+//    asks for the second half 128 cycles after the first and finds the line on its way):
+//    requested a k-step apart the same kernel ran at 1065 TF (16384^3), bursts of sixteen
+//    requests in every other step at 1262, spread as now at 1385-1453.
+// NOT the default. Measured at 16384^3 / 8192^3 / 4096^3 beside the eight-wave kernel on one box:
+// 1385 / 1436 / 1315 against 1502 / 1526 / 1446 TF (92-94 %); with the K loop's DMA removed 1732-
+// 1847 TF (the eight-wave kernel: 1811). It draws 1373 W at a sampled 1.97 GHz where the eight-
+// wave kernel sits at the 1400 W cap at 1.73 GHz (`scripts/gemm_power_probe.py`): it is not
+// power-bound, its matrix pipe waits -- neither for memory (dropping the counted waits changes
+// nothing) nor much at the barrier (1408 without it), but at the issue of the DMA requests
+// themselves: four lanes per 64-byte half line are sixteen lines per request where the 128-byte
+// rows of the other kernels are eight, and with one wave per SIMD the wave that waits for the
+// address unit is the wave that feeds the matrix pipe. Full lines need 64 KiB K-tile slots, of
+// which 160 KiB hold two and a half; the vendor kernel gets its depth from registers instead.
+constexpr int RS_STAGE_BYTES = 32768, RS_STAGES = 5;
+
+// DBG (timing experiments, -DDTF_GEMM_EXPERIMENTS only; results are wrong when set): 1 = no
+// LDS-DMA in the K loop, 4 = no barrier
+template <bool OUT_F32, int DBG = 0>
+__global__ __launch_bounds__(W4_THREADS) void gemm_bf16_nt_w4ring_kernel(
+    const char* __restrict__ A, const char* __restrict__ Bt, void* __restrict__ C, int M, int N,
+    int K, long lda, long ldb, long ldc, int tiles_m, int tiles_n, float alpha, float beta) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  int tm, tn;
+  pp_tile_of_block(blockIdx.x, tiles_m, tiles_n, tm, tn, false);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int nks = K / 32;                       // stages (k-steps) of this product
+
+  f32x4 acc[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // DMA: this wave fills pieces 4 * wave .. 4 * wave + 3 (16 rows each) of the stage's A half and
+  // of its Bt half; the per-lane byte offsets are loop-invariant, the stage's 64 bytes of k are
+  // the instruction's scalar offset
+  unsigned voff_a[4], voff_b[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int trow = (wave * 4 + j) * 16 + (lane >> 2);
+    const int kc = (lane & 3) ^ ((-(trow >> 2)) & 3);
+    int ra = m0 + trow, rb = n0 + trow;
+    ra = ra < M - 1 ? ra : M - 1;
+    rb = rb < N - 1 ? rb : N - 1;
+    voff_a[j] = (unsigned)(ra - m0) * (unsigned)(lda * 2) + 16u * kc;
+    voff_b[j] = (unsigned)(rb - n0) * (unsigned)(ldb * 2) + 16u * kc;
+  }
+  const __amdgpu_buffer_rsrc_t a_rsrc = tile_rsrc(A + (long)m0 * lda * 2);
+  const __amdgpu_buffer_rsrc_t b_rsrc = tile_rsrc(Bt + (long)n0 * ldb * 2);
+
+  const int frow = lane & 15, fq = lane >> 4;
+  // lane's byte offset inside a 16-row block of a stage half, plus the wave's quarter
+  const int lane_off = frow * 64 + ((fq ^ ((-(frow >> 2)) & 3)) << 4);
+  const int a_off = lane_off + wr * 8192;                // A rows wr * 128 ...
+  const int b_off = lane_off + 16384 + wc * 8192;        // Bt rows wc * 128 ...
+
+  i32x4 fa[2][8], fb[2][8];
+// one DMA instruction of stage ST (clamped) into ring slot SLOT: D = 0..3 A pieces, 4..7 Bt pieces
+#define DTF_RS_DMA(ST, SLOT_BYTES, D)                                                            \
+  {                                                                                              \
+    const int st_ = (ST) < nks ? (ST) : nks - 1;                                                 \
+    char* dst_ = smem + (SLOT_BYTES) + ((D) >= 4 ? 16384 : 0) + (wave * 4 + ((D) & 3)) * 1024;   \
+    if ((D) >= 4)                                                                                \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (lds_void*)dst_, 16, voff_b[(D) & 3],     \
+                                               st_ * 64, 0, 0);                                  \
+    else                                                                                         \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_void*)dst_, 16, voff_a[(D) & 3],     \
+                                               st_ * 64, 0, 0);                                  \
+  }
+// one k-step: 64 MFMAs on fragment set CUR; the fragments of the next stage (ring slot at byte
+// RD) go into set NXT; pieces P0 .. P0 + 3 (0-3 A, 4-7 Bt) of stages ST_DMA and ST_DMA + 1 are
+// requested into the ring slots at bytes WR and WR2, piece by piece for both stages (the two
+// stages of a K-tile are the two halves of the same 128-byte lines: requested back to back by
+// the same wave, the second request finds the line already on its way)
+#define DTF_RS_STEP(CUR, NXT, RD, P0, ST_DMA, WR, WR2)                                           \
+  {                                                                                              \
+    const char* rda_ = smem + (RD) + a_off;                                                      \
+    const char* rdb_ = smem + (RD) + b_off;                                                      \
+    _Pragma("unroll") for (int n_ = 0; n_ < 64; ++n_) {                                          \
+      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"                                      \
+                   : "+a"(acc[n_ >> 3][n_ & 7])                                                  \
+                   : "v"(fb[CUR][n_ & 7]), "v"(fa[CUR][n_ >> 3]));                               \
+      /* a fragment read every fourth slot (the Bt fragments, all needed by the next step's     \
+         first eight MFMAs, first), a DMA request every eighth slot between them: pieces P0 ..   \
+         P0 + 3 of both stages, the two halves of a line eight slots apart */                    \
+      if ((n_ & 3) == 0) {                                                                       \
+        const int f_ = (n_ >> 2) & 7;                                                            \
+        if (n_ < 32)                                                                             \
+          fb[NXT][f_] = *reinterpret_cast<const i32x4*>(rdb_ + f_ * 1024);                       \
+        else                                                                                     \
+          fa[NXT][f_] = *reinterpret_cast<const i32x4*>(rda_ + f_ * 1024);                       \
+      } else if (!(DBG & 1) && (n_ & 7) == 2) {                                                  \
+        const int piece_ = (P0) + (n_ >> 4);                                                     \
+        if (n_ & 8) DTF_RS_DMA((ST_DMA) + 1, WR2, piece_)                                        \
+        else DTF_RS_DMA(ST_DMA, WR, piece_)                                                      \
+      }                                                                                          \
+      __builtin_amdgcn_sched_barrier(0);                                                         \
+    }                                                                                            \
+  }
+
+  // prologue: stages 0..3 in flight (pairwise interleaved), stage 0 landed and visible, its
+  // fragments requested
+#pragma unroll
+  for (int st = 0; st < 4; st += 2)
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      DTF_RS_DMA(st, st * RS_STAGE_BYTES, d)
+      DTF_RS_DMA(st + 1, (st + 1) * RS_STAGE_BYTES, d)
+    }
+  asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    fa[0][i] = *reinterpret_cast<const i32x4*>(smem + a_off + i * 1024);
+    fb[0][i] = *reinterpret_cast<const i32x4*>(smem + b_off + i * 1024);
+  }
+
+  // ring positions (bytes): rd = slot of stage s + 1, wr = slot of stage s + 4 (= that of stage
+  // s - 1), wr2 = slot of stage s + 5 (= that of stage s, whose fragments are in registers)
+  int rd = RS_STAGE_BYTES, wr_slot = 4 * RS_STAGE_BYTES, wr2_slot = 0;
+  auto next = [](int v) { return v == 4 * RS_STAGE_BYTES ? 0 : v + RS_STAGE_BYTES; };
+  auto advance = [&]() {
+    rd = next(rd);
+    wr_slot = next(wr_slot);
+    wr2_slot = next(wr2_slot);
+  };
+  for (int s = 0; s < nks; s += 2) {
+    // stage s + 1 has landed for this wave (stages s + 2, s + 3 may still be in flight) ...
+    if (!(DBG & 1)) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(DBG & 4)) __builtin_amdgcn_s_barrier();      // ... and for every wave; all are done reading slot wr
+    __builtin_amdgcn_sched_barrier(0);
+    DTF_RS_STEP(0, 1, rd, 0, s + 4, wr_slot, wr2_slot)
+    // stage s + 2 has landed: of the pair (s + 2, s + 3) at most the last piece of s + 3 and the
+    // eight requests of this step are still in flight  (K % 64 == 0: an even stage count)
+    if (!(DBG & 1)) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(DBG & 4)) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    rd = next(rd);
+    DTF_RS_STEP(1, 0, rd, 4, s + 4, wr_slot, wr2_slot)
+    advance();
+    wr_slot = next(wr_slot);
+    wr2_slot = next(wr2_slot);
+  }
+#undef DTF_RS_STEP
+#undef DTF_RS_DMA
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // nothing may outlive the workgroup
+  // the last MFMAs were issued from inline asm: cover their result latency before the
+  // epilogue reads the accumulators
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int row = m0 + wr * 128 + i * 16 + frow;
+    if (row >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int col = n0 + wc * 128 + j * 16 + 4 * fq;
+      if (col >= N) continue;
+      f32x4 v = acc[i][j] * alpha;
+      if (OUT_F32) {
+        float* dst = reinterpret_cast<float*>(C) + (long)row * ldc + col;
+        if (col + 3 < N) {
+          if (beta != 0.f) v += *reinterpret_cast<const f32x4*>(dst) * beta;
+          *reinterpret_cast<f32x4*>(dst) = v;
+        } else {
+          for (int r = 0; r < 4 && col + r < N; ++r)
+            dst[r] = beta != 0.f ? v[r] + beta * dst[r] : v[r];
+        }
+      } else {
+        unsigned short* dst = reinterpret_cast<unsigned short*>(C) + (long)row * ldc + col;
+        if (beta != 0.f) {
+          for (int r = 0; r < 4 && col + r < N; ++r) v[r] += beta * dtf_bf16_to_f32(dst[r]);
+        }
+        if (col + 3 < N) {
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (short)dtf_f32_to_bf16(v[r]);
+          *reinterpret_cast<bf16x4*>(dst) = o;
+        } else {
+          for (int r = 0; r < 4 && col + r < N; ++r) dst[r] = dtf_f32_to_bf16(v[r]);
+        }
+      }
+    }
+  }
+}
+
 // ---- generic, fully predicated bf16 GEMM (any shape, NN / NT / TN / TT via strides) -------------
 // C[m,n] = alpha * sum_k A(m,k) * B(k,n), A(m,k) = A[m*a_rs + k*a_cs], B(k,n) = B[k*b_rs + n*b_cs]
 constexpr int GB = 64, GK = 32;
@@ -1301,6 +1512,37 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
   }); }
   dim3 grid(tiles_m * tiles_n), block(NTHREADS);
   const dim3 pp_grid(dtf_pp_grid(tiles_m * tiles_n));
+  if ((variant & 15) == 7) {       // four-wave kernel on the five-stage ring
+    const size_t rs_lds = (size_t)RS_STAGES * RS_STAGE_BYTES;       // all 160 KiB of the CU
+    { static DtfPerDeviceOnce once__; dtf_once_per_device(once__, [&] {
+      dtf_allow_lds(gemm_bf16_nt_w4ring_kernel<true>, rs_lds);
+      dtf_allow_lds(gemm_bf16_nt_w4ring_kernel<false>, rs_lds);
+    }); }
+#ifdef DTF_GEMM_EXPERIMENTS
+#define DTF_RS_DBG(D)                                                                          \
+  if ((variant >> 4) == D) {                                                                   \
+    { static DtfPerDeviceOnce once__; dtf_once_per_device(once__, [&] {                        \
+      dtf_allow_lds((gemm_bf16_nt_w4ring_kernel<false, D>), rs_lds); }); }                     \
+    hipLaunchKernelGGL((gemm_bf16_nt_w4ring_kernel<false, D>), grid, dim3(W4_THREADS), rs_lds, \
+                       stream, (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc,     \
+                       tiles_m, tiles_n, alpha, beta);                                         \
+    DTF_LAUNCH_CHECK();                                                                        \
+    return DTF_OK;                                                                             \
+  }
+    DTF_RS_DBG(1) DTF_RS_DBG(4) DTF_RS_DBG(5)
+#undef DTF_RS_DBG
+#endif
+    if (out_f32)
+      hipLaunchKernelGGL(gemm_bf16_nt_w4ring_kernel<true>, grid, dim3(W4_THREADS), rs_lds, stream,
+                         (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tiles_m,
+                         tiles_n, alpha, beta);
+    else
+      hipLaunchKernelGGL(gemm_bf16_nt_w4ring_kernel<false>, grid, dim3(W4_THREADS), rs_lds,
+                         stream, (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc,
+                         tiles_m, tiles_n, alpha, beta);
+    DTF_LAUNCH_CHECK();
+    return DTF_OK;
+  }
   if ((variant & 15) == 3) {       // four-wave kernel
         const size_t w4_lds = 2 * BUF_BYTES;
     { static DtfPerDeviceOnce once__; dtf_once_per_device(once__, [&] {

@@ -731,6 +731,18 @@ def _mul_grad(op, g):
     return _unbroadcast(multiply(g, y), x, y), _unbroadcast(multiply(g, x), y, x)
 
 
+@gradient("Pow")
+def _pow_grad(op, g):
+    """d/dx x^y = y x^(y-1); d/dy x^y = x^y ln x, taken as 0 where x <= 0 (TensorFlow's
+    convention: the logarithm is not evaluated into the result there)."""
+    x, y = op.inputs
+    z = op.outputs[0]
+    gx = multiply(g, multiply(y, pow(x, subtract(y, 1.0))))
+    safe_log = where(greater(x, 0.0), log(x), zeros_like(x))
+    gy = multiply(g, multiply(z, safe_log))
+    return _unbroadcast(gx, x, y), _unbroadcast(gy, y, x)
+
+
 @gradient("RealDiv")
 def _div_grad(op, g):
     x, y = op.inputs

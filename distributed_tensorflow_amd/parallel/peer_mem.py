@@ -399,14 +399,14 @@ def all_gather_rows(buf: SymmetricBuffer, rows_per_rank: int) -> None:
     buf.finish()
 
 
-def reduce_scatter_rows(partial: SymmetricBuffer, out: torch.Tensor, row0: int, rows: int,
-                        staging: Optional[torch.Tensor] = None) -> None:
+def reduce_scatter_rows(partial: SymmetricBuffer, out: torch.Tensor, row0: int,
+                        rows: int) -> None:
     """``out = sum over ranks of partial[row0:row0+rows]`` in rank order (deterministic): the
     ``reduce_partials`` kernel reads the peers' rows in place through the mapped views, so they
     cross xGMI once and are never staged in local memory. Call
     :meth:`SymmetricBuffer.quiesce` first so that every rank's partials are complete; under
     ``sync="flags"`` the kernel's completion is acknowledged to the peers (they may rewrite
-    their partials). ``staging`` is accepted for compatibility and unused."""
+    their partials)."""
     from ..ops import hip
     w = partial.world
     if w > 8:

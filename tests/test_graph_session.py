@@ -500,6 +500,27 @@ def test_mean_squared_error_is_one_op_with_its_own_gradient():
     assert np.allclose(dt, -2.0 * (pred_v - b) / b.size, rtol=1e-5, atol=1e-7)
 
 
+def test_pow_gradient_for_base_and_exponent():
+    """``tf.pow`` / ``**`` differentiate with respect to both operands (broadcast exponent
+    included); where the base is not positive the exponent's gradient is 0, as in TensorFlow."""
+    xv = np.abs(np.random.RandomState(0).randn(3, 4)).astype(np.float32) + 0.1
+    with tf.Graph().as_default():
+        x = tf.placeholder(tf.float32, [3, 4])
+        y = tf.Variable(tf.constant(np.full((4,), 1.5, np.float32)))
+        z = tf.reduce_sum(tf.pow(x, y)) + tf.reduce_sum(x ** 2.0)
+        gx, gy = tf.gradients(z, [x, y])
+        with tf.Session() as sess:
+            sess.run(tf.global_variables_initializer())
+            a, b = sess.run([gx, gy], {x: xv})
+            neg = sess.run(tf.gradients(tf.reduce_sum(tf.pow(x, 2.0 * tf.ones([4]))), [x])[0],
+                           {x: -xv})
+    xt = torch.tensor(xv, requires_grad=True)
+    yt = torch.full((4,), 1.5, requires_grad=True)
+    (torch.pow(xt, yt).sum() + (xt ** 2).sum()).backward()
+    assert np.allclose(a, xt.grad.numpy(), rtol=1e-5) and np.allclose(b, yt.grad.numpy(), rtol=1e-5)
+    assert np.allclose(neg, -2.0 * xv, rtol=1e-5)
+
+
 def test_cos_and_sin_with_gradients():
     with tf.Graph().as_default():
         x = tf.placeholder(tf.float32, [5])

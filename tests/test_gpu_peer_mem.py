@@ -156,8 +156,10 @@ def test_sharded_tf_matmul_rehearsed_on_one_gpu(world, dtype, mode, collective, 
     # (the fp32 case asserts overlap below: panels of 2048 x 4096 x 4096, ~0.7 ms each, long
     # against the time the host needs to queue the copies behind them)
     m, n, k = (8192, 4096, 4096) if dtype == "fp32" and collective == "peer" else (4096, 2048, 2048)
+    overlap_case = dtype == "fp32" and collective == "peer"
+    panels = 4 if overlap_case else 2          # (three hand-overs in which a push can overlap)
     results = _spawn_facade(world, tmp_path, DTF_SHAPE="%d,%d,%d" % (m, n, k), DTF_DTYPE=dtype,
-                            DTF_SHARD=mode, DTF_COLLECTIVE=collective, DTF_PANELS="2")
+                            DTF_SHARD=mode, DTF_COLLECTIVE=collective, DTF_PANELS=str(panels))
     want = {("m", "peer"): "m_shard_allgather_direct", ("m", "rccl"): "m_shard_allgather",
             ("2d", "rccl"): "block_2d_allgather", ("k", "rccl"): "k_shard_allreduce"}
     for res in results:
@@ -171,10 +173,13 @@ def test_sharded_tf_matmul_rehearsed_on_one_gpu(world, dtype, mode, collective, 
             assert res["a_local"] == [m // world, k]
         assert res["panel_products"] >= (2 if mode != "k" or world else 1)
         if collective == "peer":
-            assert res["panels"] == 2 and res["transfers"] >= 2 * (world - 1)
+            assert res["panels"] == panels and res["transfers"] >= panels * (world - 1)
             # panel 0's pushes are queued behind its product and run under panel 1's. Asserted
             # where a panel's product is long against the host's time to queue the copies; the
             # short bf16 / fp8 panels of the small shape are over before an eagerly issued,
             # traced step gets the next launch out
-            if dtype == "fp32":
-                assert res["overlap_us"] > 0.0, res
+    if overlap_case:
+        # (the ranks time-slice ONE GPU here and their copies are kernels that need free CUs: a
+        # single rank can come out with its pushes serialised behind its products, so the
+        # overlap is asked of the run, not of every rank)
+        assert any(res["overlap_us"] > 0.0 for res in results), results

@@ -1159,6 +1159,204 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_bf16_nt_w4ring_kernel(
   }
 }
 
+// ---- four-wave kernel with a register-staged load ring (variant 8) ------------------------------
+// Same block tile, LDS image (128-byte rows, full lines) and 2 x 2 waves of 128 x 128 outputs as the
+// four-wave kernels above, but the prefetch depth comes from REGISTERS: a K-tile's 64 KiB travel
+// global -> VGPR (16 buffer loads of 16 bytes per lane) -> LDS (16 ds_write_b128), two register
+// sets alternate, and the loads of tile t + 3 are issued while tile t is multiplied -- they are
+// written to LDS three to four k-steps later. Per K-tile and wave: 128 MFMAs, 32 fragment reads,
+// 16 loads, 16 LDS writes, ONE barrier.
+//  step (t, 0): MFMAs of (t, 0) | reads the fragments of (t, 1) from buffer t | writes the register
+//               set of tile t + 1 into buffer t + 1 (whose last readers passed the previous
+//               barrier) and, behind each write, requests that register's part of tile t + 3
+//  barrier      (tile t + 1 visible; every wave done with buffer t's k-step-1 fragments next step)
+//  step (t, 1): MFMAs of (t, 1) | reads the fragments of (t + 1, 0) from buffer t + 1
+// NOT the default. Measured at 16384^3 / 8192^3 / 4096^3 beside the eight-wave kernel on one box:
+// 1409 / 1416 / 1334 against 1550 / 1579 / 1472 TF. With the LDS writes removed (loads kept) it
+// runs at 1856 / 1832 / 1636, with the loads removed (writes kept) at 1675 / 1601 / 1497: the
+// loads into registers are free, the sixteen ds_write_b128 per K-tile and wave are not, and
+// neither a longer prefetch distance (two against three k-steps) nor relaxed fragment reads
+// changed the result. It sits at 1394 W and a sampled 1.88 GHz: register staging pays for the
+// extra register-file and LDS-write traffic in energy as well -- the vendor kernel's LDS
+// instruction count (reads only, `profiles/gemm_bf16_16384_pmc_r3.txt`) says it fills LDS by DMA
+// too.
+// Fragments: the eight Bt fragments of a k-step stay in registers, double-buffered across steps
+// (2 x 32 VGPRs); the eight A fragments are single-buffered (32 VGPRs): m-tile i's register is
+// refilled for the next step as soon as its eight MFMAs are issued -- 96 registers where the
+// kernels above hold 128, which is what leaves room for the two load sets (128) next to the 256
+// accumulator registers.
+// Contract: M and N multiples of 256 (no row clamping: the loads' lane offsets are two registers
+// per operand), K a multiple of 128 (two K-tiles per loop trip).
+template <bool OUT_F32, int DBG = 0>
+__global__ __launch_bounds__(W4_THREADS) void gemm_bf16_nt_w4reg_kernel(
+    const char* __restrict__ A, const char* __restrict__ Bt, void* __restrict__ C, int M, int N,
+    int K, long lda, long ldb, long ldc, int tiles_m, int tiles_n, float alpha, float beta) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  int tm, tn;
+  pp_tile_of_block(blockIdx.x, tiles_m, tiles_n, tm, tn, false);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int nkt = K / BK;
+
+  f32x4 acc[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // loads: this wave moves pieces 8 * wave + j (j = 0..7; a piece = 8 rows of 128 bytes) of the A
+  // tile and of the Bt tile. Lane i of a piece handles row i / 8, LDS position i % 8 and fetches
+  // chunk (i % 8) ^ swizzle(row); the swizzle of piece p's rows is (4 p + i / 16) & 7, which
+  // depends on j only through its parity -- two lane offsets per operand, the rest is scalar
+  unsigned voff_a[2], voff_b[2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par) {
+    const int kc = (lane & 7) ^ ((4 * par + (lane >> 4)) & 7);
+    voff_a[par] = (unsigned)(wave * 64 + (lane >> 3)) * (unsigned)(lda * 2) + 16u * kc;
+    voff_b[par] = (unsigned)(wave * 64 + (lane >> 3)) * (unsigned)(ldb * 2) + 16u * kc;
+  }
+  const int piece_a = (int)(lda * 16), piece_b = (int)(ldb * 16);   // bytes from piece to piece
+  const __amdgpu_buffer_rsrc_t a_rsrc = tile_rsrc(A + (long)m0 * lda * 2);
+  const __amdgpu_buffer_rsrc_t b_rsrc = tile_rsrc(Bt + (long)n0 * ldb * 2);
+
+  const int frow = lane & 15, fq = lane >> 4;
+  const int lane_off0 = chunk_off(frow, fq), lane_off1 = chunk_off(frow, 4 + fq);
+  const int a_base = wr * 16384;                    // wave's 8 row blocks of 2 KiB in the A tile
+  const int b_base = TILE_BYTES + wc * 16384;       // ... in the Bt tile
+  char* const wr_lane = smem + wave * 8192 + lane * 16;   // this lane's slot in the wave's pieces
+
+  i32x4 g[2][16];          // two load sets: [set][0..7 A pieces, 8..15 Bt pieces]
+  i32x4 fa[8], fb[2][8];   // A fragments (refilled for the next step as m-tiles finish), Bt
+                           // fragments of this step / the next
+
+// load Q (0..15) of K-tile KT into set GS
+#define DTF_WR_LOAD(GS, Q, KT)                                                                   \
+  {                                                                                              \
+    const int kt_ = (KT) < nkt ? (KT) : nkt - 1;                                                 \
+    if ((Q) < 8)                                                                                 \
+      g[GS][Q] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, voff_a[(Q) & 1],                  \
+                                                       kt_ * 128 + ((Q) & 7) * piece_a, 0);      \
+    else                                                                                         \
+      g[GS][Q] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, voff_b[(Q) & 1],                  \
+                                                       kt_ * 128 + ((Q) & 7) * piece_b, 0);      \
+  }
+// LDS write Q of set GS into K-tile buffer BUFI
+#define DTF_WR_STORE(GS, Q, BUFI)                                                                \
+  *reinterpret_cast<i32x4*>(wr_lane + (BUFI) * BUF_BYTES + ((Q) >= 8 ? TILE_BYTES : 0) +         \
+                            ((Q) & 7) * 1024) = g[GS][Q];
+// one k-step of 64 MFMAs, m-tile by m-tile. FS: fragment set of this step's Bt fragments (the
+// next step's go into FS ^ 1). The next step's fragments come from buffer RB at lane offset RL;
+// this step's remaining A fragments from buffer CB at lane offset CL. MEM(q): the step's q-th
+// (0..15) load or LDS write.
+#define DTF_WR_STEP(FS, CB, CL, RB, RL, MEM)                                                     \
+  {                                                                                              \
+    const char* cur_a_ = smem + (CB) * BUF_BYTES + a_base + (CL);                                \
+    const char* nxt_a_ = smem + (RB) * BUF_BYTES + a_base + (RL);                                \
+    const char* nxt_b_ = smem + (RB) * BUF_BYTES + b_base + (RL);                                \
+    _Pragma("unroll") for (int n_ = 0; n_ < 64; ++n_) {                                          \
+      const int i_ = n_ >> 3, j_ = n_ & 7;                                                       \
+      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"                                      \
+                   : "+a"(acc[i_][j_])                                                           \
+                   : "v"(fb[FS][j_]), "v"(fa[i_]));                                              \
+      if (j_ == 0) {                                                                             \
+        /* m-tile 7's fragment of THIS step (its register was busy until the last step ended);  \
+           then, behind every finished m-tile, its fragment of the next step */                  \
+        if (i_ == 0) fa[7] = *reinterpret_cast<const i32x4*>(cur_a_ + 7 * 2048);                 \
+        else fa[i_ - 1] = *reinterpret_cast<const i32x4*>(nxt_a_ + (i_ - 1) * 2048);             \
+      } else if (j_ == 1) {                                                                      \
+        fb[(FS) ^ 1][i_] = *reinterpret_cast<const i32x4*>(nxt_b_ + i_ * 2048);                  \
+      } else if (j_ == 2) {                                                                      \
+        MEM(2 * i_, 0)                                                                           \
+      } else if (j_ == 3) {                                                                      \
+        MEM(2 * i_, 1)                                                                           \
+      } else if (j_ == 5) {                                                                      \
+        MEM(2 * i_ + 1, 0)                                                                       \
+      } else if (j_ == 6) {                                                                      \
+        MEM(2 * i_ + 1, 1)                                                                       \
+      }                                                                                          \
+      __builtin_amdgcn_sched_barrier(0);                                                         \
+    }                                                                                            \
+  }
+
+  // prologue: tiles 0 and 1 requested, tile 0 written to buffer 0 and visible, tile 2 requested
+  // into the set tile 0 has left, the fragments of (0, 0) read
+#pragma unroll
+  for (int q = 0; q < 16; ++q) DTF_WR_LOAD(0, q, 0)
+#pragma unroll
+  for (int q = 0; q < 16; ++q) DTF_WR_LOAD(1, q, 1)
+#pragma unroll
+  for (int q = 0; q < 16; ++q) DTF_WR_STORE(0, q, 0)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int q = 0; q < 16; ++q) DTF_WR_LOAD(0, q, 2)
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (j < 7) fa[j] = *reinterpret_cast<const i32x4*>(smem + a_base + lane_off0 + j * 2048);
+    fb[0][j] = *reinterpret_cast<const i32x4*>(smem + b_base + lane_off0 + j * 2048);
+  }
+
+  for (int t = 0; t < nkt; t += 2) {
+    // tile t (buffer 0): (t, 0) writes tile t + 1 (set 1) into buffer 1
+    // ... and, behind each write, requests the same register's part of tile t + 3
+#define DTF_MEM_A(Q, PH)                                                                         \
+  if ((PH) == 0) { if (!(DBG & 2)) { DTF_WR_STORE(1, Q, 1) } }                                   \
+  else if (!(DBG & 1)) { DTF_WR_LOAD(1, Q, t + 3) }
+    DTF_WR_STEP(0, 0, lane_off0, 0, lane_off1, DTF_MEM_A)
+#undef DTF_MEM_A
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(DBG & 4)) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+#define DTF_MEM_B(Q, PH)
+    DTF_WR_STEP(1, 0, lane_off1, 1, lane_off0, DTF_MEM_B)
+    // tile t + 1 (buffer 1): (t + 1, 0) writes tile t + 2 (set 0) into buffer 0
+#define DTF_MEM_C(Q, PH)                                                                         \
+  if ((PH) == 0) { if (!(DBG & 2)) { DTF_WR_STORE(0, Q, 0) } }                                   \
+  else if (!(DBG & 1)) { DTF_WR_LOAD(0, Q, t + 4) }
+    DTF_WR_STEP(0, 1, lane_off0, 1, lane_off1, DTF_MEM_C)
+#undef DTF_MEM_C
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(DBG & 4)) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    DTF_WR_STEP(1, 1, lane_off1, 0, lane_off0, DTF_MEM_B)
+#undef DTF_MEM_B
+  }
+#undef DTF_WR_STEP
+#undef DTF_WR_STORE
+#undef DTF_WR_LOAD
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the inline-asm MFMAs' result latency
+
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int row = m0 + wr * 128 + i * 16 + frow;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int col = n0 + wc * 128 + j * 16 + 4 * fq;
+      f32x4 v = acc[i][j] * alpha;
+      if (OUT_F32) {
+        float* dst = reinterpret_cast<float*>(C) + (long)row * ldc + col;
+        if (beta != 0.f) v += *reinterpret_cast<const f32x4*>(dst) * beta;
+        *reinterpret_cast<f32x4*>(dst) = v;
+      } else {
+        unsigned short* dst = reinterpret_cast<unsigned short*>(C) + (long)row * ldc + col;
+        if (beta != 0.f) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += beta * dtf_bf16_to_f32(dst[r]);
+        }
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (short)dtf_f32_to_bf16(v[r]);
+        *reinterpret_cast<bf16x4*>(dst) = o;
+      }
+    }
+  }
+}
+
 // ---- generic, fully predicated bf16 GEMM (any shape, NN / NT / TN / TT via strides) -------------
 // C[m,n] = alpha * sum_k A(m,k) * B(k,n), A(m,k) = A[m*a_rs + k*a_cs], B(k,n) = B[k*b_rs + n*b_cs]
 constexpr int GB = 64, GK = 32;
@@ -1512,6 +1710,38 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
   }); }
   dim3 grid(tiles_m * tiles_n), block(NTHREADS);
   const dim3 pp_grid(dtf_pp_grid(tiles_m * tiles_n));
+  if ((variant & 15) == 8) {       // four-wave kernel, register-staged loads
+    if (M % BM || N % BN || K % (2 * BK)) return DTF_ERR_UNSUPPORTED;
+    const size_t wr_lds = 2 * BUF_BYTES;
+    { static DtfPerDeviceOnce once__; dtf_once_per_device(once__, [&] {
+      dtf_allow_lds(gemm_bf16_nt_w4reg_kernel<true>, wr_lds);
+      dtf_allow_lds(gemm_bf16_nt_w4reg_kernel<false>, wr_lds);
+    }); }
+#ifdef DTF_GEMM_EXPERIMENTS
+#define DTF_WRG_DBG(D)                                                                         \
+  if ((variant >> 4) == D) {                                                                   \
+    { static DtfPerDeviceOnce once__; dtf_once_per_device(once__, [&] {                        \
+      dtf_allow_lds((gemm_bf16_nt_w4reg_kernel<false, D>), wr_lds); }); }                      \
+    hipLaunchKernelGGL((gemm_bf16_nt_w4reg_kernel<false, D>), grid, dim3(W4_THREADS), wr_lds,  \
+                       stream, (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc,     \
+                       tiles_m, tiles_n, alpha, beta);                                         \
+    DTF_LAUNCH_CHECK();                                                                        \
+    return DTF_OK;                                                                             \
+  }
+    DTF_WRG_DBG(1) DTF_WRG_DBG(2) DTF_WRG_DBG(3) DTF_WRG_DBG(4) DTF_WRG_DBG(7)
+#undef DTF_WRG_DBG
+#endif
+    if (out_f32)
+      hipLaunchKernelGGL(gemm_bf16_nt_w4reg_kernel<true>, grid, dim3(W4_THREADS), wr_lds, stream,
+                         (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tiles_m,
+                         tiles_n, alpha, beta);
+    else
+      hipLaunchKernelGGL(gemm_bf16_nt_w4reg_kernel<false>, grid, dim3(W4_THREADS), wr_lds,
+                         stream, (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc,
+                         tiles_m, tiles_n, alpha, beta);
+    DTF_LAUNCH_CHECK();
+    return DTF_OK;
+  }
   if ((variant & 15) == 7) {       // four-wave kernel on the five-stage ring
     const size_t rs_lds = (size_t)RS_STAGES * RS_STAGE_BYTES;       // all 160 KiB of the CU
     { static DtfPerDeviceOnce once__; dtf_once_per_device(once__, [&] {

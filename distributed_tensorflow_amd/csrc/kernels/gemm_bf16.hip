@@ -330,10 +330,11 @@ __device__ __forceinline__ void pp_tile_of_block(int bid, int tiles_m, int tiles
 //   fragment reads. The three instructions enter the counted vmcnt waits of the phases that issue
 //   them (they sit in the queue before that phase's tile DMA, so those phases wait for
 //   vmcnt(9) instead of vmcnt(6)).
-// MI = 16-row MFMA tiles per wave and A half (4: block tiles of 256 rows; 3: of 192 rows, for
-//   grids whose 256-row tiling leaves a quarter or more of the last round of workgroups idle --
-//   3072^2 outputs are 144 tiles of 256 x 256 on 256 CUs but 192 tiles of 192 x 256). A half of
-//   a 192-row tile is 96 rows; it is still STAGED as 128 rows (the LDS image, the DMA stream and
+// MI = 16-row MFMA tiles per wave and A half (4: block tiles of 256 rows; 3: of 192 rows; 2: of
+//   128 rows -- for grids whose 256-row tiling leaves much of a round of workgroups idle: 3072^2
+//   outputs are 144 tiles of 256 x 256 on 256 CUs but 192 tiles of 192 x 256, 2048 x 4096 are 128
+//   or 256). A half of a 192-row tile is 96 rows (64 of a 128-row tile); it is still STAGED as 128
+//   rows (the LDS image, the DMA stream and
 //   its counted waits stay those of the 256-row kernel; the 32 extra rows are the next half's or
 //   the next tile's, clamped at the matrix edge, and are not read).
 template <bool OUT_F32, int DBG, bool FP8, bool MERGE = false, bool MX = false, int MI = 4>
@@ -350,7 +351,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
   // sa_pair / sb_quad: bytes from one K-tile pair (A) / quad (Bt) of scales to the next -- the
   // row-tile count of the matrix the scales were made for, which may be taller than this call's
   static_assert(!MX || (FP8 && MERGE), "block scales: fp8 operands, merged schedule");
-  static_assert(MI == 4 || (MI == 3 && !FP8 && MERGE), "192-row tiles: bf16, merged schedule");
+  static_assert(MI == 4 || ((MI == 3 || MI == 2) && !FP8 && MERGE),
+                "192- and 128-row tiles: bf16, merged schedule");
   constexpr int BM_ROWS = 64 * MI, HALF_ROWS = 32 * MI;    // block tile / A half, in rows
   // ksplits > 1 (few output tiles, long K): work item (split, tile) multiplies K-range `split`
   // of K / ksplits columns and writes its partial tile to C + split * plane (elements); a
@@ -1631,8 +1633,9 @@ __global__ __launch_bounds__(T128_THREADS) void gemm_bf16_nt_t128_kernel(
 // kernel: K % 64 == 0, lda/ldb % 8 == 0, 16-byte aligned A/Bt, ldc % 4 == 0 and 16-byte
 // (fp32) / 8-byte (bf16) aligned C. Returns DTF_ERR_UNSUPPORTED otherwise (callers then use
 // dtf_gemm_bf16_generic).
-// variant & 15: 0 = default (4; 5 or 6 for tile grids that fill the chip badly), 1 = two-phase
-// double-buffer, 6 = ping-pong on 192 x 256 block tiles,
+// variant & 15: 0 = default (4; 5, 6 or 9 for tile grids that fill the chip badly), 1 = two-phase
+// double-buffer, 6 / 9 = ping-pong on 192 x 256 / 128 x 256 block tiles, 7 / 8 = the four-wave
+// kernels on an LDS ring / with register-staged loads,
 // 2 = ping-pong with one quadrant per phase, 3 = four-wave kernel (128x128 per wave),
 // 4 = ping-pong with two quadrants per phase, 5 = 128x128 tiles with two workgroups per CU;
 // variant >> 4: timing-experiment bits of the one-quadrant ping-pong kernel (0 in production).
@@ -1662,23 +1665,37 @@ static int dtf_pp_grid(int ntiles) {
   return ntiles < cus ? ntiles : cus;
 }
 
-// Block tiles of 192 x 256 instead of 256 x 256? The persistent kernel's time goes with
-// (rounds of the chip) x (rows of a tile): 3072^2 outputs are one round of 256-row tiles with 112
-// CUs idle, or one round of 192-row tiles with 64 idle and three quarters of the work per CU;
-// 6144^2 are three rounds either way. Taken when that product is at least a tenth smaller
-// (measured, 192- against 256-row tiles and torch.matmul: 3072^3 1180 / 1068 / 1038 TF, 6144^3
-// 1448 / 1323 / 1398, 3000 x 3072 x 4096 1209 / 1091 / 1085; 7168^3, where the rule keeps 256
-// rows, 1302 / 1338 / 1167). Grids of 33-128 tiles of 256 x 256, which otherwise run on 128 x 128
-// tiles, take 192-row tiles when those make at least 128 workgroups (2048 x 4096 x 4096: 176
-// tiles, 1130 TF against 1077 on 128 x 128 tiles; 2048^3, 88 tiles: 537 against 680).
-static bool dtf_pp_prefers_192_rows(int M, int N) {
+// Rows of the ping-pong kernel's block tile (columns are always 256): 256, 192 or 128. The
+// persistent kernel's time goes with (rounds of the chip) x (rows of a tile): 3072^2 outputs are
+// one round of 256-row tiles with 112 CUs idle, or one round of 192-row tiles with 64 idle and
+// three quarters of the work per CU; 2048 x 4096 outputs are 128 tiles of 256 rows (half the
+// chip) or one full round of 128-row tiles. A smaller tile moves more operand bytes per flop and
+// hands the matrix pipe over more often, so it must win by its penalty (8 % for 192 rows, 15 %
+// for 128) and put a workgroup on at least 70 % of the CUs. Measured (smaller tile / 256-row or
+// 128 x 128 tiles / torch.matmul, TF): 3072^3 1180 / 1068 / 1038, 6144^3 1448 / 1323 / 1398,
+// 3000 x 3072 x 4096 1209 / 1091 / 1085 (192 rows); 2048 x 4096 x 4096 1236 / 1124 / 1257,
+// 3072 x 2048 x 4096 1034 / 937 / 1158, 1024 x 8192 x 8192 1286 / 1175 / 1306 (128 rows);
+// where the rule keeps the other kernels: 7168^3 1302 (192) against 1338, 2048^3 628 (128 rows,
+// 128 workgroups) against 683 on 128 x 128 tiles, 2560 x 4096 x 4096 889 (128) against 1278 (192).
+// Grids of at most 32 tiles of 256 x 256 are left to the split-K plan.
+static int dtf_pp_rows(int M, int N) {
   const long cus = dtf_pp_grid(1 << 30);
   const long tn = (N + BN - 1) / BN;
-  const long t256 = (long)((M + 255) / 256) * tn, t192 = (long)((M + 191) / 192) * tn;
-  if (t256 <= 32) return false;
-  if (t256 <= 128) return t192 >= 128 && t192 <= cus;
-  const long cost256 = ((t256 + cus - 1) / cus) * 256, cost192 = ((t192 + cus - 1) / cus) * 192;
-  return cost192 * 10 <= cost256 * 9;
+  const long t256 = (long)((M + 255) / 256) * tn;
+  if (t256 <= 32) return 256;
+  int best = 256;
+  long best_cost = ((t256 + cus - 1) / cus) * 256 * 100;
+  const int rows[2] = {192, 128}, penalty[2] = {108, 115};
+  for (int c = 0; c < 2; ++c) {
+    const long t = (long)((M + rows[c] - 1) / rows[c]) * tn;
+    if (t * 10 < cus * 7) continue;
+    const long cost = ((t + cus - 1) / cus) * rows[c] * penalty[c];
+    if (cost < best_cost) {
+      best = rows[c];
+      best_cost = cost;
+    }
+  }
+  return best;
 }
 
 template <typename KernelT>
@@ -1859,8 +1876,27 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
     return DTF_OK;
   }
 #endif
+  const int pp_rows = variant == 0 ? dtf_pp_rows(M, N) : 256;
+  if ((variant & 15) == 9 || pp_rows == 128) {       // 128-row block tiles (MI = 2)
+    { static DtfPerDeviceOnce once__; dtf_once_per_device(once__, [&] {
+      dtf_allow_lds(gemm_nt_pp_kernel<true, 0, false, true, false, 2>, lds);
+      dtf_allow_lds(gemm_nt_pp_kernel<false, 0, false, true, false, 2>, lds);
+    }); }
+    const int tm128r = (M + 127) / 128;
+    const dim3 grid128r(dtf_pp_grid(tm128r * tiles_n));
+    if (out_f32)
+      hipLaunchKernelGGL((gemm_nt_pp_kernel<true, 0, false, true, false, 2>), grid128r, block, lds,
+                         stream, (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc,
+                         tm128r, tiles_n, alpha, beta, 1, 0L, nullptr, nullptr);
+    else
+      hipLaunchKernelGGL((gemm_nt_pp_kernel<false, 0, false, true, false, 2>), grid128r, block,
+                         lds, stream, (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc,
+                         tm128r, tiles_n, alpha, beta, 1, 0L, nullptr, nullptr);
+    DTF_LAUNCH_CHECK();
+    return DTF_OK;
+  }
   // 192-row block tiles (variant 6, or by default when they need fewer row-rounds of the chip)
-  if ((variant & 15) == 6 || (variant == 0 && dtf_pp_prefers_192_rows(M, N))) {
+  if ((variant & 15) == 6 || pp_rows == 192) {
     { static DtfPerDeviceOnce once__; dtf_once_per_device(once__, [&] {
       dtf_allow_lds(gemm_nt_pp_kernel<true, 0, false, true, false, 3>, lds);
       dtf_allow_lds(gemm_nt_pp_kernel<false, 0, false, true, false, 3>, lds);
@@ -1969,6 +2005,8 @@ DTF_API int dtf_gemm_bf16_nt_mirrored(const void* A, const void* Bt, void* C,
     dtf_allow_lds(gemm_nt_pp_kernel<false, 0, false, true>, lds);
     dtf_allow_lds(gemm_nt_pp_kernel<true, 0, false, true, false, 3>, lds);
     dtf_allow_lds(gemm_nt_pp_kernel<false, 0, false, true, false, 3>, lds);
+    dtf_allow_lds(gemm_nt_pp_kernel<true, 0, false, true, false, 2>, lds);
+    dtf_allow_lds(gemm_nt_pp_kernel<false, 0, false, true, false, 2>, lds);
   }); }
   const dim3 block(NTHREADS);
 #define DTF_MIRRORED(F32, MIV, TM)                                                               \
@@ -1976,9 +2014,13 @@ DTF_API int dtf_gemm_bf16_nt_mirrored(const void* A, const void* Bt, void* C,
                      dim3(dtf_pp_grid((TM) * tiles_n)), block, lds, stream, (const char*)A,      \
                      (const char*)Bt, C, M, N, K, lda, ldb, ldc, (TM), tiles_n, alpha, 0.f, 1,   \
                      0L, nullptr, nullptr, 0, 0, mirrors, nmirrors)
-  if (dtf_pp_prefers_192_rows(M, N)) {
+  const int pp_rows = dtf_pp_rows(M, N);
+  if (pp_rows == 192) {
     const int tm = (M + 191) / 192;
     if (out_f32) DTF_MIRRORED(true, 3, tm); else DTF_MIRRORED(false, 3, tm);
+  } else if (pp_rows == 128) {
+    const int tm = (M + 127) / 128;
+    if (out_f32) DTF_MIRRORED(true, 2, tm); else DTF_MIRRORED(false, 2, tm);
   } else {
     const int tm = (M + BM - 1) / BM;
     if (out_f32) DTF_MIRRORED(true, 4, tm); else DTF_MIRRORED(false, 4, tm);
@@ -2050,6 +2092,7 @@ DTF_API int dtf_gemm_bf16_splits(int M, int N, int K) {
   const long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   if (tiles > 32 && tiles <= 128) {
     if (N % 4 != 0) return 1;
+    if (dtf_pp_rows(M, N) != 256) return 1;      // a 192- or 128-row tiling fills the chip unsplit
     // the most splits that still leave at most one work item per CU and divide K into whole
     // K-tiles; worth it from 144 work items on (1280 x 2048 x 8192, 40 tiles: 54 us split four
     // ways, 79 us unsplit)

@@ -176,6 +176,28 @@ def test_gemm_bf16_register_staged_four_wave_kernel(hip, m, n, k, out_dtype):
     assert torch.equal(o8, o4)
 
 
+def test_gemm_bf16_default_plan_is_exact_on_random_shapes(hip):
+    """Whatever the default launch picks for a shape -- 256-, 192- or 128-row ping-pong tiles,
+    128 x 128 tiles, a K split, padded images for an odd K -- integer data must come out exact.
+    Forty shapes drawn from the ranges where the choices change."""
+    rng = np.random.RandomState(123)
+    picks = set()
+    for _ in range(40):
+        m = int(rng.choice([rng.randint(1, 700), rng.randint(1500, 4200)]))
+        n = int(rng.choice([rng.randint(1, 700), rng.randint(1500, 4200)]))
+        k = int(rng.choice([64 * rng.randint(1, 12), rng.randint(65, 600), 4096, 8192]))
+        if m * n * k > 3e10:
+            k = 256
+        g = torch.Generator().manual_seed(m * 7 + n)
+        a = torch.randint(-2, 3, (m, k), generator=g).float()
+        bt = torch.randint(-2, 3, (n, k), generator=g).float()
+        got = hip.gemm_bf16_nt(a.bfloat16().cuda(), bt.bfloat16().cuda(), torch.float32)
+        want = a.cuda() @ bt.cuda().t()
+        assert torch.equal(got, want), (m, n, k)
+        picks.add((hip.lib().dtf_gemm_bf16_splits(m, n, k) > 1, m >= 1500, n >= 1500))
+    assert len(picks) >= 4
+
+
 def test_gemm_bf16_identity_asymmetric(hip):
     n = 512
     b = ((torch.arange(n * n).reshape(n, n) % 13) - 6).float()

@@ -196,7 +196,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_nt_kernel(
 //    of a SIMD is in its MFMA segment its partner is in its load segment: the matrix pipe
 //    always has a feeder, and the loads of one group hide under the MFMAs of the other.
 //  * Hazards: a staged half-tile is read one full phase (two barriers) after the vmcnt that
-//    retired it, and a slot is restaged at least two phases after its last read.
+//    retired it. A slot is restaged by a DMA issued behind a barrier that every wave passes only
+//    after its own fragment reads have returned (s_waitcnt lgkmcnt(0) in front of the phase's
+//    first barrier), and the slots a phase restages are those the PREVIOUS phases read: no DMA
+//    can land in a slot with a read of it still queued, however short the memory latency is.
 // ESIZE = bytes per element (2: bf16, 1: fp8); a K-tile is always 128 bytes of k per row, and
 // lda / ldb are in elements.
 // The DMA is a buffer load: its address is (block tile's base, an SGPR resource) + (K-tile's byte
@@ -371,7 +374,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
   // (`profiles/gemm_bf16_pp_tweaks.jsonl`); fp8 16384^3 3159 against 3131 TF.
   constexpr int dbg = DBG;
   constexpr bool SETPRIO = !MERGE || MX || (DBG & 256) != 0;
-  constexpr bool DMA_FIRST = MERGE && !MX && (DBG & 2048) == 0;
+  // (DMA ahead of the reads only on 256-row tiles: with the shorter phases of the 192- and 128-row
+  // tiles the reads belong first -- 3072^3 1191 against 1166 TF, 1024 x 8192 x 8192 1302 against
+  // 1223 -- and the LDS wait in front of the barrier then costs nothing. Bit 6: no LDS wait,
+  // A/B only)
+  constexpr bool DMA_FIRST = MERGE && !MX && MI == 4 && (DBG & 2048) == 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -518,6 +525,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
       stage_half<MX>(a_tile, b_tile, voff, (dbg & 2) ? 0 : g0 + (P) + 6, nkt, ((P) + 2) & 3,         \
                  (((P) + 6) >> 2) & 1, smem, wave, a_half_bytes, b_half_bytes);                                              \
     if (!(dbg & 4)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                             \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    /* (as in the merged phase below) */   \
     __builtin_amdgcn_sched_barrier(0);                                                           \
     __builtin_amdgcn_s_barrier();                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                           \
@@ -571,6 +579,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
       }                                                                                          \
     }                                                                                            \
     if constexpr ((dbg & 8) != 0) ts2 = __builtin_amdgcn_s_memtime();                            \
+    /* the fragment reads of slots that are restaged behind this barrier have RETURNED before   \
+       this wave passes it (phases 0 / 2: the B1 half's four reads, restaged a phase later,     \
+       may stay in flight): a DMA can only overwrite slots nobody is still reading */            \
+    if constexpr ((dbg & 64) == 0) {                                                             \
+      if (MX || ((P) & 1)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    \
+      else asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");                                    \
+    }                                                                                            \
     __builtin_amdgcn_sched_barrier(0);                                                           \
     __builtin_amdgcn_s_barrier();                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                           \
@@ -1849,6 +1864,22 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
     DTF_LAUNCH_CHECK();                                                                         \
     return DTF_OK;                                                                              \
   }
+#define DTF_PP_TWEAK_MI(D, MIV, ROWS)                                                           \
+  if (dbg == D + 1 + (4 - MIV)) {                                                               \
+    { static DtfPerDeviceOnce once__; dtf_once_per_device(once__, [&] {                         \
+      dtf_allow_lds((gemm_nt_pp_kernel<false, D, false, true, false, MIV>), lds); }); }         \
+    const int tmr = (M + ROWS - 1) / ROWS;                                                      \
+    hipLaunchKernelGGL((gemm_nt_pp_kernel<false, D, false, true, false, MIV>),                  \
+                       dim3(dtf_pp_grid(tmr * tiles_n)), block, lds, stream, (const char*)A,    \
+                       (const char*)Bt, C, M, N, K, lda, ldb, ldc, tmr, tiles_n, alpha, beta,   \
+                       1, 0L, nullptr, nullptr);                                                \
+    DTF_LAUNCH_CHECK();                                                                         \
+    return DTF_OK;                                                                              \
+  }
+    // (experiment number + 1 / + 2: the same bits on 192- / 128-row tiles)
+    DTF_PP_TWEAK(64) DTF_PP_TWEAK(2112) DTF_PP_TWEAK_MI(64, 3, 192) DTF_PP_TWEAK_MI(64, 2, 128)
+    DTF_PP_TWEAK_MI(2048, 3, 192) DTF_PP_TWEAK_MI(2048, 2, 128) DTF_PP_TWEAK_MI(2112, 3, 192)
+    DTF_PP_TWEAK_MI(2112, 2, 128)
     DTF_PP_TWEAK(256) DTF_PP_TWEAK(2048) DTF_PP_TWEAK(2304) DTF_PP_TWEAK(4096)
 #undef DTF_PP_TWEAK
     if (dbg == 8)

@@ -583,8 +583,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
        this wave passes it (phases 0 / 2: the B1 half's four reads, restaged a phase later,     \
        may stay in flight): a DMA can only overwrite slots nobody is still reading */            \
     if constexpr ((dbg & 64) == 0) {                                                             \
-      if (MX || ((P) & 1)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    \
-      else asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");                                    \
+      /* (block scales: the two scale reads behind the fragment reads are of the wave's own     \
+         strip and may stay in flight as well) */                                                \
+      if constexpr (MX) {                                                                        \
+        if ((P) & 1) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");                          \
+        else asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");                                  \
+      } else {                                                                                   \
+        if ((P) & 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                          \
+        else asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");                                  \
+      }                                                                                          \
     }                                                                                            \
     __builtin_amdgcn_sched_barrier(0);                                                           \
     __builtin_amdgcn_s_barrier();                                                                \

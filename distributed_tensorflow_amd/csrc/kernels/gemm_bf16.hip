@@ -354,8 +354,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
   // sa_pair / sb_quad: bytes from one K-tile pair (A) / quad (Bt) of scales to the next -- the
   // row-tile count of the matrix the scales were made for, which may be taller than this call's
   static_assert(!MX || (FP8 && MERGE), "block scales: fp8 operands, merged schedule");
-  static_assert(MI == 4 || ((MI == 3 || MI == 2) && !FP8 && MERGE),
-                "192- and 128-row tiles: bf16, merged schedule");
+  static_assert(MI == 4 || ((MI == 3 || MI == 2) && !MX && MERGE),
+                "192- and 128-row tiles: merged schedule, no block scales");
   constexpr int BM_ROWS = 64 * MI, HALF_ROWS = 32 * MI;    // block tile / A half, in rows
   // ksplits > 1 (few output tiles, long K): work item (split, tile) multiplies K-range `split`
   // of K / ksplits columns and writes its partial tile to C + split * plane (elements); a
@@ -507,8 +507,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
 #define DTF_MFMA_QUAD(MH, NH)                                                                    \
   if constexpr (FP8) {                                                                           \
     DTF_MFMA_F8(MH, NH, 0, 0) DTF_MFMA_F8(MH, NH, 0, 1) DTF_MFMA_F8(MH, NH, 1, 0)                \
-    DTF_MFMA_F8(MH, NH, 1, 1) DTF_MFMA_F8(MH, NH, 2, 0) DTF_MFMA_F8(MH, NH, 2, 1)                \
-    DTF_MFMA_F8(MH, NH, 3, 0) DTF_MFMA_F8(MH, NH, 3, 1)                                          \
+    DTF_MFMA_F8(MH, NH, 1, 1)                                                                    \
+    if constexpr (MI > 2) { DTF_MFMA_F8(MH, NH, 2, 0) DTF_MFMA_F8(MH, NH, 2, 1) }                \
+    if constexpr (MI > 3) { DTF_MFMA_F8(MH, NH, 3, 0) DTF_MFMA_F8(MH, NH, 3, 1) }                \
   } else {                                                                                       \
     _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) _Pragma("unroll") for (int i = 0; i < MI;   \
                                                                             ++i)                 \
@@ -2204,6 +2205,30 @@ DTF_API int dtf_gemm_fp8_nt(const void* A, const void* Bt, void* C, int M, int N
     dtf_allow_lds(gemm_nt_pp_kernel<false, 0, true, true>, lds);
   }); }
   const dim3 grid(tiles_m * tiles_n), block(NTHREADS);     // one tile per workgroup (no tile loop)
+  // 192- or 128-row block tiles where they fill the chip better (the rule of the bf16 launch)
+  int pp_rows = dtf_pp_rows(M, N);
+#ifdef DTF_GEMM_EXPERIMENTS
+  if (getenv("DTF_FP8_FORCE_256")) pp_rows = 256;
+#endif
+  if (pp_rows != 256) {
+    { static DtfPerDeviceOnce once__; dtf_once_per_device(once__, [&] {
+      dtf_allow_lds(gemm_nt_pp_kernel<true, 0, true, true, false, 3>, lds);
+      dtf_allow_lds(gemm_nt_pp_kernel<false, 0, true, true, false, 3>, lds);
+      dtf_allow_lds(gemm_nt_pp_kernel<true, 0, true, true, false, 2>, lds);
+      dtf_allow_lds(gemm_nt_pp_kernel<false, 0, true, true, false, 2>, lds);
+    }); }
+    const int tmr = (M + pp_rows - 1) / pp_rows;
+    const dim3 grid_r(tmr * tiles_n);
+#define DTF_FP8_ROWS(F32, MIV)                                                                   \
+  hipLaunchKernelGGL((gemm_nt_pp_kernel<F32, 0, true, true, false, MIV>), grid_r, block, lds,    \
+                     stream, (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tmr,    \
+                     tiles_n, alpha, beta, 1, 0L, nullptr, nullptr)
+    if (pp_rows == 192) { if (out_f32) DTF_FP8_ROWS(true, 3); else DTF_FP8_ROWS(false, 3); }
+    else { if (out_f32) DTF_FP8_ROWS(true, 2); else DTF_FP8_ROWS(false, 2); }
+#undef DTF_FP8_ROWS
+    DTF_LAUNCH_CHECK();
+    return DTF_OK;
+  }
 #ifdef DTF_GEMM_EXPERIMENTS
   if (const char* tw = getenv("DTF_FP8_TWEAK"); tw && !out_f32) {
     const int bits = atoi(tw);

@@ -680,6 +680,25 @@ def test_gemm_bf16_writes_only_its_output(hip, m, n, k, out_dtype, variant):
 
 
 @pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("m,n,k", [(3072, 3072, 256), (2048, 4096, 256), (3000, 3072, 384),
+                                   (2945, 2816, 128)])
+def test_gemm_fp8_on_192_and_128_row_tiles(hip, m, n, k, out_dtype):
+    """Shapes for which the fp8 launch takes 192- or 128-row block tiles (the rule of the bf16
+    launch), a ragged last tile row included: exact on integer data over repeated launches,
+    alpha / beta applied."""
+    g = torch.Generator().manual_seed(m + k)
+    a = torch.randint(-2, 3, (m, k), generator=g).float()
+    bt = torch.randint(-2, 3, (n, k), generator=g).float()
+    want = a.cuda() @ bt.cuda().t()
+    for _ in range(3):
+        got = hip.gemm_fp8_nt(a.to(FP8).cuda(), bt.to(FP8).cuda(), out_dtype)
+        assert torch.equal(got.float(), want.to(out_dtype).float())
+    acc = torch.ones(m, n, device="cuda", dtype=out_dtype)
+    hip.gemm_fp8_nt(a.to(FP8).cuda(), bt.to(FP8).cuda(), out_dtype, alpha=0.5, beta=2.0, out=acc)
+    assert torch.equal(acc.float(), (0.5 * want + 2.0).to(out_dtype).float())
+
+
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("m,n,k", [(512, 300, 1000), (513, 1001, 1003), (300, 258, 784)])
 def test_gemm_fp8_off_grid_shapes(hip, m, n, k, out_dtype):
     """K that is not a multiple of 128, odd K, odd N: the fp8 product runs the block-scaled-MFMA

@@ -57,6 +57,16 @@ __device__ __forceinline__ unsigned short dtf_f32_to_bf16(float f) {
   return (unsigned short)(u >> 16);
 }
 
+// two f32 -> two bf16 in one dword (lo | hi << 16) with the hardware convert of gfx950
+// (v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays a quiet NaN -- the results of
+// dtf_f32_to_bf16 in one instruction instead of five per element)
+__device__ __forceinline__ unsigned dtf_f32x2_to_bf16x2(float lo, float hi) {
+  typedef float dtf_f32x2_t __attribute__((ext_vector_type(2)));
+  typedef __bf16 dtf_bf16x2_t __attribute__((ext_vector_type(2)));
+  const dtf_f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, dtf_bf16x2_t));
+}
+
 // f32 -> OCP fp8 e4m3fn (bias 7, 3 mantissa bits, no infinities, max 448), round-to-nearest-
 // even, SATURATING: |f| beyond 448 becomes +-448 (0x7e), never NaN. NaN -> 0x7f.
 __device__ __forceinline__ unsigned char dtf_f32_to_e4m3(float f) {

@@ -73,7 +73,7 @@ def test_gemm_f32_bias_activation(hip, act):
     assert (out.double() - ref).abs().max().item() < 2e-5
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 9])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 9, 10])
 @pytest.mark.parametrize("m,n,k", [(256, 256, 64), (512, 768, 256), (1024, 1024, 1024),
                                    (300, 520, 128), (2048, 256, 4096), (256, 512, 192),
                                    (1, 1, 64), (257, 255, 320)])
@@ -89,7 +89,7 @@ def test_gemm_bf16_nt_fast(hip, m, n, k, out_dtype, variant):
     assert err < tol, (err, tol)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 9])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 9, 10])
 @pytest.mark.parametrize("m,n,k", [(512, 768, 256), (768, 512, 1344), (4096, 4096, 2048)])
 def test_gemm_bf16_nt_exact_integers(hip, variant, m, n, k):
     """Exact small-integer data: any fragment-layout, staging or pipeline-hazard bug shows as
@@ -102,6 +102,27 @@ def test_gemm_bf16_nt_exact_integers(hip, variant, m, n, k):
         c = hip.gemm_bf16_nt(a.bfloat16().cuda(), bt.bfloat16().cuda(), torch.float32,
                              variant=variant)
         assert torch.equal(c, ref)
+
+
+@pytest.mark.parametrize("variant", [0, 4, 6, 9, 10])
+@pytest.mark.parametrize("m,n,k", [(1024, 1024, 256), (768, 1280, 192), (1000, 1024, 128)])
+def test_gemm_bf16_out_is_the_fp32_result_rounded_once(hip, variant, m, n, k):
+    """The bf16 epilogue (interior tiles: hardware converts, one 16-byte store per lane; edge
+    tiles: the general path) writes exactly the fp32-out result cast to bf16 -- random data,
+    large and tiny magnitudes, an infinity."""
+    g = torch.Generator().manual_seed(m + k + variant)
+    a = (torch.randn(m, k, generator=g) * torch.logspace(-20, 20, m).unsqueeze(1)).bfloat16().cuda()
+    bt = torch.randn(n, k, generator=g).bfloat16().cuda()
+    a[5, 7] = float("inf")
+    wide = hip.gemm_bf16_nt(a, bt, torch.float32, variant=variant)
+    narrow = hip.gemm_bf16_nt(a, bt, torch.bfloat16, variant=variant)
+    want = wide.bfloat16()
+    finite = ~torch.isnan(wide)
+    assert torch.equal(narrow[finite].view(torch.int16), want[finite].view(torch.int16))
+    assert bool(torch.isnan(narrow[~finite].float()).all())
+    scaled = hip.gemm_bf16_nt(a, bt, torch.bfloat16, variant=variant, alpha=0.37)
+    want = (wide * 0.37).bfloat16()
+    assert torch.equal(scaled[finite].view(torch.int16), want[finite].view(torch.int16))
 
 
 @pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
@@ -663,7 +684,7 @@ def test_gemm_f32_writes_only_its_output(hip, m, n, k):
     assert bool((big[:3] == 12345.0).all()) and bool((big[3 + m:] == 12345.0).all())
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 9])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 9, 10])
 @pytest.mark.parametrize("m,n,k", [(300, 520, 128), (257, 255, 320), (512, 768, 256), (1, 1, 64)])
 @pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
 def test_gemm_bf16_writes_only_its_output(hip, m, n, k, out_dtype, variant):

@@ -1647,6 +1647,32 @@ __global__ __launch_bounds__(T128_THREADS) void gemm_bf16_nt_t128_kernel(
   }
 
   // swapped-operand accumulator: lane holds C[m = frow][n = 4*fq + r], r = 0..3
+  // (interior tile, bf16 out: the short epilogue of the ping-pong kernel -- no per-lane bounds,
+  // hardware converts, pairs of 16x16 tiles traded between the odd and even 16-lane rows so
+  // that a lane stores 16 contiguous bytes)
+  if (!OUT_F32 && beta == 0.f && (ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 &&
+      m0 + T128 <= M && n0 + T128 <= N) {
+    const int colx = (fq & 1) ? 16 + 4 * (fq - 1) : 4 * fq;
+    char* crow = reinterpret_cast<char*>(C) +
+                 ((long)(m0 + wr * 64 + frow) * ldc + n0 + wc * 64 + colx) * 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp) {
+        const f32x4 v0 = acc[i][2 * jp] * alpha, v1 = acc[i][2 * jp + 1] * alpha;
+        const unsigned p0a = dtf_f32x2_to_bf16x2(v0[0], v0[1]);
+        const unsigned p0b = dtf_f32x2_to_bf16x2(v0[2], v0[3]);
+        const unsigned p1a = dtf_f32x2_to_bf16x2(v1[0], v1[1]);
+        const unsigned p1b = dtf_f32x2_to_bf16x2(v1[2], v1[3]);
+        const auto sa = __builtin_amdgcn_permlane16_swap(p0a, p1a, false, false);
+        const auto sb = __builtin_amdgcn_permlane16_swap(p0b, p1b, false, false);
+        u32x4 o = {sa[0], sb[0], sa[1], sb[1]};
+        *reinterpret_cast<u32x4*>(crow + jp * 64) = o;
+      }
+      crow += ldc * 32;
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = m0 + wr * 64 + i * 16 + frow;

@@ -545,11 +545,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_pp_kernel(
   {                                                                                              \
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0;                     \
     if constexpr ((dbg & 8) != 0) ts0 = __builtin_amdgcn_s_memtime();                            \
-    if constexpr (DMA_FIRST) {                                                                   \
-      stage_half<MX>(a_tile, b_tile, voff, g0 + 2 * (P) + 6, nkt, (2 * (P) + 2) & 3,             \
-                     ((2 * (P) + 6) >> 2) & 1, smem, wave, a_half_bytes, b_half_bytes);          \
-      stage_half<MX>(a_tile, b_tile, voff, g0 + 2 * (P) + 7, nkt, (2 * (P) + 3) & 3,             \
-                     ((2 * (P) + 7) >> 2) & 1, smem, wave, a_half_bytes, b_half_bytes);          \
+    if constexpr (DMA_FIRST && !(dbg & 1)) {                                                     \
+      stage_half<MX>(a_tile, b_tile, voff, (dbg & 2) ? 0 : g0 + 2 * (P) + 6, nkt,                \
+                     (2 * (P) + 2) & 3, ((2 * (P) + 6) >> 2) & 1, smem, wave, a_half_bytes,      \
+                     b_half_bytes);                                                              \
+      stage_half<MX>(a_tile, b_tile, voff, (dbg & 2) ? 0 : g0 + 2 * (P) + 7, nkt,                \
+                     (2 * (P) + 3) & 3, ((2 * (P) + 7) >> 2) & 1, smem, wave, a_half_bytes,      \
+                     b_half_bytes);                                                              \
       __builtin_amdgcn_sched_barrier(0);                                                         \
     }                                                                                            \
     READS;                                                                                       \
@@ -1828,6 +1830,7 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
     DTF_P2_DBG(1) DTF_P2_DBG(2) DTF_P2_DBG(4) DTF_P2_DBG(8) DTF_P2_DBG(5) DTF_P2_DBG(16)
     DTF_P2_DBG(32) DTF_P2_DBG(48) DTF_P2_DBG(65) DTF_P2_DBG(69) DTF_P2_DBG(144)
     DTF_P2_DBG(256) DTF_P2_DBG(260) DTF_P2_DBG(768) DTF_P2_DBG(1280) DTF_P2_DBG(1792)
+    DTF_P2_DBG(2048) DTF_P2_DBG(2052)
 #undef DTF_P2_DBG
 #endif
     if (out_f32)
@@ -1979,7 +1982,7 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
     DTF_PP_TWEAK(64) DTF_PP_TWEAK(2112) DTF_PP_TWEAK_MI(64, 3, 192) DTF_PP_TWEAK_MI(64, 2, 128)
     DTF_PP_TWEAK_MI(2048, 3, 192) DTF_PP_TWEAK_MI(2048, 2, 128) DTF_PP_TWEAK_MI(2112, 3, 192)
     DTF_PP_TWEAK_MI(2112, 2, 128)
-    DTF_PP_TWEAK(256) DTF_PP_TWEAK(2048) DTF_PP_TWEAK(2304) DTF_PP_TWEAK(4096) DTF_PP_TWEAK(8192)
+    DTF_PP_TWEAK(256) DTF_PP_TWEAK(2048) DTF_PP_TWEAK(2304) DTF_PP_TWEAK(4096) DTF_PP_TWEAK(8192) DTF_PP_TWEAK(2) DTF_PP_TWEAK(1)
 #undef DTF_PP_TWEAK
     if (dbg == 8)
       hipLaunchKernelGGL((gemm_nt_pp_kernel<false, 8, false, true>), pp_grid, block, lds + 1024,

@@ -53,7 +53,10 @@
 //   shifted by its wave id so that the four waves never ask the address unit in the same slot
 //   (one copy of the loop per wave) 1473 against 1524 (b = 2430); unpermuted source addresses and
 //   the transposed MFMA order no change; the chunk walk 1545 against 1573; non-temporal A
-//   requests 1524; every request an L2 hit (K-tile 0 restaged) b = 2228.
+//   requests 1524; every request an L2 hit (K-tile 0 restaged) b = 2228; the three-barrier plan
+//   of the library's hand-written kernel (DBG bit 2048) 1559 against 1560; each workgroup
+//   starting its K walk at another K-tile and wrapping around (what the library calls
+//   StaggerU) 1262-1471 against 1539 -- the CUs of an XCD then no longer share panels in L2.
 // What did pay: issuing the request's M0 write one slot ahead of the load (see DTF_P2_M0: 1528
 // -> 1566 TF), and the short epilogue for interior tiles (a from 48 to 28 thousand cycles; also
 // taken over by the ping-pong kernel).
@@ -63,7 +66,7 @@
 // 8 = no counted vmcnt waits, 16 = unpermuted source chunks, 32 = A fragment in the inner MFMA
 // loop (results stay correct), 64 = no fragment reads in the K loop, 128 = 4-byte instead of
 // 16-byte requests, 256 = the library's request spacing, 512 = chunk walk, 1024 = non-temporal
-// A requests
+// A requests, 2048 = the three-barrier plan
 template <int... Is, typename F>
 __device__ __forceinline__ void dtf_static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
   (f(std::integral_constant<int, Is>{}), ...);
@@ -78,23 +81,47 @@ __device__ __forceinline__ void dtf_static_for(F&& f) {
 // (dtf_p2_action) and, independently, one LDS-DMA request (dtf_p2_dma).
 enum : int { P2_NONE, P2_RD_B1, P2_RD_A1, P2_RD_B0N, P2_RD_A0N, P2_LGKM0, P2_BARRIER, P2_VMWAIT };
 struct P2Act { int kind, arg; };
-constexpr P2Act dtf_p2_action(int s, bool spread) {
+// plan 0: requests spread evenly; plan 1: the request spacing of the vendor library's generated
+// kernel (four barriers); plan 2: that of its hand-written kernel -- THREE barriers: one wait
+// (vmcnt(13), slot 91) and one barrier (slot 92) for the whole of K-tile t+1, behind which all 16
+// fragments of (t+1, 0) are read
+constexpr P2Act dtf_p2_action(int s, int plan) {
   if (s < 16 && (s & 1) == 0) return {P2_RD_B1, s >> 1};
   if (s == 19 || s == 50) return {P2_LGKM0, 0};
-  if (s == 20 || s == 51 || s == 68 || s == 105) return {P2_BARRIER, 0};
+  if (s == 20 || s == 51) return {P2_BARRIER, 0};
+  if (plan == 2) {
+    if (s >= 24 && s <= 36 && (s - 24) % 3 == 0) return {P2_RD_A1, (s - 24) / 3};      // 0-4
+    if (s == 38 || s == 40 || s == 42) return {P2_RD_A1, 5 + ((s - 38) >> 1)};
+    if (s == 91) return {P2_VMWAIT, 13};
+    if (s == 92) return {P2_BARRIER, 0};
+    if (s >= 93 && s <= 107 && (s & 1) == 1) return {P2_RD_B0N, (s - 93) >> 1};
+    if (s >= 109 && s <= 123 && (s & 1) == 1) return {P2_RD_A0N, (s - 109) >> 1};
+    return {P2_NONE, 0};
+  }
+  if (s == 68 || s == 105) return {P2_BARRIER, 0};
   if (s >= 24 && s <= 40 && ((s - 24) & 3) == 0) return {P2_RD_A1, (s - 24) >> 2};
   if (s == 42 || s == 44 || s == 46) return {P2_RD_A1, 5 + ((s - 42) >> 1)};
-  if (s == 67) return {P2_VMWAIT, spread ? 16 : 18};
+  if (s == 67) return {P2_VMWAIT, plan == 0 ? 16 : 18};
   if (s >= 69 && s <= 83 && (s & 1) == 1) return {P2_RD_B0N, (s - 69) >> 1};
-  if (s == 104) return {P2_VMWAIT, spread ? 13 : 15};
+  if (s == 104) return {P2_VMWAIT, plan == 0 ? 13 : 15};
   if (s >= 106 && s <= 120 && (s & 1) == 0) return {P2_RD_A0N, (s - 106) >> 1};
   return {P2_NONE, 0};
 }
 // LDS-DMA piece (0-7: Bt, 8-15: A) requested in slot s, or -1
-constexpr int dtf_p2_dma(int s, bool spread) {
-  if (spread) {       // Bt at 22, 28, .., 64; A at 70, 78, .., 126
+constexpr int dtf_p2_dma(int s, int plan) {
+  if (plan == 0) {       // Bt at 22, 28, .., 64; A at 70, 78, .., 126
     if (s >= 22 && s <= 64 && (s - 22) % 6 == 0) return (s - 22) / 6;
     if (s >= 70 && s <= 126 && ((s - 70) & 7) == 0) return 8 + ((s - 70) >> 3);
+    return -1;
+  }
+  if (plan == 2) {
+    if (s >= 22 && s <= 34 && (s - 22) % 3 == 0) return (s - 22) / 3;         // Bt 0-4
+    if (s == 52 || s == 55 || s == 58) return 5 + (s - 52) / 3;               // Bt 5-7
+    if (s == 61 || s == 64) return 8 + (s - 61) / 3;                          // A 0-1
+    if (s == 85 || s == 87 || s == 89) return 10 + ((s - 85) >> 1);           // A 2-4
+    if (s == 96) return 13;
+    if (s == 102) return 14;
+    if (s == 124) return 15;
     return -1;
   }
   if (s >= 22 && s <= 38 && ((s - 22) & 3) == 0) return (s - 22) >> 2;        // Bt 0-4
@@ -218,7 +245,7 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_bf16_nt_w4p2_kernel(
       asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"                                      \
                    : "+a"(acc[(s_ >> 3) & 7][s_ & 7])                                            \
                    : "v"(fb[s_ >> 6][s_ & 7]), "v"(fa[s_ >> 6][(s_ >> 3) & 7]));                 \
-      constexpr bool spread_ = (DBG & 256) == 0;                                                 \
+      constexpr int spread_ = (DBG & 2048) ? 2 : (DBG & 256) ? 1 : 0;                            \
       constexpr P2Act act_ = dtf_p2_action(s_, spread_);                                         \
       constexpr int dma_ = dtf_p2_dma(s_, spread_);                                              \
       constexpr int dma_next_ = s_ < 127 ? dtf_p2_dma(s_ + 1, spread_) : -1;                     \
@@ -257,7 +284,7 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_bf16_nt_w4p2_kernel(
   // counted waits of the K loop rely on that order)
 #define DTF_P2_PROLOGUE()                                                                        \
   _Pragma("unroll") for (int t_ = 0; t_ < 2; ++t_) {                                             \
-    const int k0_ = (t_ < nkt ? t_ : nkt - 1) * 128;                                             \
+    const int k0_ = (t_ < nkt ? t_ : nkt - 1) * 128;                                         \
     _Pragma("unroll") for (int p_ = 0; p_ < 16; ++p_) {                                          \
       DTF_P2_M0(p_, t_);                                                                         \
       asm volatile("s_nop 0");                                                                   \

@@ -12,6 +12,7 @@ from distributed_tensorflow_amd.ops import hip  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=8192)
 ap.add_argument("--k", type=int, default=0, help="K of the bf16 product (default: n)")
+ap.add_argument("--pad", type=int, default=0, help="bf16: operands are views of buffers this many elements wider than K")
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--variant", type=int, default=0)
 ap.add_argument("--iters", type=int, default=5)
@@ -21,8 +22,8 @@ args = ap.parse_args()
 n = args.n
 if args.dtype == "bf16":
     k = args.k or n
-    a = (torch.rand(n, k, device="cuda") * 2 - 1).bfloat16()
-    bt = (torch.rand(n, k, device="cuda") * 2 - 1).bfloat16()
+    a = (torch.rand(n, k + args.pad, device="cuda") * 2 - 1).bfloat16()[:, :k]
+    bt = (torch.rand(n, k + args.pad, device="cuda") * 2 - 1).bfloat16()[:, :k]
     out = torch.empty(n, n, device="cuda", dtype=torch.bfloat16)
     for _ in range(args.iters):
         if args.impl == "torch":

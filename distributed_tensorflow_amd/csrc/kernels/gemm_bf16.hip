@@ -321,7 +321,8 @@ __device__ __forceinline__ void pp_tile_of_block(int bid, int tiles_m, int tiles
 //   8-register operands) and spills with the few more the tile loop keeps live, so it runs one
 //   tile per workgroup. (A persistent fp8 build with one set of staging offsets per operand
 //   spilled six registers outside the K loop and measured the same as this one: 3133 against
-//   3131 TF at 16384^3, 3052 against 3030 at 8192^3.)
+//   3131 TF at 16384^3, 3052 against 3030 at 8192^3; built again on top of the short interior-tile
+//   epilogue it filled all 256 VGPRs, spilled four and ran at 2617 against 3119.)
 // MX = true (FP8 only): block-scaled operands in the OCP MX manner -- every 32 consecutive k of a
 //   row share one E8M0 scale (a power of two), applied by the MFMA itself. The instruction takes
 //   the scale of (row r, 32-block b of its 128 k) from lane 16 b + r of a scale register, one byte

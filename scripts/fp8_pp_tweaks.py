@@ -29,8 +29,9 @@ def ours(bits):
 
 kernels = {"torch._scaled_mm": lambda: torch._scaled_mm(a, bt.t(), scale_a=one, scale_b=one,
                                                         out_dtype=torch.bfloat16),
-           "shipped": ours(0), "tweak256": ours(256), "tweak2048": ours(2048),
-           "tweak2304": ours(2304)}
+           "shipped": ours(0)}
+for t in (sys.argv[3].split(",") if len(sys.argv) > 3 else ["256", "2048", "2304"]):
+    kernels["tweak" + t] = ours(int(t))
 ours(0)()
 ref = out.clone()
 equal = {}

@@ -1831,7 +1831,8 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
     DTF_P2_DBG(1) DTF_P2_DBG(2) DTF_P2_DBG(4) DTF_P2_DBG(8) DTF_P2_DBG(5) DTF_P2_DBG(16)
     DTF_P2_DBG(32) DTF_P2_DBG(48) DTF_P2_DBG(65) DTF_P2_DBG(69) DTF_P2_DBG(144)
     DTF_P2_DBG(256) DTF_P2_DBG(260) DTF_P2_DBG(768) DTF_P2_DBG(1280) DTF_P2_DBG(1792)
-    DTF_P2_DBG(2048) DTF_P2_DBG(2052)
+    DTF_P2_DBG(2048) DTF_P2_DBG(2052) DTF_P2_DBG(4096) DTF_P2_DBG(8192) DTF_P2_DBG(16384)
+    DTF_P2_DBG(32768) DTF_P2_DBG(65536) DTF_P2_DBG(12288) DTF_P2_DBG(49152)
 #undef DTF_P2_DBG
 #endif
     if (out_f32)

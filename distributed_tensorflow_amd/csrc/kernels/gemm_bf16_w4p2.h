@@ -57,6 +57,11 @@
 //   of the library's hand-written kernel (DBG bit 2048) 1559 against 1560; each workgroup
 //   starting its K walk at another K-tile and wrapping around (what the library calls
 //   StaggerU) 1262-1471 against 1539 -- the CUs of an XCD then no longer share panels in L2.
+//   Dropping ONE of the four barriers saves 0.5-0.9 % of the cycles, a pair of them 1.4 %, all four
+//   6-7 %: what costs is not a barrier but the lock-step that any remaining barrier keeps the
+//   four waves in -- they then ask the LDS (fragment reads, DMA writes) and the address unit in
+//   the same cycles. The eight-wave kernel has the same lock-step but a second wave per SIMD
+//   to run in the gaps.
 // What did pay: issuing the request's M0 write one slot ahead of the load (see DTF_P2_M0: 1528
 // -> 1566 TF), and the short epilogue for interior tiles (a from 48 to 28 thousand cycles; also
 // taken over by the ping-pong kernel).
@@ -66,7 +71,8 @@
 // 8 = no counted vmcnt waits, 16 = unpermuted source chunks, 32 = A fragment in the inner MFMA
 // loop (results stay correct), 64 = no fragment reads in the K loop, 128 = 4-byte instead of
 // 16-byte requests, 256 = the library's request spacing, 512 = chunk walk, 1024 = non-temporal
-// A requests, 2048 = the three-barrier plan
+// A requests, 2048 = the three-barrier plan, 4096 / 8192 / 16384 / 32768 = without the first /
+// second / third / fourth barrier of the K-tile, 65536 = without the two LDS waits
 template <int... Is, typename F>
 __device__ __forceinline__ void dtf_static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
   (f(std::integral_constant<int, Is>{}), ...);
@@ -261,9 +267,11 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_bf16_nt_w4p2_kernel(
       } else if constexpr (act_.kind == P2_RD_A0N) {                                             \
         fa[0][act_.arg] = DTF_P2_RD(NXT, a_rd, off0, act_.arg);                                  \
       } else if constexpr (act_.kind == P2_LGKM0) {                                              \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                       \
+        if (!(DBG & 65536)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   \
       } else if constexpr (act_.kind == P2_BARRIER) {                                            \
-        if (!(DBG & 4)) __builtin_amdgcn_s_barrier();                                            \
+        /* bits 12-15: drop the barrier of slot 20 / 51 / 68 / 105 alone */                      \
+        constexpr int which_ = s_ == 20 ? 4096 : s_ == 51 ? 8192 : s_ == 68 ? 16384 : 32768;     \
+        if (!(DBG & 4) && !(DBG & which_)) __builtin_amdgcn_s_barrier();                         \
       } else if constexpr (act_.kind == P2_VMWAIT) {                                             \
         if (!(DBG & 9)) {                                                                        \
           if constexpr (act_.arg == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");        \

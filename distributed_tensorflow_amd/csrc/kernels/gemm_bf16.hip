@@ -1556,8 +1556,18 @@ __global__ __launch_bounds__(256) void gemm_fp8_generic_kernel(
 // cover each other's barrier and DMA waits. (A four-buffer ring with counted waits, one
 // workgroup per CU, measured SLOWER on every grid of at most 256 such tiles -- 2048^3 617 against
 // 687 TF, 2048 x 2048 x 4096 713 against 798: these products are bound by the operand traffic
-// from L2, 64 flop per byte, not by the latency a deeper ring would hide.) A product of 2048^2 outputs is 64 tiles of 256^2
-// (a quarter of the chip) but 256 tiles of 128^2.
+// from L2, 64 flop per byte, not by the latency a deeper ring would hide. Built a second time --
+// counted vmcnt(16), one barrier per K-tile, the interior-tile epilogue -- it was slower again:
+// 1024^3 15.1 against 11.8 us, 1024 x 1024 x 4096 48.8 against 39.4, 2048^3 29.1 against 24.0.
+// A K-tile costs this kernel 0.55-0.6 us whatever the grid: four waves of 64 x 64 outputs read
+// 64 KiB of fragments per K-tile and workgroup next to the 32 KiB the DMA writes, twice the LDS
+// bytes per flop of the 128 x 64 waves of the ping-pong kernel.) A product of 2048^2 outputs is
+// 64 tiles of 256^2 (a quarter of the chip) but 256 tiles of 128^2.
+// Grids of at most 32 tiles of 256^2 with K <= 2048 run here too instead of the split-K plan
+// (two launches and a pass over fp32 planes): 1024^3 11.8 against 25.4 us, 2048 x 1024 x 1024
+// 12.4 / 28.1, 1280^3 14.7 / 29.1, 512 x 1024 x 1024 11.7 / 22.8, 1024 x 1024 x 2048 21.9 /
+// 26.5; from K = 3072 on the split plan wins (1024 x 1024 x 3072 34.1 against 29.2, K = 4096
+// 39.4 against 29.4) -- `scripts/bf16_small_sweep.py`, `scripts/bf16_small_sweep2.py`.
 namespace {
 
 constexpr int T128 = 128;
@@ -1731,6 +1741,10 @@ __global__ __launch_bounds__(T128_THREADS) void gemm_bf16_nt_t128_kernel(
 // tiles) 1035 vs 1388 TF.
 #ifndef DTF_T128_BELOW_TILES
 #define DTF_T128_BELOW_TILES 129
+#endif
+// ... and grids of at most 32 such tiles up to this K (longer K: split-K on 256x256 tiles)
+#ifndef DTF_T128_SMALL_GRID_MAX_K
+#define DTF_T128_SMALL_GRID_MAX_K 2048
 #endif
 
 // workgroups of the persistent ping-pong kernel: one per CU (128 KiB of LDS each), fewer when
@@ -2051,7 +2065,8 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
   }
   // 128x128 tiles (variant 5, or by default when 256x256 tiles would leave CUs idle)
   if ((variant & 15) == 5 ||
-      (variant == 0 && tiles_m * tiles_n > 32 && tiles_m * tiles_n < DTF_T128_BELOW_TILES)) {
+      (variant == 0 && tiles_m * tiles_n > 32 && tiles_m * tiles_n < DTF_T128_BELOW_TILES) ||
+      (variant == 0 && tiles_m * tiles_n <= 32 && K <= DTF_T128_SMALL_GRID_MAX_K)) {
         const size_t t_lds = 2 * T128_BUF_BYTES;
     { static DtfPerDeviceOnce once__; dtf_once_per_device(once__, [&] {
       dtf_allow_lds(gemm_bf16_nt_t128_kernel<true>, t_lds);
@@ -2238,7 +2253,7 @@ DTF_API int dtf_gemm_bf16_splits(int M, int N, int K) {
     }
     return 1;
   }
-  if (tiles > 32 || K < 1024) return 1;
+  if (tiles > 32 || K <= DTF_T128_SMALL_GRID_MAX_K) return 1;    // (small K: 128x128 tiles, unsplit)
   int splits = 1;
   while (splits < 8 && tiles * splits * 2 <= 256 && K % (splits * 2 * BK) == 0 &&
          K / (splits * 2) >= 512)

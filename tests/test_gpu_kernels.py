@@ -885,7 +885,7 @@ def test_gemm_bf16_k_not_multiple_of_tile(hip, m, n, k, out_dtype):
 
 @pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("m,n,k,splits", [(512, 768, 4096, None), (300, 260, 2048, 4),
-                                          (1024, 2048, 2048, None), (256, 256, 1024, 2)])
+                                          (1024, 2048, 4096, None), (256, 256, 1024, 2)])
 def test_gemm_bf16_split_k(hip, m, n, k, splits, out_dtype):
     """Few output tiles + long K: the ping-pong kernel runs (split, tile) work items into fp32
     planes and a second kernel sums them in split order. Small-integer data makes every
@@ -897,6 +897,8 @@ def test_gemm_bf16_split_k(hip, m, n, k, splits, out_dtype):
     ad, bd = a.bfloat16().cuda(), bt.bfloat16().cuda()
     if splits is None:
         assert hip.lib().dtf_gemm_bf16_splits(m, n, k) > 1
+        # ... and the same grid with a short K is left to the unsplit 128 x 128-tile kernel
+        assert hip.lib().dtf_gemm_bf16_splits(m, n, 2048) == 1
     ref = a @ bt.t()
     out = hip.gemm_bf16_nt(ad, bd, out_dtype, splits=splits)
     assert torch.equal(out.float().cpu(), ref.to(out_dtype).float())

@@ -1769,7 +1769,10 @@ static int dtf_pp_grid(int ntiles) {
 // three quarters of the work per CU; 2048 x 4096 outputs are 128 tiles of 256 rows (half the
 // chip) or one full round of 128-row tiles. A smaller tile moves more operand bytes per flop and
 // hands the matrix pipe over more often, so it must win by its penalty (8 % for 192 rows, 15 %
-// for 128) and put a workgroup on at least 70 % of the CUs. Measured (smaller tile / 256-row or
+// for 128) and put a workgroup on more than half of the CUs (with 130-176 workgroups of 128 rows
+// it still beats the 128 x 128-tile kernel by 4-7 %: 2304^2 x 4096 51.1 against 53.3 us, 2048 x
+// 2560 x 4096 49.0 / 51.5, 1664 x 2560 x 4096 48.0 / 50.4; with exactly 128 it loses, 2048^2 x 4096
+// 47.4 / 41.4 -- `scripts/bf16_rows_threshold_sweep.py`). Measured (smaller tile / 256-row or
 // 128 x 128 tiles / torch.matmul, TF): 3072^3 1180 / 1068 / 1038, 6144^3 1448 / 1323 / 1398,
 // 3000 x 3072 x 4096 1209 / 1091 / 1085 (192 rows); 2048 x 4096 x 4096 1236 / 1124 / 1257,
 // 3072 x 2048 x 4096 1034 / 937 / 1158, 1024 x 8192 x 8192 1286 / 1175 / 1306 (128 rows);
@@ -1786,7 +1789,7 @@ static int dtf_pp_rows(int M, int N) {
   const int rows[2] = {192, 128}, penalty[2] = {108, 115};
   for (int c = 0; c < 2; ++c) {
     const long t = (long)((M + rows[c] - 1) / rows[c]) * tn;
-    if (t * 10 < cus * 7) continue;
+    if (t * 2 <= cus) continue;      // (at most half the CUs: 128 x 128 tiles fill the chip better)
     const long cost = ((t + cus - 1) / cus) * rows[c] * penalty[c];
     if (cost < best_cost) {
       best = rows[c];

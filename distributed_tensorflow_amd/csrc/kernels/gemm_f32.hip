@@ -232,8 +232,8 @@ static int gemm_f32_slot_occupancy(int M, int N) {
   return t128 <= 256 ? 1 : 2;
 }
 
-// Split-K plan: number of K splits (1 = none). A 64x64-tile grid of up to ~1000 workgroups that
-// leaves CUs idle in its last round gains from up to 4 splits; tiny grids (the MLP's 100x100 outputs with K = 784) take as many splits as give
+// Split-K plan: number of K splits (1 = none). A 64x64-tile grid of at most 160 workgroups with a
+// long K gains from up to 4 splits; tiny grids (the MLP's 100x100 outputs with K = 784) take as many splits as give
 // every CU a workgroup, each split keeping at least four K-tiles.
 DTF_API int dtf_gemm_f32_splits(int M, int N, int K, int* kchunk_out) {
   int splits = 1, kchunk = K;
@@ -243,15 +243,19 @@ DTF_API int dtf_gemm_f32_splits(int M, int N, int K, int* kchunk_out) {
     if (tiles <= 64) {
       want = (int)(256 / tiles);
       if (want > 32) want = 32;
-    } else if (tiles < 1024) {
-      // a grid that fills whole rounds of the 256 CUs (1000^3: 256 tiles) runs unsplit at the
-      // vendor library's speed (23.5 us); a ragged one (1536^3: 576 tiles = 2.25 rounds) gains
-      // from finer work items
-      const long rounds = (tiles + 255) / 256;
-      if (tiles * 10 < rounds * 256 * 9) {
-        want = (int)((1024 + tiles - 1) / tiles);
-        if (want > 4) want = 4;
-      }
+    } else if (tiles <= 160 && K >= 2048) {
+      // fewer workgroups than two thirds of the CUs and a long K: finer work items (1024 x 4096 x
+      // 512, 128 tiles: 42 us split four ways, 71 unsplit; 768 x 2048 x 768, 144 tiles: 36 / 42;
+      // with 200 or 256 tiles the split loses, 1280 x 2048 x 640 44 / 41, 1024 x 2048 x 1024 48 / 44). Larger grids, or a short K, run unsplit: three or four 64 x 64
+      // workgroups share a CU, so grids of up to ~1000 tiles are one resident round whatever
+      // their count, and a split costs them a second launch and a pass over the planes (GPU time
+      // from a kernel trace, unsplit / split by the earlier ragged-round rule: 768^3 18.9 / 24.5
+      // us, 896^3 20.9 / 30.1, 1280^3 48.7 / 54.5, 1664^3 86.7 / 100.2, 1920^3 120.9 / 134.5;
+      // 1536^3 82.8 / 81.2 and 1792^3 114.0 / 113.0 were the rule's best cases --
+      // `scripts/f32_split_trace.sh`)
+      want = (int)(512 / tiles);
+      if (want > 4) want = 4;
+      if (want > K / 512) want = K / 512;
     }
     if (want > 1) {
       int chunk = ((K + want - 1) / want + 15) / 16 * 16;

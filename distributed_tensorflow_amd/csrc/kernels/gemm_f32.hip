@@ -56,6 +56,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_slot_kernel(GemmF32Args p) 
 
 // C = act(op(A) op(B) + bias) for small outputs: one 16x16 tile per workgroup (gemm_f32_body.h)
 template <bool A_KC, bool B_KC, int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_f32_skinny32_kernel(SkinnyArgs p) {
+  gemm_f32_skinny32_block<A_KC, B_KC, NW>(p, blockIdx.x);
+}
+
+template <bool A_KC, bool B_KC, int NW>
 __global__ __launch_bounds__(64 * NW) void gemm_f32_skinny_kernel(SkinnyArgs p) {
   gemm_f32_skinny_block<A_KC, B_KC, 0, NW>(p, blockIdx.x);
 }
@@ -213,6 +218,13 @@ int launch(const float* A, const float* B, float* C, const float* bias, int M, i
 // or four workgroups to a CU (3072^3: 130 TF, 5120^3: 140).
 DTF_API int dtf_gemm_f32_tile(int M, int N, int K) {
   if (gemm_f32_skinny_fits(M, N, K)) return 16;       // one 16x16 tile per workgroup, no split
+  // one 32x32 tile per workgroup while those are at most one per CU and K is short: the 64x64
+  // tiling would be at most 64 workgroups plus a K split. GPU time by kernel trace, this kernel /
+  // 64x64 tiles with their split / torch.matmul: 384^3 8.0 / 11.4 / 6.1 us, 512^3 8.6 / 13.3 / 7.7,
+  // 256 x 512 x 1024 9.0 / 13.5 / 7.8, 1024 x 512 x 256 8.7 / 13.7 / 7.5, 512 x 1024 x 512 13.5 /
+  // 16.1 / 10.2; it loses from two tiles per CU on (640^3 17.1 / 16.1) and from K = 1536 on
+  // (480 x 1536 x 480 20.1 / 18.4) -- `scripts/f32_tile32_trace.sh`
+  if ((long)((M + 31) / 32) * ((N + 31) / 32) <= 256 && K <= 1024) return 32;
   const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
   if (K >= 4 * BK) {       // (the slot-dealt kernel's prologue holds two K-tiles)
     if (t128 >= 230 && t128 <= 256) return 128;
@@ -289,8 +301,29 @@ DTF_API int dtf_gemm_f32_ex(const float* A, const float* B, float* C, const floa
   if (trans_b) n_load = N;
   if (m_load < M || m_load > M + 3 || (trans_a && m_load > lda)) return DTF_ERR_BAD_ARG;
   if (n_load < N || n_load > N + 3 || (!trans_b && n_load > ldb)) return DTF_ERR_BAD_ARG;
-  if (tile != 16 && tile != 64 && tile != 128 && tile != 129 && tile != 256)
+  if (tile != 16 && tile != 32 && tile != 64 && tile != 128 && tile != 129 && tile != 256)
     tile = dtf_gemm_f32_tile(M, N, K);
+  if (tile == 32) {      // one 32x32 tile per workgroup, K over four or eight waves, no split
+    const int tiles_m = (M + SK32_T - 1) / SK32_T, tiles_n = (N + SK32_T - 1) / SK32_T;
+    const SkinnyArgs args{A, B, C, bias, M, N, K, lda, ldb, ldc, act, 0.f, tiles_n};
+    dim3 grid(tiles_m * tiles_n);
+#define DTF_SKINNY32_CASE(AKC, BKC)                                                              \
+  do {                                                                                           \
+    if (gemm_f32_skinny32_waves(K) == 8)                                                         \
+      hipLaunchKernelGGL((gemm_f32_skinny32_kernel<AKC, BKC, 8>), grid, dim3(512), 0, stream,    \
+                         args);                                                                  \
+    else                                                                                         \
+      hipLaunchKernelGGL((gemm_f32_skinny32_kernel<AKC, BKC, 4>), grid, dim3(256), 0, stream,    \
+                         args);                                                                  \
+  } while (0)
+    if (!trans_a && !trans_b) DTF_SKINNY32_CASE(true, false);
+    else if (!trans_a && trans_b) DTF_SKINNY32_CASE(true, true);
+    else if (trans_a && !trans_b) DTF_SKINNY32_CASE(false, false);
+    else DTF_SKINNY32_CASE(false, true);
+#undef DTF_SKINNY32_CASE
+    DTF_LAUNCH_CHECK();
+    return DTF_OK;
+  }
   if (tile == 16) {
     const int tiles_m = (M + SK_T - 1) / SK_T, tiles_n = (N + SK_T - 1) / SK_T;
     const SkinnyArgs args{A, B, C, bias, M, N, K, lda, ldb, ldc, act, 0.f, tiles_n};

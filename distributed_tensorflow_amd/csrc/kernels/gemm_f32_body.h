@@ -864,6 +864,116 @@ __device__ __forceinline__ void gemm_f32_skinny_block(const SkinnyArgs& p, const
   else *out = dtf_apply_act(v + bv, p.act);
 }
 
+// ---- small-product kernel on 32x32 tiles -------------------------------------------------------
+// The same idea one size up, for products whose 64x64 tiling leaves most CUs idle but whose
+// 16x16 tiling is thousands of workgroups (384^3 ... 768^3): one 32x32 output tile per workgroup,
+// K dealt to NW waves, operands straight from memory into v_mfma_f32_32x32x2_f32 (lane l holds
+// row / column l & 31 and the k of half l >> 5), partial tiles summed through LDS in wave order.
+// A K-block is 8 k = four MFMAs: with a K-contiguous operand a lane loads 16 bytes (k0 + 4 half
+// + j, j = 0..3) and MFMA j takes element j, so it multiplies k0 + j and k0 + 4 + j; otherwise
+// element j is k0 + 2 j + half. Both operands always use the same assignment.
+constexpr int SK32_T = 32;
+constexpr int SK32_U = 4;           // K-blocks of 8 in flight per wave
+
+template <bool A_KC, bool B_KC>
+__device__ __forceinline__ void skinny32_load(SkinnyFrag& f, const float* __restrict__ A,
+                                              const float* __restrict__ B, long lda, long ldb,
+                                              int am, int bn, int half, int k0, int k_end,
+                                              bool a_vec, bool b_vec) {
+  if (A_KC) {
+    const int k = k0 + 4 * half;
+    const float* pa = A + (long)am * lda + k;
+    if (a_vec && k + 3 < k_end) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(pa);
+      f.a[0] = v[0]; f.a[1] = v[1]; f.a[2] = v[2]; f.a[3] = v[3];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) f.a[j] = k + j < k_end ? pa[j] : 0.f;
+    }
+    if (B_KC) {
+      const float* pb = B + (long)bn * ldb + k;
+      if (b_vec && k + 3 < k_end) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(pb);
+        f.b[0] = v[0]; f.b[1] = v[1]; f.b[2] = v[2]; f.b[3] = v[3];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f.b[j] = k + j < k_end ? pb[j] : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) f.b[j] = k + j < k_end ? B[(long)(k + j) * ldb + bn] : 0.f;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + 2 * j + half;
+      f.a[j] = k < k_end ? A[(long)k * lda + am] : 0.f;
+      f.b[j] = k < k_end ? (B_KC ? B[(long)bn * ldb + k] : B[(long)k * ldb + bn]) : 0.f;
+    }
+  }
+}
+
+// NW: waves per workgroup (4 or 8)
+template <bool A_KC, bool B_KC, int NW>
+__device__ __forceinline__ void gemm_f32_skinny32_block(const SkinnyArgs& p, const int bid) {
+  __shared__ float red[NW][SK32_T][SK32_T + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = (bid / p.tiles_n) * SK32_T, n0 = (bid % p.tiles_n) * SK32_T;
+  const int lm = lane & 31, half = lane >> 5;
+  // rows / columns past the edge re-read the last valid one; their results are dropped
+  const int am = m0 + lm < p.M ? m0 + lm : p.M - 1;
+  const int bn = n0 + lm < p.N ? n0 + lm : p.N - 1;
+  const bool a_vec = A_KC && (p.lda % 4 == 0) && ((uintptr_t)p.A % 16 == 0);
+  const bool b_vec = B_KC && (p.ldb % 4 == 0) && ((uintptr_t)p.B % 16 == 0);
+
+  const int nkb = (p.K + 7) / 8;
+  const int per = (nkb + NW - 1) / NW;
+  const int kb0 = wave * per;
+  const int kb1 = kb0 + per < nkb ? kb0 + per : nkb;
+
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+  SkinnyFrag cur[SK32_U], nxt[SK32_U];
+#pragma unroll
+  for (int u = 0; u < SK32_U; ++u)
+    skinny32_load<A_KC, B_KC>(cur[u], p.A, p.B, p.lda, p.ldb, am, bn, half, (kb0 + u) * 8,
+                              kb0 + u < kb1 ? p.K : 0, a_vec, b_vec);
+  for (int kb = kb0; kb < kb1; kb += SK32_U) {
+#pragma unroll
+    for (int u = 0; u < SK32_U; ++u)
+      skinny32_load<A_KC, B_KC>(nxt[u], p.A, p.B, p.lda, p.ldb, am, bn, half,
+                                (kb + SK32_U + u) * 8, kb + SK32_U + u < kb1 ? p.K : 0, a_vec,
+                                b_vec);
+#pragma unroll
+    for (int u = 0; u < SK32_U; ++u) {
+      // (blocks past the wave's range hold zeros: fma(0, 0, acc) leaves acc as it is)
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[u].a[0], cur[u].b[0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[u].a[1], cur[u].b[1], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[u].a[2], cur[u].b[2], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[u].a[3], cur[u].b[3], acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < SK32_U; ++u) cur[u] = nxt[u];
+  }
+  // C/D fragment of the 32x32 MFMA: col = lane & 31, row = 8 (i / 4) + 4 (lane >> 5) + i % 4
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+    red[wave][8 * (i >> 2) + 4 * half + (i & 3)][lm] = acc0[i] + acc1[i];
+  __syncthreads();
+  for (int e = tid; e < SK32_T * SK32_T; e += 64 * NW) {
+    const int r = e >> 5, c = e & 31;
+    const int orow = m0 + r, ocol = n0 + c;
+    if (orow >= p.M || ocol >= p.N) continue;
+    float v = red[0][r][c];                          // wave order
+#pragma unroll
+    for (int w = 1; w < NW; ++w) v += red[w][r][c];
+    p.C[(long)orow * p.ldc + ocol] = dtf_apply_act(v + (p.bias ? p.bias[ocol] : 0.f), p.act);
+  }
+}
+
+__host__ __device__ inline int gemm_f32_skinny32_waves(long K) { return K > 256 ? 8 : 4; }
+
 // waves per workgroup the small-product kernel runs with for a given K
 __host__ __device__ inline int gemm_f32_skinny_waves(long K) { return K > 256 ? 16 : 4; }
 

@@ -268,7 +268,7 @@ def gemm_f32(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: b
              tile: int = 0, plan_mnk: Optional[Sequence[int]] = None) -> torch.Tensor:
     """``act(op(a) @ op(b) + bias)`` on the fp32 MFMA kernels. ``a`` is [M,K] ([K,M] when
     ``trans_a``), ``b`` is [K,N] ([N,K] when ``trans_b``). ``tile``: 0 = chosen from the shape;
-    16 (small-product kernel), 64, 128 or 256 force a block tile (128 and 256 run the
+    16 / 32 (small-product kernels), 64, 128 or 256 force a block tile (128 and 256 run the
     slot-scheduled kernel when the operands are 16-byte aligned with contiguous dimensions that
     are multiples of 4, the general kernel otherwise); 129 = 128x128 tiles on the general kernel
     whatever the operands, for measurements. ``plan_mnk``: choose tile and K split
@@ -315,7 +315,7 @@ def gemm_f32(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: b
         splits = L.dtf_gemm_f32_splits(m, n, k, None)
     splits = max(1, min(int(splits), 64))
     a_ptr, b_ptr, kk, m_load, n_load = a.data_ptr(), b.data_ptr(), k, m, n
-    if tile != 16 and m * n * k >= _F32_PAD_MIN_WORK:
+    if tile not in (16, 32) and m * n * k >= _F32_PAD_MIN_WORK:
         # The kernels' fast loads want 16-byte aligned rows and a K that is a multiple of 4 for
         # K-contiguous operands; an operand that is contiguous along M / N may have any M / N as
         # long as its rows can be read up to the next multiple of 4. Operands that do not

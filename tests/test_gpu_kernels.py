@@ -104,6 +104,33 @@ def test_gemm_bf16_nt_exact_integers(hip, variant, m, n, k):
         assert torch.equal(c, ref)
 
 
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("m,k,n", [(32, 8, 32), (33, 9, 31), (512, 512, 512), (500, 300, 700),
+                                   (257, 1000, 129), (64, 4096, 64), (1, 1, 1)])
+def test_gemm_f32_small_product_kernel_on_32x32_tiles(hip, m, k, n, ta, tb):
+    """One 32 x 32 tile per workgroup, K dealt to four or eight waves, operands straight from
+    memory (all four storage layouts, ragged edges, a K that is no multiple of the 8-k block,
+    views off the 16-byte grid): exact on integer data, bias and activation applied; and the
+    default plan takes this kernel for products of at most 256 such tiles with K <= 1024."""
+    g = torch.Generator().manual_seed(m * 3 + k + n)
+    a = torch.randint(-3, 4, (k, m) if ta else (m, k), generator=g).float().cuda()
+    b = torch.randint(-3, 4, (n, k) if tb else (k, n), generator=g).float().cuda()
+    bias = torch.randint(-2, 3, (n,), generator=g).float().cuda()
+    ref = (a.t() if ta else a) @ (b.t() if tb else b) + bias
+    got = hip.gemm_f32(a, b, bias=bias, trans_a=ta, trans_b=tb, tile=32)
+    assert torch.equal(got, ref)
+    got = hip.gemm_f32(a, b, bias=bias, trans_a=ta, trans_b=tb, tile=32, activation=hip.ACTIVATIONS["relu"])
+    assert torch.equal(got, torch.relu(ref))
+    if not ta and not tb and m > 4 and k > 8:
+        wide = torch.randint(-3, 4, (m, k + 5), generator=g).float().cuda()
+        view = wide[:, 3:3 + k]
+        assert torch.equal(hip.gemm_f32(view, b, tile=32), view @ b)
+    L = hip.lib()
+    assert L.dtf_gemm_f32_tile(512, 512, 512) == 32 and L.dtf_gemm_f32_tile(384, 384, 1024) == 32
+    assert L.dtf_gemm_f32_tile(640, 640, 640) == 64 and L.dtf_gemm_f32_tile(512, 512, 2048) == 64
+    assert L.dtf_gemm_f32_tile(100, 100, 784) == 16
+
+
 @pytest.mark.parametrize("variant", [0, 4, 6, 9, 10])
 @pytest.mark.parametrize("m,n,k", [(1024, 1024, 256), (768, 1280, 192), (1000, 1024, 128)])
 def test_gemm_bf16_out_is_the_fp32_result_rounded_once(hip, variant, m, n, k):

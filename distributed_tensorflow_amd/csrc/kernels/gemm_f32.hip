@@ -269,6 +269,14 @@ DTF_API int dtf_gemm_f32_splits(int M, int N, int K, int* kchunk_out) {
       if (want > 4) want = 4;
       if (want > K / 512) want = K / 512;
     }
+    else if (tiles < 1024 && K >= 4096) {
+      // a long K pays for the second launch, and a grid that is not a whole number of workgroups
+      // per CU then gains from finer work items (576 tiles, 1536 x 4096 x 1536: 161 us split four
+      // ways, 184 unsplit; 1536 x 8192 x 1536 303 / 359; 784 tiles, 1792 x 4096 x 1792 220 / 241);
+      // an even one does not (512 tiles, 2048 x 4096 x 1024: 141 / 132)
+      const long rounds = (tiles + 255) / 256;
+      if (tiles * 10 < rounds * 256 * 9) want = 4;
+    }
     if (want > 1) {
       int chunk = ((K + want - 1) / want + 15) / 16 * 16;
       if (chunk < 64) chunk = 64;

@@ -25,6 +25,7 @@ for m, k, n in shapes:
                 res["t%d_s%d" % (tile, s)] = timed(lambda: hip.gemm_f32(a, b, out=out, tile=tile, splits=s))
             except Exception:
                 pass
+    res["default_again"] = timed(lambda: hip.gemm_f32(a, b, out=out))
     best = min((v, k2) for k2, v in res.items() if k2.startswith("t") and k2 != "torch")
     print(json.dumps({"m_k_n": [m, k, n], "default_plan": plan, "best": best[1], "default_over_best": round(res["default"] / best[0], 3),
                       "us": {k2: round(v, 1) for k2, v in res.items()}}), flush=True)

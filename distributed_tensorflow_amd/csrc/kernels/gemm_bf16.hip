@@ -1563,11 +1563,10 @@ __global__ __launch_bounds__(256) void gemm_fp8_generic_kernel(
 // 64 KiB of fragments per K-tile and workgroup next to the 32 KiB the DMA writes, twice the LDS
 // bytes per flop of the 128 x 64 waves of the ping-pong kernel.) A product of 2048^2 outputs is
 // 64 tiles of 256^2 (a quarter of the chip) but 256 tiles of 128^2.
-// Grids of at most 32 tiles of 256^2 with K <= 2048 run here too instead of the split-K plan
-// (two launches and a pass over fp32 planes): 1024^3 11.8 against 25.4 us, 2048 x 1024 x 1024
-// 12.4 / 28.1, 1280^3 14.7 / 29.1, 512 x 1024 x 1024 11.7 / 22.8, 1024 x 1024 x 2048 21.9 /
-// 26.5; from K = 3072 on the split plan wins (1024 x 1024 x 3072 34.1 against 29.2, K = 4096
-// 39.4 against 29.4) -- `scripts/bf16_small_sweep.py`, `scripts/bf16_small_sweep2.py`.
+// Grids of at most 32 tiles of 256^2 run here too -- unsplit below K = 2048 (1024^3 11.8 us
+// where the split plan on 256^2 tiles took 25.4, 2048 x 1024 x 1024 12.4 / 28.1, 1280^3 14.7 /
+// 29.1), as the work items of a K split from there on (see dtf_gemm_bf16_splits) --
+// `scripts/bf16_small_sweep.py`, `scripts/bf16_small_sweep2.py`, `scripts/bf16_split_t128_trace.py`.
 namespace {
 
 constexpr int T128 = 128;
@@ -1578,14 +1577,22 @@ constexpr int T128_BUF_BYTES = 2 * T128_TILE_BYTES;
 template <bool OUT_F32>
 __global__ __launch_bounds__(T128_THREADS) void gemm_bf16_nt_t128_kernel(
     const char* __restrict__ A, const char* __restrict__ Bt, void* __restrict__ C, int M, int N,
-    int K, long lda, long ldb, long ldc, int tiles_m, int tiles_n, float alpha, float beta) {
+    int K, long lda, long ldb, long ldc, int tiles_m, int tiles_n, float alpha, float beta,
+    int ksplits, long plane) {
+  // ksplits > 1: workgroup (split, tile) multiplies K-range `split` of K / ksplits columns and
+  // writes its partial tile to C + split * plane (elements); planes_reduce_kernel sums them
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (A tile | B tile)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
 
   const int ntiles = tiles_m * tiles_n;
-  const int id = dtf_xcd_remap(blockIdx.x, ntiles);
+  const int split = blockIdx.x / ntiles;
+  const int id = dtf_xcd_remap(blockIdx.x - split * ntiles, ntiles);
+  K /= ksplits;
+  A += (long)split * K * 2;
+  Bt += (long)split * K * 2;
+  C = reinterpret_cast<char*>(C) + (long)split * plane * (OUT_F32 ? 4 : 2);
   constexpr int GROUP = 8;
   const int per_group = GROUP * tiles_n;
   const int g = id / per_group;
@@ -1742,7 +1749,7 @@ __global__ __launch_bounds__(T128_THREADS) void gemm_bf16_nt_t128_kernel(
 #ifndef DTF_T128_BELOW_TILES
 #define DTF_T128_BELOW_TILES 129
 #endif
-// ... and grids of at most 32 such tiles up to this K (longer K: split-K on 256x256 tiles)
+// ... and grids of at most 32 such tiles: unsplit below this K, K-split from it on
 #ifndef DTF_T128_SMALL_GRID_MAX_K
 #define DTF_T128_SMALL_GRID_MAX_K 2048
 #endif
@@ -2069,7 +2076,7 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
   // 128x128 tiles (variant 5, or by default when 256x256 tiles would leave CUs idle)
   if ((variant & 15) == 5 ||
       (variant == 0 && tiles_m * tiles_n > 32 && tiles_m * tiles_n < DTF_T128_BELOW_TILES) ||
-      (variant == 0 && tiles_m * tiles_n <= 32 && K <= DTF_T128_SMALL_GRID_MAX_K)) {
+      (variant == 0 && tiles_m * tiles_n <= 32)) {
         const size_t t_lds = 2 * T128_BUF_BYTES;
     { static DtfPerDeviceOnce once__; dtf_once_per_device(once__, [&] {
       dtf_allow_lds(gemm_bf16_nt_t128_kernel<true>, t_lds);
@@ -2080,11 +2087,11 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
     if (out_f32)
       hipLaunchKernelGGL(gemm_bf16_nt_t128_kernel<true>, t_grid, t_block, t_lds, stream,
                          (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tm128,
-                         tn128, alpha, beta);
+                         tn128, alpha, beta, 1, 0L);
     else
       hipLaunchKernelGGL(gemm_bf16_nt_t128_kernel<false>, t_grid, t_block, t_lds, stream,
                          (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tm128,
-                         tn128, alpha, beta);
+                         tn128, alpha, beta, 1, 0L);
     DTF_LAUNCH_CHECK();
     return DTF_OK;
   }
@@ -2241,6 +2248,19 @@ __global__ __launch_bounds__(256) void planes_reduce_kernel(const float* __restr
 // 2048 x 4096 x 8192: 120 / 140 / 137; 2048 x 2048 x 16384: 119 / 160 / 126). Below K = 6144
 // (four ways) or 8192 (two ways) the planes cost more than the traffic saved
 // (`profiles/gemm_bf16_splitk_scan.jsonl`).
+// Whether a K split of this product runs its work items on 128x128 tiles (env DTF_BF16_SPLIT_T128
+// = 0 / 1 overrides, for measurements)
+// on: grids of at most 32 tiles of 256x256. GPU time by kernel trace, best split on 128x128
+// tiles / best split on 256x256 tiles / torch.matmul: 1024 x 1024 x 4096 23.0 / 30.4 / 18.7 us,
+// 512 x 512 x 4096 16.6 / 25.3 / 10.9, 256 x 256 x 8192 14.7 / 23.7 / 10.2, 1024 x 2048 x 4096 31.2 /
+// 38.1, 2048 x 1024 x 4096 30.7 / 38.2, 1024 x 1024 x 8192 33.2 / 38.4
+// (`scripts/bf16_split_t128_trace.py`).
+static bool dtf_gemm_bf16_split_on_t128(int M, int N, int K, int ksplits) {
+  if (const char* e = getenv("DTF_BF16_SPLIT_T128")) return atoi(e) != 0;
+  (void)K; (void)ksplits;
+  return (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN) <= 32;
+}
+
 DTF_API int dtf_gemm_bf16_splits(int M, int N, int K) {
   const long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   if (tiles > 32 && tiles <= 128) {
@@ -2256,10 +2276,15 @@ DTF_API int dtf_gemm_bf16_splits(int M, int N, int K) {
     }
     return 1;
   }
-  if (tiles > 32 || K <= DTF_T128_SMALL_GRID_MAX_K) return 1;    // (small K: 128x128 tiles, unsplit)
+  // Small grids run on 128x128 tiles; from K = 2048 on, split until their work items number about
+  // one per CU, each keeping at least four K-tiles (GPU time by kernel trace, K = 2048, split /
+  // unsplit: 1024^2 outputs 17.9 / 21.8 us, 512^2 14.1 / 20.2, 256^2 11.1 / 20.4, 768^2 16.3 / 20.7;
+  // at K = 1024 the unsplit form wins, 12.1 against 16.4)
+  if (tiles > 32 || K < DTF_T128_SMALL_GRID_MAX_K) return 1;
+  const long t128 = (long)((M + T128 - 1) / T128) * ((N + T128 - 1) / T128);
   int splits = 1;
-  while (splits < 8 && tiles * splits * 2 <= 256 && K % (splits * 2 * BK) == 0 &&
-         K / (splits * 2) >= 512)
+  while (splits < 16 && t128 * splits * 2 <= 256 && K % (splits * 2 * BK) == 0 &&
+         K / (splits * 2) >= 256)
     splits *= 2;
   return splits;
 }
@@ -2284,6 +2309,28 @@ DTF_API int dtf_gemm_bf16_nt_splitk(const void* A, const void* Bt, void* C, floa
     dtf_allow_lds(gemm_nt_pp_kernel<true, 0, false, true>, lds);
   }); }
   const long plane = (long)M * N;
+  if (dtf_gemm_bf16_split_on_t128(M, N, K, ksplits)) {
+    // the split work items on 128x128 tiles: four times as many, each a quarter of the size
+    const size_t t_lds = 2 * T128_BUF_BYTES;
+    { static DtfPerDeviceOnce once__; dtf_once_per_device(once__, [&] {
+      dtf_allow_lds(gemm_bf16_nt_t128_kernel<true>, t_lds);
+    }); }
+    const int tm128 = (M + T128 - 1) / T128, tn128 = (N + T128 - 1) / T128;
+    hipLaunchKernelGGL(gemm_bf16_nt_t128_kernel<true>, dim3(tm128 * tn128 * ksplits),
+                       dim3(T128_THREADS), t_lds, stream, (const char*)A, (const char*)Bt,
+                       (void*)workspace, M, N, K, lda, ldb, (long)N, tm128, tn128, 1.0f, 0.0f,
+                       ksplits, plane);
+    const long work = plane / 4;
+    const int blocks = (int)((work + 255) / 256 > 2048 ? 2048 : (work + 255) / 256);
+    if (out_f32)
+      hipLaunchKernelGGL(planes_reduce_kernel<true>, dim3(blocks), dim3(256), 0, stream,
+                         workspace, ksplits, plane, C, ldc, M, N, alpha, beta);
+    else
+      hipLaunchKernelGGL(planes_reduce_kernel<false>, dim3(blocks), dim3(256), 0, stream,
+                         workspace, ksplits, plane, C, ldc, M, N, alpha, beta);
+    DTF_LAUNCH_CHECK();
+    return DTF_OK;
+  }
   const dim3 grid(dtf_pp_grid(tiles_m * tiles_n * ksplits)), block(NTHREADS);
   hipLaunchKernelGGL((gemm_nt_pp_kernel<true, 0, false, true>), grid, block, lds, stream,
                      (const char*)A, (const char*)Bt, (void*)workspace, M, N, K, lda, ldb,

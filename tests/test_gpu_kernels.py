@@ -914,8 +914,9 @@ def test_gemm_bf16_k_not_multiple_of_tile(hip, m, n, k, out_dtype):
 @pytest.mark.parametrize("m,n,k,splits", [(512, 768, 4096, None), (300, 260, 2048, 4),
                                           (1024, 2048, 4096, None), (256, 256, 1024, 2)])
 def test_gemm_bf16_split_k(hip, m, n, k, splits, out_dtype):
-    """Few output tiles + long K: the ping-pong kernel runs (split, tile) work items into fp32
-    planes and a second kernel sums them in split order. Small-integer data makes every
+    """Few output tiles + long K: (split, tile) work items -- on 128 x 128 tiles for grids of at
+    most 32 large tiles, on the ping-pong kernel otherwise -- go into fp32 planes and a second
+    kernel sums them in split order. Small-integer data makes every
     partial sum exact, so the result must equal the unsplit product bit for bit; alpha and
     beta are applied once, in the reduction."""
     g = torch.Generator().manual_seed(m + n + k)
@@ -925,7 +926,7 @@ def test_gemm_bf16_split_k(hip, m, n, k, splits, out_dtype):
     if splits is None:
         assert hip.lib().dtf_gemm_bf16_splits(m, n, k) > 1
         # ... and the same grid with a short K is left to the unsplit 128 x 128-tile kernel
-        assert hip.lib().dtf_gemm_bf16_splits(m, n, 2048) == 1
+        assert hip.lib().dtf_gemm_bf16_splits(m, n, 1024) == 1
     ref = a @ bt.t()
     out = hip.gemm_bf16_nt(ad, bd, out_dtype, splits=splits)
     assert torch.equal(out.float().cpu(), ref.to(out_dtype).float())

@@ -36,8 +36,10 @@
 //  * gemm_nt_pp_kernel -- the default for large grids (bf16 and, instantiated with the
 //    block-scaled MFMA, fp8): quadrant-phased ping-pong of two wave groups, persistent over
 //    tiles, optional split-K work items for grids of at most 32 tiles (described below);
-//  * gemm_bf16_nt_t128_kernel -- 128x128 tiles, two workgroups per CU, for grids of 33-128
-//    large tiles;
+//  * gemm_bf16_nt_t128ws_kernel -- 128x128 tiles, four multiplying + four request-issuing
+//    waves, for grids with a CU for every such tile and the work items of their K splits;
+//  * gemm_bf16_nt_t128_kernel -- 128x128 tiles, two workgroups per CU, for grids of up to 128
+//    large tiles with more than one 128x128 tile per CU;
 //  * gemm_bf16_nt_kernel (variant 1) -- the plain double-buffered schedule described above;
 //  * gemm_bf16_nt_w4_kernel (variant 3) -- one wave per SIMD with 128x128 outputs per wave, kept
 //    with its measured ablations.
@@ -49,6 +51,7 @@
 
 #include <atomic>
 #include <mutex>
+#include <type_traits>
 #include <utility>
 
 namespace {
@@ -1550,23 +1553,26 @@ __global__ __launch_bounds__(256) void gemm_fp8_generic_kernel(
 
 }  // namespace
 
-// ---- 128x128 tile kernel for grids that leave CUs idle at 256x256 -----------------------------
-// 256 threads = 4 waves as 2(M) x 2(N), 64x64 outputs per wave, K-tile 64, the same LDS image
-// and MFMA as above. Two 32 KiB K-tile buffers per workgroup, so two workgroups share a CU and
-// cover each other's barrier and DMA waits. (A four-buffer ring with counted waits, one
-// workgroup per CU, measured SLOWER on every grid of at most 256 such tiles -- 2048^3 617 against
-// 687 TF, 2048 x 2048 x 4096 713 against 798: these products are bound by the operand traffic
-// from L2, 64 flop per byte, not by the latency a deeper ring would hide. Built a second time --
-// counted vmcnt(16), one barrier per K-tile, the interior-tile epilogue -- it was slower again:
-// 1024^3 15.1 against 11.8 us, 1024 x 1024 x 4096 48.8 against 39.4, 2048^3 29.1 against 24.0.
-// A K-tile costs this kernel 0.55-0.6 us whatever the grid: four waves of 64 x 64 outputs read
-// 64 KiB of fragments per K-tile and workgroup next to the 32 KiB the DMA writes, twice the LDS
-// bytes per flop of the 128 x 64 waves of the ping-pong kernel.) A product of 2048^2 outputs is
-// 64 tiles of 256^2 (a quarter of the chip) but 256 tiles of 128^2.
-// Grids of at most 32 tiles of 256^2 run here too -- unsplit below K = 2048 (1024^3 11.8 us
-// where the split plan on 256^2 tiles took 25.4, 2048 x 1024 x 1024 12.4 / 28.1, 1280^3 14.7 /
-// 29.1), as the work items of a K split from there on (see dtf_gemm_bf16_splits) --
-// `scripts/bf16_small_sweep.py`, `scripts/bf16_small_sweep2.py`, `scripts/bf16_split_t128_trace.py`.
+// ---- 128x128 tile kernels for grids that leave CUs idle at 256x256 ----------------------------
+// Four multiplying waves as 2(M) x 2(N), 64x64 outputs per wave, K-tile 64, the same LDS image
+// and MFMA as above. A product of 2048^2 outputs is 64 tiles of 256^2 (a quarter of the chip)
+// but 256 tiles of 128^2. Two forms:
+//  * gemm_bf16_nt_t128_kernel: 256 threads, two 32 KiB K-tile buffers, so two workgroups share a
+//    CU and cover each other's barrier and request waits: grids of more than one tile per CU.
+//  * gemm_bf16_nt_t128ws_kernel: 512 threads, waves 4-7 do nothing but issue the LDS-DMA
+//    requests (two K-tiles ahead, three buffers, one barrier per K-tile): grids with a CU for
+//    every tile, and the work items of a K split. A wave that issues a request waits 60-180
+//    clocks for the address unit before its next instruction, eight times per K-tile, and with
+//    one four-wave workgroup on the CU its SIMD runs nothing else meanwhile: a K-tile took the
+//    four-wave form 0.6 us whatever the grid, with two buffers or a ring of three or four
+//    (equal or slower), and slower still with the requests spread between the MFMAs of a
+//    two-buffer loop (0.78 us: the newest request's latency is then exposed). With the requests
+//    on waves of their own it takes 0.4 us. GPU time by kernel trace, four waves / with request
+//    waves / torch.matmul: 1024^3 12.7 / 10.0 / 8.9 us, 1024 x 1024 x 4096 40.1 / 26.6 / 19.2 (the
+//    default plan splits K there: 22.0), 1536^3 19.5 / 13.8 / 15.7, 2048^3 24.0 / 19.5 / 22.2,
+//    2048 x 2048 x 4096 42.8 / 32.1 / 36.6, 1280^3 14.9 / 11.8 / 12.2, 2048 x 1024 x 1024 13.1 /
+//    10.4 / 10.6; 2560^3 (400 tiles, two per CU) 38.3 / 40.7 / 36.7 stays on the four-wave form
+//    (`scripts/t128_spread_trace.sh`, `profiles/gemm_bf16_t128_request_waves.txt`).
 namespace {
 
 constexpr int T128 = 128;
@@ -1574,8 +1580,8 @@ constexpr int T128_THREADS = 256;
 constexpr int T128_TILE_BYTES = T128 * BK * 2;     // 16 KiB per operand tile
 constexpr int T128_BUF_BYTES = 2 * T128_TILE_BYTES;
 
-template <bool OUT_F32>
-__global__ __launch_bounds__(T128_THREADS) void gemm_bf16_nt_t128_kernel(
+template <bool OUT_F32, bool WS>
+__device__ __forceinline__ void gemm_bf16_nt_t128_body(
     const char* __restrict__ A, const char* __restrict__ Bt, void* __restrict__ C, int M, int N,
     int K, long lda, long ldb, long ldc, int tiles_m, int tiles_n, float alpha, float beta,
     int ksplits, long plane) {
@@ -1583,7 +1589,10 @@ __global__ __launch_bounds__(T128_THREADS) void gemm_bf16_nt_t128_kernel(
   // writes its partial tile to C + split * plane (elements); planes_reduce_kernel sums them
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (A tile | B tile)
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // WS: eight waves, 0-3 multiply (64x64 outputs each), 4-7 only issue the LDS-DMA requests
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = wave8 & 3;
+  const bool producer = WS && wave8 >= 4;
   const int wr = wave >> 1, wc = wave & 1;
 
   const int ntiles = tiles_m * tiles_n;
@@ -1637,8 +1646,82 @@ __global__ __launch_bounds__(T128_THREADS) void gemm_bf16_nt_t128_kernel(
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nkt = K / BK;
-  stage(0, smem);
+  if (!WS || producer) stage(0, smem);
   const int frow = lane & 15, fq = lane >> 4;
+  if (WS) {
+    // Three K-tile buffers, the requests two K-tiles ahead, one barrier per K-tile. A wave that
+    // issues an LDS-DMA request waits 60-180 clocks for the address unit before its next
+    // instruction, eight times per K-tile; with one workgroup of four waves on the CU nothing
+    // else runs on its SIMD in that time. So waves 4-7 (one per SIMD) issue all the requests
+    // and waves 0-3 only read fragments and multiply.
+    if (producer) {
+      if (nkt > 1) stage(1, smem + T128_BUF_BYTES);
+      unsigned nxt2 = 2 * T128_BUF_BYTES;            // byte offset of tile kt + 2's buffer
+      for (int kt = 0; kt < nkt; ++kt) {
+        // own pieces of tile kt have landed (the newest tile's eight requests stay in flight);
+        // behind the barrier the multiplying waves are done with the buffer of tile kt - 1
+        if (kt + 1 < nkt)
+          asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (kt + 2 < nkt) stage(kt + 2, smem + nxt2);
+        nxt2 = nxt2 == 2 * T128_BUF_BYTES ? 0 : nxt2 + T128_BUF_BYTES;
+      }
+      return;
+    }
+    // (fragment reads and their counted waits are written out: inside a loop the compiler
+    // waits for all sixteen reads before the first MFMA)
+    const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>((lds_void*)smem);
+    unsigned a_rd[2], b_rd[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      a_rd[s2] = lds0 + chunk_off(wr * 64 + frow, 4 * s2 + fq);
+      b_rd[s2] = lds0 + T128_TILE_BYTES + chunk_off(wc * 64 + frow, 4 * s2 + fq);
+    }
+#define DTF_T128_RD(DST, ADDR, OFF) \
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
+#define DTF_T128_WAIT(N, S2, I)                                                              \
+  asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                   \
+               : "+v"(bf[S2][0]), "+v"(bf[S2][1]), "+v"(bf[S2][2]), "+v"(bf[S2][3]),         \
+                 "+v"(af[S2][I]))
+    unsigned cur = 0;                                 // byte offset of tile kt's buffer
+    for (int kt = 0; kt < nkt; ++kt) {
+      asm volatile("s_barrier" ::: "memory");
+      bf16x8 af[2][4], bf[2][4];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const unsigned ba = b_rd[s2] + cur, aa = a_rd[s2] + cur;
+        DTF_T128_RD(bf[s2][0], ba, 0);
+        DTF_T128_RD(bf[s2][1], ba, 2048);
+        DTF_T128_RD(bf[s2][2], ba, 4096);
+        DTF_T128_RD(bf[s2][3], ba, 6144);
+        DTF_T128_RD(af[s2][0], aa, 0);
+        DTF_T128_RD(af[s2][1], aa, 2048);
+        DTF_T128_RD(af[s2][2], aa, 4096);
+        DTF_T128_RD(af[s2][3], aa, 6144);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (s2 == 0 && i == 0) DTF_T128_WAIT(11, 0, 0);
+          if (s2 == 0 && i == 1) DTF_T128_WAIT(10, 0, 1);
+          if (s2 == 0 && i == 2) DTF_T128_WAIT(9, 0, 2);
+          if (s2 == 0 && i == 3) DTF_T128_WAIT(8, 0, 3);
+          if (s2 == 1 && i == 0) DTF_T128_WAIT(3, 1, 0);
+          if (s2 == 1 && i == 1) DTF_T128_WAIT(2, 1, 1);
+          if (s2 == 1 && i == 2) DTF_T128_WAIT(1, 1, 2);
+          if (s2 == 1 && i == 3) DTF_T128_WAIT(0, 1, 3);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] =
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[s2][j], af[s2][i], acc[i][j], 0, 0, 0);
+        }
+      cur = cur == 2 * T128_BUF_BYTES ? 0 : cur + T128_BUF_BYTES;
+    }
+#undef DTF_T128_RD
+#undef DTF_T128_WAIT
+  } else
   for (int kt = 0; kt < nkt; ++kt) {
     // tile kt has landed for every wave, and every wave is done reading the other buffer
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1728,6 +1811,26 @@ __global__ __launch_bounds__(T128_THREADS) void gemm_bf16_nt_t128_kernel(
   }
 }
 
+template <bool OUT_F32>
+__global__ __launch_bounds__(T128_THREADS) void gemm_bf16_nt_t128_kernel(
+    const char* __restrict__ A, const char* __restrict__ Bt, void* __restrict__ C, int M, int N,
+    int K, long lda, long ldb, long ldc, int tiles_m, int tiles_n, float alpha, float beta,
+    int ksplits, long plane) {
+  gemm_bf16_nt_t128_body<OUT_F32, false>(A, Bt, C, M, N, K, lda, ldb, ldc, tiles_m, tiles_n,
+                                         alpha, beta, ksplits, plane);
+}
+
+// the same tile with four request-issuing waves next to the four multiplying ones, three K-tile
+// buffers: one workgroup per CU
+template <bool OUT_F32>
+__global__ __launch_bounds__(2 * T128_THREADS) void gemm_bf16_nt_t128ws_kernel(
+    const char* __restrict__ A, const char* __restrict__ Bt, void* __restrict__ C, int M, int N,
+    int K, long lda, long ldb, long ldc, int tiles_m, int tiles_n, float alpha, float beta,
+    int ksplits, long plane) {
+  gemm_bf16_nt_t128_body<OUT_F32, true>(A, Bt, C, M, N, K, lda, ldb, ldc, tiles_m, tiles_n,
+                                        alpha, beta, ksplits, plane);
+}
+
 }  // namespace
 
 // C[M,N] (bf16, or fp32 when out_f32) = alpha * A[M,K] * Bt[N,K]^T. Requirements of the fast
@@ -1738,7 +1841,8 @@ __global__ __launch_bounds__(T128_THREADS) void gemm_bf16_nt_t128_kernel(
 // double-buffer, 6 / 9 = ping-pong on 192 x 256 / 128 x 256 block tiles, 7 / 8 = the four-wave
 // kernels on an LDS ring / with register-staged loads,
 // 2 = ping-pong with one quadrant per phase, 3 = four-wave kernel (128x128 per wave),
-// 4 = ping-pong with two quadrants per phase, 5 = 128x128 tiles with two workgroups per CU;
+// 4 = ping-pong with two quadrants per phase, 5 = 128x128 tiles with two workgroups per CU,
+// 11 = 128x128 tiles with request-issuing waves (one workgroup per CU);
 // variant >> 4: timing-experiment bits of the one-quadrant ping-pong kernel (0 in production).
 // The staging DMA addresses a block tile with 32-bit offsets: 256 rows of lda / ldb bytes must
 // stay below 4 GiB (DTF_ERR_UNSUPPORTED otherwise).
@@ -1748,10 +1852,6 @@ __global__ __launch_bounds__(T128_THREADS) void gemm_bf16_nt_t128_kernel(
 // tiles) 1035 vs 1388 TF.
 #ifndef DTF_T128_BELOW_TILES
 #define DTF_T128_BELOW_TILES 129
-#endif
-// ... and grids of at most 32 such tiles: unsplit below this K, K-split from it on
-#ifndef DTF_T128_SMALL_GRID_MAX_K
-#define DTF_T128_SMALL_GRID_MAX_K 2048
 #endif
 
 // workgroups of the persistent ping-pong kernel: one per CU (128 KiB of LDS each), fewer when
@@ -2073,17 +2173,32 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
     DTF_LAUNCH_CHECK();
     return DTF_OK;
   }
-  // 128x128 tiles (variant 5, or by default when 256x256 tiles would leave CUs idle)
-  if ((variant & 15) == 5 ||
-      (variant == 0 && tiles_m * tiles_n > 32 && tiles_m * tiles_n < DTF_T128_BELOW_TILES) ||
-      (variant == 0 && tiles_m * tiles_n <= 32)) {
-        const size_t t_lds = 2 * T128_BUF_BYTES;
+  // 128x128 tiles (variants 5 and 11, or by default when 256x256 tiles would leave CUs idle):
+  // with request-issuing waves when every tile has a CU of its own (variant 11), else the
+  // four-wave form, two workgroups per CU (variant 5)
+  if ((variant & 15) == 5 || (variant & 15) == 11 ||
+      (variant == 0 && tiles_m * tiles_n < DTF_T128_BELOW_TILES)) {
+    const size_t t_lds = 2 * T128_BUF_BYTES, t_lds3 = 3 * T128_BUF_BYTES;
     { static DtfPerDeviceOnce once__; dtf_once_per_device(once__, [&] {
       dtf_allow_lds(gemm_bf16_nt_t128_kernel<true>, t_lds);
       dtf_allow_lds(gemm_bf16_nt_t128_kernel<false>, t_lds);
+      dtf_allow_lds(gemm_bf16_nt_t128ws_kernel<true>, t_lds3);
+      dtf_allow_lds(gemm_bf16_nt_t128ws_kernel<false>, t_lds3);
     }); }
     const int tm128 = (M + T128 - 1) / T128, tn128 = (N + T128 - 1) / T128;
     const dim3 t_grid(tm128 * tn128), t_block(T128_THREADS);
+    if ((variant & 15) == 11 || (variant == 0 && dtf_pp_grid(tm128 * tn128) == tm128 * tn128)) {
+      if (out_f32)
+        hipLaunchKernelGGL(gemm_bf16_nt_t128ws_kernel<true>, t_grid, dim3(2 * T128_THREADS),
+                           t_lds3, stream, (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb,
+                           ldc, tm128, tn128, alpha, beta, 1, 0L);
+      else
+        hipLaunchKernelGGL(gemm_bf16_nt_t128ws_kernel<false>, t_grid, dim3(2 * T128_THREADS),
+                           t_lds3, stream, (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb,
+                           ldc, tm128, tn128, alpha, beta, 1, 0L);
+      DTF_LAUNCH_CHECK();
+      return DTF_OK;
+    }
     if (out_f32)
       hipLaunchKernelGGL(gemm_bf16_nt_t128_kernel<true>, t_grid, t_block, t_lds, stream,
                          (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tm128,
@@ -2266,6 +2381,11 @@ DTF_API int dtf_gemm_bf16_splits(int M, int N, int K) {
   if (tiles > 32 && tiles <= 128) {
     if (N % 4 != 0) return 1;
     if (dtf_pp_rows(M, N) != 256) return 1;      // a 192- or 128-row tiling fills the chip unsplit
+    // a CU for every 128x128 tile: the kernel with request-issuing waves, unsplit (2048 x 2048 x
+    // 8192 58 us against 70 split on 256x256 tiles, 1280 x 2048 x 8192 52 / 60, 1536 x 2048 x
+    // 6144 43 / 49)
+    const int t128 = ((M + T128 - 1) / T128) * ((N + T128 - 1) / T128);
+    if (dtf_pp_grid(t128) == t128) return 1;
     // the most splits that still leave at most one work item per CU and divide K into whole
     // K-tiles; worth it from 144 work items on (1280 x 2048 x 8192, 40 tiles: 54 us split four
     // ways, 79 us unsplit)
@@ -2276,15 +2396,21 @@ DTF_API int dtf_gemm_bf16_splits(int M, int N, int K) {
     }
     return 1;
   }
-  // Small grids run on 128x128 tiles; from K = 2048 on, split until their work items number about
-  // one per CU, each keeping at least four K-tiles (GPU time by kernel trace, K = 2048, split /
-  // unsplit: 1024^2 outputs 17.9 / 21.8 us, 512^2 14.1 / 20.2, 256^2 11.1 / 20.4, 768^2 16.3 / 20.7;
-  // at K = 1024 the unsplit form wins, 12.1 against 16.4)
-  if (tiles > 32 || K < DTF_T128_SMALL_GRID_MAX_K) return 1;
+  // Small grids run on 128x128 tiles with request-issuing waves (0.4 us per K-tile where the
+  // four-wave form took 0.6), unsplit while K is short: a split costs a second launch and a pass
+  // over fp32 planes, 9-12 us on 1024^2 outputs and about 6 on 512^2. From K = 3072 on (2048 for
+  // at most 16 tiles) they are split until the work items number about one per CU, each keeping
+  // at least eight K-tiles. GPU time by kernel trace, unsplit / 2 / 4 / 8 / 16 splits:
+  // 1024 x 1024 x 2048 15.6 / 16.9 / 17.6 / 21.7 us, 1024 x 1024 x 4096 26.3 / 22.5 / 22.0 / 26.6 /
+  // 39.3, 512 x 512 x 4096 24.4 / 19.7 / 15.8 / 15.1 / 16.6, 512 x 512 x 2048 14.1 / 14.7 / 13.0 / 13.5,
+  // 256 x 256 x 8192 45.0 / 30.1 / 19.8 / 15.1 / 13.3, 1024 x 2048 x 4096 28.4 / 26.6 / 31.3,
+  // 1024 x 2048 x 2048 17.2 / 19.8 / 24.9 (`scripts/bf16_ws_plan_trace.sh`)
+  if (tiles > 32) return 1;
   const long t128 = (long)((M + T128 - 1) / T128) * ((N + T128 - 1) / T128);
+  if (K < (t128 <= 16 ? 2048 : 3072)) return 1;
   int splits = 1;
   while (splits < 16 && t128 * splits * 2 <= 256 && K % (splits * 2 * BK) == 0 &&
-         K / (splits * 2) >= 256)
+         K / (splits * 2) >= 512)
     splits *= 2;
   return splits;
 }
@@ -2311,15 +2437,21 @@ DTF_API int dtf_gemm_bf16_nt_splitk(const void* A, const void* Bt, void* C, floa
   const long plane = (long)M * N;
   if (dtf_gemm_bf16_split_on_t128(M, N, K, ksplits)) {
     // the split work items on 128x128 tiles: four times as many, each a quarter of the size
-    const size_t t_lds = 2 * T128_BUF_BYTES;
+    const size_t t_lds = 2 * T128_BUF_BYTES, t_lds3 = 3 * T128_BUF_BYTES;
     { static DtfPerDeviceOnce once__; dtf_once_per_device(once__, [&] {
       dtf_allow_lds(gemm_bf16_nt_t128_kernel<true>, t_lds);
+      dtf_allow_lds(gemm_bf16_nt_t128ws_kernel<true>, t_lds3);
     }); }
     const int tm128 = (M + T128 - 1) / T128, tn128 = (N + T128 - 1) / T128;
-    hipLaunchKernelGGL(gemm_bf16_nt_t128_kernel<true>, dim3(tm128 * tn128 * ksplits),
-                       dim3(T128_THREADS), t_lds, stream, (const char*)A, (const char*)Bt,
-                       (void*)workspace, M, N, K, lda, ldb, (long)N, tm128, tn128, 1.0f, 0.0f,
-                       ksplits, plane);
+    const int items = tm128 * tn128 * ksplits;
+    if (dtf_pp_grid(items) == items)        // a CU for every work item: request-issuing waves
+      hipLaunchKernelGGL(gemm_bf16_nt_t128ws_kernel<true>, dim3(items), dim3(2 * T128_THREADS),
+                         t_lds3, stream, (const char*)A, (const char*)Bt, (void*)workspace, M, N,
+                         K, lda, ldb, (long)N, tm128, tn128, 1.0f, 0.0f, ksplits, plane);
+    else
+      hipLaunchKernelGGL(gemm_bf16_nt_t128_kernel<true>, dim3(items), dim3(T128_THREADS), t_lds,
+                         stream, (const char*)A, (const char*)Bt, (void*)workspace, M, N, K, lda,
+                         ldb, (long)N, tm128, tn128, 1.0f, 0.0f, ksplits, plane);
     const long work = plane / 4;
     const int blocks = (int)((work + 255) / 256 > 2048 ? 2048 : (work + 255) / 256);
     if (out_f32)

@@ -73,7 +73,7 @@ def test_gemm_f32_bias_activation(hip, act):
     assert (out.double() - ref).abs().max().item() < 2e-5
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 9, 10])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 9, 10, 11])
 @pytest.mark.parametrize("m,n,k", [(256, 256, 64), (512, 768, 256), (1024, 1024, 1024),
                                    (300, 520, 128), (2048, 256, 4096), (256, 512, 192),
                                    (1, 1, 64), (257, 255, 320)])
@@ -89,7 +89,7 @@ def test_gemm_bf16_nt_fast(hip, m, n, k, out_dtype, variant):
     assert err < tol, (err, tol)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 9, 10])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 9, 10, 11])
 @pytest.mark.parametrize("m,n,k", [(512, 768, 256), (768, 512, 1344), (4096, 4096, 2048)])
 def test_gemm_bf16_nt_exact_integers(hip, variant, m, n, k):
     """Exact small-integer data: any fragment-layout, staging or pipeline-hazard bug shows as
@@ -711,7 +711,7 @@ def test_gemm_f32_writes_only_its_output(hip, m, n, k):
     assert bool((big[:3] == 12345.0).all()) and bool((big[3 + m:] == 12345.0).all())
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 9, 10])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 9, 10, 11])
 @pytest.mark.parametrize("m,n,k", [(300, 520, 128), (257, 255, 320), (512, 768, 256), (1, 1, 64)])
 @pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
 def test_gemm_bf16_writes_only_its_output(hip, m, n, k, out_dtype, variant):

@@ -1580,7 +1580,7 @@ constexpr int T128_THREADS = 256;
 constexpr int T128_TILE_BYTES = T128 * BK * 2;     // 16 KiB per operand tile
 constexpr int T128_BUF_BYTES = 2 * T128_TILE_BYTES;
 
-template <bool OUT_F32, int WS>
+template <bool OUT_F32, int WS, bool FP8 = false>
 __device__ __forceinline__ void gemm_bf16_nt_t128_body(
     const char* __restrict__ A, const char* __restrict__ Bt, void* __restrict__ C, int M, int N,
     int K, long lda, long ldb, long ldc, int tiles_m, int tiles_n, float alpha, float beta,
@@ -1599,8 +1599,13 @@ __device__ __forceinline__ void gemm_bf16_nt_t128_body(
   const int split = blockIdx.x / ntiles;
   const int id = dtf_xcd_remap(blockIdx.x - split * ntiles, ntiles);
   K /= ksplits;
-  A += (long)split * K * 2;
-  Bt += (long)split * K * 2;
+  // FP8: e4m3 operands, K-tile 128 -- the same 128 bytes per row, LDS image, requests and
+  // fragment reads; a lane's two 16-byte reads form the operand of one block-scaled MFMA with
+  // unit scales (see gemm_nt_pp_kernel)
+  static_assert(!FP8 || WS, "fp8 operands: only the form with request-issuing waves");
+  constexpr int ES = FP8 ? 1 : 2;
+  A += (long)split * K * ES;
+  Bt += (long)split * K * ES;
   C = reinterpret_cast<char*>(C) + (long)split * plane * (OUT_F32 ? 4 : 2);
   constexpr int GROUP = 8;
   const int per_group = GROUP * tiles_n;
@@ -1622,11 +1627,11 @@ __device__ __forceinline__ void gemm_bf16_nt_t128_body(
     int ra = m0 + trow, rb = n0 + trow;
     ra = ra < M - 1 ? ra : M - 1;
     rb = rb < N - 1 ? rb : N - 1;
-    voff_a[j] = (unsigned)(ra - m0) * (unsigned)(lda * 2) + 16u * kc;
-    voff_b[j] = (unsigned)(rb - n0) * (unsigned)(ldb * 2) + 16u * kc;
+    voff_a[j] = (unsigned)(ra - m0) * (unsigned)(lda * ES) + 16u * kc;
+    voff_b[j] = (unsigned)(rb - n0) * (unsigned)(ldb * ES) + 16u * kc;
   }
-  const __amdgpu_buffer_rsrc_t a_rsrc = tile_rsrc(A + (long)m0 * lda * 2);
-  const __amdgpu_buffer_rsrc_t b_rsrc = tile_rsrc(Bt + (long)n0 * ldb * 2);
+  const __amdgpu_buffer_rsrc_t a_rsrc = tile_rsrc(A + (long)m0 * lda * ES);
+  const __amdgpu_buffer_rsrc_t b_rsrc = tile_rsrc(Bt + (long)n0 * ldb * ES);
   auto stage = [&](int kt, char* buf) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -1645,7 +1650,7 @@ __device__ __forceinline__ void gemm_bf16_nt_t128_body(
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nkt = K / BK;
+  const int nkt = K / (FP8 ? 2 * BK : BK);
   if (!WS || producer) stage(0, smem);
   const int frow = lane & 15, fq = lane >> 4;
   if (WS) {
@@ -1703,6 +1708,23 @@ __device__ __forceinline__ void gemm_bf16_nt_t128_body(
         DTF_T128_RD(af[s2][2], aa, 4096);
         DTF_T128_RD(af[s2][3], aa, 6144);
       }
+      if constexpr (FP8) {
+        // (reads return in order: a row of MFMAs waits for its second A fragment, the 13th +
+        // i-th read)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (i == 0) DTF_T128_WAIT(3, 1, 0);
+          if (i == 1) DTF_T128_WAIT(2, 1, 1);
+          if (i == 2) DTF_T128_WAIT(1, 1, 2);
+          if (i == 3) DTF_T128_WAIT(0, 1, 3);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
+                __builtin_shufflevector((i32x4)bf[0][j], (i32x4)bf[1][j], 0, 1, 2, 3, 4, 5, 6, 7),
+                __builtin_shufflevector((i32x4)af[0][i], (i32x4)af[1][i], 0, 1, 2, 3, 4, 5, 6, 7),
+                acc[i][j], 0, 0, 0, 0x7f7f7f7fu, 0, 0x7f7f7f7fu);
+        }
+      } else {
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -1720,6 +1742,7 @@ __device__ __forceinline__ void gemm_bf16_nt_t128_body(
             acc[i][j] =
                 __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[s2][j], af[s2][i], acc[i][j], 0, 0, 0);
         }
+      }
       cur = cur == 2 * T128_BUF_BYTES ? 0 : cur + T128_BUF_BYTES;
     }
 #undef DTF_T128_RD
@@ -1832,6 +1855,15 @@ __global__ __launch_bounds__(2 * T128_THREADS) void gemm_bf16_nt_t128ws_kernel(
     int ksplits, long plane) {
   gemm_bf16_nt_t128_body<OUT_F32, 1>(A, Bt, C, M, N, K, lda, ldb, ldc, tiles_m, tiles_n,
                                         alpha, beta, ksplits, plane);
+}
+
+template <bool OUT_F32>
+__global__ __launch_bounds__(2 * T128_THREADS) void gemm_fp8_nt_t128ws_kernel(
+    const char* __restrict__ A, const char* __restrict__ Bt, void* __restrict__ C, int M, int N,
+    int K, long lda, long ldb, long ldc, int tiles_m, int tiles_n, float alpha, float beta,
+    int ksplits, long plane) {
+  gemm_bf16_nt_t128_body<OUT_F32, 1, true>(A, Bt, C, M, N, K, lda, ldb, ldc, tiles_m, tiles_n,
+                                           alpha, beta, ksplits, plane);
 }
 
 }  // namespace
@@ -2501,6 +2533,25 @@ DTF_API int dtf_gemm_fp8_nt(const void* A, const void* Bt, void* C, int M, int N
     dtf_allow_lds(gemm_nt_pp_kernel<false, 0, true, true>, lds);
   }); }
   const dim3 grid(tiles_m * tiles_n), block(NTHREADS);     // one tile per workgroup (no tile loop)
+  // a CU for every 128x128 tile: the kernel with request-issuing waves (2048^3 fp8: see below)
+  const int tm128 = (M + T128 - 1) / T128, tn128 = (N + T128 - 1) / T128;
+  if (dtf_pp_grid(tm128 * tn128) == tm128 * tn128) {
+    const size_t t_lds3 = 3 * T128_BUF_BYTES;
+    { static DtfPerDeviceOnce once__; dtf_once_per_device(once__, [&] {
+      dtf_allow_lds(gemm_fp8_nt_t128ws_kernel<true>, t_lds3);
+      dtf_allow_lds(gemm_fp8_nt_t128ws_kernel<false>, t_lds3);
+    }); }
+    if (out_f32)
+      hipLaunchKernelGGL(gemm_fp8_nt_t128ws_kernel<true>, dim3(tm128 * tn128),
+                         dim3(2 * T128_THREADS), t_lds3, stream, (const char*)A, (const char*)Bt,
+                         C, M, N, K, lda, ldb, ldc, tm128, tn128, alpha, beta, 1, 0L);
+    else
+      hipLaunchKernelGGL(gemm_fp8_nt_t128ws_kernel<false>, dim3(tm128 * tn128),
+                         dim3(2 * T128_THREADS), t_lds3, stream, (const char*)A, (const char*)Bt,
+                         C, M, N, K, lda, ldb, ldc, tm128, tn128, alpha, beta, 1, 0L);
+    DTF_LAUNCH_CHECK();
+    return DTF_OK;
+  }
   // 192- or 128-row block tiles where they fill the chip better (the rule of the bf16 launch)
   int pp_rows = dtf_pp_rows(M, N);
 #ifdef DTF_GEMM_EXPERIMENTS
@@ -2558,6 +2609,61 @@ DTF_API int dtf_gemm_fp8_nt(const void* A, const void* Bt, void* C, int M, int N
     hipLaunchKernelGGL((gemm_nt_pp_kernel<false, 0, true, true>), grid, block, lds, stream,
                        (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tiles_m,
                        tiles_n, alpha, beta, 1, 0L, nullptr, nullptr);
+  DTF_LAUNCH_CHECK();
+  return DTF_OK;
+}
+
+// K splits of an fp8 product (1 = unsplit): the rule of the small bf16 grids in K-tiles of 128
+// elements -- at most 32 tiles of 256 x 256, at least 48 K-tiles (32 for at most 16 tiles of
+// 128 x 128), work items of at least eight K-tiles, about one per CU.
+DTF_API int dtf_gemm_fp8_splits(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0 || K % 128 || N % 4) return 1;
+  const long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  if (tiles > 32) return 1;
+  const long t128 = (long)((M + T128 - 1) / T128) * ((N + T128 - 1) / T128);
+  const int nkt = K / 128;
+  if (nkt < (t128 <= 16 ? 32 : 48)) return 1;
+  int splits = 1;
+  while (splits < 16 && t128 * splits * 2 <= 256 && nkt % (splits * 2) == 0 &&
+         nkt / (splits * 2) >= 8)
+    splits *= 2;
+  return splits;
+}
+
+// Split-K form of dtf_gemm_fp8_nt: `workspace` holds ksplits * M * N floats; (split, tile) work
+// items on the 128x128-tile kernel with request-issuing waves write fp32 planes, a second kernel
+// sums them in split order and applies alpha / beta. Same operand contract; additionally
+// N % 4 == 0, K % (ksplits * 128) == 0 and a CU for every work item (DTF_ERR_UNSUPPORTED
+// otherwise: the caller runs the unsplit launch).
+DTF_API int dtf_gemm_fp8_nt_splitk(const void* A, const void* Bt, void* C, float* workspace, int M,
+                                   int N, int K, long lda, long ldb, long ldc, float alpha,
+                                   float beta, int out_f32, int ksplits, hipStream_t stream) {
+  if (!A || !Bt || !C || !workspace || M <= 0 || N <= 0 || K <= 0 || ksplits < 2 || ksplits > 64)
+    return DTF_ERR_BAD_ARG;
+  if (lda < K || ldb < K || ldc < N) return DTF_ERR_BAD_ARG;
+  if (K % (ksplits * 128) || N % 4 || lda % 16 || ldb % 16 || ldc % 4 || ((uintptr_t)A & 15) ||
+      ((uintptr_t)Bt & 15) || ((uintptr_t)C & (out_f32 ? 15 : 7)) || ((uintptr_t)workspace & 15))
+    return DTF_ERR_UNSUPPORTED;
+  if (lda * BM >= (1L << 32) || ldb * BN >= (1L << 32)) return DTF_ERR_UNSUPPORTED;
+  const int tm128 = (M + T128 - 1) / T128, tn128 = (N + T128 - 1) / T128;
+  const int items = tm128 * tn128 * ksplits;
+  if (dtf_pp_grid(items) != items) return DTF_ERR_UNSUPPORTED;
+  const size_t t_lds3 = 3 * T128_BUF_BYTES;
+  { static DtfPerDeviceOnce once__; dtf_once_per_device(once__, [&] {
+    dtf_allow_lds(gemm_fp8_nt_t128ws_kernel<true>, t_lds3);
+  }); }
+  const long plane = (long)M * N;
+  hipLaunchKernelGGL(gemm_fp8_nt_t128ws_kernel<true>, dim3(items), dim3(2 * T128_THREADS), t_lds3,
+                     stream, (const char*)A, (const char*)Bt, (void*)workspace, M, N, K, lda, ldb,
+                     (long)N, tm128, tn128, 1.0f, 0.0f, ksplits, plane);
+  const long work = plane / 4;
+  const int blocks = (int)((work + 255) / 256 > 2048 ? 2048 : (work + 255) / 256);
+  if (out_f32)
+    hipLaunchKernelGGL(planes_reduce_kernel<true>, dim3(blocks), dim3(256), 0, stream, workspace,
+                       ksplits, plane, C, ldc, M, N, alpha, beta);
+  else
+    hipLaunchKernelGGL(planes_reduce_kernel<false>, dim3(blocks), dim3(256), 0, stream, workspace,
+                       ksplits, plane, C, ldc, M, N, alpha, beta);
   DTF_LAUNCH_CHECK();
   return DTF_OK;
 }

@@ -116,6 +116,8 @@ def _declare(L: ctypes.CDLL) -> None:
         "dtf_gemm_bf16_nt_splitk": [P, P, P, P, I, I, I, LG, LG, LG, F, F, I, I, P],
         "dtf_gemm_bf16_generic": [P, P, P, I, I, I, LG, LG, LG, LG, LG, F, F, I, P],
         "dtf_gemm_fp8_nt": [P, P, P, I, I, I, LG, LG, LG, F, F, I, P],
+        "dtf_gemm_fp8_splits": [I, I, I],
+        "dtf_gemm_fp8_nt_splitk": [P, P, P, P, I, I, I, LG, LG, LG, F, F, I, I, P],
         "dtf_gemm_fp8_generic": [P, P, P, I, I, I, LG, LG, LG, LG, LG, F, F, I, P],
         "dtf_gemm_fp8_mx_nt": [P, P, P, P, P, I, I, I, LG, LG, LG, LG, LG, F, F, I, P],
         "dtf_quantize_mx_fp8": [P, I, LG, LG, LG, P, LG, P, P, I, P],
@@ -547,11 +549,14 @@ FP8_MAX = 448.0
 
 def gemm_fp8_nt(a: torch.Tensor, bt: torch.Tensor, out_dtype: torch.dtype = torch.bfloat16,
                 alpha: float = 1.0, out: Optional[torch.Tensor] = None,
-                force_generic: bool = False, beta: float = 0.0) -> torch.Tensor:
+                force_generic: bool = False, beta: float = 0.0,
+                splits: Optional[int] = None) -> torch.Tensor:
     """``alpha * a @ bt.T (+ beta * out)`` with a [M,K], bt [N,K] in OCP fp8 e4m3 (both K-contiguous), fp32
     accumulate, bf16 or fp32 result. ``alpha`` is where the product of the operands'
-    dequantisation scales goes. Shapes the 256x256x128 block-scaled-MFMA kernel cannot take run
-    on the predicated generic kernel."""
+    dequantisation scales goes. Shapes the block-scaled-MFMA kernels (256x256x128 tiles, or
+    128x128x128 with request-issuing waves when every such tile has a CU) cannot take run
+    on the predicated generic kernel. ``splits``: K splits for grids with few output tiles
+    (default: the library's plan; 1 = never split)."""
     a = _req(a, FP8, "gemm_fp8_nt a")
     bt = _req(bt, FP8, "gemm_fp8_nt bt")
     if a.dim() != 2 or bt.dim() != 2 or a.shape[1] != bt.shape[1]:
@@ -593,11 +598,24 @@ def gemm_fp8_nt(a: torch.Tensor, bt: torch.Tensor, out_dtype: torch.dtype = torc
                 images.append(img)
             if out_ok:
                 return gemm_fp8_nt(images[0], images[1], out_dtype, alpha=alpha, out=out,
-                                   beta=beta)
+                                   beta=beta, splits=splits)
             n4 = (n + 3) // 4 * 4
             tmp = torch.empty((m, n4), dtype=out_dtype, device=a.device)
-            gemm_fp8_nt(images[0], images[1], out_dtype, alpha=alpha, out=tmp[:, :n])
+            gemm_fp8_nt(images[0], images[1], out_dtype, alpha=alpha, out=tmp[:, :n],
+                        splits=splits)
             return copy_2d(tmp[:, :n], out)
+    if splits is None:
+        splits = 1 if force_generic else lib().dtf_gemm_fp8_splits(m, n, k)
+    if splits > 1 and not force_generic:
+        ws = torch.empty(splits * m * n, dtype=torch.float32, device=a.device)
+        code = lib().dtf_gemm_fp8_nt_splitk(a.data_ptr(), bt.data_ptr(), out.data_ptr(),
+                                            ws.data_ptr(), m, n, k, a.stride(0), bt.stride(0),
+                                            out.stride(0), float(alpha), float(beta), out_f32,
+                                            int(splits), _stream())
+        if code == 0:
+            return out
+        if code != -2:
+            _check(code, "gemm_fp8_nt (split-K)")
     code = -2 if force_generic else lib().dtf_gemm_fp8_nt(
         a.data_ptr(), bt.data_ptr(), out.data_ptr(), m, n, k, a.stride(0), bt.stride(0),
         out.stride(0), float(alpha), float(beta), out_f32, _stream())

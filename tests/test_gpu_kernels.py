@@ -747,6 +747,54 @@ def test_gemm_fp8_on_192_and_128_row_tiles(hip, m, n, k, out_dtype):
 
 
 @pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("m,n,k", [(128, 128, 128), (300, 520, 256), (257, 252, 384), (1, 4, 128),
+                                   (1024, 1024, 1024), (2048, 256, 4096), (1536, 1792, 640)])
+def test_gemm_fp8_on_128x128_tiles_with_request_waves(hip, m, n, k, out_dtype):
+    """fp8 products with a CU for every 128 x 128 tile run on the kernel whose waves 4-7 only
+    issue the LDS-DMA requests (three K-tile buffers, requests two K-tiles ahead): one, two,
+    three and many K-tiles, ragged edges, repeated launches; exact on integer data, alpha / beta
+    applied, nothing written outside the result."""
+    g = torch.Generator().manual_seed(m + n + k)
+    a = torch.randint(-2, 3, (m, k), generator=g).float()
+    bt = torch.randint(-2, 3, (n, k), generator=g).float()
+    ad, bd = a.to(FP8).cuda(), bt.to(FP8).cuda()
+    want = a.cuda() @ bt.cuda().t()
+    for _ in range(3):
+        got = hip.gemm_fp8_nt(ad, bd, out_dtype, splits=1)
+        assert torch.equal(got.float(), want.to(out_dtype).float())
+    big, view, sentinel, origin = _guarded(m, n, out_dtype, pad_cols=4)
+    view.fill_(1.0)
+    hip.gemm_fp8_nt(ad, bd, out_dtype, alpha=0.5, beta=2.0, out=view, splits=1)
+    assert torch.equal(view.float(), (0.5 * want + 2.0).to(out_dtype).float())
+    assert _band_intact(big, (m, n), origin, sentinel)
+
+
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("m,n,k,splits", [(512, 512, 4096, None), (256, 256, 8192, None),
+                                          (300, 260, 2048, 4), (1024, 1024, 8192, None)])
+def test_gemm_fp8_split_k(hip, m, n, k, splits, out_dtype):
+    """Few output tiles + long K in fp8: (split, tile) work items on the 128 x 128-tile kernel go
+    into fp32 planes and a second kernel sums them in split order; exact on integer data, equal
+    to the unsplit product bit for bit, alpha and beta applied once in the reduction."""
+    g = torch.Generator().manual_seed(m + n + k)
+    a = torch.randint(-2, 3, (m, k), generator=g).float()
+    bt = torch.randint(-2, 3, (n, k), generator=g).float()
+    ad, bd = a.to(FP8).cuda(), bt.to(FP8).cuda()
+    if splits is None:
+        assert hip.lib().dtf_gemm_fp8_splits(m, n, k) > 1
+        assert hip.lib().dtf_gemm_fp8_splits(m, n, 1024) == 1
+    ref = a @ bt.t()
+    out = hip.gemm_fp8_nt(ad, bd, out_dtype, splits=splits)
+    assert torch.equal(out.float().cpu(), ref.to(out_dtype).float())
+    assert torch.equal(out, hip.gemm_fp8_nt(ad, bd, out_dtype, splits=1))
+    base = torch.randint(-4, 5, (m, n), generator=g).float().to(out_dtype).cuda()
+    acc = base.clone()
+    hip.gemm_fp8_nt(ad, bd, out_dtype, alpha=0.5, out=acc, beta=2.0, splits=splits)
+    want = (0.5 * ref + 2.0 * base.float().cpu()).to(out_dtype).float()
+    assert torch.equal(acc.float().cpu(), want)
+
+
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("m,n,k", [(512, 300, 1000), (513, 1001, 1003), (300, 258, 784)])
 def test_gemm_fp8_off_grid_shapes(hip, m, n, k, out_dtype):
     """K that is not a multiple of 128, odd K, odd N: the fp8 product runs the block-scaled-MFMA

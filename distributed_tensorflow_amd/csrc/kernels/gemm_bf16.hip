@@ -1857,6 +1857,206 @@ __global__ __launch_bounds__(2 * T128_THREADS) void gemm_bf16_nt_t128ws_kernel(
                                         alpha, beta, ksplits, plane);
 }
 
+// ---- 64x64 tiles with request-issuing waves: products of at most one such tile per CU ---------
+// The kernel above is bound by its request path (32 KiB per K-tile and CU in 0.4 us), so a
+// product of few 128x128 tiles runs faster on four times as many CUs with a quarter of the tile
+// each: waves 0-3 multiply 32x32 outputs each, waves 4-7 issue the four requests a K-tile needs
+// of each of them (8 KiB per operand tile), three buffers of 16 KiB, one barrier per K-tile.
+constexpr int T64 = 64;
+constexpr int T64_TILE_BYTES = T64 * BK * 2;       // 8 KiB per operand tile
+constexpr int T64_BUF_BYTES = 2 * T64_TILE_BYTES;
+
+template <bool OUT_F32, bool FP8>
+__global__ __launch_bounds__(512) void gemm_nt_t64ws_kernel(
+    const char* __restrict__ A, const char* __restrict__ Bt, void* __restrict__ C, int M, int N,
+    int K, long lda, long ldb, long ldc, int tiles_m, int tiles_n, float alpha, float beta,
+    int ksplits, long plane) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 3 x (A tile | B tile)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = wave8 & 3;
+  const bool producer = wave8 >= 4;
+  const int wr = wave >> 1, wc = wave & 1;
+  constexpr int ES = FP8 ? 1 : 2;
+
+  const int ntiles = tiles_m * tiles_n;
+  const int split = blockIdx.x / ntiles;
+  const int id = dtf_xcd_remap(blockIdx.x - split * ntiles, ntiles);
+  K /= ksplits;
+  A += (long)split * K * ES;
+  Bt += (long)split * K * ES;
+  C = reinterpret_cast<char*>(C) + (long)split * plane * (OUT_F32 ? 4 : 2);
+  constexpr int GROUP = 8;
+  const int per_group = GROUP * tiles_n;
+  const int g = id / per_group;
+  const int first_m = g * GROUP;
+  const int gsize = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
+  const int tm = first_m + (id % per_group) % gsize;
+  const int tn = (id % per_group) / gsize;
+  const int m0 = tm * T64, n0 = tn * T64;
+  const int nkt = K / (FP8 ? 2 * BK : BK);
+
+  if (producer) {
+    // 8 pieces of 8 rows per operand tile, two per wave
+    unsigned voff_a[2], voff_b[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int piece = wave * 2 + j;
+      const int trow = piece * 8 + (lane >> 3);
+      const int kc = (lane & 7) ^ ((trow >> 1) & 7);
+      int ra = m0 + trow, rb = n0 + trow;
+      ra = ra < M - 1 ? ra : M - 1;
+      rb = rb < N - 1 ? rb : N - 1;
+      voff_a[j] = (unsigned)(ra - m0) * (unsigned)(lda * ES) + 16u * kc;
+      voff_b[j] = (unsigned)(rb - n0) * (unsigned)(ldb * ES) + 16u * kc;
+    }
+    const __amdgpu_buffer_rsrc_t a_rsrc = tile_rsrc(A + (long)m0 * lda * ES);
+    const __amdgpu_buffer_rsrc_t b_rsrc = tile_rsrc(Bt + (long)n0 * ldb * ES);
+    auto stage = [&](int kt, char* buf) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int piece = wave * 2 + j;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_void*)(buf + piece * 1024), 16,
+                                                 voff_a[j], kt * 128, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            b_rsrc, (lds_void*)(buf + T64_TILE_BYTES + piece * 1024), 16, voff_b[j], kt * 128, 0,
+            0);
+      }
+    };
+    stage(0, smem);
+    if (nkt > 1) stage(1, smem + T64_BUF_BYTES);
+    unsigned nxt2 = 2 * T64_BUF_BYTES;
+    for (int kt = 0; kt < nkt; ++kt) {
+      // own pieces of tile kt have landed (the newest tile's four requests stay in flight);
+      // behind the barrier the multiplying waves are done with the buffer of tile kt - 1
+      if (kt + 1 < nkt)
+        asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      if (kt + 2 < nkt) stage(kt + 2, smem + nxt2);
+      nxt2 = nxt2 == 2 * T64_BUF_BYTES ? 0 : nxt2 + T64_BUF_BYTES;
+    }
+    return;
+  }
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int frow = lane & 15, fq = lane >> 4;
+  const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>((lds_void*)smem);
+  unsigned a_rd[2], b_rd[2];
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+    a_rd[s2] = lds0 + chunk_off(wr * 32 + frow, 4 * s2 + fq);
+    b_rd[s2] = lds0 + T64_TILE_BYTES + chunk_off(wc * 32 + frow, 4 * s2 + fq);
+  }
+#define DTF_T64_RD(DST, ADDR, OFF) \
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
+#define DTF_T64_WAIT(N, S2, I) \
+  asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(bf[S2][0]), "+v"(bf[S2][1]), "+v"(af[S2][I]))
+  unsigned cur = 0;
+  for (int kt = 0; kt < nkt; ++kt) {
+    asm volatile("s_barrier" ::: "memory");
+    bf16x8 af[2][2], bf[2][2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const unsigned ba = b_rd[s2] + cur, aa = a_rd[s2] + cur;
+      DTF_T64_RD(bf[s2][0], ba, 0);
+      DTF_T64_RD(bf[s2][1], ba, 2048);
+      DTF_T64_RD(af[s2][0], aa, 0);
+      DTF_T64_RD(af[s2][1], aa, 2048);
+    }
+    if constexpr (FP8) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if (i == 0) DTF_T64_WAIT(1, 1, 0);
+        if (i == 1) DTF_T64_WAIT(0, 1, 1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
+              __builtin_shufflevector((i32x4)bf[0][j], (i32x4)bf[1][j], 0, 1, 2, 3, 4, 5, 6, 7),
+              __builtin_shufflevector((i32x4)af[0][i], (i32x4)af[1][i], 0, 1, 2, 3, 4, 5, 6, 7),
+              acc[i][j], 0, 0, 0, 0x7f7f7f7fu, 0, 0x7f7f7f7fu);
+      }
+    } else {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          if (s2 == 0 && i == 0) DTF_T64_WAIT(5, 0, 0);
+          if (s2 == 0 && i == 1) DTF_T64_WAIT(4, 0, 1);
+          if (s2 == 1 && i == 0) DTF_T64_WAIT(1, 1, 0);
+          if (s2 == 1 && i == 1) DTF_T64_WAIT(0, 1, 1);
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] =
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[s2][j], af[s2][i], acc[i][j], 0, 0, 0);
+        }
+    }
+    cur = cur == 2 * T64_BUF_BYTES ? 0 : cur + T64_BUF_BYTES;
+  }
+#undef DTF_T64_RD
+#undef DTF_T64_WAIT
+
+  // lane holds C[m = frow][n = 4*fq + r], r = 0..3, of each 16x16 tile (interior tile, bf16 out:
+  // the short epilogue of the kernels above)
+  if (!OUT_F32 && beta == 0.f && (ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 &&
+      m0 + T64 <= M && n0 + T64 <= N) {
+    const int colx = (fq & 1) ? 16 + 4 * (fq - 1) : 4 * fq;
+    char* crow = reinterpret_cast<char*>(C) +
+                 ((long)(m0 + wr * 32 + frow) * ldc + n0 + wc * 32 + colx) * 2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const f32x4 v0 = acc[i][0] * alpha, v1 = acc[i][1] * alpha;
+      const unsigned p0a = dtf_f32x2_to_bf16x2(v0[0], v0[1]);
+      const unsigned p0b = dtf_f32x2_to_bf16x2(v0[2], v0[3]);
+      const unsigned p1a = dtf_f32x2_to_bf16x2(v1[0], v1[1]);
+      const unsigned p1b = dtf_f32x2_to_bf16x2(v1[2], v1[3]);
+      const auto sa = __builtin_amdgcn_permlane16_swap(p0a, p1a, false, false);
+      const auto sb = __builtin_amdgcn_permlane16_swap(p0b, p1b, false, false);
+      u32x4 o = {sa[0], sb[0], sa[1], sb[1]};
+      *reinterpret_cast<u32x4*>(crow) = o;
+      crow += ldc * 32;
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = m0 + wr * 32 + i * 16 + frow;
+    if (row >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wc * 32 + j * 16 + 4 * fq;
+      if (col >= N) continue;
+      f32x4 v = acc[i][j] * alpha;
+      if (OUT_F32) {
+        float* dst = reinterpret_cast<float*>(C) + (long)row * ldc + col;
+        if (col + 3 < N) {
+          if (beta != 0.f) v += *reinterpret_cast<const f32x4*>(dst) * beta;
+          *reinterpret_cast<f32x4*>(dst) = v;
+        } else {
+          for (int r = 0; r < 4 && col + r < N; ++r)
+            dst[r] = beta != 0.f ? v[r] + beta * dst[r] : v[r];
+        }
+      } else {
+        unsigned short* dst = reinterpret_cast<unsigned short*>(C) + (long)row * ldc + col;
+        if (beta != 0.f)
+          for (int r = 0; r < 4 && col + r < N; ++r) v[r] += beta * dtf_bf16_to_f32(dst[r]);
+        if (col + 3 < N) {
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (short)dtf_f32_to_bf16(v[r]);
+          *reinterpret_cast<bf16x4*>(dst) = o;
+        } else {
+          for (int r = 0; r < 4 && col + r < N; ++r) dst[r] = dtf_f32_to_bf16(v[r]);
+        }
+      }
+    }
+  }
+}
+
 template <bool OUT_F32>
 __global__ __launch_bounds__(2 * T128_THREADS) void gemm_fp8_nt_t128ws_kernel(
     const char* __restrict__ A, const char* __restrict__ Bt, void* __restrict__ C, int M, int N,
@@ -1877,7 +2077,8 @@ __global__ __launch_bounds__(2 * T128_THREADS) void gemm_fp8_nt_t128ws_kernel(
 // kernels on an LDS ring / with register-staged loads,
 // 2 = ping-pong with one quadrant per phase, 3 = four-wave kernel (128x128 per wave),
 // 4 = ping-pong with two quadrants per phase, 5 = 128x128 tiles with two workgroups per CU,
-// 11 = 128x128 tiles with request-issuing waves (one workgroup per CU);
+// 11 = 128x128 tiles with request-issuing waves (one workgroup per CU), 12 = 64x64 tiles with
+// request-issuing waves;
 // variant >> 4: timing-experiment bits of the one-quadrant ping-pong kernel (0 in production).
 // The staging DMA addresses a block tile with 32-bit offsets: 256 rows of lda / ldb bytes must
 // stay below 4 GiB (DTF_ERR_UNSUPPORTED otherwise).
@@ -1945,6 +2146,30 @@ template <typename KernelT>
 static void dtf_allow_lds(KernelT kernel, size_t lds) {
   hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
+
+// launch of the 64x64-tile kernel (operand contract checked by the caller)
+template <bool FP8>
+static void dtf_launch_t64ws(const void* A, const void* Bt, void* C, int M, int N, int K, long lda,
+                             long ldb, long ldc, float alpha, float beta, int out_f32, int ksplits,
+                             long plane, hipStream_t stream) {
+  const size_t lds3 = 3 * T64_BUF_BYTES;
+  { static DtfPerDeviceOnce once__; dtf_once_per_device(once__, [&] {
+    dtf_allow_lds(gemm_nt_t64ws_kernel<true, FP8>, lds3);
+    dtf_allow_lds(gemm_nt_t64ws_kernel<false, FP8>, lds3);
+  }); }
+  const int tm = (M + T64 - 1) / T64, tn = (N + T64 - 1) / T64;
+  if (out_f32)
+    hipLaunchKernelGGL((gemm_nt_t64ws_kernel<true, FP8>), dim3(tm * tn * ksplits), dim3(512), lds3,
+                       stream, (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tm, tn,
+                       alpha, beta, ksplits, plane);
+  else
+    hipLaunchKernelGGL((gemm_nt_t64ws_kernel<false, FP8>), dim3(tm * tn * ksplits), dim3(512),
+                       lds3, stream, (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc,
+                       tm, tn, alpha, beta, ksplits, plane);
+}
+
+// number of 64x64 tiles of an M x N result
+static int dtf_t64_tiles(int M, int N) { return ((M + T64 - 1) / T64) * ((N + T64 - 1) / T64); }
 
 DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int N, int K, long lda,
                              long ldb, long ldc, float alpha, float beta, int out_f32,
@@ -2208,6 +2433,14 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
     DTF_LAUNCH_CHECK();
     return DTF_OK;
   }
+  // 64x64 tiles with request-issuing waves (variant 12, or by default when every such tile has
+  // a CU of its own)
+  if ((variant & 15) == 12 ||
+      (variant == 0 && dtf_pp_grid(dtf_t64_tiles(M, N)) == dtf_t64_tiles(M, N))) {
+    dtf_launch_t64ws<false>(A, Bt, C, M, N, K, lda, ldb, ldc, alpha, beta, out_f32, 1, 0L, stream);
+    DTF_LAUNCH_CHECK();
+    return DTF_OK;
+  }
   // 128x128 tiles (variants 5 and 11, or by default when 256x256 tiles would leave CUs idle):
   // with request-issuing waves when every tile has a CU of its own (variant 11), else the
   // four-wave form, two workgroups per CU (variant 5)
@@ -2411,7 +2644,26 @@ static bool dtf_gemm_bf16_split_on_t128(int M, int N, int K, int ksplits) {
   return (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN) <= 32;
 }
 
+// K splits of a product of at most 256 tiles of 64 x 64 whose K is `nkt` K-tiles long: work
+// items on the 64x64-tile kernel, at most one per CU, each of at least eight K-tiles -- and only
+// if the K-tiles a workgroup is spared (0.23 us each) outweigh the second launch and the pass
+// over the fp32 planes (about 5 us on 512^2 outputs, 6-7 above). GPU time by kernel trace,
+// unsplit / best split / torch.matmul, bf16: 512 x 512 x 4096 17.5 / 12.5 (4) / 10.6, 256 x 256 x
+// 8192 22.7 / 9.2 (8) / 10.2, 512 x 1024 x 2048 8.8 / 11.5 (2) / 10.0, 1024^2 outputs have no split
+// with a CU per work item: 1024 x 1024 x 4096 18.5 (22.4 split four ways on 128x128 tiles) / 18.2,
+// 1024 x 1024 x 8192 30.5 (32.4) / 29.5 (`profiles/gemm_bf16_ws_plan.txt`).
+static int dtf_t64_splits(int t64, int nkt) {
+  int s = 1;
+  while (s < 16 && t64 * s * 2 <= 256 && nkt % (s * 2) == 0 && nkt / (s * 2) >= 8) s *= 2;
+  if (s > 1 && nkt * (s - 1) / s <= (t64 <= 64 ? 24 : 30)) s = 1;
+  return s;
+}
+
 DTF_API int dtf_gemm_bf16_splits(int M, int N, int K) {
+  if (M > 0 && N > 0 && K > 0 && N % 4 == 0 && K % BK == 0 && dtf_t64_tiles(M, N) <= 256) {
+    const int s = dtf_t64_splits(dtf_t64_tiles(M, N), K / BK);
+    if (s > 1 || K / BK < 192) return s;     // (very long K: the rule of the 128x128 tiles below)
+  }
   const long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   if (tiles > 32 && tiles <= 128) {
     if (N % 4 != 0) return 1;
@@ -2479,7 +2731,11 @@ DTF_API int dtf_gemm_bf16_nt_splitk(const void* A, const void* Bt, void* C, floa
     }); }
     const int tm128 = (M + T128 - 1) / T128, tn128 = (N + T128 - 1) / T128;
     const int items = tm128 * tn128 * ksplits;
-    if (dtf_pp_grid(items) == items)        // a CU for every work item: request-issuing waves
+    const int items64 = dtf_t64_tiles(M, N) * ksplits;
+    if (dtf_pp_grid(items64) == items64)    // a CU for every 64x64 work item
+      dtf_launch_t64ws<false>(A, Bt, workspace, M, N, K, lda, ldb, (long)N, 1.0f, 0.0f, 1, ksplits,
+                              plane, stream);
+    else if (dtf_pp_grid(items) == items)   // a CU for every work item: request-issuing waves
       hipLaunchKernelGGL(gemm_bf16_nt_t128ws_kernel<true>, dim3(items), dim3(2 * T128_THREADS),
                          t_lds3, stream, (const char*)A, (const char*)Bt, (void*)workspace, M, N,
                          K, lda, ldb, (long)N, tm128, tn128, 1.0f, 0.0f, ksplits, plane);
@@ -2535,6 +2791,11 @@ DTF_API int dtf_gemm_fp8_nt(const void* A, const void* Bt, void* C, int M, int N
   const dim3 grid(tiles_m * tiles_n), block(NTHREADS);     // one tile per workgroup (no tile loop)
   // a CU for every 128x128 tile: the kernel with request-issuing waves (2048^3 fp8: see below)
   const int tm128 = (M + T128 - 1) / T128, tn128 = (N + T128 - 1) / T128;
+  if (dtf_pp_grid(dtf_t64_tiles(M, N)) == dtf_t64_tiles(M, N)) {
+    dtf_launch_t64ws<true>(A, Bt, C, M, N, K, lda, ldb, ldc, alpha, beta, out_f32, 1, 0L, stream);
+    DTF_LAUNCH_CHECK();
+    return DTF_OK;
+  }
   if (dtf_pp_grid(tm128 * tn128) == tm128 * tn128) {
     const size_t t_lds3 = 3 * T128_BUF_BYTES;
     { static DtfPerDeviceOnce once__; dtf_once_per_device(once__, [&] {
@@ -2618,6 +2879,10 @@ DTF_API int dtf_gemm_fp8_nt(const void* A, const void* Bt, void* C, int M, int N
 // 128 x 128), work items of at least eight K-tiles, about one per CU.
 DTF_API int dtf_gemm_fp8_splits(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0 || K % 128 || N % 4) return 1;
+  if (dtf_t64_tiles(M, N) <= 256) {
+    const int s = dtf_t64_splits(dtf_t64_tiles(M, N), K / 128);
+    if (s > 1 || K / 128 < 192) return s;
+  }
   const long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   if (tiles > 32) return 1;
   const long t128 = (long)((M + T128 - 1) / T128) * ((N + T128 - 1) / T128);
@@ -2653,6 +2918,11 @@ DTF_API int dtf_gemm_fp8_nt_splitk(const void* A, const void* Bt, void* C, float
     dtf_allow_lds(gemm_fp8_nt_t128ws_kernel<true>, t_lds3);
   }); }
   const long plane = (long)M * N;
+  const int items64 = dtf_t64_tiles(M, N) * ksplits;
+  if (dtf_pp_grid(items64) == items64)
+    dtf_launch_t64ws<true>(A, Bt, workspace, M, N, K, lda, ldb, (long)N, 1.0f, 0.0f, 1, ksplits,
+                           plane, stream);
+  else
   hipLaunchKernelGGL(gemm_fp8_nt_t128ws_kernel<true>, dim3(items), dim3(2 * T128_THREADS), t_lds3,
                      stream, (const char*)A, (const char*)Bt, (void*)workspace, M, N, K, lda, ldb,
                      (long)N, tm128, tn128, 1.0f, 0.0f, ksplits, plane);

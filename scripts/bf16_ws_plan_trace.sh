@@ -8,7 +8,7 @@ import csv, glob, sys
 shapes = sys.argv[1].split(",")
 f = glob.glob("gpurun_out/prof/wsplan/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-names = ["unsplit", "s2", "s4", "s8", "s16", "default", "torch"]
+names = ["unsplit", "t64", "s2", "s4", "s8", "s16", "default", "torch"]
 total, count, i, line, started = 0.0, 0, 0, {}, False
 for r in rows:
     n = r["Kernel_Name"]; d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
@@ -17,10 +17,10 @@ for r in rows:
             started = True          # the marker in front of a shape's first case
         else:
             if count:
-                line[names[i % 7]] = round(total / 20, 2)
+                line[names[i % 8]] = round(total / 20, 2)
             i += 1
-            if i % 7 == 0:
-                print(shapes[i // 7 - 1], line); line = {}; started = False
+            if i % 8 == 0:
+                print(shapes[i // 8 - 1], line); line = {}; started = False
         total, count = 0.0, 0
     elif started and ("gemm_bf16" in n or "Cijk" in n or "gemm_nt" in n or "planes_reduce" in n):
         total += d; count += 1

@@ -73,7 +73,7 @@ def test_gemm_f32_bias_activation(hip, act):
     assert (out.double() - ref).abs().max().item() < 2e-5
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 9, 10, 11])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 12])
 @pytest.mark.parametrize("m,n,k", [(256, 256, 64), (512, 768, 256), (1024, 1024, 1024),
                                    (300, 520, 128), (2048, 256, 4096), (256, 512, 192),
                                    (1, 1, 64), (257, 255, 320)])
@@ -89,7 +89,7 @@ def test_gemm_bf16_nt_fast(hip, m, n, k, out_dtype, variant):
     assert err < tol, (err, tol)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 9, 10, 11])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 12])
 @pytest.mark.parametrize("m,n,k", [(512, 768, 256), (768, 512, 1344), (4096, 4096, 2048)])
 def test_gemm_bf16_nt_exact_integers(hip, variant, m, n, k):
     """Exact small-integer data: any fragment-layout, staging or pipeline-hazard bug shows as
@@ -711,7 +711,7 @@ def test_gemm_f32_writes_only_its_output(hip, m, n, k):
     assert bool((big[:3] == 12345.0).all()) and bool((big[3 + m:] == 12345.0).all())
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 9, 10, 11])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 12])
 @pytest.mark.parametrize("m,n,k", [(300, 520, 128), (257, 255, 320), (512, 768, 256), (1, 1, 64)])
 @pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
 def test_gemm_bf16_writes_only_its_output(hip, m, n, k, out_dtype, variant):
@@ -770,10 +770,13 @@ def test_gemm_fp8_on_128x128_tiles_with_request_waves(hip, m, n, k, out_dtype):
 
 
 @pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
-@pytest.mark.parametrize("m,n,k,splits", [(512, 512, 4096, None), (256, 256, 8192, None),
-                                          (300, 260, 2048, 4), (1024, 1024, 8192, None)])
+@pytest.mark.parametrize("m,n,k,splits", [(512, 512, 8192, None), (512, 512, 4096, 4),
+                                          (256, 256, 8192, None),
+                                          (300, 260, 2048, 4), (512, 1024, 8192, None),
+                                          (1024, 1024, 32768, None), (1024, 1024, 8192, 4)])
 def test_gemm_fp8_split_k(hip, m, n, k, splits, out_dtype):
-    """Few output tiles + long K in fp8: (split, tile) work items on the 128 x 128-tile kernel go
+    """Few output tiles + long K in fp8: (split, tile) work items on the 64 x 64-tile kernel (a CU
+    for every item) or the 128 x 128-tile one (1024^2 outputs with a very long K) go
     into fp32 planes and a second kernel sums them in split order; exact on integer data, equal
     to the unsplit product bit for bit, alpha and beta applied once in the reduction."""
     g = torch.Generator().manual_seed(m + n + k)
@@ -960,10 +963,12 @@ def test_gemm_bf16_k_not_multiple_of_tile(hip, m, n, k, out_dtype):
 
 @pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("m,n,k,splits", [(512, 768, 4096, None), (300, 260, 2048, 4),
-                                          (1024, 2048, 4096, None), (256, 256, 1024, 2)])
+                                          (1024, 2048, 4096, None), (256, 256, 1024, 2),
+                                          (1024, 1024, 16384, None), (1024, 1024, 4096, 4)])
 def test_gemm_bf16_split_k(hip, m, n, k, splits, out_dtype):
-    """Few output tiles + long K: (split, tile) work items -- on 128 x 128 tiles for grids of at
-    most 32 large tiles, on the ping-pong kernel otherwise -- go into fp32 planes and a second
+    """Few output tiles + long K: (split, tile) work items -- on 64 x 64 tiles when each has a CU,
+    on 128 x 128 tiles for other grids of at most 32 large tiles, on the ping-pong kernel
+    otherwise -- go into fp32 planes and a second
     kernel sums them in split order. Small-integer data makes every
     partial sum exact, so the result must equal the unsplit product bit for bit; alpha and
     beta are applied once, in the reduction."""

@@ -2057,6 +2057,227 @@ __global__ __launch_bounds__(512) void gemm_nt_t64ws_kernel(
   }
 }
 
+// ---- 128x256 tiles with request-issuing waves: grids of at most one such tile per CU ---------
+// For grids too large for a CU per 128x128 tile: the same structure with 64x128 outputs per
+// multiplying wave -- 48 KiB of requests per K-tile for twice the flops of the 128x128 tile (0.75
+// of its bytes per flop), twelve requests per K-tile and request wave, three buffers of 48 KiB.
+constexpr int TW_M = 128, TW_N = 256;
+constexpr int TW_A_BYTES = TW_M * BK * 2;          // 16 KiB
+constexpr int TW_B_BYTES = TW_N * BK * 2;          // 32 KiB
+constexpr int TW_BUF_BYTES = TW_A_BYTES + TW_B_BYTES;
+
+template <bool OUT_F32, bool FP8>
+__global__ __launch_bounds__(512) void gemm_nt_t128x256ws_kernel(
+    const char* __restrict__ A, const char* __restrict__ Bt, void* __restrict__ C, int M, int N,
+    int K, long lda, long ldb, long ldc, int tiles_m, int tiles_n, float alpha, float beta) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 3 x (A tile | B tile)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = wave8 & 3;
+  const bool producer = wave8 >= 4;
+  const int wr = wave >> 1, wc = wave & 1;
+  constexpr int ES = FP8 ? 1 : 2;
+
+  const int ntiles = tiles_m * tiles_n;
+  const int id = dtf_xcd_remap(blockIdx.x, ntiles);
+  constexpr int GROUP = 8;
+  const int per_group = GROUP * tiles_n;
+  const int g = id / per_group;
+  const int first_m = g * GROUP;
+  const int gsize = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
+  const int tm = first_m + (id % per_group) % gsize;
+  const int tn = (id % per_group) / gsize;
+  const int m0 = tm * TW_M, n0 = tn * TW_N;
+  const int nkt = K / (FP8 ? 2 * BK : BK);
+
+  if (producer) {
+    // 16 pieces of 8 rows of the A tile and 32 of the B tile: four and eight per wave
+    unsigned voff_a[4], voff_b[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int piece_b = wave * 8 + j;
+      const int trow_b = piece_b * 8 + (lane >> 3);
+      int rb = n0 + trow_b;
+      rb = rb < N - 1 ? rb : N - 1;
+      voff_b[j] = (unsigned)(rb - n0) * (unsigned)(ldb * ES) +
+                  16u * ((lane & 7) ^ ((trow_b >> 1) & 7));
+      if (j < 4) {
+        const int piece_a = wave * 4 + j;
+        const int trow_a = piece_a * 8 + (lane >> 3);
+        int ra = m0 + trow_a;
+        ra = ra < M - 1 ? ra : M - 1;
+        voff_a[j] = (unsigned)(ra - m0) * (unsigned)(lda * ES) +
+                    16u * ((lane & 7) ^ ((trow_a >> 1) & 7));
+      }
+    }
+    const __amdgpu_buffer_rsrc_t a_rsrc = tile_rsrc(A + (long)m0 * lda * ES);
+    const __amdgpu_buffer_rsrc_t b_rsrc = tile_rsrc(Bt + (long)n0 * ldb * ES);
+    auto stage = [&](int kt, char* buf) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            b_rsrc, (lds_void*)(buf + TW_A_BYTES + (wave * 8 + j) * 1024), 16, voff_b[j],
+            kt * 128, 0, 0);
+        if (j < 4)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(
+              a_rsrc, (lds_void*)(buf + (wave * 4 + j) * 1024), 16, voff_a[j], kt * 128, 0, 0);
+      }
+    };
+    stage(0, smem);
+    if (nkt > 1) stage(1, smem + TW_BUF_BYTES);
+    unsigned nxt2 = 2 * TW_BUF_BYTES;
+    for (int kt = 0; kt < nkt; ++kt) {
+      // own pieces of tile kt have landed (the newest tile's twelve requests stay in flight);
+      // behind the barrier the multiplying waves are done with the buffer of tile kt - 1
+      if (kt + 1 < nkt)
+        asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      if (kt + 2 < nkt) stage(kt + 2, smem + nxt2);
+      nxt2 = nxt2 == 2 * TW_BUF_BYTES ? 0 : nxt2 + TW_BUF_BYTES;
+    }
+    return;
+  }
+
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int frow = lane & 15, fq = lane >> 4;
+  const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>((lds_void*)smem);
+  unsigned a_rd[2], b_rd[2];
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+    a_rd[s2] = lds0 + chunk_off(wr * 64 + frow, 4 * s2 + fq);
+    b_rd[s2] = lds0 + TW_A_BYTES + chunk_off(wc * 128 + frow, 4 * s2 + fq);
+  }
+#define DTF_TW_RD(DST, ADDR, OFF) \
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
+#define DTF_TW_WAIT(N, S2, I)                                                                \
+  asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                   \
+               : "+v"(bf[S2][0]), "+v"(bf[S2][1]), "+v"(bf[S2][2]), "+v"(bf[S2][3]),         \
+                 "+v"(bf[S2][4]), "+v"(bf[S2][5]), "+v"(bf[S2][6]), "+v"(bf[S2][7]),         \
+                 "+v"(af[S2][I]))
+  unsigned cur = 0;
+  for (int kt = 0; kt < nkt; ++kt) {
+    asm volatile("s_barrier" ::: "memory");
+    bf16x8 af[2][4], bf[2][8];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const unsigned ba = b_rd[s2] + cur, aa = a_rd[s2] + cur;
+      DTF_TW_RD(bf[s2][0], ba, 0);
+      DTF_TW_RD(bf[s2][1], ba, 2048);
+      DTF_TW_RD(bf[s2][2], ba, 4096);
+      DTF_TW_RD(bf[s2][3], ba, 6144);
+      DTF_TW_RD(bf[s2][4], ba, 8192);
+      DTF_TW_RD(bf[s2][5], ba, 10240);
+      DTF_TW_RD(bf[s2][6], ba, 12288);
+      DTF_TW_RD(bf[s2][7], ba, 14336);
+      DTF_TW_RD(af[s2][0], aa, 0);
+      DTF_TW_RD(af[s2][1], aa, 2048);
+      DTF_TW_RD(af[s2][2], aa, 4096);
+      DTF_TW_RD(af[s2][3], aa, 6144);
+    }
+    // 24 reads, returned in order: a row of MFMAs waits for the read of its A fragment
+    if constexpr (FP8) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (i == 0) DTF_TW_WAIT(3, 1, 0);
+        if (i == 1) DTF_TW_WAIT(2, 1, 1);
+        if (i == 2) DTF_TW_WAIT(1, 1, 2);
+        if (i == 3) DTF_TW_WAIT(0, 1, 3);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
+              __builtin_shufflevector((i32x4)bf[0][j], (i32x4)bf[1][j], 0, 1, 2, 3, 4, 5, 6, 7),
+              __builtin_shufflevector((i32x4)af[0][i], (i32x4)af[1][i], 0, 1, 2, 3, 4, 5, 6, 7),
+              acc[i][j], 0, 0, 0, 0x7f7f7f7fu, 0, 0x7f7f7f7fu);
+      }
+    } else {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (s2 == 0 && i == 0) DTF_TW_WAIT(15, 0, 0);
+          if (s2 == 0 && i == 1) DTF_TW_WAIT(14, 0, 1);
+          if (s2 == 0 && i == 2) DTF_TW_WAIT(13, 0, 2);
+          if (s2 == 0 && i == 3) DTF_TW_WAIT(12, 0, 3);
+          if (s2 == 1 && i == 0) DTF_TW_WAIT(3, 1, 0);
+          if (s2 == 1 && i == 1) DTF_TW_WAIT(2, 1, 1);
+          if (s2 == 1 && i == 2) DTF_TW_WAIT(1, 1, 2);
+          if (s2 == 1 && i == 3) DTF_TW_WAIT(0, 1, 3);
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            acc[i][j] =
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[s2][j], af[s2][i], acc[i][j], 0, 0, 0);
+        }
+    }
+    cur = cur == 2 * TW_BUF_BYTES ? 0 : cur + TW_BUF_BYTES;
+  }
+#undef DTF_TW_RD
+#undef DTF_TW_WAIT
+
+  // lane holds C[m = frow][n = 4*fq + r], r = 0..3, of each 16x16 tile (interior tile, bf16 out:
+  // the short epilogue of the kernels above)
+  if (!OUT_F32 && beta == 0.f && (ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 &&
+      m0 + TW_M <= M && n0 + TW_N <= N) {
+    const int colx = (fq & 1) ? 16 + 4 * (fq - 1) : 4 * fq;
+    char* crow = reinterpret_cast<char*>(C) +
+                 ((long)(m0 + wr * 64 + frow) * ldc + n0 + wc * 128 + colx) * 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int jp = 0; jp < 4; ++jp) {
+        const f32x4 v0 = acc[i][2 * jp] * alpha, v1 = acc[i][2 * jp + 1] * alpha;
+        const unsigned p0a = dtf_f32x2_to_bf16x2(v0[0], v0[1]);
+        const unsigned p0b = dtf_f32x2_to_bf16x2(v0[2], v0[3]);
+        const unsigned p1a = dtf_f32x2_to_bf16x2(v1[0], v1[1]);
+        const unsigned p1b = dtf_f32x2_to_bf16x2(v1[2], v1[3]);
+        const auto sa = __builtin_amdgcn_permlane16_swap(p0a, p1a, false, false);
+        const auto sb = __builtin_amdgcn_permlane16_swap(p0b, p1b, false, false);
+        u32x4 o = {sa[0], sb[0], sa[1], sb[1]};
+        *reinterpret_cast<u32x4*>(crow + jp * 64) = o;
+      }
+      crow += ldc * 32;
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = m0 + wr * 64 + i * 16 + frow;
+    if (row >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int col = n0 + wc * 128 + j * 16 + 4 * fq;
+      if (col >= N) continue;
+      f32x4 v = acc[i][j] * alpha;
+      if (OUT_F32) {
+        float* dst = reinterpret_cast<float*>(C) + (long)row * ldc + col;
+        if (col + 3 < N) {
+          if (beta != 0.f) v += *reinterpret_cast<const f32x4*>(dst) * beta;
+          *reinterpret_cast<f32x4*>(dst) = v;
+        } else {
+          for (int r = 0; r < 4 && col + r < N; ++r)
+            dst[r] = beta != 0.f ? v[r] + beta * dst[r] : v[r];
+        }
+      } else {
+        unsigned short* dst = reinterpret_cast<unsigned short*>(C) + (long)row * ldc + col;
+        if (beta != 0.f)
+          for (int r = 0; r < 4 && col + r < N; ++r) v[r] += beta * dtf_bf16_to_f32(dst[r]);
+        if (col + 3 < N) {
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (short)dtf_f32_to_bf16(v[r]);
+          *reinterpret_cast<bf16x4*>(dst) = o;
+        } else {
+          for (int r = 0; r < 4 && col + r < N; ++r) dst[r] = dtf_f32_to_bf16(v[r]);
+        }
+      }
+    }
+  }
+}
+
 template <bool OUT_F32>
 __global__ __launch_bounds__(2 * T128_THREADS) void gemm_fp8_nt_t128ws_kernel(
     const char* __restrict__ A, const char* __restrict__ Bt, void* __restrict__ C, int M, int N,
@@ -2086,6 +2307,9 @@ __global__ __launch_bounds__(2 * T128_THREADS) void gemm_fp8_nt_t128ws_kernel(
 // 128x128 tiles. Measured (128x128 against 256x256 tiles): 2048^3 (64 tiles) 617 vs 395 TF,
 // 2048x4096x4096 (128 tiles) 1020 vs 853 TF; 3072^3 (144 tiles) 707 vs 870 TF, 4096^3 (256
 // tiles) 1035 vs 1388 TF.
+#ifndef DTF_TW_MAX_TILES
+#define DTF_TW_MAX_TILES 208
+#endif
 #ifndef DTF_T128_BELOW_TILES
 #define DTF_T128_BELOW_TILES 129
 #endif
@@ -2170,6 +2394,27 @@ static void dtf_launch_t64ws(const void* A, const void* Bt, void* C, int M, int 
 
 // number of 64x64 tiles of an M x N result
 static int dtf_t64_tiles(int M, int N) { return ((M + T64 - 1) / T64) * ((N + T64 - 1) / T64); }
+
+// launch of the 128x256-tile kernel (operand contract checked by the caller)
+template <bool FP8>
+static void dtf_launch_t128x256ws(const void* A, const void* Bt, void* C, int M, int N, int K,
+                                  long lda, long ldb, long ldc, float alpha, float beta,
+                                  int out_f32, hipStream_t stream) {
+  const size_t lds3 = 3 * TW_BUF_BYTES;
+  { static DtfPerDeviceOnce once__; dtf_once_per_device(once__, [&] {
+    dtf_allow_lds(gemm_nt_t128x256ws_kernel<true, FP8>, lds3);
+    dtf_allow_lds(gemm_nt_t128x256ws_kernel<false, FP8>, lds3);
+  }); }
+  const int tm = (M + TW_M - 1) / TW_M, tn = (N + TW_N - 1) / TW_N;
+  if (out_f32)
+    hipLaunchKernelGGL((gemm_nt_t128x256ws_kernel<true, FP8>), dim3(tm * tn), dim3(512), lds3,
+                       stream, (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tm, tn,
+                       alpha, beta);
+  else
+    hipLaunchKernelGGL((gemm_nt_t128x256ws_kernel<false, FP8>), dim3(tm * tn), dim3(512), lds3,
+                       stream, (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tm, tn,
+                       alpha, beta);
+}
 
 DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int N, int K, long lda,
                              long ldb, long ldc, float alpha, float beta, int out_f32,
@@ -2430,6 +2675,20 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
       hipLaunchKernelGGL((gemm_nt_pp_kernel<false, 0, false, true, false, 3>), grid192, block, lds,
                          stream, (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc,
                          tm192, tiles_n, alpha, beta, 1, 0L, nullptr, nullptr);
+    DTF_LAUNCH_CHECK();
+    return DTF_OK;
+  }
+  // 128x256 tiles with request-issuing waves (variant 13; by default for grids of more than one
+  // 128x128 tile per CU whose 128x256 tiles leave a fifth of the CUs idle or more: with every CU
+  // busy the product is bound by what the L2s deliver to all of them and the eight-wave tilings
+  // are as fast or faster -- 2048 x 4096 x 4096 1010 against 1177 TFLOP/s -- with CUs to spare it
+  // is not: 2560^3 941 against 791, torch.matmul 877; `scripts/bf16_tw_trace.sh`)
+  const int tw_tiles = ((M + TW_M - 1) / TW_M) * ((N + TW_N - 1) / TW_N);
+  if ((variant & 15) == 13 ||
+      (variant == 0 && tw_tiles <= DTF_TW_MAX_TILES &&
+       dtf_pp_grid(((M + T128 - 1) / T128) * ((N + T128 - 1) / T128)) !=
+           ((M + T128 - 1) / T128) * ((N + T128 - 1) / T128))) {
+    dtf_launch_t128x256ws<false>(A, Bt, C, M, N, K, lda, ldb, ldc, alpha, beta, out_f32, stream);
     DTF_LAUNCH_CHECK();
     return DTF_OK;
   }
@@ -2810,6 +3069,18 @@ DTF_API int dtf_gemm_fp8_nt(const void* A, const void* Bt, void* C, int M, int N
       hipLaunchKernelGGL(gemm_fp8_nt_t128ws_kernel<false>, dim3(tm128 * tn128),
                          dim3(2 * T128_THREADS), t_lds3, stream, (const char*)A, (const char*)Bt,
                          C, M, N, K, lda, ldb, ldc, tm128, tn128, alpha, beta, 1, 0L);
+    DTF_LAUNCH_CHECK();
+    return DTF_OK;
+  }
+  // 128x256 tiles with request-issuing waves, by the rule of the bf16 launch
+  // (2560^3 1550 against 1354 TFLOP/s on the eight-wave tilings, torch._scaled_mm 1423;
+  // 2560 x 2560 x 8192 2080 / 1911 / 1887; 1280 x 4096 x 4096 1637 / 1419 / 1539)
+  bool tw_ok = ((M + TW_M - 1) / TW_M) * ((N + TW_N - 1) / TW_N) <= DTF_TW_MAX_TILES;
+#ifdef DTF_GEMM_EXPERIMENTS
+  if (getenv("DTF_FP8_NO_TW")) tw_ok = false;
+#endif
+  if (tw_ok) {
+    dtf_launch_t128x256ws<true>(A, Bt, C, M, N, K, lda, ldb, ldc, alpha, beta, out_f32, stream);
     DTF_LAUNCH_CHECK();
     return DTF_OK;
   }

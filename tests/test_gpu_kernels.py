@@ -73,7 +73,7 @@ def test_gemm_f32_bias_activation(hip, act):
     assert (out.double() - ref).abs().max().item() < 2e-5
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 12])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 12, 13])
 @pytest.mark.parametrize("m,n,k", [(256, 256, 64), (512, 768, 256), (1024, 1024, 1024),
                                    (300, 520, 128), (2048, 256, 4096), (256, 512, 192),
                                    (1, 1, 64), (257, 255, 320)])
@@ -89,7 +89,7 @@ def test_gemm_bf16_nt_fast(hip, m, n, k, out_dtype, variant):
     assert err < tol, (err, tol)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 12])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 12, 13])
 @pytest.mark.parametrize("m,n,k", [(512, 768, 256), (768, 512, 1344), (4096, 4096, 2048)])
 def test_gemm_bf16_nt_exact_integers(hip, variant, m, n, k):
     """Exact small-integer data: any fragment-layout, staging or pipeline-hazard bug shows as
@@ -711,7 +711,7 @@ def test_gemm_f32_writes_only_its_output(hip, m, n, k):
     assert bool((big[:3] == 12345.0).all()) and bool((big[3 + m:] == 12345.0).all())
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 12])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 12, 13])
 @pytest.mark.parametrize("m,n,k", [(300, 520, 128), (257, 255, 320), (512, 768, 256), (1, 1, 64)])
 @pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
 def test_gemm_bf16_writes_only_its_output(hip, m, n, k, out_dtype, variant):
@@ -729,9 +729,10 @@ def test_gemm_bf16_writes_only_its_output(hip, m, n, k, out_dtype, variant):
 
 @pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("m,n,k", [(3072, 3072, 256), (2048, 4096, 256), (3000, 3072, 384),
-                                   (2945, 2816, 128)])
+                                   (2945, 2816, 128), (2560, 2560, 384), (2300, 2820, 256)])
 def test_gemm_fp8_on_192_and_128_row_tiles(hip, m, n, k, out_dtype):
-    """Shapes for which the fp8 launch takes 192- or 128-row block tiles (the rule of the bf16
+    """Shapes for which the fp8 launch takes 192- or 128-row block tiles or the 128 x 256-tile
+    kernel with request-issuing waves (the rules of the bf16
     launch), a ragged last tile row included: exact on integer data over repeated launches,
     alpha / beta applied."""
     g = torch.Generator().manual_seed(m + k)

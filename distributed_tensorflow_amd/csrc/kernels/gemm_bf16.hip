@@ -3072,10 +3072,14 @@ DTF_API int dtf_gemm_fp8_nt(const void* A, const void* Bt, void* C, int M, int N
     DTF_LAUNCH_CHECK();
     return DTF_OK;
   }
-  // 128x256 tiles with request-issuing waves, by the rule of the bf16 launch
+  // 128x256 tiles with request-issuing waves
   // (2560^3 1550 against 1354 TFLOP/s on the eight-wave tilings, torch._scaled_mm 1423;
   // 2560 x 2560 x 8192 2080 / 1911 / 1887; 1280 x 4096 x 4096 1637 / 1419 / 1539)
-  bool tw_ok = ((M + TW_M - 1) / TW_M) * ((N + TW_N - 1) / TW_N) <= DTF_TW_MAX_TILES;
+  // In fp8 it is ahead with every CU busy as well (2048 x 4096 x 4096 2136 against 1926,
+  // torch._scaled_mm 1628; 2048 x 4096 x 8192 2543 / 2268 / 2048): any grid of at most one such
+  // tile per CU.
+  const int tw_tiles = ((M + TW_M - 1) / TW_M) * ((N + TW_N - 1) / TW_N);
+  bool tw_ok = dtf_pp_grid(tw_tiles) == tw_tiles;
 #ifdef DTF_GEMM_EXPERIMENTS
   if (getenv("DTF_FP8_NO_TW")) tw_ok = false;
 #endif

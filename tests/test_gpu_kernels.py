@@ -1333,6 +1333,29 @@ def test_gemm_bf16_unsplit_rows_have_shape_independent_bits(hip, out_dtype):
     small = hip.gemm_bf16_nt(a[:512], bt, out_dtype, splits=1)           # 32 tiles
     assert torch.equal(full[1024:2048], mid)
     assert torch.equal(full[:512], small)
+    # ... and the kernels with request-issuing waves: 64 x 64 tiles (a CU per tile), 128 x 128
+    # tiles, 128 x 256 tiles (2560^2 outputs: 200 of them), explicitly and as the plan picks them
+    assert torch.equal(full[:256, :1024], hip.gemm_bf16_nt(a[:256], bt[:1024], out_dtype, splits=1))
+    assert torch.equal(full[:2560, :2560],
+                       hip.gemm_bf16_nt(a[:2560], bt[:2560], out_dtype, splits=1))
+    for variant in (11, 12, 13):
+        assert torch.equal(full[:1024, :1024], hip.gemm_bf16_nt(a[:1024], bt[:1024], out_dtype,
+                                                                variant=variant))
+
+
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
+def test_gemm_fp8_unsplit_rows_have_shape_independent_bits(hip, out_dtype):
+    """The same for fp8: the 256 x 256 kernel (4096^2 outputs), the 128 x 256-tile kernel (2048 x
+    4096 and 2560^2), the 128 x 128-tile one (1536 x 1024) and the 64 x 64-tile one (512 x 1024)
+    give a row of the product the same bits."""
+    g = torch.Generator().manual_seed(6)
+    a = (torch.rand(4096, 2048, generator=g) * 2 - 1).to(FP8).cuda()
+    bt = (torch.rand(4096, 2048, generator=g) * 2 - 1).to(FP8).cuda()
+    full = hip.gemm_fp8_nt(a, bt, out_dtype, splits=1)
+    assert torch.equal(full[2048:], hip.gemm_fp8_nt(a[2048:], bt, out_dtype, splits=1))
+    assert torch.equal(full[:2560, :2560], hip.gemm_fp8_nt(a[:2560], bt[:2560], out_dtype, splits=1))
+    assert torch.equal(full[:1536, :1024], hip.gemm_fp8_nt(a[:1536], bt[:1024], out_dtype, splits=1))
+    assert torch.equal(full[:512, :1024], hip.gemm_fp8_nt(a[:512], bt[:1024], out_dtype, splits=1))
 
 
 @pytest.mark.parametrize("dtype", [torch.int32, torch.int64])

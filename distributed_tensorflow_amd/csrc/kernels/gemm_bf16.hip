@@ -2682,10 +2682,13 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
   // 128x128 tile per CU whose 128x256 tiles leave a fifth of the CUs idle or more: with every CU
   // busy the product is bound by what the L2s deliver to all of them and the eight-wave tilings
   // are as fast or faster -- 2048 x 4096 x 4096 1010 against 1177 TFLOP/s -- with CUs to spare it
-  // is not: 2560^3 941 against 791, torch.matmul 877; `scripts/bf16_tw_trace.sh`)
+  // is not: 2560^3 941 against 791, torch.matmul 877; up to K = 2048 it is ahead with every CU
+  // busy too -- 4096 x 2048 x 2048 1085 against 1021, 3584 x 2048 x 2048 979 / 907, 2560 x 3072 x
+  // 2048 1050 / 994; `scripts/bf16_tw_trace.sh`)
   const int tw_tiles = ((M + TW_M - 1) / TW_M) * ((N + TW_N - 1) / TW_N);
   if ((variant & 15) == 13 ||
-      (variant == 0 && tw_tiles <= DTF_TW_MAX_TILES &&
+      (variant == 0 &&
+       (tw_tiles <= DTF_TW_MAX_TILES || (dtf_pp_grid(tw_tiles) == tw_tiles && K <= 2048)) &&
        dtf_pp_grid(((M + T128 - 1) / T128) * ((N + T128 - 1) / T128)) !=
            ((M + T128 - 1) / T128) * ((N + T128 - 1) / T128))) {
     dtf_launch_t128x256ws<false>(A, Bt, C, M, N, K, lda, ldb, ldc, alpha, beta, out_f32, stream);

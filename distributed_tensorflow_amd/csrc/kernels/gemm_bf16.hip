@@ -1580,6 +1580,73 @@ constexpr int T128_THREADS = 256;
 constexpr int T128_TILE_BYTES = T128 * BK * 2;     // 16 KiB per operand tile
 constexpr int T128_BUF_BYTES = 2 * T128_TILE_BYTES;
 
+// Epilogue of the 128x128-, 64x64- and 128x256-tile kernels: a wave's NI x NJ grid of 16x16
+// accumulator tiles (swapped-operand layout: lane holds C[m = frow][n = 4*fq + r], r = 0..3) to
+// C at (row0, col0). Interior tile with a bf16 result and no accumulate: the short epilogue of
+// the ping-pong kernel -- no per-lane bounds, hardware converts, pairs of 16x16 tiles traded
+// between the odd and even 16-lane rows so that a lane stores 16 contiguous bytes.
+template <bool OUT_F32, int NI, int NJ>
+__device__ __forceinline__ void dtf_store_wave_tile(const f32x4 (&acc)[NI][NJ], void* C, long ldc,
+                                                    int M, int N, int row0, int col0, int lane,
+                                                    float alpha, float beta, bool interior) {
+  const int frow = lane & 15, fq = lane >> 4;
+  if (!OUT_F32 && beta == 0.f && (ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 &&
+      interior) {
+    const int colx = (fq & 1) ? 16 + 4 * (fq - 1) : 4 * fq;
+    char* crow = reinterpret_cast<char*>(C) + ((long)(row0 + frow) * ldc + col0 + colx) * 2;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+#pragma unroll
+      for (int jp = 0; jp < NJ / 2; ++jp) {
+        const f32x4 v0 = acc[i][2 * jp] * alpha, v1 = acc[i][2 * jp + 1] * alpha;
+        const unsigned p0a = dtf_f32x2_to_bf16x2(v0[0], v0[1]);
+        const unsigned p0b = dtf_f32x2_to_bf16x2(v0[2], v0[3]);
+        const unsigned p1a = dtf_f32x2_to_bf16x2(v1[0], v1[1]);
+        const unsigned p1b = dtf_f32x2_to_bf16x2(v1[2], v1[3]);
+        const auto sa = __builtin_amdgcn_permlane16_swap(p0a, p1a, false, false);
+        const auto sb = __builtin_amdgcn_permlane16_swap(p0b, p1b, false, false);
+        u32x4 o = {sa[0], sb[0], sa[1], sb[1]};
+        *reinterpret_cast<u32x4*>(crow + jp * 64) = o;
+      }
+      crow += ldc * 32;
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int row = row0 + i * 16 + frow;
+    if (row >= M) continue;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int col = col0 + j * 16 + 4 * fq;
+      if (col >= N) continue;
+      f32x4 v = acc[i][j] * alpha;
+      if (OUT_F32) {
+        float* dst = reinterpret_cast<float*>(C) + (long)row * ldc + col;
+        if (col + 3 < N) {
+          if (beta != 0.f) v += *reinterpret_cast<const f32x4*>(dst) * beta;
+          *reinterpret_cast<f32x4*>(dst) = v;
+        } else {
+          for (int r = 0; r < 4 && col + r < N; ++r)
+            dst[r] = beta != 0.f ? v[r] + beta * dst[r] : v[r];
+        }
+      } else {
+        unsigned short* dst = reinterpret_cast<unsigned short*>(C) + (long)row * ldc + col;
+        if (beta != 0.f)
+          for (int r = 0; r < 4 && col + r < N; ++r) v[r] += beta * dtf_bf16_to_f32(dst[r]);
+        if (col + 3 < N) {
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (short)dtf_f32_to_bf16(v[r]);
+          *reinterpret_cast<bf16x4*>(dst) = o;
+        } else {
+          for (int r = 0; r < 4 && col + r < N; ++r) dst[r] = dtf_f32_to_bf16(v[r]);
+        }
+      }
+    }
+  }
+}
+
 template <bool OUT_F32, int WS, bool FP8 = false>
 __device__ __forceinline__ void gemm_bf16_nt_t128_body(
     const char* __restrict__ A, const char* __restrict__ Bt, void* __restrict__ C, int M, int N,
@@ -1775,66 +1842,8 @@ __device__ __forceinline__ void gemm_bf16_nt_t128_body(
     }
   }
 
-  // swapped-operand accumulator: lane holds C[m = frow][n = 4*fq + r], r = 0..3
-  // (interior tile, bf16 out: the short epilogue of the ping-pong kernel -- no per-lane bounds,
-  // hardware converts, pairs of 16x16 tiles traded between the odd and even 16-lane rows so
-  // that a lane stores 16 contiguous bytes)
-  if (!OUT_F32 && beta == 0.f && (ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 &&
-      m0 + T128 <= M && n0 + T128 <= N) {
-    const int colx = (fq & 1) ? 16 + 4 * (fq - 1) : 4 * fq;
-    char* crow = reinterpret_cast<char*>(C) +
-                 ((long)(m0 + wr * 64 + frow) * ldc + n0 + wc * 64 + colx) * 2;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-      for (int jp = 0; jp < 2; ++jp) {
-        const f32x4 v0 = acc[i][2 * jp] * alpha, v1 = acc[i][2 * jp + 1] * alpha;
-        const unsigned p0a = dtf_f32x2_to_bf16x2(v0[0], v0[1]);
-        const unsigned p0b = dtf_f32x2_to_bf16x2(v0[2], v0[3]);
-        const unsigned p1a = dtf_f32x2_to_bf16x2(v1[0], v1[1]);
-        const unsigned p1b = dtf_f32x2_to_bf16x2(v1[2], v1[3]);
-        const auto sa = __builtin_amdgcn_permlane16_swap(p0a, p1a, false, false);
-        const auto sb = __builtin_amdgcn_permlane16_swap(p0b, p1b, false, false);
-        u32x4 o = {sa[0], sb[0], sa[1], sb[1]};
-        *reinterpret_cast<u32x4*>(crow + jp * 64) = o;
-      }
-      crow += ldc * 32;
-    }
-    return;
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = m0 + wr * 64 + i * 16 + frow;
-    if (row >= M) continue;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int col = n0 + wc * 64 + j * 16 + 4 * fq;
-      if (col >= N) continue;
-      f32x4 v = acc[i][j] * alpha;
-      if (OUT_F32) {
-        float* dst = reinterpret_cast<float*>(C) + (long)row * ldc + col;
-        if (col + 3 < N) {
-          if (beta != 0.f) v += *reinterpret_cast<const f32x4*>(dst) * beta;
-          *reinterpret_cast<f32x4*>(dst) = v;
-        } else {
-          for (int r = 0; r < 4 && col + r < N; ++r)
-            dst[r] = beta != 0.f ? v[r] + beta * dst[r] : v[r];
-        }
-      } else {
-        unsigned short* dst = reinterpret_cast<unsigned short*>(C) + (long)row * ldc + col;
-        if (beta != 0.f)
-          for (int r = 0; r < 4 && col + r < N; ++r) v[r] += beta * dtf_bf16_to_f32(dst[r]);
-        if (col + 3 < N) {
-          bf16x4 o;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = (short)dtf_f32_to_bf16(v[r]);
-          *reinterpret_cast<bf16x4*>(dst) = o;
-        } else {
-          for (int r = 0; r < 4 && col + r < N; ++r) dst[r] = dtf_f32_to_bf16(v[r]);
-        }
-      }
-    }
-  }
+  dtf_store_wave_tile<OUT_F32, 4, 4>(acc, C, ldc, M, N, m0 + wr * 64, n0 + wc * 64, lane, alpha,
+                                     beta, m0 + T128 <= M && n0 + T128 <= N);
 }
 
 template <bool OUT_F32>
@@ -2000,61 +2009,8 @@ __global__ __launch_bounds__(512) void gemm_nt_t64ws_kernel(
 #undef DTF_T64_RD
 #undef DTF_T64_WAIT
 
-  // lane holds C[m = frow][n = 4*fq + r], r = 0..3, of each 16x16 tile (interior tile, bf16 out:
-  // the short epilogue of the kernels above)
-  if (!OUT_F32 && beta == 0.f && (ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 &&
-      m0 + T64 <= M && n0 + T64 <= N) {
-    const int colx = (fq & 1) ? 16 + 4 * (fq - 1) : 4 * fq;
-    char* crow = reinterpret_cast<char*>(C) +
-                 ((long)(m0 + wr * 32 + frow) * ldc + n0 + wc * 32 + colx) * 2;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const f32x4 v0 = acc[i][0] * alpha, v1 = acc[i][1] * alpha;
-      const unsigned p0a = dtf_f32x2_to_bf16x2(v0[0], v0[1]);
-      const unsigned p0b = dtf_f32x2_to_bf16x2(v0[2], v0[3]);
-      const unsigned p1a = dtf_f32x2_to_bf16x2(v1[0], v1[1]);
-      const unsigned p1b = dtf_f32x2_to_bf16x2(v1[2], v1[3]);
-      const auto sa = __builtin_amdgcn_permlane16_swap(p0a, p1a, false, false);
-      const auto sb = __builtin_amdgcn_permlane16_swap(p0b, p1b, false, false);
-      u32x4 o = {sa[0], sb[0], sa[1], sb[1]};
-      *reinterpret_cast<u32x4*>(crow) = o;
-      crow += ldc * 32;
-    }
-    return;
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = m0 + wr * 32 + i * 16 + frow;
-    if (row >= M) continue;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = n0 + wc * 32 + j * 16 + 4 * fq;
-      if (col >= N) continue;
-      f32x4 v = acc[i][j] * alpha;
-      if (OUT_F32) {
-        float* dst = reinterpret_cast<float*>(C) + (long)row * ldc + col;
-        if (col + 3 < N) {
-          if (beta != 0.f) v += *reinterpret_cast<const f32x4*>(dst) * beta;
-          *reinterpret_cast<f32x4*>(dst) = v;
-        } else {
-          for (int r = 0; r < 4 && col + r < N; ++r)
-            dst[r] = beta != 0.f ? v[r] + beta * dst[r] : v[r];
-        }
-      } else {
-        unsigned short* dst = reinterpret_cast<unsigned short*>(C) + (long)row * ldc + col;
-        if (beta != 0.f)
-          for (int r = 0; r < 4 && col + r < N; ++r) v[r] += beta * dtf_bf16_to_f32(dst[r]);
-        if (col + 3 < N) {
-          bf16x4 o;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = (short)dtf_f32_to_bf16(v[r]);
-          *reinterpret_cast<bf16x4*>(dst) = o;
-        } else {
-          for (int r = 0; r < 4 && col + r < N; ++r) dst[r] = dtf_f32_to_bf16(v[r]);
-        }
-      }
-    }
-  }
+  dtf_store_wave_tile<OUT_F32, 2, 2>(acc, C, ldc, M, N, m0 + wr * 32, n0 + wc * 32, lane, alpha,
+                                     beta, m0 + T64 <= M && n0 + T64 <= N);
 }
 
 // ---- 128x256 tiles with request-issuing waves: grids of at most one such tile per CU ---------
@@ -2218,64 +2174,8 @@ __global__ __launch_bounds__(512) void gemm_nt_t128x256ws_kernel(
 #undef DTF_TW_RD
 #undef DTF_TW_WAIT
 
-  // lane holds C[m = frow][n = 4*fq + r], r = 0..3, of each 16x16 tile (interior tile, bf16 out:
-  // the short epilogue of the kernels above)
-  if (!OUT_F32 && beta == 0.f && (ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 &&
-      m0 + TW_M <= M && n0 + TW_N <= N) {
-    const int colx = (fq & 1) ? 16 + 4 * (fq - 1) : 4 * fq;
-    char* crow = reinterpret_cast<char*>(C) +
-                 ((long)(m0 + wr * 64 + frow) * ldc + n0 + wc * 128 + colx) * 2;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-      for (int jp = 0; jp < 4; ++jp) {
-        const f32x4 v0 = acc[i][2 * jp] * alpha, v1 = acc[i][2 * jp + 1] * alpha;
-        const unsigned p0a = dtf_f32x2_to_bf16x2(v0[0], v0[1]);
-        const unsigned p0b = dtf_f32x2_to_bf16x2(v0[2], v0[3]);
-        const unsigned p1a = dtf_f32x2_to_bf16x2(v1[0], v1[1]);
-        const unsigned p1b = dtf_f32x2_to_bf16x2(v1[2], v1[3]);
-        const auto sa = __builtin_amdgcn_permlane16_swap(p0a, p1a, false, false);
-        const auto sb = __builtin_amdgcn_permlane16_swap(p0b, p1b, false, false);
-        u32x4 o = {sa[0], sb[0], sa[1], sb[1]};
-        *reinterpret_cast<u32x4*>(crow + jp * 64) = o;
-      }
-      crow += ldc * 32;
-    }
-    return;
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = m0 + wr * 64 + i * 16 + frow;
-    if (row >= M) continue;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int col = n0 + wc * 128 + j * 16 + 4 * fq;
-      if (col >= N) continue;
-      f32x4 v = acc[i][j] * alpha;
-      if (OUT_F32) {
-        float* dst = reinterpret_cast<float*>(C) + (long)row * ldc + col;
-        if (col + 3 < N) {
-          if (beta != 0.f) v += *reinterpret_cast<const f32x4*>(dst) * beta;
-          *reinterpret_cast<f32x4*>(dst) = v;
-        } else {
-          for (int r = 0; r < 4 && col + r < N; ++r)
-            dst[r] = beta != 0.f ? v[r] + beta * dst[r] : v[r];
-        }
-      } else {
-        unsigned short* dst = reinterpret_cast<unsigned short*>(C) + (long)row * ldc + col;
-        if (beta != 0.f)
-          for (int r = 0; r < 4 && col + r < N; ++r) v[r] += beta * dtf_bf16_to_f32(dst[r]);
-        if (col + 3 < N) {
-          bf16x4 o;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = (short)dtf_f32_to_bf16(v[r]);
-          *reinterpret_cast<bf16x4*>(dst) = o;
-        } else {
-          for (int r = 0; r < 4 && col + r < N; ++r) dst[r] = dtf_f32_to_bf16(v[r]);
-        }
-      }
-    }
-  }
+  dtf_store_wave_tile<OUT_F32, 4, 8>(acc, C, ldc, M, N, m0 + wr * 64, n0 + wc * 128, lane, alpha,
+                                     beta, m0 + TW_M <= M && n0 + TW_N <= N);
 }
 
 template <bool OUT_F32>

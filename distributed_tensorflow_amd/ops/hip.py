@@ -433,7 +433,11 @@ def gemm_bf16_nt(a: torch.Tensor, bt: torch.Tensor, out_dtype: torch.dtype = tor
     qualifies (operands with another K, an odd pitch or an offset start, and results with an
     odd pitch, get there through padded copies when the product is large enough to care) and
     the predicated generic kernel otherwise. ``splits``: K splits for grids with
-    few output tiles (default: the library's plan; 1 = never split)."""
+    few output tiles (default: the library's plan; 1 = never split). ``variant``: 0 = the
+    library's choice of kernel by grid (256/192/128-row ping-pong tiles, or the kernels with
+    request-issuing waves on 64x64, 128x128 or 128x256 tiles); another value forces one kernel
+    (4 ping-pong, 5 / 11 the two forms of the 128x128 tile, 12 64x64 tiles, 13 128x256 tiles, 3 /
+    7 / 8 / 10 the four-wave schedules: see ``csrc/kernels/gemm_bf16.hip``)."""
     a = _req(a, torch.bfloat16, "gemm_bf16_nt a")
     bt = _req(bt, torch.bfloat16, "gemm_bf16_nt bt")
     if a.dim() != 2 or bt.dim() != 2 or a.shape[1] != bt.shape[1]:

@@ -2207,6 +2207,7 @@ __global__ __launch_bounds__(2 * T128_THREADS) void gemm_fp8_nt_t128ws_kernel(
 // 128x128 tiles. Measured (128x128 against 256x256 tiles): 2048^3 (64 tiles) 617 vs 395 TF,
 // 2048x4096x4096 (128 tiles) 1020 vs 853 TF; 3072^3 (144 tiles) 707 vs 870 TF, 4096^3 (256
 // tiles) 1035 vs 1388 TF.
+// (tiles of 128x256 per 256 CUs up to which the bf16 launch takes the 128x256-tile kernel at any K)
 #ifndef DTF_TW_MAX_TILES
 #define DTF_TW_MAX_TILES 208
 #endif
@@ -2540,6 +2541,24 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
     return DTF_OK;
   }
 #endif
+  // 128x256 tiles with request-issuing waves (variant 13; by default for grids of more than one
+  // 128x128 tile per CU whose 128x256 tiles leave a fifth of the CUs idle or more: with every CU
+  // busy the product is bound by what the L2s deliver to all of them and the eight-wave tilings
+  // are as fast or faster -- 2048 x 4096 x 4096 1010 against 1177 TFLOP/s -- with CUs to spare it
+  // is not: 2560^3 941 against 791, torch.matmul 877; up to K = 2048 it is ahead with every CU
+  // busy too -- 4096 x 2048 x 2048 1085 against 1021, 3584 x 2048 x 2048 979 / 907, 2560 x 3072 x
+  // 2048 1050 / 994; `scripts/bf16_tw_trace.sh`)
+  const int tw_tiles = ((M + TW_M - 1) / TW_M) * ((N + TW_N - 1) / TW_N);
+  if ((variant & 15) == 13 ||
+      (variant == 0 &&
+       (tw_tiles * 256L <= (long)DTF_TW_MAX_TILES * dtf_pp_grid(1 << 20) ||
+        (dtf_pp_grid(tw_tiles) == tw_tiles && K <= 2048)) &&
+       dtf_pp_grid(((M + T128 - 1) / T128) * ((N + T128 - 1) / T128)) !=
+           ((M + T128 - 1) / T128) * ((N + T128 - 1) / T128))) {
+    dtf_launch_t128x256ws<false>(A, Bt, C, M, N, K, lda, ldb, ldc, alpha, beta, out_f32, stream);
+    DTF_LAUNCH_CHECK();
+    return DTF_OK;
+  }
   const int pp_rows = variant == 0 ? dtf_pp_rows(M, N) : 256;
   if ((variant & 15) == 9 || pp_rows == 128) {       // 128-row block tiles (MI = 2)
     { static DtfPerDeviceOnce once__; dtf_once_per_device(once__, [&] {
@@ -2575,23 +2594,6 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
       hipLaunchKernelGGL((gemm_nt_pp_kernel<false, 0, false, true, false, 3>), grid192, block, lds,
                          stream, (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc,
                          tm192, tiles_n, alpha, beta, 1, 0L, nullptr, nullptr);
-    DTF_LAUNCH_CHECK();
-    return DTF_OK;
-  }
-  // 128x256 tiles with request-issuing waves (variant 13; by default for grids of more than one
-  // 128x128 tile per CU whose 128x256 tiles leave a fifth of the CUs idle or more: with every CU
-  // busy the product is bound by what the L2s deliver to all of them and the eight-wave tilings
-  // are as fast or faster -- 2048 x 4096 x 4096 1010 against 1177 TFLOP/s -- with CUs to spare it
-  // is not: 2560^3 941 against 791, torch.matmul 877; up to K = 2048 it is ahead with every CU
-  // busy too -- 4096 x 2048 x 2048 1085 against 1021, 3584 x 2048 x 2048 979 / 907, 2560 x 3072 x
-  // 2048 1050 / 994; `scripts/bf16_tw_trace.sh`)
-  const int tw_tiles = ((M + TW_M - 1) / TW_M) * ((N + TW_N - 1) / TW_N);
-  if ((variant & 15) == 13 ||
-      (variant == 0 &&
-       (tw_tiles <= DTF_TW_MAX_TILES || (dtf_pp_grid(tw_tiles) == tw_tiles && K <= 2048)) &&
-       dtf_pp_grid(((M + T128 - 1) / T128) * ((N + T128 - 1) / T128)) !=
-           ((M + T128 - 1) / T128) * ((N + T128 - 1) / T128))) {
-    dtf_launch_t128x256ws<false>(A, Bt, C, M, N, K, lda, ldb, ldc, alpha, beta, out_f32, stream);
     DTF_LAUNCH_CHECK();
     return DTF_OK;
   }
@@ -2815,14 +2817,16 @@ static bool dtf_gemm_bf16_split_on_t128(int M, int N, int K, int ksplits) {
 // with a CU per work item: 1024 x 1024 x 4096 18.5 (22.4 split four ways on 128x128 tiles) / 18.2,
 // 1024 x 1024 x 8192 30.5 (32.4) / 29.5 (`profiles/gemm_bf16_ws_plan.txt`).
 static int dtf_t64_splits(int t64, int nkt) {
+  const int cus = dtf_pp_grid(1 << 20);
   int s = 1;
-  while (s < 16 && t64 * s * 2 <= 256 && nkt % (s * 2) == 0 && nkt / (s * 2) >= 8) s *= 2;
+  while (s < 16 && t64 * s * 2 <= cus && nkt % (s * 2) == 0 && nkt / (s * 2) >= 8) s *= 2;
   if (s > 1 && nkt * (s - 1) / s <= (t64 <= 64 ? 24 : 30)) s = 1;
   return s;
 }
 
 DTF_API int dtf_gemm_bf16_splits(int M, int N, int K) {
-  if (M > 0 && N > 0 && K > 0 && N % 4 == 0 && K % BK == 0 && dtf_t64_tiles(M, N) <= 256) {
+  if (M > 0 && N > 0 && K > 0 && N % 4 == 0 && K % BK == 0 &&
+      dtf_pp_grid(dtf_t64_tiles(M, N)) == dtf_t64_tiles(M, N)) {
     const int s = dtf_t64_splits(dtf_t64_tiles(M, N), K / BK);
     if (s > 1 || K / BK < 192) return s;     // (very long K: the rule of the 128x128 tiles below)
   }
@@ -3057,7 +3061,7 @@ DTF_API int dtf_gemm_fp8_nt(const void* A, const void* Bt, void* C, int M, int N
 // 128 x 128), work items of at least eight K-tiles, about one per CU.
 DTF_API int dtf_gemm_fp8_splits(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0 || K % 128 || N % 4) return 1;
-  if (dtf_t64_tiles(M, N) <= 256) {
+  if (dtf_pp_grid(dtf_t64_tiles(M, N)) == dtf_t64_tiles(M, N)) {
     const int s = dtf_t64_splits(dtf_t64_tiles(M, N), K / 128);
     if (s > 1 || K / 128 < 192) return s;
   }

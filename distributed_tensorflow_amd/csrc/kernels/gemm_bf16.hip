@@ -2559,7 +2559,11 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
     DTF_LAUNCH_CHECK();
     return DTF_OK;
   }
-  const int pp_rows = variant == 0 ? dtf_pp_rows(M, N) : 256;
+  // (a grid with a CU for every 128x128 tile goes to the kernels with request-issuing waves
+  // below, whatever the row-tile rule would make of a ragged N)
+  const int t128_all = ((M + T128 - 1) / T128) * ((N + T128 - 1) / T128);
+  const int pp_rows =
+      variant == 0 && dtf_pp_grid(t128_all) != t128_all ? dtf_pp_rows(M, N) : 256;
   if ((variant & 15) == 9 || pp_rows == 128) {       // 128-row block tiles (MI = 2)
     { static DtfPerDeviceOnce once__; dtf_once_per_device(once__, [&] {
       dtf_allow_lds(gemm_nt_pp_kernel<true, 0, false, true, false, 2>, lds);

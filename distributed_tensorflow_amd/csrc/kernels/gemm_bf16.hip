@@ -2267,6 +2267,12 @@ static int dtf_pp_rows(int M, int N) {
   return best;
 }
 
+// Which kernel the last bf16 / fp8 launch of this process took (the `variant` numbers: 4 the
+// 256x256 ping-pong kernel, 6 / 9 its 192- / 128-row tilings, 5 / 11 the two forms of the 128x128
+// tile, 12 64x64 tiles, 13 128x256 tiles; 0 = another path). For tests of the launch plan.
+static std::atomic<int> g_last_kernel{0};
+DTF_API int dtf_gemm_last_kernel() { return g_last_kernel.load(std::memory_order_relaxed); }
+
 template <typename KernelT>
 static void dtf_allow_lds(KernelT kernel, size_t lds) {
   hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -2277,6 +2283,7 @@ template <bool FP8>
 static void dtf_launch_t64ws(const void* A, const void* Bt, void* C, int M, int N, int K, long lda,
                              long ldb, long ldc, float alpha, float beta, int out_f32, int ksplits,
                              long plane, hipStream_t stream) {
+  g_last_kernel.store(12, std::memory_order_relaxed);
   const size_t lds3 = 3 * T64_BUF_BYTES;
   { static DtfPerDeviceOnce once__; dtf_once_per_device(once__, [&] {
     dtf_allow_lds(gemm_nt_t64ws_kernel<true, FP8>, lds3);
@@ -2301,6 +2308,7 @@ template <bool FP8>
 static void dtf_launch_t128x256ws(const void* A, const void* Bt, void* C, int M, int N, int K,
                                   long lda, long ldb, long ldc, float alpha, float beta,
                                   int out_f32, hipStream_t stream) {
+  g_last_kernel.store(13, std::memory_order_relaxed);
   const size_t lds3 = 3 * TW_BUF_BYTES;
   { static DtfPerDeviceOnce once__; dtf_once_per_device(once__, [&] {
     dtf_allow_lds(gemm_nt_t128x256ws_kernel<true, FP8>, lds3);
@@ -2326,6 +2334,7 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
       ((uintptr_t)C & (out_f32 ? 15 : 7)))
     return DTF_ERR_UNSUPPORTED;
   if (lda * 2 * BM >= (1L << 32) || ldb * 2 * BN >= (1L << 32)) return DTF_ERR_UNSUPPORTED;
+  g_last_kernel.store(0, std::memory_order_relaxed);
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const size_t lds = 2 * BUF_BYTES;   // 128 KiB
     { static DtfPerDeviceOnce once__; dtf_once_per_device(once__, [&] {
@@ -2565,6 +2574,7 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
   const int pp_rows =
       variant == 0 && dtf_pp_grid(t128_all) != t128_all ? dtf_pp_rows(M, N) : 256;
   if ((variant & 15) == 9 || pp_rows == 128) {       // 128-row block tiles (MI = 2)
+    g_last_kernel.store(9, std::memory_order_relaxed);
     { static DtfPerDeviceOnce once__; dtf_once_per_device(once__, [&] {
       dtf_allow_lds(gemm_nt_pp_kernel<true, 0, false, true, false, 2>, lds);
       dtf_allow_lds(gemm_nt_pp_kernel<false, 0, false, true, false, 2>, lds);
@@ -2584,6 +2594,7 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
   }
   // 192-row block tiles (variant 6, or by default when they need fewer row-rounds of the chip)
   if ((variant & 15) == 6 || pp_rows == 192) {
+    g_last_kernel.store(6, std::memory_order_relaxed);
     { static DtfPerDeviceOnce once__; dtf_once_per_device(once__, [&] {
       dtf_allow_lds(gemm_nt_pp_kernel<true, 0, false, true, false, 3>, lds);
       dtf_allow_lds(gemm_nt_pp_kernel<false, 0, false, true, false, 3>, lds);
@@ -2624,6 +2635,7 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
     const int tm128 = (M + T128 - 1) / T128, tn128 = (N + T128 - 1) / T128;
     const dim3 t_grid(tm128 * tn128), t_block(T128_THREADS);
     if ((variant & 15) == 11 || (variant == 0 && dtf_pp_grid(tm128 * tn128) == tm128 * tn128)) {
+      g_last_kernel.store(11, std::memory_order_relaxed);
       if (out_f32)
         hipLaunchKernelGGL(gemm_bf16_nt_t128ws_kernel<true>, t_grid, dim3(2 * T128_THREADS),
                            t_lds3, stream, (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb,
@@ -2635,6 +2647,7 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
       DTF_LAUNCH_CHECK();
       return DTF_OK;
     }
+    g_last_kernel.store(5, std::memory_order_relaxed);
     if (out_f32)
       hipLaunchKernelGGL(gemm_bf16_nt_t128_kernel<true>, t_grid, t_block, t_lds, stream,
                          (const char*)A, (const char*)Bt, C, M, N, K, lda, ldb, ldc, tm128,
@@ -2647,6 +2660,7 @@ DTF_API int dtf_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int 
     return DTF_OK;
   }
   if ((variant & 15) == 4 || variant == 0) {       // ping-pong with two-quadrant phases
+    g_last_kernel.store(4, std::memory_order_relaxed);
         { static DtfPerDeviceOnce once__; dtf_once_per_device(once__, [&] {
       dtf_allow_lds(gemm_nt_pp_kernel<true, 0, false, true>, lds);
       dtf_allow_lds(gemm_nt_pp_kernel<false, 0, false, true>, lds);
@@ -2952,6 +2966,7 @@ DTF_API int dtf_gemm_fp8_nt(const void* A, const void* Bt, void* C, int M, int N
       ((uintptr_t)C & (out_f32 ? 15 : 7)))
     return DTF_ERR_UNSUPPORTED;
   if (lda * BM >= (1L << 32) || ldb * BN >= (1L << 32)) return DTF_ERR_UNSUPPORTED;
+  g_last_kernel.store(4, std::memory_order_relaxed);     // (overwritten by the branches below)
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const size_t lds = 2 * BUF_BYTES;
     { static DtfPerDeviceOnce once__; dtf_once_per_device(once__, [&] {
@@ -2967,6 +2982,7 @@ DTF_API int dtf_gemm_fp8_nt(const void* A, const void* Bt, void* C, int M, int N
     return DTF_OK;
   }
   if (dtf_pp_grid(tm128 * tn128) == tm128 * tn128) {
+    g_last_kernel.store(11, std::memory_order_relaxed);
     const size_t t_lds3 = 3 * T128_BUF_BYTES;
     { static DtfPerDeviceOnce once__; dtf_once_per_device(once__, [&] {
       dtf_allow_lds(gemm_fp8_nt_t128ws_kernel<true>, t_lds3);
@@ -3005,6 +3021,7 @@ DTF_API int dtf_gemm_fp8_nt(const void* A, const void* Bt, void* C, int M, int N
   if (getenv("DTF_FP8_FORCE_256")) pp_rows = 256;
 #endif
   if (pp_rows != 256) {
+    g_last_kernel.store(pp_rows == 192 ? 6 : 9, std::memory_order_relaxed);
     { static DtfPerDeviceOnce once__; dtf_once_per_device(once__, [&] {
       dtf_allow_lds(gemm_nt_pp_kernel<true, 0, true, true, false, 3>, lds);
       dtf_allow_lds(gemm_nt_pp_kernel<false, 0, true, true, false, 3>, lds);

@@ -117,6 +117,7 @@ def _declare(L: ctypes.CDLL) -> None:
         "dtf_gemm_bf16_generic": [P, P, P, I, I, I, LG, LG, LG, LG, LG, F, F, I, P],
         "dtf_gemm_fp8_nt": [P, P, P, I, I, I, LG, LG, LG, F, F, I, P],
         "dtf_gemm_fp8_splits": [I, I, I],
+        "dtf_gemm_last_kernel": [],
         "dtf_gemm_fp8_nt_splitk": [P, P, P, P, I, I, I, LG, LG, LG, F, F, I, I, P],
         "dtf_gemm_fp8_generic": [P, P, P, I, I, I, LG, LG, LG, LG, LG, F, F, I, P],
         "dtf_gemm_fp8_mx_nt": [P, P, P, P, P, I, I, I, LG, LG, LG, LG, LG, F, F, I, P],

@@ -1343,6 +1343,28 @@ def test_gemm_bf16_unsplit_rows_have_shape_independent_bits(hip, out_dtype):
                                                                 variant=variant))
 
 
+def test_gemm_launch_plan_picks_the_kernel_by_grid(hip):
+    """The default bf16 / fp8 launch takes, by the shape of the tile grid: 64 x 64 tiles with
+    request-issuing waves while each has a CU, 128 x 128 tiles likewise, 128 x 256 tiles for mid
+    grids that leave CUs idle (fp8: any grid of at most one per CU; bf16 also full grids up to
+    K = 2048), the 192- / 128-row eight-wave tilings where they fill the chip better, the
+    256 x 256 kernel otherwise (the kernel ids are the ``variant`` numbers)."""
+    L = hip.lib()
+    cases = [((1024, 1024, 1024), 12, 12), ((512, 1024, 256), 12, 12),
+             ((2048, 2048, 512), 11, 11), ((1536, 1792, 256), 11, 11), ((2048, 1920, 256), 11, 11),
+             ((2560, 2560, 256), 13, 13), ((4096, 2048, 2048), 13, 13),
+             ((4096, 2048, 4096), 9, 13), ((3072, 3072, 256), 6, 6),
+             ((4096, 4096, 256), 4, 4), ((8192, 8192, 128), 4, 4)]
+    for (m, n, k), want_bf16, want_fp8 in cases:
+        a = torch.zeros(m, k, device="cuda", dtype=torch.bfloat16)
+        bt = torch.zeros(n, k, device="cuda", dtype=torch.bfloat16)
+        hip.gemm_bf16_nt(a, bt, torch.bfloat16, splits=1)
+        assert L.dtf_gemm_last_kernel() == want_bf16, ("bf16", m, n, k, L.dtf_gemm_last_kernel())
+        hip.gemm_fp8_nt(a.to(FP8), bt.to(FP8), torch.bfloat16, splits=1)
+        assert L.dtf_gemm_last_kernel() == want_fp8, ("fp8", m, n, k, L.dtf_gemm_last_kernel())
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
 def test_gemm_fp8_unsplit_rows_have_shape_independent_bits(hip, out_dtype):
     """The same for fp8: the 256 x 256 kernel (4096^2 outputs), the 128 x 256-tile kernel (2048 x

@@ -1874,13 +1874,14 @@ __global__ __launch_bounds__(2 * T128_THREADS) void gemm_bf16_nt_t128ws_kernel(
 constexpr int T64 = 64;
 constexpr int T64_TILE_BYTES = T64 * BK * 2;       // 8 KiB per operand tile
 constexpr int T64_BUF_BYTES = 2 * T64_TILE_BYTES;
+constexpr int T64_PAIR_BYTES = 2 * T64_BUF_BYTES;  // two K-tiles
 
 template <bool OUT_F32, bool FP8>
 __global__ __launch_bounds__(512) void gemm_nt_t64ws_kernel(
     const char* __restrict__ A, const char* __restrict__ Bt, void* __restrict__ C, int M, int N,
     int K, long lda, long ldb, long ldc, int tiles_m, int tiles_n, float alpha, float beta,
     int ksplits, long plane) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // 3 x (A tile | B tile)
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // three buffers of (A tile | B tile) sets
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave = wave8 & 3;
@@ -1904,6 +1905,7 @@ __global__ __launch_bounds__(512) void gemm_nt_t64ws_kernel(
   const int tn = (id % per_group) / gsize;
   const int m0 = tm * T64, n0 = tn * T64;
   const int nkt = K / (FP8 ? 2 * BK : BK);
+  const int npairs = (nkt + 1) >> 1;
 
   if (producer) {
     // 8 pieces of 8 rows per operand tile, two per wave
@@ -1932,18 +1934,25 @@ __global__ __launch_bounds__(512) void gemm_nt_t64ws_kernel(
             0);
       }
     };
-    stage(0, smem);
-    if (nkt > 1) stage(1, smem + T64_BUF_BYTES);
-    unsigned nxt2 = 2 * T64_BUF_BYTES;
-    for (int kt = 0; kt < nkt; ++kt) {
-      // own pieces of tile kt have landed (the newest tile's four requests stay in flight);
-      // behind the barrier the multiplying waves are done with the buffer of tile kt - 1
-      if (kt + 1 < nkt)
-        asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    // K-tiles travel in pairs (one barrier per 128 k): a pair is eight requests per wave; behind
+    // an odd last tile its own requests are issued once more, so that the counted wait is the
+    // same for every pair (the multiplying waves do not read that half)
+    auto stage_pair = [&](int p, char* buf) {
+      stage(2 * p, buf);
+      stage(2 * p + 1 < nkt ? 2 * p + 1 : nkt - 1, buf + T64_BUF_BYTES);
+    };
+    stage_pair(0, smem);
+    if (npairs > 1) stage_pair(1, smem + T64_PAIR_BYTES);
+    unsigned nxt2 = 2 * T64_PAIR_BYTES;
+    for (int p = 0; p < npairs; ++p) {
+      // own pieces of pair p have landed (the newest pair's eight requests stay in flight);
+      // behind the barrier the multiplying waves are done with the buffer of pair p - 1
+      if (p + 1 < npairs)
+        asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
       else
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-      if (kt + 2 < nkt) stage(kt + 2, smem + nxt2);
-      nxt2 = nxt2 == 2 * T64_BUF_BYTES ? 0 : nxt2 + T64_BUF_BYTES;
+      if (p + 2 < npairs) stage_pair(p + 2, smem + nxt2);
+      nxt2 = nxt2 == 2 * T64_PAIR_BYTES ? 0 : nxt2 + T64_PAIR_BYTES;
     }
     return;
   }
@@ -1965,9 +1974,10 @@ __global__ __launch_bounds__(512) void gemm_nt_t64ws_kernel(
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
 #define DTF_T64_WAIT(N, S2, I) \
   asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(bf[S2][0]), "+v"(bf[S2][1]), "+v"(af[S2][I]))
-  unsigned cur = 0;
+  unsigned pair = 0;
   for (int kt = 0; kt < nkt; ++kt) {
-    asm volatile("s_barrier" ::: "memory");
+    if (!(kt & 1)) asm volatile("s_barrier" ::: "memory");      // one barrier per pair of K-tiles
+    const unsigned cur = pair + (kt & 1) * T64_BUF_BYTES;
     bf16x8 af[2][2], bf[2][2];
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
@@ -2004,7 +2014,7 @@ __global__ __launch_bounds__(512) void gemm_nt_t64ws_kernel(
                 __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[s2][j], af[s2][i], acc[i][j], 0, 0, 0);
         }
     }
-    cur = cur == 2 * T64_BUF_BYTES ? 0 : cur + T64_BUF_BYTES;
+    if (kt & 1) pair = pair == 2 * T64_PAIR_BYTES ? 0 : pair + T64_PAIR_BYTES;
   }
 #undef DTF_T64_RD
 #undef DTF_T64_WAIT
@@ -2026,7 +2036,7 @@ template <bool OUT_F32, bool FP8>
 __global__ __launch_bounds__(512) void gemm_nt_t128x256ws_kernel(
     const char* __restrict__ A, const char* __restrict__ Bt, void* __restrict__ C, int M, int N,
     int K, long lda, long ldb, long ldc, int tiles_m, int tiles_n, float alpha, float beta) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // 3 x (A tile | B tile)
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // three buffers of (A tile | B tile) sets
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave = wave8 & 3;
@@ -2284,7 +2294,7 @@ static void dtf_launch_t64ws(const void* A, const void* Bt, void* C, int M, int 
                              long ldb, long ldc, float alpha, float beta, int out_f32, int ksplits,
                              long plane, hipStream_t stream) {
   g_last_kernel.store(12, std::memory_order_relaxed);
-  const size_t lds3 = 3 * T64_BUF_BYTES;
+  const size_t lds3 = 3 * T64_PAIR_BYTES;
   { static DtfPerDeviceOnce once__; dtf_once_per_device(once__, [&] {
     dtf_allow_lds(gemm_nt_t64ws_kernel<true, FP8>, lds3);
     dtf_allow_lds(gemm_nt_t64ws_kernel<false, FP8>, lds3);

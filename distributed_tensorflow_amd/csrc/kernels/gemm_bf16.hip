@@ -1728,7 +1728,11 @@ __device__ __forceinline__ void gemm_bf16_nt_t128_body(
     // and waves 0-3 only read fragments and multiply. (A fourth buffer, with the multiplying
     // waves fetching the next tile's first fragments ahead of the barrier so that their MFMAs
     // start right behind it, changed nothing: 26.8 -> 27.3 us at 1024 x 1024 x 4096. What is
-    // left is the request path itself: 32 KiB per K-tile and CU in 0.4 us.)
+    // left is the request path itself: 32 KiB per K-tile and CU in 0.4 us. K-tiles travelling in
+    // pairs as in the 64x64-tile kernel -- two buffers of a pair, one barrier per pair, the next
+    // pair requested behind it -- measured slower, 2048^3 21.0 against 19.5 us, 1536^3 16.9 / 13.8:
+    // three pair buffers would not fit in LDS, and with two the requests run only one pair ahead
+    // and the wait in front of the barrier is a full one.)
     if (producer) {
       if (nkt > 1) stage(1, smem + T128_BUF_BYTES);
       unsigned nxt2 = 2 * T128_BUF_BYTES;            // byte offset of tile kt + 2's buffer

@@ -2845,14 +2845,15 @@ static bool dtf_gemm_bf16_split_on_t128(int M, int N, int K, int ksplits) {
 // if the K-tiles a workgroup is spared (0.23 us each) outweigh the second launch and the pass
 // over the fp32 planes (about 5 us on 512^2 outputs, 6-7 above). GPU time by kernel trace,
 // unsplit / best split / torch.matmul, bf16: 512 x 512 x 4096 17.5 / 12.5 (4) / 10.6, 256 x 256 x
-// 8192 22.7 / 9.2 (8) / 10.2, 512 x 1024 x 2048 8.8 / 11.5 (2) / 10.0, 1024^2 outputs have no split
+// 8192 22.7 / 9.2 (8) / 10.2, 512 x 1024 x 2048 8.8 / 11.5 (2) / 10.0, 512 x 1024 x 4096 14.2 / 14.8
+// (2) / 14.5 and 640 x 640 x 4096 13.8 / 14.3 (2) / 13.9 with paired K-tiles; 1024^2 outputs have no split
 // with a CU per work item: 1024 x 1024 x 4096 18.5 (22.4 split four ways on 128x128 tiles) / 18.2,
 // 1024 x 1024 x 8192 30.5 (32.4) / 29.5 (`profiles/gemm_bf16_ws_plan.txt`).
 static int dtf_t64_splits(int t64, int nkt) {
   const int cus = dtf_pp_grid(1 << 20);
   int s = 1;
   while (s < 16 && t64 * s * 2 <= cus && nkt % (s * 2) == 0 && nkt / (s * 2) >= 8) s *= 2;
-  if (s > 1 && nkt * (s - 1) / s <= (t64 <= 64 ? 24 : 30)) s = 1;
+  if (s > 1 && nkt * (s - 1) / s <= (t64 <= 64 ? 24 : 32)) s = 1;
   return s;
 }
 

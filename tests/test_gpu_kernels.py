@@ -773,7 +773,7 @@ def test_gemm_fp8_on_128x128_tiles_with_request_waves(hip, m, n, k, out_dtype):
 @pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("m,n,k,splits", [(512, 512, 8192, None), (512, 512, 4096, 4),
                                           (256, 256, 8192, None),
-                                          (300, 260, 2048, 4), (512, 1024, 8192, None),
+                                          (300, 260, 2048, 4), (512, 1024, 16384, None),
                                           (1024, 1024, 32768, None), (1024, 1024, 8192, 4)])
 def test_gemm_fp8_split_k(hip, m, n, k, splits, out_dtype):
     """Few output tiles + long K in fp8: (split, tile) work items on the 64 x 64-tile kernel (a CU
@@ -963,7 +963,8 @@ def test_gemm_bf16_k_not_multiple_of_tile(hip, m, n, k, out_dtype):
 
 
 @pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
-@pytest.mark.parametrize("m,n,k,splits", [(512, 768, 4096, None), (300, 260, 2048, 4),
+@pytest.mark.parametrize("m,n,k,splits", [(512, 768, 8192, None), (512, 768, 4096, 2),
+                                          (300, 260, 2048, 4),
                                           (1024, 2048, 4096, None), (256, 256, 1024, 2),
                                           (1024, 1024, 16384, None), (1024, 1024, 4096, 4)])
 def test_gemm_bf16_split_k(hip, m, n, k, splits, out_dtype):
